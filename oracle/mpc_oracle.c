@@ -1,0 +1,665 @@
+/* TEST INFRASTRUCTURE - CPU float64 oracle for the batched bicycle-model MPC solve.
+ *
+ * Not shipped and never on the product path: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library (as the checker / the
+ * reported CPU baseline).  PARITY UNPINNED by the reference's own tests: the
+ * reference (SaeedRahmani/MPC-RL_for_AVs) has no tests or golden vectors and its
+ * solver stack (casadi 3.6.6 -> IPOPT/MUMPS, agents/pure_mpc.py:285-300) is not
+ * installed here.  This file restates the *problem* of PureMPC_Agent._solve
+ * exactly and solves it to a tighter tolerance (1e-8) than the reference's IPOPT
+ * call (tol 1e-6); its answers are pinned by the independent KKT certifier in
+ * oracle/nlp_spec.py and by oracle/scipy_crosscheck.py.
+ *
+ * Problem restated (all citations relative to /root/reference):
+ *   variables   X[k]=(x,y,theta,v) k=0..N, U[k]=(a,delta) k=0..N-1      agents/pure_mpc.py:88-93,260
+ *   objective   10*sum_k<N [4 perp^2 + 2 para^2 + ws (v-vref)^2 + .5 (theta-h)^2]
+ *               + wc*.01*sum |U_k|^2 + wd*.01*sum_{k>=1} |U_k-U_{k-1}|^2  agents/pure_mpc.py:128-212
+ *               ws = 100 when is_collide                                  agents/pure_mpc.py:143-147
+ *   optional    + w_distance*sum_k sum_j (d<1?1000:100)/(d+1e-6)^2
+ *               + w_collision*is_collide*3000*sum_k v_k^2                 agents/archive/pure_mpc.py:189-206,
+ *                                                                         agents/pure_mpc.py:169-183
+ *   dynamics    explicit-Euler kinematic bicycle, beta=atan(.5 tan delta)  agents/pure_mpc.py:220-257
+ *   bounds      x,y in [-500,500], theta in [-pi,pi], v in [0,30],
+ *               a in [-5,5], delta in [-pi/3,pi/3]                        agents/pure_mpc.py:272-280
+ *   cold start  X[k]=state, U=0                                           agents/pure_mpc.py:240-246
+ *
+ * Algorithm (ours; the reference delegates to IPOPT): primal-dual interior point
+ * with monotone barrier decrease, exact Lagrangian Hessian with IPOPT-style
+ * inertia correction (delta_w), stage-wise Riccati factorisation of the KKT
+ * system (state augmented with the previous control to carry the input-rate
+ * cost), l1-merit backtracking line search, fraction-to-the-boundary rule.
+ * X[0] is eliminated (it is pinned by the equality X[0]=state).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NMAX 64
+#define VMAX 16
+#define WHEELBASE 2.5
+#define PI 3.14159265358979323846
+
+typedef struct {
+    int N, V, cc;
+    double dt, x0[4];
+    double rx[NMAX + 1], ry[NMAX + 1], rv[NMAX + 1], rh[NMAX + 1], rs[NMAX + 1], rc[NMAX + 1];
+    double ws, wc, wd;
+    double ox[VMAX], oy[VMAX], osx[VMAX], osy[VMAX];
+    double wdist, wcoll; /* wcoll already multiplied by 3000*is_collide */
+    double sf;           /* objective scale factor (IPOPT-style gradient-based scaling), 1 = unscaled */
+} prob_t;
+
+static const double XLO[4] = {-500.0, -500.0, -PI, 0.0};
+static const double XHI[4] = {500.0, 500.0, PI, 30.0};
+static const double ULO[2] = {-5.0, -PI / 3.0};
+static const double UHI[2] = {5.0, PI / 3.0};
+
+typedef struct {
+    double f[4];                   /* f(x,u) */
+    double S, C, sb, cb, bp, bpp;  /* sin/cos(theta+beta), sin/cos beta, beta', beta'' */
+} dyn_t;
+
+static void dyn_eval(const double *x, const double *u, dyn_t *d) {
+    double t = tan(u[1]);
+    double beta = atan(0.5 * t);
+    double den = 4.0 + t * t;
+    d->bp = 2.0 * (1.0 + t * t) / den;
+    d->bpp = 12.0 * t * (1.0 + t * t) / (den * den);
+    d->sb = sin(beta);
+    d->cb = cos(beta);
+    d->S = sin(x[2] + beta);
+    d->C = cos(x[2] + beta);
+    d->f[0] = x[3] * d->C;
+    d->f[1] = x[3] * d->S;
+    d->f[2] = x[3] / WHEELBASE * d->sb;
+    d->f[3] = u[0];
+}
+
+/* stage state cost (node k, 1<=k<=N-1), gradient lx[4] and Hessian Q[4][4] */
+static double stage_cost_raw(const prob_t *p, int k, const double *x, double *lx, double (*Q)[4], double (*Qg)[4]);
+static double stage_cost(const prob_t *p, int k, const double *x, double *lx, double (*Q)[4], double (*Qg)[4]) {
+    double J = stage_cost_raw(p, k, x, lx, Q, Qg);
+    if (p->sf != 1.0) {
+        if (lx) for (int i = 0; i < 4; ++i) lx[i] *= p->sf;
+        if (Q) for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Q[i][j] *= p->sf;
+        if (Qg) for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Qg[i][j] *= p->sf;
+    }
+    return J * p->sf;
+}
+static double stage_cost_raw(const prob_t *p, int k, const double *x, double *lx, double (*Q)[4], double (*Qg)[4]) {
+    double s = p->rs[k], c = p->rc[k];
+    double dx = x[0] - p->rx[k], dy = x[1] - p->ry[k];
+    double perp = dx * s - dy * c, para = dx * c + dy * s;
+    double dv = x[3] - p->rv[k], dth = x[2] - p->rh[k];
+    double J = 10.0 * (4 * perp * perp + 2 * para * para + p->ws * dv * dv + 0.5 * dth * dth);
+    if (lx) {
+        lx[0] = 10.0 * (8 * perp * s + 4 * para * c);
+        lx[1] = 10.0 * (-8 * perp * c + 4 * para * s);
+        lx[2] = 10.0 * dth;
+        lx[3] = 20.0 * p->ws * dv;
+    }
+    if (Q) {
+        memset(Q, 0, 16 * sizeof(double));
+        Q[0][0] = 10.0 * (8 * s * s + 4 * c * c);
+        Q[0][1] = Q[1][0] = 10.0 * (-8 * s * c + 4 * c * s);
+        Q[1][1] = 10.0 * (8 * c * c + 4 * s * s);
+        Q[2][2] = 10.0;
+        Q[3][3] = 20.0 * p->ws;
+        if (Qg) memcpy(Qg, Q, 16 * sizeof(double));
+    }
+    if (p->cc) {
+        for (int j = 0; j < p->V; ++j) {
+            double px = x[0] - (p->ox[j] + k * p->osx[j]);
+            double py = x[1] - (p->oy[j] + k * p->osy[j]);
+            double d = sqrt(px * px + py * py);
+            double cst = (d < 1.0 ? 1000.0 : 100.0) * p->wdist;
+            double de = d + 1e-6;
+            J += cst / (de * de);
+            if (lx || Q) {
+                double dpsi = -2.0 * cst / (de * de * de);
+                double nx = px / d, ny = py / d;
+                if (lx) {
+                    lx[0] += dpsi * nx;
+                    lx[1] += dpsi * ny;
+                }
+                if (Q) {
+                    double d2psi = 6.0 * cst / (de * de * de * de);
+                    double tt = dpsi / d;
+                    Q[0][0] += d2psi * nx * nx + tt * (1 - nx * nx);
+                    Q[0][1] += (d2psi - tt) * nx * ny;
+                    Q[1][0] += (d2psi - tt) * nx * ny;
+                    Q[1][1] += d2psi * ny * ny + tt * (1 - ny * ny);
+                    if (Qg) { /* convex (Gauss-Newton-like) part: radial curvature only */
+                        Qg[0][0] += d2psi * nx * nx;
+                        Qg[0][1] += d2psi * nx * ny;
+                        Qg[1][0] += d2psi * nx * ny;
+                        Qg[1][1] += d2psi * ny * ny;
+                    }
+                }
+            }
+        }
+        J += p->wcoll * x[3] * x[3];
+        if (lx) lx[3] += 2.0 * p->wcoll * x[3];
+        if (Q) Q[3][3] += 2.0 * p->wcoll;
+        if (Q && Qg) Qg[3][3] += 2.0 * p->wcoll;
+    }
+    return J;
+}
+
+typedef struct {
+    double tol, mu_init;
+    int max_iter;
+} opts_t;
+
+typedef struct {
+    double x[NMAX + 1][4], u[NMAX][2];
+    double zxl[NMAX + 1][4], zxu[NMAX + 1][4], zul[NMAX][2], zuu[NMAX][2];
+    double lam[NMAX + 1][4]; /* equality multipliers (IPOPT sign: L = f + lam'g), filled at exit */
+} iter_t;
+
+/* bounds relaxed like IPOPT's bound_relax_factor = 1e-8 so that a strict interior always exists */
+static double xlo_r(int i) { return XLO[i] - 1e-8 * fmax(1.0, fabs(XLO[i])); }
+static double xhi_r(int i) { return XHI[i] + 1e-8 * fmax(1.0, fabs(XHI[i])); }
+static double ulo_r(int i) { return ULO[i] - 1e-8 * fmax(1.0, fabs(ULO[i])); }
+static double uhi_r(int i) { return UHI[i] + 1e-8 * fmax(1.0, fabs(UHI[i])); }
+
+/* barrier objective of a dynamically feasible trajectory (node-0 state cost is a constant and dropped) */
+static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
+    int N = p->N;
+    double J = 0.0, bar = 0.0;
+    for (int k = 0; k < N; ++k) {
+        const double *u = it->u[k];
+        if (k >= 1) J += stage_cost(p, k, it->x[k], NULL, NULL, NULL);
+        J += 0.01 * p->sf * p->wc * (u[0] * u[0] + u[1] * u[1]);
+        if (k >= 1) {
+            double d0 = u[0] - it->u[k - 1][0], d1 = u[1] - it->u[k - 1][1];
+            J += 0.01 * p->sf * p->wd * (d0 * d0 + d1 * d1);
+        }
+        for (int i = 0; i < 2; ++i) bar -= log(u[i] - ulo_r(i)) + log(uhi_r(i) - u[i]);
+    }
+    for (int k = 1; k <= N; ++k)
+        for (int i = 0; i < 4; ++i) bar -= log(it->x[k][i] - xlo_r(i)) + log(xhi_r(i) - it->x[k][i]);
+    return J + mu * bar;
+}
+
+/* solve one instance.
+ * status: 0 converged, 1 max_iter reached, 2 factorisation failure, 3 start not strictly feasible */
+static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, double *kkt_out) {
+    const int N = p->N;
+    const double dt = p->dt;
+    double rd_full = 0.02 * p->wd, rc = 0.02 * p->wc;
+    double mu = o->mu_init;
+    const double mu_min = o->tol / 10.0;
+    int status = 1, iter = 0;
+    const double kap_eps = getenv("ORACLE_KEPS") ? atof(getenv("ORACLE_KEPS")) : 10.0;
+    const double kap_mu = getenv("ORACLE_KMU") ? atof(getenv("ORACLE_KMU")) : 0.2;
+
+    static _Thread_local double A[NMAX][4][4], Bm[NMAX][4][2];
+    static _Thread_local double lxs[NMAX + 1][4], Qs[NMAX + 1][4][4], Qgs[NMAX + 1][4][4], lus[NMAX][2], lps[NMAX][2];
+    static _Thread_local double Wtt[NMAX], Wtv[NMAX], Wtd[NMAX], Wvd[NMAX], Wdd[NMAX];
+    static _Thread_local double Kx[NMAX][2][4], Kp[NMAX][2][2], kf[NMAX][2], yv[NMAX + 2][4];
+    static _Thread_local iter_t trial;
+
+    /* ---- cold start of the reference (pure_mpc.py:240-246: controls 0) rolled out through the dynamics;
+     *      a standing vehicle gets a_0 > 0 so that v_1.. are strictly inside v >= 0 */
+    memset(it, 0, sizeof(*it));
+    for (int i = 0; i < 4; ++i) it->x[0][i] = p->x0[i];
+    if (p->x0[3] < 0.01) it->u[0][0] = (0.01 - p->x0[3]) / dt;
+    for (int k = 0; k < N; ++k) {
+        dyn_t d;
+        dyn_eval(it->x[k], it->u[k], &d);
+        for (int i = 0; i < 4; ++i) it->x[k + 1][i] = it->x[k][i] + dt * d.f[i];
+        for (int i = 0; i < 2; ++i) it->zul[k][i] = it->zuu[k][i] = 1.0;
+        for (int i = 0; i < 4; ++i) it->zxl[k + 1][i] = it->zxu[k + 1][i] = 1.0;
+    }
+    for (int k = 1; k <= N; ++k)
+        for (int i = 0; i < 4; ++i)
+            if (!(it->x[k][i] > xlo_r(i)) || !(it->x[k][i] < xhi_r(i))) {
+                *iters_out = 0;
+                if (kkt_out) *kkt_out = INFINITY;
+                return 3;
+            }
+    for (int i = 0; i < 2; ++i)
+        if (!(it->u[0][i] > ulo_r(i)) || !(it->u[0][i] < uhi_r(i))) {
+            *iters_out = 0;
+            if (kkt_out) *kkt_out = INFINITY;
+            return 3;
+        }
+
+    /* ---- objective scaling like IPOPT's gradient-based scaling (nlp_scaling_max_gradient = 100):
+     *      sf = 100 / max(100, |grad f|_inf at the starting trajectory) */
+    {
+        double gmax = 0.0, lx[4];
+        p->sf = 1.0;
+        for (int k = 1; k < N; ++k) {
+            stage_cost(p, k, it->x[k], lx, NULL, NULL);
+            for (int i = 0; i < 4; ++i) gmax = fmax(gmax, fabs(lx[i]));
+        }
+        gmax = fmax(gmax, 0.02 * (p->wc + p->wd) * fabs(it->u[0][0]));
+        p->sf = 100.0 / fmax(100.0, gmax);
+        rd_full *= p->sf;
+        rc *= p->sf;
+    }
+
+    for (iter = 0; iter <= o->max_iter; ++iter) {
+        /* ---------------- stage derivatives along the current (feasible) trajectory ---------------- */
+        for (int k = 0; k < N; ++k) {
+            dyn_t d;
+            const double *x = it->x[k], *u = it->u[k];
+            dyn_eval(x, u, &d);
+            memset(A[k], 0, sizeof(A[k]));
+            memset(Bm[k], 0, sizeof(Bm[k]));
+            for (int i = 0; i < 4; ++i) A[k][i][i] = 1.0;
+            A[k][0][2] = -dt * x[3] * d.S;
+            A[k][0][3] = dt * d.C;
+            A[k][1][2] = dt * x[3] * d.C;
+            A[k][1][3] = dt * d.S;
+            A[k][2][3] = dt * d.sb / WHEELBASE;
+            Bm[k][0][1] = -dt * x[3] * d.S * d.bp;
+            Bm[k][1][1] = dt * x[3] * d.C * d.bp;
+            Bm[k][2][1] = dt * x[3] / WHEELBASE * d.cb * d.bp;
+            Bm[k][3][0] = dt;
+            if (k >= 1) stage_cost(p, k, x, lxs[k], Qs[k], Qgs[k]);
+            double rdk = (k >= 1) ? rd_full : 0.0;
+            for (int i = 0; i < 2; ++i) {
+                double dprev = (k >= 1) ? (u[i] - it->u[k - 1][i]) : 0.0;
+                lus[k][i] = rc * u[i] + rdk * dprev;
+                lps[k][i] = -rdk * dprev;
+            }
+        }
+        memset(lxs[N], 0, sizeof(lxs[N]));
+        memset(Qs[N], 0, sizeof(Qs[N]));
+        memset(Qgs[N], 0, sizeof(Qgs[N]));
+
+        /* ---------------- adjoint sweep: y_k = dL/dx_k with the current bound multipliers -------------
+         * (y = -lam in IPOPT's sign convention); dual residual r_u and the constraint curvature terms */
+        double err_d = 0.0, sum_lam = 0.0, sum_z = 0.0;
+        for (int i = 0; i < 4; ++i) {
+            yv[N][i] = -it->zxl[N][i] + it->zxu[N][i];
+            yv[N + 1][i] = 0.0;
+        }
+        for (int k = N - 1; k >= 0; --k) {
+            const double *y = yv[k + 1];
+            for (int i = 0; i < 2; ++i) {
+                double r = lus[k][i] - it->zul[k][i] + it->zuu[k][i] + ((k + 1 < N) ? lps[k + 1][i] : 0.0);
+                for (int j = 0; j < 4; ++j) r += Bm[k][j][i] * y[j];
+                err_d = fmax(err_d, fabs(r));
+                sum_z += it->zul[k][i] + it->zuu[k][i];
+            }
+            for (int i = 0; i < 4; ++i) {
+                sum_lam += fabs(y[i]);
+                sum_z += it->zxl[k + 1][i] + it->zxu[k + 1][i];
+            }
+            if (k >= 1)
+                for (int i = 0; i < 4; ++i) {
+                    double s = lxs[k][i] - it->zxl[k][i] + it->zxu[k][i];
+                    for (int j = 0; j < 4; ++j) s += A[k][j][i] * y[j];
+                    yv[k][i] = s;
+                }
+            /* exact curvature  sum_i y_i * d2(dt f_i)  over (theta, v, delta) */
+            dyn_t d;
+            dyn_eval(it->x[k], it->u[k], &d);
+            double v = it->x[k][3];
+            double g = -(y[0] * d.C + y[1] * d.S);
+            double h = -(y[0] * d.S - y[1] * d.C);
+            Wtt[k] = dt * v * g;
+            Wtv[k] = dt * h;
+            Wtd[k] = dt * v * g * d.bp;
+            Wvd[k] = dt * h * d.bp + dt * y[2] * d.cb * d.bp / WHEELBASE;
+            Wdd[k] = dt * v * (g * d.bp * d.bp + h * d.bpp) +
+                     dt * y[2] * v / WHEELBASE * (-d.sb * d.bp * d.bp + d.cb * d.bpp);
+        }
+        const int nvar = 6 * N, ncon = 4 * N;
+        double s_d = fmax(100.0, (sum_lam + sum_z) / (nvar + ncon)) / 100.0;
+        double s_c = fmax(100.0, sum_z / nvar) / 100.0;
+        double err_c0 = 0.0;
+        for (;;) {
+            double ec = 0.0;
+            err_c0 = 0.0;
+            for (int k = 1; k <= N; ++k)
+                for (int i = 0; i < 4; ++i) {
+                    double cl = (it->x[k][i] - xlo_r(i)) * it->zxl[k][i], cu = (xhi_r(i) - it->x[k][i]) * it->zxu[k][i];
+                    ec = fmax(ec, fmax(fabs(cl - mu), fabs(cu - mu)));
+                    err_c0 = fmax(err_c0, fmax(cl, cu));
+                }
+            for (int k = 0; k < N; ++k)
+                for (int i = 0; i < 2; ++i) {
+                    double cl = (it->u[k][i] - ulo_r(i)) * it->zul[k][i], cu = (uhi_r(i) - it->u[k][i]) * it->zuu[k][i];
+                    ec = fmax(ec, fmax(fabs(cl - mu), fabs(cu - mu)));
+                    err_c0 = fmax(err_c0, fmax(cl, cu));
+                }
+            double E_mu = fmax(err_d / s_d, ec / s_c);
+            if (E_mu <= kap_eps * mu && mu > mu_min) {
+                mu = fmax(mu_min, fmin(kap_mu * mu, pow(mu, 1.5)));
+                continue;
+            }
+            break;
+        }
+        double E0 = fmax(err_d / s_d, err_c0 / s_c);
+        if (kkt_out) *kkt_out = E0;
+        if (E0 <= o->tol) {
+            status = 0;
+            break;
+        }
+        if (iter == o->max_iter) break;
+
+        /* ---------------- backward (Riccati / DDP) sweep with the exact Lagrangian Hessian ------------------
+         * A control block Huu_k that is not positive definite (the reduced Hessian is then indefinite) is
+         * replaced stage-locally by V |Lambda| V' (eigenvalues reflected, floored): the step solves a
+         * convexified QP exactly, stays a descent direction, and no re-factorisation is needed. */
+        double dV1 = 0.0, delta_w = 0.0;
+        int nmod = 0, ok = 0, gn = 0;
+        double need = 0.0;
+        for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
+            ok = 1;
+            dV1 = 0.0;
+            double Pxx[4][4], Pxp[4][2], Ppp[2][2] = {{0, 0}, {0, 0}}, px[4], pp[2] = {0, 0};
+            memset(Pxx, 0, sizeof(Pxx));
+            memset(Pxp, 0, sizeof(Pxp));
+            for (int i = 0; i < 4; ++i) {
+                double sl = it->x[N][i] - xlo_r(i), su = xhi_r(i) - it->x[N][i];
+                Pxx[i][i] = it->zxl[N][i] / sl + it->zxu[N][i] / su + delta_w;
+                px[i] = -mu / sl + mu / su;
+            }
+            for (int k = N - 1; k >= 0; --k) {
+                const double rdk = (k >= 1) ? rd_full : 0.0;
+                double Lxx[4][4], Lxu[4][2], Luu[2][2], lx[4], lu[2];
+                memset(Lxx, 0, sizeof(Lxx));
+                memset(Lxu, 0, sizeof(Lxu));
+                memset(lx, 0, sizeof(lx));
+                if (k >= 1) {
+                    for (int i = 0; i < 4; ++i) {
+                        for (int j = 0; j < 4; ++j) Lxx[i][j] = gn ? Qgs[k][i][j] : Qs[k][i][j];
+                        double sl = it->x[k][i] - xlo_r(i), su = xhi_r(i) - it->x[k][i];
+                        Lxx[i][i] += it->zxl[k][i] / sl + it->zxu[k][i] / su + delta_w;
+                        lx[i] = lxs[k][i] - mu / sl + mu / su;
+                    }
+                    if (!gn) {
+                        Lxx[2][2] += Wtt[k];
+                        Lxx[2][3] += Wtv[k];
+                        Lxx[3][2] += Wtv[k];
+                        Lxu[2][1] = Wtd[k];
+                        Lxu[3][1] = Wvd[k];
+                    }
+                }
+                for (int i = 0; i < 2; ++i) {
+                    double sl = it->u[k][i] - ulo_r(i), su = uhi_r(i) - it->u[k][i];
+                    Luu[i][i] = rc + rdk + it->zul[k][i] / sl + it->zuu[k][i] / su + delta_w;
+                    lu[i] = lus[k][i] - mu / sl + mu / su;
+                }
+                Luu[0][1] = Luu[1][0] = 0.0;
+                if (!gn) Luu[1][1] += Wdd[k];
+                double PA[4][4], PB[4][2];
+                for (int i = 0; i < 4; ++i) {
+                    for (int j = 0; j < 4; ++j) {
+                        double s = 0;
+                        for (int m = 0; m < 4; ++m) s += Pxx[i][m] * A[k][m][j];
+                        PA[i][j] = s;
+                    }
+                    for (int j = 0; j < 2; ++j) {
+                        double s = 0;
+                        for (int m = 0; m < 4; ++m) s += Pxx[i][m] * Bm[k][m][j];
+                        PB[i][j] = s;
+                    }
+                }
+                double Hxx[4][4], Hxu[4][2], Huu[2][2], hx[4], hu[2];
+                for (int i = 0; i < 4; ++i) {
+                    for (int j = 0; j < 4; ++j) {
+                        double s = Lxx[i][j];
+                        for (int m = 0; m < 4; ++m) s += A[k][m][i] * PA[m][j];
+                        Hxx[i][j] = s;
+                    }
+                    for (int j = 0; j < 2; ++j) {
+                        double s = Lxu[i][j];
+                        for (int m = 0; m < 4; ++m) s += A[k][m][i] * (PB[m][j] + Pxp[m][j]);
+                        Hxu[i][j] = s;
+                    }
+                    double s = lx[i];
+                    for (int m = 0; m < 4; ++m) s += A[k][m][i] * px[m];
+                    hx[i] = s;
+                }
+                for (int i = 0; i < 2; ++i) {
+                    for (int j = 0; j < 2; ++j) {
+                        double s = Luu[i][j] + Ppp[i][j];
+                        for (int m = 0; m < 4; ++m)
+                            s += Bm[k][m][i] * (PB[m][j] + Pxp[m][j]) + Pxp[m][i] * Bm[k][m][j];
+                        Huu[i][j] = s;
+                    }
+                    double s = lu[i] + pp[i];
+                    for (int m = 0; m < 4; ++m) s += Bm[k][m][i] * px[m];
+                    hu[i] = s;
+                }
+                /* 2x2 symmetric eigen-decomposition; reflect / floor the eigenvalues if needed */
+                double ha = Huu[0][0], hb = 0.5 * (Huu[0][1] + Huu[1][0]), hc = Huu[1][1];
+                double hm = 0.5 * (ha + hc), hd = sqrt(0.25 * (ha - hc) * (ha - hc) + hb * hb);
+                double l1 = hm + hd, l2 = hm - hd;
+                (void)l1;
+                if (!(ha > 0.0) || !(hc > 0.0) || !(ha * hc - hb * hb > 1e-12 * ha * hc)) {
+                    ok = 0;
+                    need = fmax(-l2, 0.0);
+                    break;
+                }
+                double det = ha * hc - hb * hb;
+                double Hi[2][2] = {{hc / det, -hb / det}, {-hb / det, ha / det}};
+                for (int i = 0; i < 2; ++i) {
+                    for (int j = 0; j < 4; ++j) Kx[k][i][j] = -(Hi[i][0] * Hxu[j][0] + Hi[i][1] * Hxu[j][1]);
+                    for (int j = 0; j < 2; ++j) Kp[k][i][j] = rdk * Hi[i][j]; /* -Huu^-1 Hup with Hup = -rd I */
+                    kf[k][i] = -(Hi[i][0] * hu[0] + Hi[i][1] * hu[1]);
+                }
+                dV1 += 0.5 * (kf[k][0] * hu[0] + kf[k][1] * hu[1]);
+                double nPxx[4][4], nPpp[2][2], nppv[2];
+                for (int i = 0; i < 4; ++i) {
+                    for (int j = 0; j < 4; ++j) nPxx[i][j] = Hxx[i][j] + Hxu[i][0] * Kx[k][0][j] + Hxu[i][1] * Kx[k][1][j];
+                    for (int j = 0; j < 2; ++j) Pxp[i][j] = Hxu[i][0] * Kp[k][0][j] + Hxu[i][1] * Kp[k][1][j];
+                    px[i] = hx[i] + Hxu[i][0] * kf[k][0] + Hxu[i][1] * kf[k][1];
+                }
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) Pxx[i][j] = 0.5 * (nPxx[i][j] + nPxx[j][i]);
+                for (int i = 0; i < 2; ++i) {
+                    for (int j = 0; j < 2; ++j) nPpp[i][j] = (i == j ? rdk : 0.0) - rdk * Kp[k][i][j];
+                    nppv[i] = lps[k][i] - rdk * kf[k][i];
+                }
+                memcpy(Ppp, nPpp, sizeof(Ppp));
+                memcpy(pp, nppv, sizeof(pp));
+            }
+            if (!ok) {
+                /* Far from a stationary point the convex Gauss-Newton model is the better fallback; close to
+                 * one (scaled dual residual <= 1) an indefinite Hessian is a property of the problem and the
+                 * exact Hessian is kept, shifted by delta_w sized from the offending eigenvalue. */
+                ++nmod;
+                if (gn) {
+                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
+                } else if (err_d / s_d > 1.0 || nmod > 12) {
+                    gn = 1;
+                    delta_w = 0.0;
+                } else {
+                    delta_w = fmax(2.0 * delta_w, delta_w + 1.5 * need + 1e-6);
+                }
+                if (delta_w > 1e40) break;
+            }
+        }
+        if (!ok) {
+            status = 2;
+            break;
+        }
+
+        /* ---------------- linear forward sweep: full primal-dual Newton step, step-length limits -------- */
+        const double tau = fmax(0.99, 1.0 - mu);
+        static _Thread_local double dxl[NMAX + 1][4], dul[NMAX][2];
+        static _Thread_local double dzxl[NMAX + 1][4], dzxu[NMAX + 1][4], dzul[NMAX][2], dzuu[NMAX][2];
+        double a_pr = 1.0, a_du = 1.0;
+        memset(dxl[0], 0, sizeof(dxl[0]));
+        for (int k = 0; k < N; ++k) {
+            for (int i = 0; i < 2; ++i) {
+                double s = kf[k][i];
+                for (int j = 0; j < 4; ++j) s += Kx[k][i][j] * dxl[k][j];
+                if (k >= 1)
+                    for (int j = 0; j < 2; ++j) s += Kp[k][i][j] * dul[k - 1][j];
+                dul[k][i] = s;
+            }
+            for (int i = 0; i < 4; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < 4; ++j) s += A[k][i][j] * dxl[k][j];
+                for (int j = 0; j < 2; ++j) s += Bm[k][i][j] * dul[k][j];
+                dxl[k + 1][i] = s;
+            }
+            for (int i = 0; i < 2; ++i) {
+                double sl = it->u[k][i] - ulo_r(i), su = uhi_r(i) - it->u[k][i], d = dul[k][i];
+                if (d < 0) a_pr = fmin(a_pr, -tau * sl / d);
+                if (d > 0) a_pr = fmin(a_pr, tau * su / d);
+                dzul[k][i] = (mu - it->zul[k][i] * d) / sl - it->zul[k][i];
+                dzuu[k][i] = (mu + it->zuu[k][i] * d) / su - it->zuu[k][i];
+                if (dzul[k][i] < 0) a_du = fmin(a_du, -tau * it->zul[k][i] / dzul[k][i]);
+                if (dzuu[k][i] < 0) a_du = fmin(a_du, -tau * it->zuu[k][i] / dzuu[k][i]);
+            }
+            for (int i = 0; i < 4; ++i) {
+                double sl = it->x[k + 1][i] - xlo_r(i), su = xhi_r(i) - it->x[k + 1][i], d = dxl[k + 1][i];
+                if (d < 0) a_pr = fmin(a_pr, -tau * sl / d);
+                if (d > 0) a_pr = fmin(a_pr, tau * su / d);
+                dzxl[k + 1][i] = (mu - it->zxl[k + 1][i] * d) / sl - it->zxl[k + 1][i];
+                dzxu[k + 1][i] = (mu + it->zxu[k + 1][i] * d) / su - it->zxu[k + 1][i];
+                if (dzxl[k + 1][i] < 0) a_du = fmin(a_du, -tau * it->zxl[k + 1][i] / dzxl[k + 1][i]);
+                if (dzxu[k + 1][i] < 0) a_du = fmin(a_du, -tau * it->zxu[k + 1][i] / dzxu[k + 1][i]);
+            }
+        }
+
+        /* ---------------- nonlinear rollout with feedback, Armijo on the barrier objective ------------- */
+        double phi0 = barrier_objective(p, it, mu), alpha = a_pr, phi1 = phi0;
+        int accepted = 0, nls = 0;
+        for (nls = 0; nls < 30; ++nls, alpha *= 0.5) {
+            int feas = 1;
+            trial = *it;
+            for (int k = 0; k < N && feas; ++k) {
+                for (int i = 0; i < 2; ++i) {
+                    double s = alpha * kf[k][i];
+                    for (int j = 0; j < 4; ++j) s += Kx[k][i][j] * (trial.x[k][j] - it->x[k][j]);
+                    if (k >= 1)
+                        for (int j = 0; j < 2; ++j) s += Kp[k][i][j] * (trial.u[k - 1][j] - it->u[k - 1][j]);
+                    trial.u[k][i] = it->u[k][i] + s;
+                    if (trial.u[k][i] - ulo_r(i) < 0.5 * (1.0 - tau) * (it->u[k][i] - ulo_r(i)) ||
+                        uhi_r(i) - trial.u[k][i] < 0.5 * (1.0 - tau) * (uhi_r(i) - it->u[k][i]))
+                        feas = 0;
+                }
+                dyn_t d;
+                dyn_eval(trial.x[k], trial.u[k], &d);
+                for (int i = 0; i < 4; ++i) {
+                    trial.x[k + 1][i] = trial.x[k][i] + dt * d.f[i];
+                    if (trial.x[k + 1][i] - xlo_r(i) < 0.5 * (1.0 - tau) * (it->x[k + 1][i] - xlo_r(i)) ||
+                        xhi_r(i) - trial.x[k + 1][i] < 0.5 * (1.0 - tau) * (xhi_r(i) - it->x[k + 1][i]))
+                        feas = 0;
+                }
+            }
+            if (!feas) continue;
+            phi1 = barrier_objective(p, &trial, mu);
+            if (phi1 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                accepted = 1;
+                break;
+            }
+        }
+        if (getenv("ORACLE_TRACE"))
+            fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
+                    iter, nmod, gn, mu, delta_w, err_d, err_c0, E0, a_pr, alpha, a_du, nls, dV1, phi0, phi1, accepted);
+        if (!accepted) trial = *it; /* keep the primal point; the dual step below still moves z */
+        /* ---------------- dual step with its own fraction-to-the-boundary length ---------------- */
+        for (int k = 1; k <= N; ++k)
+            for (int i = 0; i < 4; ++i) {
+                double sln = trial.x[k][i] - xlo_r(i), sun = xhi_r(i) - trial.x[k][i];
+                double zl = it->zxl[k][i] + a_du * dzxl[k][i], zu = it->zxu[k][i] + a_du * dzxu[k][i];
+                trial.zxl[k][i] = fmax(fmin(zl, 1e10 * mu / sln), mu / (1e10 * sln));
+                trial.zxu[k][i] = fmax(fmin(zu, 1e10 * mu / sun), mu / (1e10 * sun));
+            }
+        for (int k = 0; k < N; ++k)
+            for (int i = 0; i < 2; ++i) {
+                double sln = trial.u[k][i] - ulo_r(i), sun = uhi_r(i) - trial.u[k][i];
+                double zl = it->zul[k][i] + a_du * dzul[k][i], zu = it->zuu[k][i] + a_du * dzuu[k][i];
+                trial.zul[k][i] = fmax(fmin(zl, 1e10 * mu / sln), mu / (1e10 * sln));
+                trial.zuu[k][i] = fmax(fmin(zu, 1e10 * mu / sun), mu / (1e10 * sun));
+            }
+        *it = trial;
+    }
+    for (int k = 1; k <= N; ++k)
+        for (int i = 0; i < 4; ++i) it->lam[k][i] = -yv[k][i] / p->sf;
+    *iters_out = iter;
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * batch entry point (same argument meaning as include/mpc_mi355x.h : mpc_solve_batch)
+ *   ref_table [M,4] x,y,v,heading; state [B,4]; ego_index [B]; vref [B,N+1] or NULL (table speeds);
+ *   weights [B,3] speed,control,input_diff; is_collide [B]; others [B,V,4] x,y,speed,heading.
+ *   flags bit0: collision-cost term on.
+ * outputs: u0 [B,2]; U [B,N,2] / X [B,N+1,4] / lam [B,N+1,4] optional (NULL to skip);
+ *   status [B]; iters [B]; kkt [B] optional.
+ * ------------------------------------------------------------------------------------------ */
+int oracle_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state,
+                       const int32_t *ego_index, const double *vref, const double *weights,
+                       const uint8_t *is_collide, const double *others, int V, uint32_t flags,
+                       double w_distance, double w_collision, double tol, int max_iter, double *u0,
+                       double *U, double *X, double *lam, int32_t *status, int32_t *iters, double *kkt,
+                       int nthreads) {
+    if (N < 1 || N > NMAX || V < 0 || V > VMAX || M < 1) return -1;
+    opts_t o = {tol, getenv("ORACLE_MU0") ? atof(getenv("ORACLE_MU0")) : 0.1, max_iter};
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int b = 0; b < B; ++b) {
+        prob_t p;
+        memset(&p, 0, sizeof(p));
+        p.N = N;
+        p.dt = dt;
+        p.V = (flags & 1u) ? V : 0;
+        p.cc = (flags & 1u) ? 1 : 0;
+        for (int i = 0; i < 4; ++i) p.x0[i] = state[4 * b + i];
+        for (int k = 0; k <= N; ++k) {
+            int idx = ego_index[b] + k;
+            if (idx > M - 1) idx = M - 1;
+            if (idx < 0) idx = 0;
+            p.rx[k] = ref_table[4 * idx + 0];
+            p.ry[k] = ref_table[4 * idx + 1];
+            p.rv[k] = vref ? vref[(size_t)b * (N + 1) + k] : ref_table[4 * idx + 2];
+            p.rh[k] = ref_table[4 * idx + 3];
+            p.rs[k] = sin(p.rh[k]);
+            p.rc[k] = cos(p.rh[k]);
+        }
+        p.ws = is_collide[b] ? 100.0 : weights[3 * b + 0];
+        p.wc = weights[3 * b + 1];
+        p.wd = weights[3 * b + 2];
+        for (int j = 0; j < p.V; ++j) {
+            const double *ov = others + ((size_t)b * V + j) * 4;
+            p.ox[j] = ov[0];
+            p.oy[j] = ov[1];
+            p.osx[j] = ov[2] * dt * cos(ov[3]);
+            p.osy[j] = ov[2] * dt * sin(ov[3]);
+        }
+        p.wdist = w_distance;
+        p.wcoll = (p.cc && is_collide[b]) ? 3000.0 * w_collision : 0.0;
+        iter_t *it = (iter_t *)malloc(sizeof(iter_t));
+        int its = 0;
+        double e = 0.0;
+        int st = solve_one(&p, &o, it, &its, &e);
+        u0[2 * b + 0] = it->u[0][0];
+        u0[2 * b + 1] = it->u[0][1];
+        if (U)
+            for (int k = 0; k < N; ++k) {
+                U[((size_t)b * N + k) * 2 + 0] = it->u[k][0];
+                U[((size_t)b * N + k) * 2 + 1] = it->u[k][1];
+            }
+        if (X)
+            for (int k = 0; k <= N; ++k)
+                for (int i = 0; i < 4; ++i) X[((size_t)b * (N + 1) + k) * 4 + i] = it->x[k][i];
+        if (lam)
+            for (int k = 0; k <= N; ++k)
+                for (int i = 0; i < 4; ++i) lam[((size_t)b * (N + 1) + k) * 4 + i] = it->lam[k][i];
+        status[b] = st;
+        iters[b] = its;
+        if (kkt) kkt[b] = e;
+        free(it);
+    }
+    return 0;
+}
