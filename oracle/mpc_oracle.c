@@ -241,7 +241,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             for (int i = 0; i < 4; ++i) gmax = fmax(gmax, fabs(lx[i]));
         }
         gmax = fmax(gmax, 0.02 * (p->wc + p->wd) * fabs(it->u[0][0]));
-        p->sf = 100.0 / fmax(100.0, gmax);
+        p->sf = 100.0 / fmin(fmax(100.0, gmax), 1e4); /* capped: a start that grazes another vehicle must not loosen the tolerance */
         rd_full *= p->sf;
         rc *= p->sf;
     }

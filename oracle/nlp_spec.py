@@ -230,7 +230,7 @@ def kkt_certificate(p: Problem, X, U, act_tol=1e-6, relax=1e-8):
     least-squares fit of the stationarity equations, then checked for sign.
     `relax` mirrors IPOPT's bound_relax_factor (1e-8), under which the reference's
     answer is feasible.
-    Returns dict(stationarity, feasibility, bound_violation, min_mult_sign, n_active).
+    Returns dict(stationarity, feasibility, bound_violation, min_bound_mult, n_active, lam).
     """
     z = pack(X, U)
     lo, hi = bounds(p)
@@ -240,11 +240,20 @@ def kkt_certificate(p: Problem, X, U, act_tol=1e-6, relax=1e-8):
     J = constraint_jac_dense(p, X, U)
     act_lo = np.where(z - lo <= act_tol)[0]
     act_hi = np.where(hi - z <= act_tol)[0]
+    # X[0] is pinned by the equality X[0] = state: its bound multipliers are redundant with lam_0
+    act_lo = act_lo[act_lo >= 4]
+    act_hi = act_hi[act_hi >= 4]
     n = z.size
     E_lo = np.zeros((n, act_lo.size)); E_lo[act_lo, np.arange(act_lo.size)] = -1.0
     E_hi = np.zeros((n, act_hi.size)); E_hi[act_hi, np.arange(act_hi.size)] = 1.0
     Mmat = np.concatenate([J.T, E_lo, E_hi], axis=1)
-    sol, *_ = np.linalg.lstsq(Mmat, -grad, rcond=None)
+    # multipliers of active bounds must be non-negative: bounded least squares (lam free, z >= 0)
+    from scipy.optimize import lsq_linear
+    nlam = J.shape[0]
+    lb = np.concatenate([np.full(nlam, -np.inf), np.zeros(Mmat.shape[1] - nlam)])
+    gscale = max(1.0, float(np.max(np.abs(grad))))
+    sol = lsq_linear(Mmat, -grad / gscale, bounds=(lb, np.full(Mmat.shape[1], np.inf)),
+                     method="bvls", tol=1e-14, max_iter=2000).x * gscale
     resid = grad + Mmat @ sol
     mult_b = sol[J.shape[0]:]
     viol = max(0.0, float(np.max(lo - z)), float(np.max(z - hi)))
