@@ -1,0 +1,109 @@
+/*
+ * mpc_mi355x.h - C ABI of the MI355X (gfx950) batched nonlinear-MPC solve engine.
+ *
+ * Drop-in boundary for the hot path of SaeedRahmani/MPC-RL_for_AVs:
+ *   PureMPC_Agent._solve()   reference agents/pure_mpc.py:80-318   (one NLP per call, CasADi -> IPOPT)
+ *   PureMPC_Agent.predict()  reference agents/pure_mpc.py:68-78
+ * The reference has no FFI for this path (it is a plain Python method that builds a CasADi graph and
+ * calls `ca.nlpsol('solver','ipopt',...)`, agents/pure_mpc.py:285-300); the entry points below are what a
+ * binding for it binds instead: plain pointers and sizes, no Python or torch types.  INTEGRATION.md shows
+ * the ctypes stub that replaces the body of `_solve`.
+ *
+ * Conventions
+ *   - all floating-point data is IEEE double; indices are int32; flags uint8 / uint32
+ *   - arrays are dense row-major with the batch index slowest: state[B][4], vref[B][N+1], ...
+ *   - every call returns 0 on success or a negative MPC_ERR_* code; mpc_last_error() gives the text
+ *   - no exceptions cross this boundary; per-instance solver outcomes go to status[] / iters[]
+ *   - a handle belongs to one (process, device); calls on one handle must not overlap
+ */
+#ifndef MPC_MI355X_H
+#define MPC_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_ABI_VERSION 1
+#define MPC_MAX_HORIZON 64
+#define MPC_MAX_OTHERS 16
+
+/* error codes (return values) */
+#define MPC_OK 0
+#define MPC_ERR_INVALID_ARG (-1)
+#define MPC_ERR_NO_DEVICE (-2)   /* no HIP device / HIP runtime error: the engine has no CPU fallback */
+#define MPC_ERR_HIP (-3)
+#define MPC_ERR_NO_REFERENCE (-4) /* mpc_set_reference() has not been called */
+
+/* mpc_solve_batch flags */
+#define MPC_FLAG_COLLISION_COST 1u /* add the distance/collision terms of agents/archive/pure_mpc.py:189-206 */
+#define MPC_FLAG_DEVICE_PTRS 2u    /* all data pointers are device memory (else host memory, copied internally) */
+#define MPC_FLAG_NO_SYNC 4u        /* with DEVICE_PTRS: enqueue only, do not synchronise the stream */
+
+/* per-instance solver status written to status[] */
+#define MPC_STATUS_CONVERGED 0
+#define MPC_STATUS_MAX_ITER 1       /* last iterate returned, like the reference (agents/pure_mpc.py:303-305) */
+#define MPC_STATUS_FACTORIZATION 2
+#define MPC_STATUS_INFEASIBLE_START 3 /* the initial state violates the state bounds of agents/pure_mpc.py:272-274 */
+
+typedef struct mpc_handle mpc_handle;
+
+typedef struct mpc_config {
+    int32_t struct_size; /* sizeof(mpc_config), for ABI evolution */
+    int32_t horizon;     /* N; reference cfg key `horizon` (config/cfg.yaml:90 default 16, BASELINE uses 20) */
+    double dt;           /* 1 / policy_frequency (agents/base_agent.py:43), 0.1 */
+    int32_t max_iter;    /* interior-point iteration cap (reference: ipopt.max_iter 1000, agents/pure_mpc.py:294) */
+    int32_t device;      /* HIP device ordinal */
+    double tol;          /* scaled KKT tolerance (reference: ipopt.tol 1e-6, agents/pure_mpc.py:295); default 1e-8 */
+    double w_distance;   /* cfg key weight_distance  (config/cfg.yaml:105), used with MPC_FLAG_COLLISION_COST */
+    double w_collision;  /* cfg key weight_collision (config/cfg.yaml:106), used with MPC_FLAG_COLLISION_COST */
+} mpc_config;
+
+/* ABI version of the loaded library (MPC_ABI_VERSION it was built with). */
+int mpc_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *mpc_last_error(void);
+
+/* Fill *cfg with the defaults (horizon 20, dt 0.1, max_iter 100, tol 1e-8, weights 10 / 1, device 0). */
+void mpc_default_config(mpc_config *cfg);
+
+/* Create an engine bound to cfg->device.  Replaces PureMPC_Agent.__init__ (agents/pure_mpc.py:24-63). */
+int mpc_create(const mpc_config *cfg, mpc_handle **out);
+
+void mpc_destroy(mpc_handle *h);
+
+/* Upload the global reference path: ref[M][4] = x, y, v, heading (host pointer).
+ * Replaces the `reference_states` property (agents/base_agent.py:118-154), M = 85 there. */
+int mpc_set_reference(mpc_handle *h, const double *ref, int32_t M);
+
+/*
+ * Solve B independent MPC instances (replaces B calls of PureMPC_Agent._solve, agents/pure_mpc.py:80-318).
+ *   state      [B][4]    x, y, theta, v of the ego vehicle               (agents/pure_mpc.py:233-238)
+ *   ego_index  [B]       index of the nearest reference point            (agents/pure_mpc.py:106-109)
+ *   vref       [B][N+1]  reference speed of stage k = ref[min(ego_index+k, M-1)][2] after
+ *                        update_reference_states (agents/pure_mpc.py:678-724); NULL = speeds of the table
+ *   weights    [B][3]    weight_speed, weight_control, weight_input_diff (agents/pure_mpc.py:96-104)
+ *   is_collide [B]       1: speed weight forced to 100 (agents/pure_mpc.py:143-147) and, with
+ *                        MPC_FLAG_COLLISION_COST, the 3000 v^2 term is active
+ *   others     [B][V][4] x, y, speed, heading of the other vehicles (constant-velocity model,
+ *                        agents/base_agent.py:172-174); read only with MPC_FLAG_COLLISION_COST; may be NULL
+ * outputs (u0 required, the rest optional = NULL):
+ *   u0     [B][2]      first control (acceleration, steer) = MPC_Action    (agents/pure_mpc.py:311-318)
+ *   U      [B][N][2]   full control sequence;  X [B][N+1][4] state trajectory
+ *   status [B], iters [B]
+ *   stream: hipStream_t to enqueue on (NULL = the null stream)
+ */
+int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t *ego_index, const double *vref,
+                    const double *weights, const uint8_t *is_collide, const double *others, int32_t V,
+                    uint32_t flags, double *u0, double *U, double *X, int32_t *status, int32_t *iters,
+                    void *stream);
+
+/* Bytes of device workspace the engine holds for batches up to B (diagnostics / capacity planning). */
+int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_MI355X_H */

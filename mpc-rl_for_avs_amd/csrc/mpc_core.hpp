@@ -1,0 +1,749 @@
+// mpc_core.hpp - per-instance interior-point DDP solver, written for one GPU lane per MPC instance.
+//
+// This is the arithmetic of the hot path: the NLP of PureMPC_Agent._solve (reference
+// agents/pure_mpc.py:80-318) solved by a primal-dual interior-point method whose Newton systems are
+// factorised stage by stage (Riccati / DDP backward sweep) and whose iterates are kept dynamically
+// feasible by nonlinear feedback rollouts.  One wave64 lane owns one instance; every per-stage quantity
+// lives in a structure-of-arrays workspace indexed [slot][stage][instance] so that the 64 lanes of a wave
+// always touch 512 contiguous bytes.  All small matrices are scalarised (no runtime-indexed arrays, which
+// hipcc would spill to scratch) and the sparsity of the bicycle-model Jacobians
+//     A = I + dt*df/dx = [1 0 a02 a03; 0 1 a12 a13; 0 0 1 a23; 0 0 0 1],   B = [0 b01; 0 b11; 0 b21; dt 0]
+// is exploited by hand.
+//
+// The same header compiles for the host (tests/cpu_core_harness.cpp) so the kernel logic can be run
+// under sanitizers without a GPU; the product never takes that path.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MPC_HD __host__ __device__ __forceinline__
+#else
+#define MPC_HD inline
+#endif
+
+namespace mpc {
+
+// ---------------------------------------------------------------------------------------------------
+// workspace slot map (doubles per stage).  Two trajectory buffers (current / trial) are swapped on accept.
+// ---------------------------------------------------------------------------------------------------
+enum : int {
+    B_X = 0,     // 4  x, y, theta, v                       (node k)
+    B_U = 4,     // 2  a, delta                             (node k < N)
+    B_DYN = 6,   // 6  S, C, sin(beta), cos(beta), beta', beta''   of (x_k, u_k)
+    B_LX = 12,   // 4  scaled stage-cost gradient at node k (1 <= k < N)
+    B_Q = 16,    // 4  scaled stage-cost Hessian q00 q01 q11 q33 (theta-theta is the constant 10*sf)
+    B_QG = 20,   // 3  convex part of q00 q01 q11 (differs from B_Q only with the collision-cost term)
+    BUF_SLOTS = 23,
+    S_BUF0 = 0,
+    S_BUF1 = BUF_SLOTS,
+    S_ZXL = 2 * BUF_SLOTS,  // 4 lower-bound multipliers of x_k
+    S_ZXU = S_ZXL + 4,      // 4
+    S_ZUL = S_ZXU + 4,      // 2
+    S_ZUU = S_ZUL + 2,      // 2
+    S_Y = S_ZUU + 2,        // 4 adjoint dL/dx_k
+    S_KX = S_Y + 4,         // 8 feedback gain on dx (row-major 2x4)
+    S_KP = S_KX + 8,        // 3 feedback gain on the previous control (symmetric 2x2: 00 01 11)
+    S_KF = S_KP + 3,        // 2 feed-forward
+    S_DXL = S_KF + 2,       // 4 linearised Newton step of x_k
+    S_DUL = S_DXL + 4,      // 2 linearised Newton step of u_k
+    S_REF = S_DUL + 2,      // 6 reference window rx ry rv rh sin(rh) cos(rh)
+    STAGE_SLOTS = S_REF + 6
+};
+
+struct SolveParams {
+    int N;            // horizon
+    int V;            // other vehicles used by the collision-cost term (0 when the term is off)
+    int max_iter;
+    int collision_cost;
+    double dt;
+    double tol;
+    double mu_init;
+    double w_distance;  // weight_distance
+};
+
+MPC_HD double fmax2(double a, double b) { return a > b ? a : b; }
+MPC_HD double fmin2(double a, double b) { return a < b ? a : b; }
+
+// bounds of the reference NLP (agents/pure_mpc.py:272-280), relaxed like IPOPT's bound_relax_factor 1e-8
+#define MPC_PI 3.14159265358979323846
+MPC_HD double xlo_r(int i) {
+    return i == 0 ? -500.0 - 5e-6 : i == 1 ? -500.0 - 5e-6 : i == 2 ? -MPC_PI - 1e-8 * MPC_PI : -1e-8;
+}
+MPC_HD double xhi_r(int i) {
+    return i == 0 ? 500.0 + 5e-6 : i == 1 ? 500.0 + 5e-6 : i == 2 ? MPC_PI + 1e-8 * MPC_PI : 30.0 + 30e-8;
+}
+MPC_HD double ulo_r(int i) { return i == 0 ? -5.0 - 5e-8 : -(MPC_PI / 3.0) - 1e-8 * (MPC_PI / 3.0); }
+MPC_HD double uhi_r(int i) { return i == 0 ? 5.0 + 5e-8 : (MPC_PI / 3.0) + 1e-8 * (MPC_PI / 3.0); }
+
+constexpr double kInvWheelbase = 1.0 / 2.5;  // Vehicle.LENGTH, agents/utils.py:18
+
+struct Dyn {
+    double S, C, sb, cb, bp, bpp;
+};
+
+// kinematic bicycle model (agents/pure_mpc.py:220-228): beta = atan(LENGTH_REAR/LENGTH * tan(delta))
+MPC_HD void dyn_eval(double theta, double delta, Dyn &d) {
+    const double t = tan(delta);
+    const double beta = atan(0.5 * t);
+    const double den = 4.0 + t * t;
+    d.bp = 2.0 * (1.0 + t * t) / den;
+    d.bpp = 12.0 * t * (1.0 + t * t) / (den * den);
+    d.sb = sin(beta);
+    d.cb = cos(beta);
+    d.S = sin(theta + beta);
+    d.C = cos(theta + beta);
+}
+
+// scaled stage cost at node k (1 <= k < N) with gradient and Hessian entries
+//   10*[4 perp^2 + 2 para^2 + ws (v-vref)^2 + .5 (theta-h)^2]     agents/pure_mpc.py:134-156,206
+//   + w_distance * sum_j (d<1?1000:100)/(d+1e-6)^2 + wcoll*v^2    agents/archive/pure_mpc.py:189-196
+template <class WS>
+MPC_HD double stage_cost(const SolveParams &P, const WS &w, int k, double sf, double ws_, double wcoll, double x0,
+                         double x1, double x2, double x3, bool derivs, double *lx, double *q, double *qg) {
+    const double rx = w.ld(S_REF + 0, k), ry = w.ld(S_REF + 1, k), rv = w.ld(S_REF + 2, k);
+    const double rh = w.ld(S_REF + 3, k), s = w.ld(S_REF + 4, k), c = w.ld(S_REF + 5, k);
+    const double dx = x0 - rx, dy = x1 - ry;
+    const double perp = dx * s - dy * c, para = dx * c + dy * s;
+    const double dv = x3 - rv, dth = x2 - rh;
+    double J = 10.0 * (4.0 * perp * perp + 2.0 * para * para + ws_ * dv * dv + 0.5 * dth * dth);
+    double g0 = 0, g1 = 0, g3 = 0, h00 = 0, h01 = 0, h11 = 0, h33 = 0, c00 = 0, c01 = 0, c11 = 0;
+    if (derivs) {
+        g0 = 10.0 * (8.0 * perp * s + 4.0 * para * c);
+        g1 = 10.0 * (-8.0 * perp * c + 4.0 * para * s);
+        g3 = 20.0 * ws_ * dv;
+        h00 = 10.0 * (8.0 * s * s + 4.0 * c * c);
+        h01 = 10.0 * (-8.0 * s * c + 4.0 * c * s);
+        h11 = 10.0 * (8.0 * c * c + 4.0 * s * s);
+        h33 = 20.0 * ws_;
+        c00 = h00;
+        c01 = h01;
+        c11 = h11;
+    }
+    if (P.collision_cost) {
+        for (int j = 0; j < P.V; ++j) {
+            const double px = x0 - (w.oth(j, 0) + k * w.oth(j, 2));
+            const double py = x1 - (w.oth(j, 1) + k * w.oth(j, 3));
+            const double d = sqrt(px * px + py * py);
+            const double cst = (d < 1.0 ? 1000.0 : 100.0) * P.w_distance;
+            const double de = d + 1e-6;
+            const double inv2 = 1.0 / (de * de);
+            J += cst * inv2;
+            if (derivs) {
+                const double dpsi = -2.0 * cst * inv2 / de;
+                const double nx = px / d, ny = py / d;
+                const double d2psi = 6.0 * cst * inv2 * inv2;
+                const double tt = dpsi / d;
+                g0 += dpsi * nx;
+                g1 += dpsi * ny;
+                h00 += d2psi * nx * nx + tt * (1.0 - nx * nx);
+                h01 += (d2psi - tt) * nx * ny;
+                h11 += d2psi * ny * ny + tt * (1.0 - ny * ny);
+                c00 += d2psi * nx * nx;
+                c01 += d2psi * nx * ny;
+                c11 += d2psi * ny * ny;
+            }
+        }
+        J += wcoll * x3 * x3;
+        if (derivs) {
+            g3 += 2.0 * wcoll * x3;
+            h33 += 2.0 * wcoll;
+        }
+    }
+    if (derivs) {
+        lx[0] = sf * g0;
+        lx[1] = sf * g1;
+        lx[2] = sf * 10.0 * dth;
+        lx[3] = sf * g3;
+        q[0] = sf * h00;
+        q[1] = sf * h01;
+        q[2] = sf * h11;
+        q[3] = sf * h33;
+        qg[0] = sf * c00;
+        qg[1] = sf * c01;
+        qg[2] = sf * c11;
+    }
+    return sf * J;
+}
+
+// One forward rollout from x0 with controls  u_k = ucur_k + alpha*kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1})
+// written into buffer `tb` (reading the current iterate from buffer `cb`); with first==true the controls of
+// `tb` are taken as they are (cold start).  Returns false when a bound would be crossed
+// (fraction-to-the-boundary rule with parameter `frac`).  J / bar receive the objective and the
+// log-barrier sum of the new trajectory.
+template <class WS>
+MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, double alpha, double frac, double sf,
+                    double ws_, double wc_, double wd_, double wcoll, const double *x0, double &Jout, double &barout) {
+    const int N = P.N;
+    const double dt = P.dt;
+    const int CB = cb * BUF_SLOTS, TB = tb * BUF_SLOTS;
+    double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
+    double J = 0.0, bar = 0.0;
+    double up0 = 0.0, up1 = 0.0;    // previous new control
+    double dup0 = 0.0, dup1 = 0.0;  // previous control change
+    for (int k = 0; k < N; ++k) {
+        double u0, u1;
+        if (first) {
+            u0 = w.ld(TB + B_U + 0, k);
+            u1 = w.ld(TB + B_U + 1, k);
+        } else {
+            const double e0 = x_0 - w.ld(CB + B_X + 0, k), e1 = x_1 - w.ld(CB + B_X + 1, k);
+            const double e2 = x_2 - w.ld(CB + B_X + 2, k), e3 = x_3 - w.ld(CB + B_X + 3, k);
+            const double c0 = w.ld(CB + B_U + 0, k), c1 = w.ld(CB + B_U + 1, k);
+            double s0 = alpha * w.ld(S_KF + 0, k) + w.ld(S_KX + 0, k) * e0 + w.ld(S_KX + 1, k) * e1 +
+                        w.ld(S_KX + 2, k) * e2 + w.ld(S_KX + 3, k) * e3;
+            double s1 = alpha * w.ld(S_KF + 1, k) + w.ld(S_KX + 4, k) * e0 + w.ld(S_KX + 5, k) * e1 +
+                        w.ld(S_KX + 6, k) * e2 + w.ld(S_KX + 7, k) * e3;
+            if (k >= 1) {
+                const double kp00 = w.ld(S_KP + 0, k), kp01 = w.ld(S_KP + 1, k), kp11 = w.ld(S_KP + 2, k);
+                s0 += kp00 * dup0 + kp01 * dup1;
+                s1 += kp01 * dup0 + kp11 * dup1;
+            }
+            u0 = c0 + s0;
+            u1 = c1 + s1;
+            dup0 = s0;
+            dup1 = s1;
+            if (u0 - ulo_r(0) < frac * (c0 - ulo_r(0)) || uhi_r(0) - u0 < frac * (uhi_r(0) - c0) ||
+                u1 - ulo_r(1) < frac * (c1 - ulo_r(1)) || uhi_r(1) - u1 < frac * (uhi_r(1) - c1))
+                return false;
+            w.st(TB + B_U + 0, k, u0);
+            w.st(TB + B_U + 1, k, u1);
+        }
+        w.st(TB + B_X + 0, k, x_0);
+        w.st(TB + B_X + 1, k, x_1);
+        w.st(TB + B_X + 2, k, x_2);
+        w.st(TB + B_X + 3, k, x_3);
+        // control costs  (agents/pure_mpc.py:161-165)
+        J += 0.01 * sf * wc_ * (u0 * u0 + u1 * u1);
+        if (k >= 1) {
+            const double d0 = u0 - up0, d1 = u1 - up1;
+            J += 0.01 * sf * wd_ * (d0 * d0 + d1 * d1);
+        }
+        bar -= log(u0 - ulo_r(0)) + log(uhi_r(0) - u0);
+        bar -= log(u1 - ulo_r(1)) + log(uhi_r(1) - u1);
+        up0 = u0;
+        up1 = u1;
+        Dyn d;
+        dyn_eval(x_2, u1, d);
+        w.st(TB + B_DYN + 0, k, d.S);
+        w.st(TB + B_DYN + 1, k, d.C);
+        w.st(TB + B_DYN + 2, k, d.sb);
+        w.st(TB + B_DYN + 3, k, d.cb);
+        w.st(TB + B_DYN + 4, k, d.bp);
+        w.st(TB + B_DYN + 5, k, d.bpp);
+        const double n0 = x_0 + dt * (x_3 * d.C);
+        const double n1 = x_1 + dt * (x_3 * d.S);
+        const double n2 = x_2 + dt * (x_3 * kInvWheelbase * d.sb);
+        const double n3 = x_3 + dt * u0;
+        if (!first) {
+            const double o0 = w.ld(CB + B_X + 0, k + 1), o1 = w.ld(CB + B_X + 1, k + 1);
+            const double o2 = w.ld(CB + B_X + 2, k + 1), o3 = w.ld(CB + B_X + 3, k + 1);
+            if (n0 - xlo_r(0) < frac * (o0 - xlo_r(0)) || xhi_r(0) - n0 < frac * (xhi_r(0) - o0) ||
+                n1 - xlo_r(1) < frac * (o1 - xlo_r(1)) || xhi_r(1) - n1 < frac * (xhi_r(1) - o1) ||
+                n2 - xlo_r(2) < frac * (o2 - xlo_r(2)) || xhi_r(2) - n2 < frac * (xhi_r(2) - o2) ||
+                n3 - xlo_r(3) < frac * (o3 - xlo_r(3)) || xhi_r(3) - n3 < frac * (xhi_r(3) - o3))
+                return false;
+        } else {
+            if (!(n0 > xlo_r(0)) || !(n0 < xhi_r(0)) || !(n1 > xlo_r(1)) || !(n1 < xhi_r(1)) || !(n2 > xlo_r(2)) ||
+                !(n2 < xhi_r(2)) || !(n3 > xlo_r(3)) || !(n3 < xhi_r(3)))
+                return false;
+        }
+        x_0 = n0;
+        x_1 = n1;
+        x_2 = n2;
+        x_3 = n3;
+        bar -= log(x_0 - xlo_r(0)) + log(xhi_r(0) - x_0);
+        bar -= log(x_1 - xlo_r(1)) + log(xhi_r(1) - x_1);
+        bar -= log(x_2 - xlo_r(2)) + log(xhi_r(2) - x_2);
+        bar -= log(x_3 - xlo_r(3)) + log(xhi_r(3) - x_3);
+        if (k + 1 < N) {
+            double lx[4], q[4], qg[3];
+            J += stage_cost(P, w, k + 1, sf, ws_, wcoll, x_0, x_1, x_2, x_3, true, lx, q, qg);
+            w.st(TB + B_LX + 0, k + 1, lx[0]);
+            w.st(TB + B_LX + 1, k + 1, lx[1]);
+            w.st(TB + B_LX + 2, k + 1, lx[2]);
+            w.st(TB + B_LX + 3, k + 1, lx[3]);
+            w.st(TB + B_Q + 0, k + 1, q[0]);
+            w.st(TB + B_Q + 1, k + 1, q[1]);
+            w.st(TB + B_Q + 2, k + 1, q[2]);
+            w.st(TB + B_Q + 3, k + 1, q[3]);
+            w.st(TB + B_QG + 0, k + 1, qg[0]);
+            w.st(TB + B_QG + 1, k + 1, qg[1]);
+            w.st(TB + B_QG + 2, k + 1, qg[2]);
+        }
+    }
+    w.st(TB + B_X + 0, N, x_0);
+    w.st(TB + B_X + 1, N, x_1);
+    w.st(TB + B_X + 2, N, x_2);
+    w.st(TB + B_X + 3, N, x_3);
+    Jout = J;
+    barout = bar;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// solve one instance.  On return the solution sits in trajectory buffer `cur_out`.
+//   ws_/wc_/wd_ : weight_speed (100 if is_collide), weight_control, weight_input_diff
+//   wcoll       : 3000 * weight_collision when the collision-cost term is on and is_collide, else 0
+// ---------------------------------------------------------------------------------------------------
+template <class WS>
+MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double ws_, double wc_, double wd_,
+                           double wcoll, int &status_out, int &iters_out, int &cur_out, double &kkt_out) {
+    const int N = P.N;
+    const double dt = P.dt;
+    int cur = 0;
+    status_out = 1;
+    iters_out = 0;
+    cur_out = 0;
+    kkt_out = INFINITY;
+
+    // ---- cold start of the reference (agents/pure_mpc.py:240-246: controls 0) rolled out through the
+    //      dynamics; a standing vehicle gets a_0 > 0 so that v_1.. are strictly inside v >= 0
+    for (int k = 0; k < N; ++k) {
+        w.st(S_BUF0 + B_U + 0, k, 0.0);
+        w.st(S_BUF0 + B_U + 1, k, 0.0);
+        w.st(S_ZUL + 0, k, 1.0);
+        w.st(S_ZUL + 1, k, 1.0);
+        w.st(S_ZUU + 0, k, 1.0);
+        w.st(S_ZUU + 1, k, 1.0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w.st(S_ZXL + i, k + 1, 1.0);
+            w.st(S_ZXU + i, k + 1, 1.0);
+        }
+    }
+    if (x0[3] < 0.01) w.st(S_BUF0 + B_U + 0, 0, (0.01 - x0[3]) / dt);
+    double sf = 1.0, Jcur = 0.0, barcur = 0.0;
+    if (!rollout(P, w, 0, 0, true, 0.0, 0.0, 1.0, ws_, wc_, wd_, wcoll, x0, Jcur, barcur)) {
+        status_out = 3;
+        return;
+    }
+    // ---- objective scaling like IPOPT's gradient-based scaling: sf = 100 / clamp(|grad f|_inf, 100, 1e4)
+    {
+        double gmax = 0.0;
+        for (int k = 1; k < N; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gmax = fmax2(gmax, fabs(w.ld(S_BUF0 + B_LX + i, k)));
+        gmax = fmax2(gmax, 0.02 * (wc_ + wd_) * fabs(w.ld(S_BUF0 + B_U + 0, 0)));
+        sf = 100.0 / fmin2(fmax2(100.0, gmax), 1e4);
+        Jcur *= sf;
+        for (int k = 1; k < N; ++k) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w.st(S_BUF0 + B_LX + i, k, sf * w.ld(S_BUF0 + B_LX + i, k));
+                w.st(S_BUF0 + B_Q + i, k, sf * w.ld(S_BUF0 + B_Q + i, k));
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w.st(S_BUF0 + B_QG + i, k, sf * w.ld(S_BUF0 + B_QG + i, k));
+        }
+    }
+    const double rd_full = 0.02 * sf * wd_, rc = 0.02 * sf * wc_, qtt = 10.0 * sf;
+    double mu = P.mu_init;
+    const double mu_min = P.tol / 10.0;
+    int iter = 0;
+
+    for (iter = 0; iter <= P.max_iter; ++iter) {
+        const int CB = cur * BUF_SLOTS;
+        // =========================== adjoint sweep: dual residual, complementarity =====================
+        double err_d = 0.0, sum_lam = 0.0, sum_z = 0.0, cmax = 0.0, cmin = INFINITY;
+        {
+            double y0, y1, y2, y3;  // y_{k+1}
+            {
+                const double zl0 = w.ld(S_ZXL + 0, N), zl1 = w.ld(S_ZXL + 1, N), zl2 = w.ld(S_ZXL + 2, N),
+                             zl3 = w.ld(S_ZXL + 3, N);
+                const double zu0 = w.ld(S_ZXU + 0, N), zu1 = w.ld(S_ZXU + 1, N), zu2 = w.ld(S_ZXU + 2, N),
+                             zu3 = w.ld(S_ZXU + 3, N);
+                y0 = -zl0 + zu0;
+                y1 = -zl1 + zu1;
+                y2 = -zl2 + zu2;
+                y3 = -zl3 + zu3;
+            }
+            double un0 = 0.0, un1 = 0.0;  // u_{k+1}
+            for (int k = N - 1; k >= 0; --k) {
+                const double u0 = w.ld(CB + B_U + 0, k), u1 = w.ld(CB + B_U + 1, k);
+                double um0 = 0.0, um1 = 0.0;
+                if (k >= 1) {
+                    um0 = w.ld(CB + B_U + 0, k - 1);
+                    um1 = w.ld(CB + B_U + 1, k - 1);
+                }
+                const double rdk = (k >= 1) ? rd_full : 0.0;
+                const double v = w.ld(CB + B_X + 3, k);
+                const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
+                const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
+                const double bp = w.ld(CB + B_DYN + 4, k);
+                const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S,
+                             a23 = dt * sb * kInvWheelbase;
+                const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
+                // store y_{k+1} for the curvature terms of the factorisation sweep
+                w.st(S_Y + 0, k + 1, y0);
+                w.st(S_Y + 1, k + 1, y1);
+                w.st(S_Y + 2, k + 1, y2);
+                w.st(S_Y + 3, k + 1, y3);
+                const double zul0 = w.ld(S_ZUL + 0, k), zul1 = w.ld(S_ZUL + 1, k);
+                const double zuu0 = w.ld(S_ZUU + 0, k), zuu1 = w.ld(S_ZUU + 1, k);
+                double r0 = rc * u0 + rdk * (u0 - um0) - zul0 + zuu0;
+                double r1 = rc * u1 + rdk * (u1 - um1) - zul1 + zuu1;
+                if (k + 1 < N) {
+                    r0 -= rd_full * (un0 - u0);
+                    r1 -= rd_full * (un1 - u1);
+                }
+                r0 += dt * y3;
+                r1 += b01 * y0 + b11 * y1 + b21 * y2;
+                err_d = fmax2(err_d, fmax2(fabs(r0), fabs(r1)));
+                sum_z += zul0 + zul1 + zuu0 + zuu1;
+                sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
+                // complementarity products of u_k and x_{k+1}
+                {
+                    const double c0 = (u0 - ulo_r(0)) * zul0, c1 = (uhi_r(0) - u0) * zuu0;
+                    const double c2 = (u1 - ulo_r(1)) * zul1, c3 = (uhi_r(1) - u1) * zuu1;
+                    cmax = fmax2(cmax, fmax2(fmax2(c0, c1), fmax2(c2, c3)));
+                    cmin = fmin2(cmin, fmin2(fmin2(c0, c1), fmin2(c2, c3)));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double xi = w.ld(CB + B_X + i, k + 1);
+                    const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
+                    const double c0 = (xi - xlo_r(i)) * zl, c1 = (xhi_r(i) - xi) * zu;
+                    cmax = fmax2(cmax, fmax2(c0, c1));
+                    cmin = fmin2(cmin, fmin2(c0, c1));
+                    sum_z += zl + zu;
+                }
+                if (k >= 1) {
+                    const double t0 = w.ld(CB + B_LX + 0, k) - w.ld(S_ZXL + 0, k) + w.ld(S_ZXU + 0, k) + y0;
+                    const double t1 = w.ld(CB + B_LX + 1, k) - w.ld(S_ZXL + 1, k) + w.ld(S_ZXU + 1, k) + y1;
+                    const double t2 = w.ld(CB + B_LX + 2, k) - w.ld(S_ZXL + 2, k) + w.ld(S_ZXU + 2, k) + a02 * y0 +
+                                      a12 * y1 + y2;
+                    const double t3 = w.ld(CB + B_LX + 3, k) - w.ld(S_ZXL + 3, k) + w.ld(S_ZXU + 3, k) + a03 * y0 +
+                                      a13 * y1 + a23 * y2 + y3;
+                    y0 = t0;
+                    y1 = t1;
+                    y2 = t2;
+                    y3 = t3;
+                }
+                un0 = u0;
+                un1 = u1;
+            }
+        }
+        const double s_d = fmax2(100.0, (sum_lam + sum_z) / (10.0 * N)) / 100.0;
+        const double s_c = fmax2(100.0, sum_z / (6.0 * N)) / 100.0;
+        // monotone barrier update (IPOPT: kappa_eps 10, kappa_mu 0.2, theta_mu 1.5)
+        for (;;) {
+            const double ec = fmax2(cmax - mu, mu - cmin);
+            const double E_mu = fmax2(err_d / s_d, ec / s_c);
+            if (E_mu <= 10.0 * mu && mu > mu_min) {
+                mu = fmax2(mu_min, fmin2(0.2 * mu, mu * sqrt(mu)));
+                continue;
+            }
+            break;
+        }
+        const double E0 = fmax2(err_d / s_d, cmax / s_c);
+        kkt_out = E0;
+        if (E0 <= P.tol) {
+            status_out = 0;
+            break;
+        }
+        if (iter == P.max_iter) break;
+
+        // =========================== Riccati / DDP factorisation sweep ================================
+        // exact Lagrangian Hessian first; if a control block is not positive definite: far from a stationary
+        // point fall back to the convex Gauss-Newton model, close to one keep the exact Hessian shifted by
+        // delta_w sized from the offending eigenvalue.
+        double dV1 = 0.0, delta_w = 0.0;
+        int nmod = 0;
+        bool ok = false, gn = false;
+        for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
+            ok = true;
+            dV1 = 0.0;
+            double need = 0.0;
+            // value function of node k+1: Pxx (sym 4x4), Pxp (4x2), Ppp (sym 2x2), px, pp
+            double p00, p01 = 0, p02 = 0, p03 = 0, p11, p12 = 0, p13 = 0, p22, p23 = 0, p33;
+            double e00 = 0, e01 = 0, e10 = 0, e11 = 0, e20 = 0, e21 = 0, e30 = 0, e31 = 0;
+            double pp00 = 0, pp01 = 0, pp11 = 0, px0, px1, px2, px3, ppv0 = 0, ppv1 = 0;
+            {
+                double sl, su;
+                double xi = w.ld(CB + B_X + 0, N);
+                sl = xi - xlo_r(0); su = xhi_r(0) - xi;
+                p00 = w.ld(S_ZXL + 0, N) / sl + w.ld(S_ZXU + 0, N) / su + delta_w; px0 = -mu / sl + mu / su;
+                xi = w.ld(CB + B_X + 1, N);
+                sl = xi - xlo_r(1); su = xhi_r(1) - xi;
+                p11 = w.ld(S_ZXL + 1, N) / sl + w.ld(S_ZXU + 1, N) / su + delta_w; px1 = -mu / sl + mu / su;
+                xi = w.ld(CB + B_X + 2, N);
+                sl = xi - xlo_r(2); su = xhi_r(2) - xi;
+                p22 = w.ld(S_ZXL + 2, N) / sl + w.ld(S_ZXU + 2, N) / su + delta_w; px2 = -mu / sl + mu / su;
+                xi = w.ld(CB + B_X + 3, N);
+                sl = xi - xlo_r(3); su = xhi_r(3) - xi;
+                p33 = w.ld(S_ZXL + 3, N) / sl + w.ld(S_ZXU + 3, N) / su + delta_w; px3 = -mu / sl + mu / su;
+            }
+            for (int k = N - 1; k >= 0; --k) {
+                const double rdk = (k >= 1) ? rd_full : 0.0;
+                const double v = w.ld(CB + B_X + 3, k);
+                const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
+                const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
+                const double bp = w.ld(CB + B_DYN + 4, k), bpp = w.ld(CB + B_DYN + 5, k);
+                const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S,
+                             a23 = dt * sb * kInvWheelbase;
+                const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
+                const double u0 = w.ld(CB + B_U + 0, k), u1 = w.ld(CB + B_U + 1, k);
+                // ---- stage Hessian / gradient (cost + barrier + constraint curvature)
+                double l00 = 0, l01 = 0, l11 = 0, l22 = 0, l23 = 0, l33 = 0, lxu21 = 0, lxu31 = 0;
+                double lx0 = 0, lx1 = 0, lx2 = 0, lx3 = 0;
+                double wdd = 0.0;
+                if (!gn) {
+                    const double yy0 = w.ld(S_Y + 0, k + 1), yy1 = w.ld(S_Y + 1, k + 1), yy2 = w.ld(S_Y + 2, k + 1);
+                    const double g = -(yy0 * C + yy1 * S), h = -(yy0 * S - yy1 * C);
+                    const double wtt = dt * v * g, wtv = dt * h;
+                    const double wtd = dt * v * g * bp;
+                    const double wvd = dt * h * bp + dt * yy2 * cbeta * bp * kInvWheelbase;
+                    wdd = dt * v * (g * bp * bp + h * bpp) +
+                          dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cbeta * bpp);
+                    if (k >= 1) {
+                        l22 = wtt;
+                        l23 = wtv;
+                        lxu21 = wtd;
+                        lxu31 = wvd;
+                    }
+                }
+                if (k >= 1) {
+                    if (gn) {
+                        l00 = w.ld(CB + B_QG + 0, k);
+                        l01 = w.ld(CB + B_QG + 1, k);
+                        l11 = w.ld(CB + B_QG + 2, k);
+                    } else {
+                        l00 = w.ld(CB + B_Q + 0, k);
+                        l01 = w.ld(CB + B_Q + 1, k);
+                        l11 = w.ld(CB + B_Q + 2, k);
+                    }
+                    l22 += qtt;
+                    l33 = w.ld(CB + B_Q + 3, k);
+                    double xi, sl, su;
+                    xi = w.ld(CB + B_X + 0, k); sl = xi - xlo_r(0); su = xhi_r(0) - xi;
+                    l00 += w.ld(S_ZXL + 0, k) / sl + w.ld(S_ZXU + 0, k) / su + delta_w;
+                    lx0 = w.ld(CB + B_LX + 0, k) - mu / sl + mu / su;
+                    xi = w.ld(CB + B_X + 1, k); sl = xi - xlo_r(1); su = xhi_r(1) - xi;
+                    l11 += w.ld(S_ZXL + 1, k) / sl + w.ld(S_ZXU + 1, k) / su + delta_w;
+                    lx1 = w.ld(CB + B_LX + 1, k) - mu / sl + mu / su;
+                    xi = w.ld(CB + B_X + 2, k); sl = xi - xlo_r(2); su = xhi_r(2) - xi;
+                    l22 += w.ld(S_ZXL + 2, k) / sl + w.ld(S_ZXU + 2, k) / su + delta_w;
+                    lx2 = w.ld(CB + B_LX + 2, k) - mu / sl + mu / su;
+                    xi = v; sl = xi - xlo_r(3); su = xhi_r(3) - xi;
+                    l33 += w.ld(S_ZXL + 3, k) / sl + w.ld(S_ZXU + 3, k) / su + delta_w;
+                    lx3 = w.ld(CB + B_LX + 3, k) - mu / sl + mu / su;
+                }
+                double luu00, luu11, lu0, lu1, lp0 = 0.0, lp1 = 0.0;
+                {
+                    double um0 = 0.0, um1 = 0.0;
+                    if (k >= 1) {
+                        um0 = w.ld(CB + B_U + 0, k - 1);
+                        um1 = w.ld(CB + B_U + 1, k - 1);
+                    }
+                    double sl = u0 - ulo_r(0), su = uhi_r(0) - u0;
+                    luu00 = rc + rdk + w.ld(S_ZUL + 0, k) / sl + w.ld(S_ZUU + 0, k) / su + delta_w;
+                    lu0 = rc * u0 + rdk * (u0 - um0) - mu / sl + mu / su;
+                    sl = u1 - ulo_r(1); su = uhi_r(1) - u1;
+                    luu11 = rc + rdk + w.ld(S_ZUL + 1, k) / sl + w.ld(S_ZUU + 1, k) / su + delta_w + wdd;
+                    lu1 = rc * u1 + rdk * (u1 - um1) - mu / sl + mu / su;
+                    lp0 = -rdk * (u0 - um0);
+                    lp1 = -rdk * (u1 - um1);
+                }
+                // ---- M = Pxx A (4x4; columns 0,1 are those of Pxx), PB = Pxx B (4x2)
+                const double m02 = p00 * a02 + p01 * a12 + p02, m03 = p00 * a03 + p01 * a13 + p02 * a23 + p03;
+                const double m12 = p01 * a02 + p11 * a12 + p12, m13 = p01 * a03 + p11 * a13 + p12 * a23 + p13;
+                const double m22 = p02 * a02 + p12 * a12 + p22, m23 = p02 * a03 + p12 * a13 + p22 * a23 + p23;
+                const double m32 = p03 * a02 + p13 * a12 + p23, m33 = p03 * a03 + p13 * a13 + p23 * a23 + p33;
+                // G = PB + Pxp
+                const double g00 = dt * p03 + e00, g01 = p00 * b01 + p01 * b11 + p02 * b21 + e01;
+                const double g10 = dt * p13 + e10, g11 = p01 * b01 + p11 * b11 + p12 * b21 + e11;
+                const double g20 = dt * p23 + e20, g21 = p02 * b01 + p12 * b11 + p22 * b21 + e21;
+                const double g30 = dt * p33 + e30, g31 = p03 * b01 + p13 * b11 + p23 * b21 + e31;
+                // ---- Hxx = Lxx + A' M  (symmetric), rows of A': r0=e0, r1=e1, r2=a02 e0+a12 e1+e2, r3=a03 e0+a13 e1+a23 e2+e3
+                const double h00 = l00 + p00, h01 = l01 + p01, h11 = l11 + p11;
+                const double h02 = m02, h03 = m03, h12 = m12, h13 = m13;
+                const double h22 = l22 + a02 * m02 + a12 * m12 + m22;
+                const double h23 = l23 + a02 * m03 + a12 * m13 + m23;
+                const double h33 = l33 + a03 * m03 + a13 * m13 + a23 * m23 + m33;
+                // ---- Hxu = Lxu + A' G
+                const double hxu00 = g00, hxu01 = g01, hxu10 = g10, hxu11 = g11;
+                const double hxu20 = a02 * g00 + a12 * g10 + g20, hxu21 = lxu21 + a02 * g01 + a12 * g11 + g21;
+                const double hxu30 = a03 * g00 + a13 * g10 + a23 * g20 + g30;
+                const double hxu31 = lxu31 + a03 * g01 + a13 * g11 + a23 * g21 + g31;
+                // ---- hx = lx + A' px
+                const double hx0 = lx0 + px0, hx1 = lx1 + px1, hx2 = lx2 + a02 * px0 + a12 * px1 + px2;
+                const double hx3 = lx3 + a03 * px0 + a13 * px1 + a23 * px2 + px3;
+                // ---- Huu = Luu + Ppp + B'(PB + Pxp) + Pxp' B ;  B' rows: r0 = dt e3, r1 = b01 e0 + b11 e1 + b21 e2
+                const double huu00 = luu00 + pp00 + dt * g30 + dt * e30;
+                const double huu01a = pp01 + dt * g31 + (e00 * b01 + e10 * b11 + e20 * b21);
+                const double huu10a = pp01 + (b01 * g00 + b11 * g10 + b21 * g20) + dt * e31;
+                const double huu11 = luu11 + pp11 + (b01 * g01 + b11 * g11 + b21 * g21) + (e01 * b01 + e11 * b11 + e21 * b21);
+                const double hu0 = lu0 + ppv0 + dt * px3;
+                const double hu1 = lu1 + ppv1 + b01 * px0 + b11 * px1 + b21 * px2;
+                const double ha = huu00, hb = 0.5 * (huu01a + huu10a), hc = huu11;
+                const double det = ha * hc - hb * hb;
+                if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
+                    const double hm = 0.5 * (ha + hc), hd = sqrt(0.25 * (ha - hc) * (ha - hc) + hb * hb);
+                    need = fmax2(-(hm - hd), 0.0);
+                    ok = false;
+                    break;
+                }
+                const double i00 = hc / det, i01 = -hb / det, i11 = ha / det;
+                // gains
+                const double kx00 = -(i00 * hxu00 + i01 * hxu01), kx01 = -(i00 * hxu10 + i01 * hxu11);
+                const double kx02 = -(i00 * hxu20 + i01 * hxu21), kx03 = -(i00 * hxu30 + i01 * hxu31);
+                const double kx10 = -(i01 * hxu00 + i11 * hxu01), kx11 = -(i01 * hxu10 + i11 * hxu11);
+                const double kx12 = -(i01 * hxu20 + i11 * hxu21), kx13 = -(i01 * hxu30 + i11 * hxu31);
+                const double kp00 = rdk * i00, kp01 = rdk * i01, kp11 = rdk * i11;
+                const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
+                w.st(S_KX + 0, k, kx00); w.st(S_KX + 1, k, kx01); w.st(S_KX + 2, k, kx02); w.st(S_KX + 3, k, kx03);
+                w.st(S_KX + 4, k, kx10); w.st(S_KX + 5, k, kx11); w.st(S_KX + 6, k, kx12); w.st(S_KX + 7, k, kx13);
+                w.st(S_KP + 0, k, kp00); w.st(S_KP + 1, k, kp01); w.st(S_KP + 2, k, kp11);
+                w.st(S_KF + 0, k, kf0); w.st(S_KF + 1, k, kf1);
+                dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
+                // value function of node k:  Pxx = sym(Hxx + Hxu Kx), Pxp = Hxu Kp, Ppp = rd I - rd Kp
+                const double n00 = h00 + hxu00 * kx00 + hxu01 * kx10;
+                const double n01 = 0.5 * ((h01 + hxu00 * kx01 + hxu01 * kx11) + (h01 + hxu10 * kx00 + hxu11 * kx10));
+                const double n02 = 0.5 * ((h02 + hxu00 * kx02 + hxu01 * kx12) + (h02 + hxu20 * kx00 + hxu21 * kx10));
+                const double n03 = 0.5 * ((h03 + hxu00 * kx03 + hxu01 * kx13) + (h03 + hxu30 * kx00 + hxu31 * kx10));
+                const double n11 = h11 + hxu10 * kx01 + hxu11 * kx11;
+                const double n12 = 0.5 * ((h12 + hxu10 * kx02 + hxu11 * kx12) + (h12 + hxu20 * kx01 + hxu21 * kx11));
+                const double n13 = 0.5 * ((h13 + hxu10 * kx03 + hxu11 * kx13) + (h13 + hxu30 * kx01 + hxu31 * kx11));
+                const double n22 = h22 + hxu20 * kx02 + hxu21 * kx12;
+                const double n23 = 0.5 * ((h23 + hxu20 * kx03 + hxu21 * kx13) + (h23 + hxu30 * kx02 + hxu31 * kx12));
+                const double n33 = h33 + hxu30 * kx03 + hxu31 * kx13;
+                e00 = hxu00 * kp00 + hxu01 * kp01; e01 = hxu00 * kp01 + hxu01 * kp11;
+                e10 = hxu10 * kp00 + hxu11 * kp01; e11 = hxu10 * kp01 + hxu11 * kp11;
+                e20 = hxu20 * kp00 + hxu21 * kp01; e21 = hxu20 * kp01 + hxu21 * kp11;
+                e30 = hxu30 * kp00 + hxu31 * kp01; e31 = hxu30 * kp01 + hxu31 * kp11;
+                px0 = hx0 + hxu00 * kf0 + hxu01 * kf1;
+                px1 = hx1 + hxu10 * kf0 + hxu11 * kf1;
+                px2 = hx2 + hxu20 * kf0 + hxu21 * kf1;
+                px3 = hx3 + hxu30 * kf0 + hxu31 * kf1;
+                p00 = n00; p01 = n01; p02 = n02; p03 = n03; p11 = n11; p12 = n12; p13 = n13; p22 = n22; p23 = n23; p33 = n33;
+                pp00 = rdk - rdk * kp00; pp01 = -rdk * kp01; pp11 = rdk - rdk * kp11;
+                ppv0 = lp0 - rdk * kf0;
+                ppv1 = lp1 - rdk * kf1;
+            }
+            if (!ok) {
+                ++nmod;
+                if (gn) {
+                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
+                } else if (err_d / s_d > 1.0 || nmod > 12) {
+                    gn = true;
+                    delta_w = 0.0;
+                } else {
+                    delta_w = fmax2(2.0 * delta_w, delta_w + 1.5 * need + 1e-6);
+                }
+                if (delta_w > 1e40) break;
+            }
+        }
+        if (!ok) {
+            status_out = 2;
+            break;
+        }
+
+        // =========================== linear forward sweep: Newton step, step-length limits ==============
+        const double tau = fmax2(0.99, 1.0 - mu);
+        double a_pr = 1.0, a_du = 1.0;
+        {
+            double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
+            for (int k = 0; k < N; ++k) {
+                double du0 = w.ld(S_KF + 0, k) + w.ld(S_KX + 0, k) * d0 + w.ld(S_KX + 1, k) * d1 + w.ld(S_KX + 2, k) * d2 +
+                             w.ld(S_KX + 3, k) * d3;
+                double du1 = w.ld(S_KF + 1, k) + w.ld(S_KX + 4, k) * d0 + w.ld(S_KX + 5, k) * d1 + w.ld(S_KX + 6, k) * d2 +
+                             w.ld(S_KX + 7, k) * d3;
+                if (k >= 1) {
+                    const double kp00 = w.ld(S_KP + 0, k), kp01 = w.ld(S_KP + 1, k), kp11 = w.ld(S_KP + 2, k);
+                    du0 += kp00 * dp0 + kp01 * dp1;
+                    du1 += kp01 * dp0 + kp11 * dp1;
+                }
+                w.st(S_DUL + 0, k, du0);
+                w.st(S_DUL + 1, k, du1);
+                const double v = w.ld(CB + B_X + 3, k);
+                const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
+                const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
+                const double bp = w.ld(CB + B_DYN + 4, k);
+                const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S,
+                             a23 = dt * sb * kInvWheelbase;
+                const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
+                const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
+                const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
+                const double n2 = d2 + a23 * d3 + b21 * du1;
+                const double n3 = d3 + dt * du0;
+                d0 = n0; d1 = n1; d2 = n2; d3 = n3;
+                dp0 = du0; dp1 = du1;
+                w.st(S_DXL + 0, k + 1, d0);
+                w.st(S_DXL + 1, k + 1, d1);
+                w.st(S_DXL + 2, k + 1, d2);
+                w.st(S_DXL + 3, k + 1, d3);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const double ui = w.ld(CB + B_U + i, k), d = (i == 0) ? du0 : du1;
+                    const double sl = ui - ulo_r(i), su = uhi_r(i) - ui;
+                    const double zl = w.ld(S_ZUL + i, k), zu = w.ld(S_ZUU + i, k);
+                    if (d < 0) a_pr = fmin2(a_pr, -tau * sl / d);
+                    if (d > 0) a_pr = fmin2(a_pr, tau * su / d);
+                    const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+                    if (dzl < 0) a_du = fmin2(a_du, -tau * zl / dzl);
+                    if (dzu < 0) a_du = fmin2(a_du, -tau * zu / dzu);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double xi = w.ld(CB + B_X + i, k + 1), d = (i == 0) ? d0 : (i == 1) ? d1 : (i == 2) ? d2 : d3;
+                    const double sl = xi - xlo_r(i), su = xhi_r(i) - xi;
+                    const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
+                    if (d < 0) a_pr = fmin2(a_pr, -tau * sl / d);
+                    if (d > 0) a_pr = fmin2(a_pr, tau * su / d);
+                    const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+                    if (dzl < 0) a_du = fmin2(a_du, -tau * zl / dzl);
+                    if (dzu < 0) a_du = fmin2(a_du, -tau * zu / dzu);
+                }
+            }
+        }
+
+        // =========================== nonlinear rollout + Armijo on the barrier objective ================
+        const double phi0 = Jcur + mu * barcur;
+        const int tb = cur ^ 1;
+        double alpha = a_pr, Jn = 0.0, barn = 0.0;
+        bool accepted = false;
+        for (int nls = 0; nls < 30; ++nls, alpha *= 0.5) {
+            if (!rollout(P, w, cur, tb, false, alpha, 0.5 * (1.0 - tau), sf, ws_, wc_, wd_, wcoll, x0, Jn, barn)) continue;
+            const double phi1 = Jn + mu * barn;
+            if (phi1 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                accepted = true;
+                break;
+            }
+        }
+        // =========================== dual step (own fraction-to-the-boundary length), accept ============
+        const int NB = (accepted ? tb : cur) * BUF_SLOTS;
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double ui = w.ld(CB + B_U + i, k), d = w.ld(S_DUL + i, k), un = w.ld(NB + B_U + i, k);
+                const double sl = ui - ulo_r(i), su = uhi_r(i) - ui;
+                const double zl = w.ld(S_ZUL + i, k), zu = w.ld(S_ZUU + i, k);
+                const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+                const double sln = un - ulo_r(i), sun = uhi_r(i) - un;
+                w.st(S_ZUL + i, k, fmax2(fmin2(zl + a_du * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
+                w.st(S_ZUU + i, k, fmax2(fmin2(zu + a_du * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double xi = w.ld(CB + B_X + i, k + 1), d = w.ld(S_DXL + i, k + 1), xn = w.ld(NB + B_X + i, k + 1);
+                const double sl = xi - xlo_r(i), su = xhi_r(i) - xi;
+                const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
+                const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+                const double sln = xn - xlo_r(i), sun = xhi_r(i) - xn;
+                w.st(S_ZXL + i, k + 1, fmax2(fmin2(zl + a_du * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
+                w.st(S_ZXU + i, k + 1, fmax2(fmin2(zu + a_du * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
+            }
+        }
+        if (accepted) {
+            cur = tb;
+            Jcur = Jn;
+            barcur = barn;
+        }
+    }
+    iters_out = iter;
+    cur_out = cur;
+}
+
+}  // namespace mpc

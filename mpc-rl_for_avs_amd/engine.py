@@ -1,0 +1,195 @@
+"""ctypes binding of the C ABI (include/mpc_mi355x.h) - the only way Python reaches the HIP kernels.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible, construction fails
+loudly (`EngineError`).  Host numpy arrays are copied by the library; torch device tensors are passed
+zero-copy as raw device pointers on the caller's stream (`solve_batch_torch`).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+from .reference_path import reference_states
+
+FLAG_COLLISION_COST = 1
+FLAG_DEVICE_PTRS = 2
+FLAG_NO_SYNC = 4
+
+STATUS_CONVERGED = 0
+STATUS_MAX_ITER = 1
+STATUS_FACTORIZATION = 2
+STATUS_INFEASIBLE_START = 3
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dt", ctypes.c_double),
+                ("max_iter", ctypes.c_int32), ("device", ctypes.c_int32), ("tol", ctypes.c_double),
+                ("w_distance", ctypes.c_double), ("w_collision", ctypes.c_double)]
+
+
+_EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_create", "mpc_destroy",
+            "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes"]
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libmpc_mi355x.so (building it first when hipcc is present and the sources are newer)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    if path is None:
+        path = _build.LIB_PATH
+        if _build.is_stale():
+            try:
+                _build.build()
+            except RuntimeError as e:  # no hipcc on this machine: a prebuilt .so must travel with the tree
+                if not os.path.exists(path):
+                    raise EngineError(f"libmpc_mi355x.so is missing and cannot be built: {e}") from e
+    if not os.path.exists(path):
+        raise EngineError(f"{path} not found: the MI355X engine has no fallback path")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process break whichever comes
+    # second.  Importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to that same copy,
+    # so the engine, torch tensors/streams and RCCL all share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(path)
+    vp, dp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
+    lib.mpc_version.restype = ctypes.c_int
+    lib.mpc_last_error.restype = ctypes.c_char_p
+    lib.mpc_default_config.argtypes = [ctypes.POINTER(_Config)]
+    lib.mpc_default_config.restype = None
+    lib.mpc_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(vp)]
+    lib.mpc_create.restype = ctypes.c_int
+    lib.mpc_destroy.argtypes = [vp]
+    lib.mpc_destroy.restype = None
+    lib.mpc_set_reference.argtypes = [vp, dp, ctypes.c_int32]
+    lib.mpc_set_reference.restype = ctypes.c_int
+    lib.mpc_solve_batch.argtypes = [vp, ctypes.c_int32, dp, ip, dp, dp, vp, dp, ctypes.c_int32, ctypes.c_uint32,
+                                    dp, dp, dp, ip, ip, vp]
+    lib.mpc_solve_batch.restype = ctypes.c_int
+    lib.mpc_workspace_bytes.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
+    lib.mpc_workspace_bytes.restype = ctypes.c_int64
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class MPCEngine:
+    """One engine per (process, GPU).  `solve_batch` replaces B calls of `PureMPC_Agent._solve`."""
+
+    def __init__(self, horizon: int = 20, dt: float = 0.1, max_iter: int = 100, tol: float = 1e-8,
+                 w_distance: float = 10.0, w_collision: float = 1.0, device: int = 0, ref_table=None):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        cfg = _Config()
+        self._lib.mpc_default_config(ctypes.byref(cfg))
+        cfg.horizon, cfg.dt, cfg.max_iter, cfg.tol = int(horizon), float(dt), int(max_iter), float(tol)
+        cfg.w_distance, cfg.w_collision, cfg.device = float(w_distance), float(w_collision), int(device)
+        rc = self._lib.mpc_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            raise EngineError(f"mpc_create failed ({rc}): {self._lib.mpc_last_error().decode()}")
+        self.horizon, self.dt, self.device = int(horizon), float(dt), int(device)
+        self.set_reference(reference_states(dt) if ref_table is None else ref_table)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self._lib.mpc_last_error().decode()}")
+
+    def set_reference(self, ref_table):
+        ref = np.ascontiguousarray(ref_table, dtype=np.float64)
+        if ref.ndim != 2 or ref.shape[1] != 4:
+            raise ValueError(f"reference table must be [M, 4], got {ref.shape}")
+        self.ref_table = ref
+        self._check(self._lib.mpc_set_reference(self._h, _ptr(ref), ref.shape[0]), "mpc_set_reference")
+
+    def workspace_bytes(self, B, V=0):
+        return int(self._lib.mpc_workspace_bytes(self._h, int(B), int(V)))
+
+    # ------------------------------------------------------------------ host (numpy) path
+    def solve_batch(self, state, ego_index, weights, is_collide, vref=None, others=None, collision_cost=False,
+                    want_trajectories=True):
+        """Solve B instances given host arrays; returns dict(u0, U, X, status, iters)."""
+        N = self.horizon
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        if state.ndim != 2 or state.shape[1] != 4:
+            raise ValueError(f"state must be [B, 4], got {state.shape}")
+        B = state.shape[0]
+        ego_index = np.ascontiguousarray(ego_index, dtype=np.int32).reshape(B)
+        weights = np.ascontiguousarray(weights, dtype=np.float64).reshape(B, 3)
+        is_collide = np.ascontiguousarray(is_collide, dtype=np.uint8).reshape(B)
+        if vref is not None:
+            vref = np.ascontiguousarray(vref, dtype=np.float64)
+            if vref.shape != (B, N + 1):
+                raise ValueError(f"vref must be [B, N+1] = {(B, N + 1)}, got {vref.shape}")
+        V = 0
+        if others is not None:
+            others = np.ascontiguousarray(others, dtype=np.float64)
+            if others.ndim != 3 or others.shape[0] != B or others.shape[2] != 4:
+                raise ValueError(f"others must be [B, V, 4], got {others.shape}")
+            V = others.shape[1]
+        u0 = np.empty((B, 2))
+        U = np.empty((B, N, 2)) if want_trajectories else None
+        X = np.empty((B, N + 1, 4)) if want_trajectories else None
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        flags = FLAG_COLLISION_COST if collision_cost else 0
+        rc = self._lib.mpc_solve_batch(self._h, B, _ptr(state), _ptr(ego_index), _ptr(vref), _ptr(weights),
+                                       _ptr(is_collide), _ptr(others), V, flags, _ptr(u0), _ptr(U), _ptr(X),
+                                       _ptr(status), _ptr(iters), None)
+        self._check(rc, "mpc_solve_batch")
+        return dict(u0=u0, U=U, X=X, status=status, iters=iters)
+
+    # ------------------------------------------------------------------ device (torch) path
+    def solve_batch_torch(self, state, ego_index, weights, is_collide, vref=None, others=None,
+                          collision_cost=False, out=None, sync=False):
+        """Zero-copy solve on torch CUDA(=HIP) tensors, enqueued on torch's current stream.
+
+        dtypes: state/weights/vref/others float64, ego_index int32, is_collide uint8; all contiguous and on
+        this engine's device.  Returns dict(u0, status, iters) of device tensors (reused when `out` given)."""
+        import torch
+        B = state.shape[0]
+        dev = state.device
+        for name, t, dt_ in (("state", state, torch.float64), ("ego_index", ego_index, torch.int32),
+                             ("weights", weights, torch.float64), ("is_collide", is_collide, torch.uint8),
+                             ("vref", vref, torch.float64), ("others", others, torch.float64)):
+            if t is None:
+                continue
+            if t.dtype != dt_ or not t.is_contiguous() or t.device != dev or not t.is_cuda:
+                raise ValueError(f"{name}: expected contiguous {dt_} tensor on {dev}")
+        if out is None:
+            out = dict(u0=torch.empty((B, 2), dtype=torch.float64, device=dev),
+                       status=torch.empty(B, dtype=torch.int32, device=dev),
+                       iters=torch.empty(B, dtype=torch.int32, device=dev))
+        V = 0 if others is None else int(others.shape[1])
+        flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.mpc_solve_batch(self._h, B, p(state), p(ego_index), p(vref), p(weights), p(is_collide),
+                                       p(others), V, flags, p(out["u0"]), p(out.get("U")), p(out.get("X")),
+                                       p(out["status"]), p(out["iters"]), stream)
+        self._check(rc, "mpc_solve_batch")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mpc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
