@@ -4,8 +4,8 @@
 // agents/pure_mpc.py:80-318) solved by a primal-dual interior-point method whose Newton systems are
 // factorised stage by stage (Riccati / DDP backward sweep) and whose iterates are kept dynamically
 // feasible by nonlinear feedback rollouts.  One wave64 lane owns one instance; every per-stage quantity
-// lives in a structure-of-arrays workspace indexed [slot][stage][instance] so that the 64 lanes of a wave
-// always touch 512 contiguous bytes.  All small matrices are scalarised (no runtime-indexed arrays, which
+// lives in a structure-of-arrays workspace indexed [slot][stage][instance] (LDS on the GPU), so the lanes of
+// a wave touch consecutive doubles.  All small matrices are scalarised (no runtime-indexed arrays, which
 // hipcc would spill to scratch) and the sparsity of the bicycle-model Jacobians
 //     A = I + dt*df/dx = [1 0 a02 a03; 0 1 a12 a13; 0 0 1 a23; 0 0 0 1],   B = [0 b01; 0 b11; 0 b21; dt 0]
 // is exploited by hand.
@@ -26,37 +26,45 @@
 namespace mpc {
 
 // ---------------------------------------------------------------------------------------------------
-// workspace slot map (doubles per stage).  Two trajectory buffers (current / trial) are swapped on accept.
+// workspace slot map (doubles per stage).  The map is kept small on purpose: 46 slots (54 with the
+// collision-cost term) x (N+1) stages x 8 B = 7.7 KB (9.1 KB) per instance at N = 20, so that 16 instances
+// fit the 160 KB LDS of one CU.  What is cheap to recompute is not stored: the reference geometry comes
+// from the shared path table by index, beta'/beta'' from sin/cos(beta), the quadratic tracking cost and its
+// derivatives from the state (only the collision-cost variant caches them), the linearised step is
+// re-run in the dual-update pass, and the never-active |x|,|y| <= 500 bounds carry no multipliers.
+// Two trajectory buffers (current / trial) are swapped on accept.
 // ---------------------------------------------------------------------------------------------------
 enum : int {
-    B_X = 0,     // 4  x, y, theta, v                       (node k)
-    B_U = 4,     // 2  a, delta                             (node k < N)
-    B_DYN = 6,   // 6  S, C, sin(beta), cos(beta), beta', beta''   of (x_k, u_k)
-    B_LX = 12,   // 4  scaled stage-cost gradient at node k (1 <= k < N)
-    B_Q = 16,    // 4  scaled stage-cost Hessian q00 q01 q11 q33 (theta-theta is the constant 10*sf)
-    B_QG = 20,   // 3  convex part of q00 q01 q11 (differs from B_Q only with the collision-cost term)
-    BUF_SLOTS = 23,
+    B_X = 0,    // 4  x, y, theta, v                       (node k)
+    B_U = 4,    // 2  a, delta                             (node k < N)
+    B_DYN = 6,  // 4  sin/cos(theta+beta), sin/cos(beta)   of (x_k, u_k)
+    BUF_SLOTS = 10,
     S_BUF0 = 0,
     S_BUF1 = BUF_SLOTS,
-    S_ZXL = 2 * BUF_SLOTS,  // 4 lower-bound multipliers of x_k
-    S_ZXU = S_ZXL + 4,      // 4
-    S_ZUL = S_ZXU + 4,      // 2
+    S_ZXL = 2 * BUF_SLOTS,  // 2 lower-bound multipliers of theta_k, v_k
+    S_ZXU = S_ZXL + 2,      // 2
+    S_ZUL = S_ZXU + 2,      // 2
     S_ZUU = S_ZUL + 2,      // 2
     S_Y = S_ZUU + 2,        // 4 adjoint dL/dx_k
     S_KX = S_Y + 4,         // 8 feedback gain on dx (row-major 2x4)
     S_KP = S_KX + 8,        // 3 feedback gain on the previous control (symmetric 2x2: 00 01 11)
     S_KF = S_KP + 3,        // 2 feed-forward
-    S_DXL = S_KF + 2,       // 4 linearised Newton step of x_k
-    S_DUL = S_DXL + 4,      // 2 linearised Newton step of u_k
-    S_REF = S_DUL + 2,      // 6 reference window rx ry rv rh sin(rh) cos(rh)
-    STAGE_SLOTS = S_REF + 6
+    S_RV = S_KF + 2,        // 1 reference speed of stage k
+    STAGE_SLOTS = S_RV + 1,  // 46
+    // collision-cost variant only: cached stage-cost derivatives of the last completed rollout
+    S_LX = STAGE_SLOTS,         // 2 scaled gradient of the distance potential wrt x, y
+    S_Q = S_LX + 2,             // 3 its scaled Hessian q00 q01 q11
+    S_QG = S_Q + 3,             // 3 convex (radial) part of q00 q01 q11
+    STAGE_SLOTS_CC = S_QG + 3   // 54
 };
 
+// reference-table columns served by WS::ref(k, c)
+enum : int { R_X = 0, R_Y = 1, R_H = 2, R_SIN = 3, R_COS = 4, REF_COLS = 5 };
+
 struct SolveParams {
-    int N;            // horizon
-    int V;            // other vehicles used by the collision-cost term (0 when the term is off)
+    int N;         // horizon
+    int V;         // other vehicles used by the collision-cost term (0 when the term is off)
     int max_iter;
-    int collision_cost;
     double dt;
     double tol;
     double mu_init;
@@ -66,113 +74,116 @@ struct SolveParams {
 MPC_HD double fmax2(double a, double b) { return a > b ? a : b; }
 MPC_HD double fmin2(double a, double b) { return a < b ? a : b; }
 
-// bounds of the reference NLP (agents/pure_mpc.py:272-280), relaxed like IPOPT's bound_relax_factor 1e-8
+// bounds of the reference NLP (agents/pure_mpc.py:272-280), relaxed like IPOPT's bound_relax_factor 1e-8.
+// State bounds: index 0 = theta in [-pi, pi], 1 = v in [0, 30]  (|x|,|y| <= 500 can never be active here).
 #define MPC_PI 3.14159265358979323846
-MPC_HD double xlo_r(int i) {
-    return i == 0 ? -500.0 - 5e-6 : i == 1 ? -500.0 - 5e-6 : i == 2 ? -MPC_PI - 1e-8 * MPC_PI : -1e-8;
-}
-MPC_HD double xhi_r(int i) {
-    return i == 0 ? 500.0 + 5e-6 : i == 1 ? 500.0 + 5e-6 : i == 2 ? MPC_PI + 1e-8 * MPC_PI : 30.0 + 30e-8;
-}
+MPC_HD double xlo_r(int i) { return i == 0 ? -MPC_PI - 1e-8 * MPC_PI : -1e-8; }
+MPC_HD double xhi_r(int i) { return i == 0 ? MPC_PI + 1e-8 * MPC_PI : 30.0 + 30e-8; }
 MPC_HD double ulo_r(int i) { return i == 0 ? -5.0 - 5e-8 : -(MPC_PI / 3.0) - 1e-8 * (MPC_PI / 3.0); }
 MPC_HD double uhi_r(int i) { return i == 0 ? 5.0 + 5e-8 : (MPC_PI / 3.0) + 1e-8 * (MPC_PI / 3.0); }
 
 constexpr double kInvWheelbase = 1.0 / 2.5;  // Vehicle.LENGTH, agents/utils.py:18
 
-struct Dyn {
-    double S, C, sb, cb, bp, bpp;
-};
-
 // kinematic bicycle model (agents/pure_mpc.py:220-228): beta = atan(LENGTH_REAR/LENGTH * tan(delta))
-MPC_HD void dyn_eval(double theta, double delta, Dyn &d) {
-    const double t = tan(delta);
-    const double beta = atan(0.5 * t);
-    const double den = 4.0 + t * t;
-    d.bp = 2.0 * (1.0 + t * t) / den;
-    d.bpp = 12.0 * t * (1.0 + t * t) / (den * den);
-    d.sb = sin(beta);
-    d.cb = cos(beta);
-    d.S = sin(theta + beta);
-    d.C = cos(theta + beta);
+MPC_HD void dyn_eval(double theta, double delta, double &S, double &C, double &sb, double &cb) {
+    const double beta = atan(0.5 * tan(delta));
+    sb = sin(beta);
+    cb = cos(beta);
+    S = sin(theta + beta);
+    C = cos(theta + beta);
+}
+// beta' = d beta / d delta and beta'' from sin/cos(beta):  tan(delta) = 2 tan(beta)
+MPC_HD void beta_derivs(double sb, double cb, double &bp, double &bpp) {
+    const double t = 2.0 * sb / cb;
+    const double t2 = t * t, den = 4.0 + t2;
+    bp = 2.0 * (1.0 + t2) / den;
+    bpp = 12.0 * t * (1.0 + t2) / (den * den);
 }
 
-// scaled stage cost at node k (1 <= k < N) with gradient and Hessian entries
-//   10*[4 perp^2 + 2 para^2 + ws (v-vref)^2 + .5 (theta-h)^2]     agents/pure_mpc.py:134-156,206
-//   + w_distance * sum_j (d<1?1000:100)/(d+1e-6)^2 + wcoll*v^2    agents/archive/pure_mpc.py:189-196
+// Quadratic tracking part of the stage cost at node k (agents/pure_mpc.py:134-156, multiplier 10 of :206):
+//   10*[4 perp^2 + 2 para^2 + ws (v-vref)^2 + .5 (theta-h)^2],  returned UNSCALED; g = gradient (x,y,theta,v)
 template <class WS>
-MPC_HD double stage_cost(const SolveParams &P, const WS &w, int k, double sf, double ws_, double wcoll, double x0,
-                         double x1, double x2, double x3, bool derivs, double *lx, double *q, double *qg) {
-    const double rx = w.ld(S_REF + 0, k), ry = w.ld(S_REF + 1, k), rv = w.ld(S_REF + 2, k);
-    const double rh = w.ld(S_REF + 3, k), s = w.ld(S_REF + 4, k), c = w.ld(S_REF + 5, k);
-    const double dx = x0 - rx, dy = x1 - ry;
+MPC_HD double track_cost(const WS &w, int k, double ws_, double x0, double x1, double x2, double x3, double *g) {
+    const double s = w.ref(k, R_SIN), c = w.ref(k, R_COS);
+    const double dx = x0 - w.ref(k, R_X), dy = x1 - w.ref(k, R_Y);
     const double perp = dx * s - dy * c, para = dx * c + dy * s;
-    const double dv = x3 - rv, dth = x2 - rh;
-    double J = 10.0 * (4.0 * perp * perp + 2.0 * para * para + ws_ * dv * dv + 0.5 * dth * dth);
-    double g0 = 0, g1 = 0, g3 = 0, h00 = 0, h01 = 0, h11 = 0, h33 = 0, c00 = 0, c01 = 0, c11 = 0;
-    if (derivs) {
-        g0 = 10.0 * (8.0 * perp * s + 4.0 * para * c);
-        g1 = 10.0 * (-8.0 * perp * c + 4.0 * para * s);
-        g3 = 20.0 * ws_ * dv;
-        h00 = 10.0 * (8.0 * s * s + 4.0 * c * c);
-        h01 = 10.0 * (-8.0 * s * c + 4.0 * c * s);
-        h11 = 10.0 * (8.0 * c * c + 4.0 * s * s);
-        h33 = 20.0 * ws_;
-        c00 = h00;
-        c01 = h01;
-        c11 = h11;
+    const double dv = x3 - w.ld(S_RV, k), dth = x2 - w.ref(k, R_H);
+    if (g) {
+        g[0] = 10.0 * (8.0 * perp * s + 4.0 * para * c);
+        g[1] = 10.0 * (-8.0 * perp * c + 4.0 * para * s);
+        g[2] = 10.0 * dth;
+        g[3] = 20.0 * ws_ * dv;
     }
-    if (P.collision_cost) {
-        for (int j = 0; j < P.V; ++j) {
-            const double px = x0 - (w.oth(j, 0) + k * w.oth(j, 2));
-            const double py = x1 - (w.oth(j, 1) + k * w.oth(j, 3));
-            const double d = sqrt(px * px + py * py);
-            const double cst = (d < 1.0 ? 1000.0 : 100.0) * P.w_distance;
-            const double de = d + 1e-6;
-            const double inv2 = 1.0 / (de * de);
-            J += cst * inv2;
-            if (derivs) {
-                const double dpsi = -2.0 * cst * inv2 / de;
-                const double nx = px / d, ny = py / d;
-                const double d2psi = 6.0 * cst * inv2 * inv2;
-                const double tt = dpsi / d;
-                g0 += dpsi * nx;
-                g1 += dpsi * ny;
-                h00 += d2psi * nx * nx + tt * (1.0 - nx * nx);
-                h01 += (d2psi - tt) * nx * ny;
-                h11 += d2psi * ny * ny + tt * (1.0 - ny * ny);
-                c00 += d2psi * nx * nx;
-                c01 += d2psi * nx * ny;
-                c11 += d2psi * ny * ny;
-            }
+    return 10.0 * (4.0 * perp * perp + 2.0 * para * para + ws_ * dv * dv + 0.5 * dth * dth);
+}
+template <class WS>
+MPC_HD void track_hess(const WS &w, int k, double &h00, double &h01, double &h11) {
+    const double s = w.ref(k, R_SIN), c = w.ref(k, R_COS);
+    h00 = 10.0 * (8.0 * s * s + 4.0 * c * c);
+    h01 = 10.0 * (-8.0 * s * c + 4.0 * c * s);
+    h11 = 10.0 * (8.0 * c * c + 4.0 * s * s);
+}
+
+// Distance potential of the optional collision-cost term (agents/archive/pure_mpc.py:189-196):
+//   w_distance * sum_j (d<1 ? 1000 : 100)/(d+1e-6)^2, d = |p - (p_j + k*step_j)|;  UNSCALED.
+// d[0..1] gradient, d[2..4] Hessian 00 01 11, d[5..7] its convex (radial) part.
+template <class WS>
+MPC_HD double dist_cost(const SolveParams &P, const WS &w, int k, double x0, double x1, double *d8) {
+    double J = 0.0, g0 = 0, g1 = 0, h00 = 0, h01 = 0, h11 = 0, c00 = 0, c01 = 0, c11 = 0;
+    for (int j = 0; j < P.V; ++j) {
+        const double px = x0 - (w.oth(j, 0) + k * w.oth(j, 2));
+        const double py = x1 - (w.oth(j, 1) + k * w.oth(j, 3));
+        const double d = sqrt(px * px + py * py);
+        const double cst = (d < 1.0 ? 1000.0 : 100.0) * P.w_distance;
+        const double de = d + 1e-6;
+        const double inv2 = 1.0 / (de * de);
+        J += cst * inv2;
+        if (d8) {
+            const double dpsi = -2.0 * cst * inv2 / de;
+            const double nx = px / d, ny = py / d;
+            const double d2psi = 6.0 * cst * inv2 * inv2;
+            const double tt = dpsi / d;
+            g0 += dpsi * nx;
+            g1 += dpsi * ny;
+            h00 += d2psi * nx * nx + tt * (1.0 - nx * nx);
+            h01 += (d2psi - tt) * nx * ny;
+            h11 += d2psi * ny * ny + tt * (1.0 - ny * ny);
+            c00 += d2psi * nx * nx;
+            c01 += d2psi * nx * ny;
+            c11 += d2psi * ny * ny;
         }
-        J += wcoll * x3 * x3;
-        if (derivs) {
-            g3 += 2.0 * wcoll * x3;
-            h33 += 2.0 * wcoll;
-        }
     }
-    if (derivs) {
-        lx[0] = sf * g0;
-        lx[1] = sf * g1;
-        lx[2] = sf * 10.0 * dth;
-        lx[3] = sf * g3;
-        q[0] = sf * h00;
-        q[1] = sf * h01;
-        q[2] = sf * h11;
-        q[3] = sf * h33;
-        qg[0] = sf * c00;
-        qg[1] = sf * c01;
-        qg[2] = sf * c11;
+    if (d8) {
+        d8[0] = g0; d8[1] = g1; d8[2] = h00; d8[3] = h01; d8[4] = h11; d8[5] = c00; d8[6] = c01; d8[7] = c11;
     }
-    return sf * J;
+    return J;
+}
+
+// scaled stage-cost gradient at node k (1 <= k < N) of the current trajectory
+template <bool CC, class WS>
+MPC_HD void cost_grad(const WS &w, int CB, int k, double sf, double ws_, double wcoll, double *lx) {
+    const double x0 = w.ld(CB + B_X + 0, k), x1 = w.ld(CB + B_X + 1, k), x2 = w.ld(CB + B_X + 2, k),
+                 x3 = w.ld(CB + B_X + 3, k);
+    double g[4];
+    track_cost(w, k, ws_, x0, x1, x2, x3, g);
+    lx[0] = sf * g[0];
+    lx[1] = sf * g[1];
+    lx[2] = sf * g[2];
+    lx[3] = sf * g[3];
+    if (CC) {
+        lx[0] += w.ld(S_LX + 0, k);
+        lx[1] += w.ld(S_LX + 1, k);
+        lx[3] += sf * 2.0 * wcoll * x3;
+    }
 }
 
 // One forward rollout from x0 with controls  u_k = ucur_k + alpha*kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1})
 // written into buffer `tb` (reading the current iterate from buffer `cb`); with first==true the controls of
 // `tb` are taken as they are (cold start).  Returns false when a bound would be crossed
-// (fraction-to-the-boundary rule with parameter `frac`).  J / bar receive the objective and the
-// log-barrier sum of the new trajectory.
-template <class WS>
+// (fraction-to-the-boundary rule with parameter `frac`).  J / bar receive the scaled objective and the
+// log-barrier sum of the new trajectory.  The collision-cost variant also caches the derivatives of the
+// distance potential along the new trajectory (S_LX / S_Q / S_QG).
+template <bool CC, class WS>
 MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, double alpha, double frac, double sf,
                     double ws_, double wc_, double wd_, double wcoll, const double *x0, double &Jout, double &barout) {
     const int N = P.N;
@@ -224,53 +235,44 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
         bar -= log(u1 - ulo_r(1)) + log(uhi_r(1) - u1);
         up0 = u0;
         up1 = u1;
-        Dyn d;
-        dyn_eval(x_2, u1, d);
-        w.st(TB + B_DYN + 0, k, d.S);
-        w.st(TB + B_DYN + 1, k, d.C);
-        w.st(TB + B_DYN + 2, k, d.sb);
-        w.st(TB + B_DYN + 3, k, d.cb);
-        w.st(TB + B_DYN + 4, k, d.bp);
-        w.st(TB + B_DYN + 5, k, d.bpp);
-        const double n0 = x_0 + dt * (x_3 * d.C);
-        const double n1 = x_1 + dt * (x_3 * d.S);
-        const double n2 = x_2 + dt * (x_3 * kInvWheelbase * d.sb);
+        double S, C, sb, cbeta;
+        dyn_eval(x_2, u1, S, C, sb, cbeta);
+        w.st(TB + B_DYN + 0, k, S);
+        w.st(TB + B_DYN + 1, k, C);
+        w.st(TB + B_DYN + 2, k, sb);
+        w.st(TB + B_DYN + 3, k, cbeta);
+        const double n0 = x_0 + dt * (x_3 * C);
+        const double n1 = x_1 + dt * (x_3 * S);
+        const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
         const double n3 = x_3 + dt * u0;
         if (!first) {
-            const double o0 = w.ld(CB + B_X + 0, k + 1), o1 = w.ld(CB + B_X + 1, k + 1);
             const double o2 = w.ld(CB + B_X + 2, k + 1), o3 = w.ld(CB + B_X + 3, k + 1);
-            if (n0 - xlo_r(0) < frac * (o0 - xlo_r(0)) || xhi_r(0) - n0 < frac * (xhi_r(0) - o0) ||
-                n1 - xlo_r(1) < frac * (o1 - xlo_r(1)) || xhi_r(1) - n1 < frac * (xhi_r(1) - o1) ||
-                n2 - xlo_r(2) < frac * (o2 - xlo_r(2)) || xhi_r(2) - n2 < frac * (xhi_r(2) - o2) ||
-                n3 - xlo_r(3) < frac * (o3 - xlo_r(3)) || xhi_r(3) - n3 < frac * (xhi_r(3) - o3))
+            if (n2 - xlo_r(0) < frac * (o2 - xlo_r(0)) || xhi_r(0) - n2 < frac * (xhi_r(0) - o2) ||
+                n3 - xlo_r(1) < frac * (o3 - xlo_r(1)) || xhi_r(1) - n3 < frac * (xhi_r(1) - o3))
                 return false;
         } else {
-            if (!(n0 > xlo_r(0)) || !(n0 < xhi_r(0)) || !(n1 > xlo_r(1)) || !(n1 < xhi_r(1)) || !(n2 > xlo_r(2)) ||
-                !(n2 < xhi_r(2)) || !(n3 > xlo_r(3)) || !(n3 < xhi_r(3)))
-                return false;
+            if (!(n2 > xlo_r(0)) || !(n2 < xhi_r(0)) || !(n3 > xlo_r(1)) || !(n3 < xhi_r(1))) return false;
         }
         x_0 = n0;
         x_1 = n1;
         x_2 = n2;
         x_3 = n3;
-        bar -= log(x_0 - xlo_r(0)) + log(xhi_r(0) - x_0);
-        bar -= log(x_1 - xlo_r(1)) + log(xhi_r(1) - x_1);
-        bar -= log(x_2 - xlo_r(2)) + log(xhi_r(2) - x_2);
-        bar -= log(x_3 - xlo_r(3)) + log(xhi_r(3) - x_3);
+        bar -= log(x_2 - xlo_r(0)) + log(xhi_r(0) - x_2);
+        bar -= log(x_3 - xlo_r(1)) + log(xhi_r(1) - x_3);
         if (k + 1 < N) {
-            double lx[4], q[4], qg[3];
-            J += stage_cost(P, w, k + 1, sf, ws_, wcoll, x_0, x_1, x_2, x_3, true, lx, q, qg);
-            w.st(TB + B_LX + 0, k + 1, lx[0]);
-            w.st(TB + B_LX + 1, k + 1, lx[1]);
-            w.st(TB + B_LX + 2, k + 1, lx[2]);
-            w.st(TB + B_LX + 3, k + 1, lx[3]);
-            w.st(TB + B_Q + 0, k + 1, q[0]);
-            w.st(TB + B_Q + 1, k + 1, q[1]);
-            w.st(TB + B_Q + 2, k + 1, q[2]);
-            w.st(TB + B_Q + 3, k + 1, q[3]);
-            w.st(TB + B_QG + 0, k + 1, qg[0]);
-            w.st(TB + B_QG + 1, k + 1, qg[1]);
-            w.st(TB + B_QG + 2, k + 1, qg[2]);
+            J += sf * track_cost(w, k + 1, ws_, x_0, x_1, x_2, x_3, (double *)nullptr);
+            if (CC) {
+                double d8[8];
+                J += sf * (dist_cost(P, w, k + 1, x_0, x_1, d8) + wcoll * x_3 * x_3);
+                w.st(S_LX + 0, k + 1, sf * d8[0]);
+                w.st(S_LX + 1, k + 1, sf * d8[1]);
+                w.st(S_Q + 0, k + 1, sf * d8[2]);
+                w.st(S_Q + 1, k + 1, sf * d8[3]);
+                w.st(S_Q + 2, k + 1, sf * d8[4]);
+                w.st(S_QG + 0, k + 1, sf * d8[5]);
+                w.st(S_QG + 1, k + 1, sf * d8[6]);
+                w.st(S_QG + 2, k + 1, sf * d8[7]);
+            }
         }
     }
     w.st(TB + B_X + 0, N, x_0);
@@ -282,12 +284,90 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
     return true;
 }
 
+// Linearised forward sweep of the Newton step along the current trajectory.
+//   APPLY == false: step-length limits a_pr (primal) and a_du (dual) by the fraction-to-the-boundary rule.
+//   APPLY == true : the dual step  z += a_du*dz  with the slacks of buffer `nb`, clamped like IPOPT (kappa_Sigma 1e10).
+template <bool APPLY, class WS>
+MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu, double tau, double &a_pr,
+                         double &a_du) {
+    const int N = P.N;
+    const double dt = P.dt;
+    const int CB = cb * BUF_SLOTS, NB = nb * BUF_SLOTS;
+    double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
+    double apr = 1.0, adu = APPLY ? a_du : 1.0;
+    for (int k = 0; k < N; ++k) {
+        double du0 = w.ld(S_KF + 0, k) + w.ld(S_KX + 0, k) * d0 + w.ld(S_KX + 1, k) * d1 + w.ld(S_KX + 2, k) * d2 +
+                     w.ld(S_KX + 3, k) * d3;
+        double du1 = w.ld(S_KF + 1, k) + w.ld(S_KX + 4, k) * d0 + w.ld(S_KX + 5, k) * d1 + w.ld(S_KX + 6, k) * d2 +
+                     w.ld(S_KX + 7, k) * d3;
+        if (k >= 1) {
+            const double kp00 = w.ld(S_KP + 0, k), kp01 = w.ld(S_KP + 1, k), kp11 = w.ld(S_KP + 2, k);
+            du0 += kp00 * dp0 + kp01 * dp1;
+            du1 += kp01 * dp0 + kp11 * dp1;
+        }
+        const double v = w.ld(CB + B_X + 3, k);
+        const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
+        const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
+        double bp, bpp;
+        beta_derivs(sb, cbeta, bp, bpp);
+        const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S, a23 = dt * sb * kInvWheelbase;
+        const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
+        const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
+        const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
+        const double n2 = d2 + a23 * d3 + b21 * du1;
+        const double n3 = d3 + dt * du0;
+        d0 = n0; d1 = n1; d2 = n2; d3 = n3;
+        dp0 = du0; dp1 = du1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double ui = w.ld(CB + B_U + i, k), d = (i == 0) ? du0 : du1;
+            const double sl = ui - ulo_r(i), su = uhi_r(i) - ui;
+            const double zl = w.ld(S_ZUL + i, k), zu = w.ld(S_ZUU + i, k);
+            const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+            if (!APPLY) {
+                if (d < 0) apr = fmin2(apr, -tau * sl / d);
+                if (d > 0) apr = fmin2(apr, tau * su / d);
+                if (dzl < 0) adu = fmin2(adu, -tau * zl / dzl);
+                if (dzu < 0) adu = fmin2(adu, -tau * zu / dzu);
+            } else {
+                const double un = w.ld(NB + B_U + i, k);
+                const double sln = un - ulo_r(i), sun = uhi_r(i) - un;
+                w.st(S_ZUL + i, k, fmax2(fmin2(zl + adu * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
+                w.st(S_ZUU + i, k, fmax2(fmin2(zu + adu * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double xi = w.ld(CB + B_X + 2 + i, k + 1), d = (i == 0) ? d2 : d3;
+            const double sl = xi - xlo_r(i), su = xhi_r(i) - xi;
+            const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
+            const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+            if (!APPLY) {
+                if (d < 0) apr = fmin2(apr, -tau * sl / d);
+                if (d > 0) apr = fmin2(apr, tau * su / d);
+                if (dzl < 0) adu = fmin2(adu, -tau * zl / dzl);
+                if (dzu < 0) adu = fmin2(adu, -tau * zu / dzu);
+            } else {
+                const double xn = w.ld(NB + B_X + 2 + i, k + 1);
+                const double sln = xn - xlo_r(i), sun = xhi_r(i) - xn;
+                w.st(S_ZXL + i, k + 1, fmax2(fmin2(zl + adu * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
+                w.st(S_ZXU + i, k + 1, fmax2(fmin2(zu + adu * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
+            }
+        }
+    }
+    if (!APPLY) {
+        a_pr = apr;
+        a_du = adu;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // solve one instance.  On return the solution sits in trajectory buffer `cur_out`.
 //   ws_/wc_/wd_ : weight_speed (100 if is_collide), weight_control, weight_input_diff
 //   wcoll       : 3000 * weight_collision when the collision-cost term is on and is_collide, else 0
+// CC selects the variant with the distance/collision terms of agents/archive/pure_mpc.py:189-206.
 // ---------------------------------------------------------------------------------------------------
-template <class WS>
+template <bool CC, class WS>
 MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double ws_, double wc_, double wd_,
                            double wcoll, int &status_out, int &iters_out, int &cur_out, double &kkt_out) {
     const int N = P.N;
@@ -303,42 +383,44 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
     for (int k = 0; k < N; ++k) {
         w.st(S_BUF0 + B_U + 0, k, 0.0);
         w.st(S_BUF0 + B_U + 1, k, 0.0);
-        w.st(S_ZUL + 0, k, 1.0);
-        w.st(S_ZUL + 1, k, 1.0);
-        w.st(S_ZUU + 0, k, 1.0);
-        w.st(S_ZUU + 1, k, 1.0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
+            w.st(S_ZUL + i, k, 1.0);
+            w.st(S_ZUU + i, k, 1.0);
             w.st(S_ZXL + i, k + 1, 1.0);
             w.st(S_ZXU + i, k + 1, 1.0);
         }
     }
     if (x0[3] < 0.01) w.st(S_BUF0 + B_U + 0, 0, (0.01 - x0[3]) / dt);
     double sf = 1.0, Jcur = 0.0, barcur = 0.0;
-    if (!rollout(P, w, 0, 0, true, 0.0, 0.0, 1.0, ws_, wc_, wd_, wcoll, x0, Jcur, barcur)) {
+    if (!rollout<CC>(P, w, 0, 0, true, 0.0, 0.0, 1.0, ws_, wc_, wd_, wcoll, x0, Jcur, barcur)) {
         status_out = 3;
         return;
     }
     // ---- objective scaling like IPOPT's gradient-based scaling: sf = 100 / clamp(|grad f|_inf, 100, 1e4)
     {
         double gmax = 0.0;
-        for (int k = 1; k < N; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gmax = fmax2(gmax, fabs(w.ld(S_BUF0 + B_LX + i, k)));
+        for (int k = 1; k < N; ++k) {
+            double lx[4];
+            cost_grad<CC>(w, 0, k, 1.0, ws_, wcoll, lx);
+            gmax = fmax2(gmax, fmax2(fmax2(fabs(lx[0]), fabs(lx[1])), fmax2(fabs(lx[2]), fabs(lx[3]))));
+        }
         gmax = fmax2(gmax, 0.02 * (wc_ + wd_) * fabs(w.ld(S_BUF0 + B_U + 0, 0)));
         sf = 100.0 / fmin2(fmax2(100.0, gmax), 1e4);
         Jcur *= sf;
-        for (int k = 1; k < N; ++k) {
+        if (CC)
+            for (int k = 1; k < N; ++k) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                w.st(S_BUF0 + B_LX + i, k, sf * w.ld(S_BUF0 + B_LX + i, k));
-                w.st(S_BUF0 + B_Q + i, k, sf * w.ld(S_BUF0 + B_Q + i, k));
+                for (int i = 0; i < 2; ++i) w.st(S_LX + i, k, sf * w.ld(S_LX + i, k));
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    w.st(S_Q + i, k, sf * w.ld(S_Q + i, k));
+                    w.st(S_QG + i, k, sf * w.ld(S_QG + i, k));
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) w.st(S_BUF0 + B_QG + i, k, sf * w.ld(S_BUF0 + B_QG + i, k));
-        }
     }
     const double rd_full = 0.02 * sf * wd_, rc = 0.02 * sf * wc_, qtt = 10.0 * sf;
+    const double q33 = sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0));
     double mu = P.mu_init;
     const double mu_min = P.tol / 10.0;
     int iter = 0;
@@ -348,17 +430,9 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         // =========================== adjoint sweep: dual residual, complementarity =====================
         double err_d = 0.0, sum_lam = 0.0, sum_z = 0.0, cmax = 0.0, cmin = INFINITY;
         {
-            double y0, y1, y2, y3;  // y_{k+1}
-            {
-                const double zl0 = w.ld(S_ZXL + 0, N), zl1 = w.ld(S_ZXL + 1, N), zl2 = w.ld(S_ZXL + 2, N),
-                             zl3 = w.ld(S_ZXL + 3, N);
-                const double zu0 = w.ld(S_ZXU + 0, N), zu1 = w.ld(S_ZXU + 1, N), zu2 = w.ld(S_ZXU + 2, N),
-                             zu3 = w.ld(S_ZXU + 3, N);
-                y0 = -zl0 + zu0;
-                y1 = -zl1 + zu1;
-                y2 = -zl2 + zu2;
-                y3 = -zl3 + zu3;
-            }
+            double y0 = 0.0, y1 = 0.0;  // y_{k+1}
+            double y2 = -w.ld(S_ZXL + 0, N) + w.ld(S_ZXU + 0, N);
+            double y3 = -w.ld(S_ZXL + 1, N) + w.ld(S_ZXU + 1, N);
             double un0 = 0.0, un1 = 0.0;  // u_{k+1}
             for (int k = N - 1; k >= 0; --k) {
                 const double u0 = w.ld(CB + B_U + 0, k), u1 = w.ld(CB + B_U + 1, k);
@@ -371,11 +445,12 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 const double v = w.ld(CB + B_X + 3, k);
                 const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
                 const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
-                const double bp = w.ld(CB + B_DYN + 4, k);
+                double bp, bpp;
+                beta_derivs(sb, cbeta, bp, bpp);
                 const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S,
                              a23 = dt * sb * kInvWheelbase;
                 const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
-                // store y_{k+1} for the curvature terms of the factorisation sweep
+                // keep y_{k+1} for the curvature terms of the factorisation sweep
                 w.st(S_Y + 0, k + 1, y0);
                 w.st(S_Y + 1, k + 1, y1);
                 w.st(S_Y + 2, k + 1, y2);
@@ -393,7 +468,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 err_d = fmax2(err_d, fmax2(fabs(r0), fabs(r1)));
                 sum_z += zul0 + zul1 + zuu0 + zuu1;
                 sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
-                // complementarity products of u_k and x_{k+1}
+                // complementarity products of u_k and (theta, v)_{k+1}
                 {
                     const double c0 = (u0 - ulo_r(0)) * zul0, c1 = (uhi_r(0) - u0) * zuu0;
                     const double c2 = (u1 - ulo_r(1)) * zul1, c3 = (uhi_r(1) - u1) * zuu1;
@@ -401,8 +476,8 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     cmin = fmin2(cmin, fmin2(fmin2(c0, c1), fmin2(c2, c3)));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double xi = w.ld(CB + B_X + i, k + 1);
+                for (int i = 0; i < 2; ++i) {
+                    const double xi = w.ld(CB + B_X + 2 + i, k + 1);
                     const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
                     const double c0 = (xi - xlo_r(i)) * zl, c1 = (xhi_r(i) - xi) * zu;
                     cmax = fmax2(cmax, fmax2(c0, c1));
@@ -410,12 +485,13 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     sum_z += zl + zu;
                 }
                 if (k >= 1) {
-                    const double t0 = w.ld(CB + B_LX + 0, k) - w.ld(S_ZXL + 0, k) + w.ld(S_ZXU + 0, k) + y0;
-                    const double t1 = w.ld(CB + B_LX + 1, k) - w.ld(S_ZXL + 1, k) + w.ld(S_ZXU + 1, k) + y1;
-                    const double t2 = w.ld(CB + B_LX + 2, k) - w.ld(S_ZXL + 2, k) + w.ld(S_ZXU + 2, k) + a02 * y0 +
-                                      a12 * y1 + y2;
-                    const double t3 = w.ld(CB + B_LX + 3, k) - w.ld(S_ZXL + 3, k) + w.ld(S_ZXU + 3, k) + a03 * y0 +
-                                      a13 * y1 + a23 * y2 + y3;
+                    double lx[4];
+                    cost_grad<CC>(w, CB, k, sf, ws_, wcoll, lx);
+                    const double t0 = lx[0] + y0;
+                    const double t1 = lx[1] + y1;
+                    const double t2 = lx[2] - w.ld(S_ZXL + 0, k) + w.ld(S_ZXU + 0, k) + a02 * y0 + a12 * y1 + y2;
+                    const double t3 =
+                        lx[3] - w.ld(S_ZXL + 1, k) + w.ld(S_ZXU + 1, k) + a03 * y0 + a13 * y1 + a23 * y2 + y3;
                     y0 = t0;
                     y1 = t1;
                     y2 = t2;
@@ -457,30 +533,27 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
             dV1 = 0.0;
             double need = 0.0;
             // value function of node k+1: Pxx (sym 4x4), Pxp (4x2), Ppp (sym 2x2), px, pp
-            double p00, p01 = 0, p02 = 0, p03 = 0, p11, p12 = 0, p13 = 0, p22, p23 = 0, p33;
+            double p00 = delta_w, p01 = 0, p02 = 0, p03 = 0, p11 = delta_w, p12 = 0, p13 = 0, p22, p23 = 0, p33;
             double e00 = 0, e01 = 0, e10 = 0, e11 = 0, e20 = 0, e21 = 0, e30 = 0, e31 = 0;
-            double pp00 = 0, pp01 = 0, pp11 = 0, px0, px1, px2, px3, ppv0 = 0, ppv1 = 0;
+            double pp00 = 0, pp01 = 0, pp11 = 0, px0 = 0.0, px1 = 0.0, px2, px3, ppv0 = 0, ppv1 = 0;
             {
-                double sl, su;
-                double xi = w.ld(CB + B_X + 0, N);
-                sl = xi - xlo_r(0); su = xhi_r(0) - xi;
-                p00 = w.ld(S_ZXL + 0, N) / sl + w.ld(S_ZXU + 0, N) / su + delta_w; px0 = -mu / sl + mu / su;
-                xi = w.ld(CB + B_X + 1, N);
-                sl = xi - xlo_r(1); su = xhi_r(1) - xi;
-                p11 = w.ld(S_ZXL + 1, N) / sl + w.ld(S_ZXU + 1, N) / su + delta_w; px1 = -mu / sl + mu / su;
-                xi = w.ld(CB + B_X + 2, N);
-                sl = xi - xlo_r(2); su = xhi_r(2) - xi;
-                p22 = w.ld(S_ZXL + 2, N) / sl + w.ld(S_ZXU + 2, N) / su + delta_w; px2 = -mu / sl + mu / su;
+                double xi = w.ld(CB + B_X + 2, N);
+                double sl = xi - xlo_r(0), su = xhi_r(0) - xi;
+                p22 = w.ld(S_ZXL + 0, N) / sl + w.ld(S_ZXU + 0, N) / su + delta_w;
+                px2 = -mu / sl + mu / su;
                 xi = w.ld(CB + B_X + 3, N);
-                sl = xi - xlo_r(3); su = xhi_r(3) - xi;
-                p33 = w.ld(S_ZXL + 3, N) / sl + w.ld(S_ZXU + 3, N) / su + delta_w; px3 = -mu / sl + mu / su;
+                sl = xi - xlo_r(1);
+                su = xhi_r(1) - xi;
+                p33 = w.ld(S_ZXL + 1, N) / sl + w.ld(S_ZXU + 1, N) / su + delta_w;
+                px3 = -mu / sl + mu / su;
             }
             for (int k = N - 1; k >= 0; --k) {
                 const double rdk = (k >= 1) ? rd_full : 0.0;
                 const double v = w.ld(CB + B_X + 3, k);
                 const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
                 const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
-                const double bp = w.ld(CB + B_DYN + 4, k), bpp = w.ld(CB + B_DYN + 5, k);
+                double bp, bpp;
+                beta_derivs(sb, cbeta, bp, bpp);
                 const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S,
                              a23 = dt * sb * kInvWheelbase;
                 const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
@@ -495,8 +568,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     const double wtt = dt * v * g, wtv = dt * h;
                     const double wtd = dt * v * g * bp;
                     const double wvd = dt * h * bp + dt * yy2 * cbeta * bp * kInvWheelbase;
-                    wdd = dt * v * (g * bp * bp + h * bpp) +
-                          dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cbeta * bpp);
+                    wdd = dt * v * (g * bp * bp + h * bpp) + dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cbeta * bpp);
                     if (k >= 1) {
                         l22 = wtt;
                         l23 = wtv;
@@ -505,30 +577,28 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     }
                 }
                 if (k >= 1) {
-                    if (gn) {
-                        l00 = w.ld(CB + B_QG + 0, k);
-                        l01 = w.ld(CB + B_QG + 1, k);
-                        l11 = w.ld(CB + B_QG + 2, k);
-                    } else {
-                        l00 = w.ld(CB + B_Q + 0, k);
-                        l01 = w.ld(CB + B_Q + 1, k);
-                        l11 = w.ld(CB + B_Q + 2, k);
+                    double lx[4];
+                    cost_grad<CC>(w, CB, k, sf, ws_, wcoll, lx);
+                    double t00, t01, t11;
+                    track_hess(w, k, t00, t01, t11);
+                    l00 = sf * t00 + delta_w;
+                    l01 = sf * t01;
+                    l11 = sf * t11 + delta_w;
+                    if (CC) {
+                        const int QS = gn ? S_QG : S_Q;
+                        l00 += w.ld(QS + 0, k);
+                        l01 += w.ld(QS + 1, k);
+                        l11 += w.ld(QS + 2, k);
                     }
-                    l22 += qtt;
-                    l33 = w.ld(CB + B_Q + 3, k);
-                    double xi, sl, su;
-                    xi = w.ld(CB + B_X + 0, k); sl = xi - xlo_r(0); su = xhi_r(0) - xi;
-                    l00 += w.ld(S_ZXL + 0, k) / sl + w.ld(S_ZXU + 0, k) / su + delta_w;
-                    lx0 = w.ld(CB + B_LX + 0, k) - mu / sl + mu / su;
-                    xi = w.ld(CB + B_X + 1, k); sl = xi - xlo_r(1); su = xhi_r(1) - xi;
-                    l11 += w.ld(S_ZXL + 1, k) / sl + w.ld(S_ZXU + 1, k) / su + delta_w;
-                    lx1 = w.ld(CB + B_LX + 1, k) - mu / sl + mu / su;
-                    xi = w.ld(CB + B_X + 2, k); sl = xi - xlo_r(2); su = xhi_r(2) - xi;
-                    l22 += w.ld(S_ZXL + 2, k) / sl + w.ld(S_ZXU + 2, k) / su + delta_w;
-                    lx2 = w.ld(CB + B_LX + 2, k) - mu / sl + mu / su;
-                    xi = v; sl = xi - xlo_r(3); su = xhi_r(3) - xi;
-                    l33 += w.ld(S_ZXL + 3, k) / sl + w.ld(S_ZXU + 3, k) / su + delta_w;
-                    lx3 = w.ld(CB + B_LX + 3, k) - mu / sl + mu / su;
+                    lx0 = lx[0];
+                    lx1 = lx[1];
+                    double xi = w.ld(CB + B_X + 2, k), sl = xi - xlo_r(0), su = xhi_r(0) - xi;
+                    l22 += qtt + w.ld(S_ZXL + 0, k) / sl + w.ld(S_ZXU + 0, k) / su + delta_w;
+                    lx2 = lx[2] - mu / sl + mu / su;
+                    sl = v - xlo_r(1);
+                    su = xhi_r(1) - v;
+                    l33 = q33 + w.ld(S_ZXL + 1, k) / sl + w.ld(S_ZXU + 1, k) / su + delta_w;
+                    lx3 = lx[3] - mu / sl + mu / su;
                 }
                 double luu00, luu11, lu0, lu1, lp0 = 0.0, lp1 = 0.0;
                 {
@@ -540,28 +610,29 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     double sl = u0 - ulo_r(0), su = uhi_r(0) - u0;
                     luu00 = rc + rdk + w.ld(S_ZUL + 0, k) / sl + w.ld(S_ZUU + 0, k) / su + delta_w;
                     lu0 = rc * u0 + rdk * (u0 - um0) - mu / sl + mu / su;
-                    sl = u1 - ulo_r(1); su = uhi_r(1) - u1;
+                    sl = u1 - ulo_r(1);
+                    su = uhi_r(1) - u1;
                     luu11 = rc + rdk + w.ld(S_ZUL + 1, k) / sl + w.ld(S_ZUU + 1, k) / su + delta_w + wdd;
                     lu1 = rc * u1 + rdk * (u1 - um1) - mu / sl + mu / su;
                     lp0 = -rdk * (u0 - um0);
                     lp1 = -rdk * (u1 - um1);
                 }
-                // ---- M = Pxx A (4x4; columns 0,1 are those of Pxx), PB = Pxx B (4x2)
+                // ---- M = Pxx A (4x4; columns 0,1 are those of Pxx), G = Pxx B + Pxp (4x2)
                 const double m02 = p00 * a02 + p01 * a12 + p02, m03 = p00 * a03 + p01 * a13 + p02 * a23 + p03;
                 const double m12 = p01 * a02 + p11 * a12 + p12, m13 = p01 * a03 + p11 * a13 + p12 * a23 + p13;
                 const double m22 = p02 * a02 + p12 * a12 + p22, m23 = p02 * a03 + p12 * a13 + p22 * a23 + p23;
                 const double m32 = p03 * a02 + p13 * a12 + p23, m33 = p03 * a03 + p13 * a13 + p23 * a23 + p33;
-                // G = PB + Pxp
                 const double g00 = dt * p03 + e00, g01 = p00 * b01 + p01 * b11 + p02 * b21 + e01;
                 const double g10 = dt * p13 + e10, g11 = p01 * b01 + p11 * b11 + p12 * b21 + e11;
                 const double g20 = dt * p23 + e20, g21 = p02 * b01 + p12 * b11 + p22 * b21 + e21;
                 const double g30 = dt * p33 + e30, g31 = p03 * b01 + p13 * b11 + p23 * b21 + e31;
-                // ---- Hxx = Lxx + A' M  (symmetric), rows of A': r0=e0, r1=e1, r2=a02 e0+a12 e1+e2, r3=a03 e0+a13 e1+a23 e2+e3
+                // ---- Hxx = Lxx + A' M (symmetric)
                 const double h00 = l00 + p00, h01 = l01 + p01, h11 = l11 + p11;
                 const double h02 = m02, h03 = m03, h12 = m12, h13 = m13;
                 const double h22 = l22 + a02 * m02 + a12 * m12 + m22;
                 const double h23 = l23 + a02 * m03 + a12 * m13 + m23;
                 const double h33 = l33 + a03 * m03 + a13 * m13 + a23 * m23 + m33;
+                (void)m32;
                 // ---- Hxu = Lxu + A' G
                 const double hxu00 = g00, hxu01 = g01, hxu10 = g10, hxu11 = g11;
                 const double hxu20 = a02 * g00 + a12 * g10 + g20, hxu21 = lxu21 + a02 * g01 + a12 * g11 + g21;
@@ -570,11 +641,12 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 // ---- hx = lx + A' px
                 const double hx0 = lx0 + px0, hx1 = lx1 + px1, hx2 = lx2 + a02 * px0 + a12 * px1 + px2;
                 const double hx3 = lx3 + a03 * px0 + a13 * px1 + a23 * px2 + px3;
-                // ---- Huu = Luu + Ppp + B'(PB + Pxp) + Pxp' B ;  B' rows: r0 = dt e3, r1 = b01 e0 + b11 e1 + b21 e2
+                // ---- Huu = Luu + Ppp + B' G + Pxp' B
                 const double huu00 = luu00 + pp00 + dt * g30 + dt * e30;
                 const double huu01a = pp01 + dt * g31 + (e00 * b01 + e10 * b11 + e20 * b21);
                 const double huu10a = pp01 + (b01 * g00 + b11 * g10 + b21 * g20) + dt * e31;
-                const double huu11 = luu11 + pp11 + (b01 * g01 + b11 * g11 + b21 * g21) + (e01 * b01 + e11 * b11 + e21 * b21);
+                const double huu11 =
+                    luu11 + pp11 + (b01 * g01 + b11 * g11 + b21 * g21) + (e01 * b01 + e11 * b11 + e21 * b21);
                 const double hu0 = lu0 + ppv0 + dt * px3;
                 const double hu1 = lu1 + ppv1 + b01 * px0 + b11 * px1 + b21 * px2;
                 const double ha = huu00, hb = 0.5 * (huu01a + huu10a), hc = huu11;
@@ -643,61 +715,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         // =========================== linear forward sweep: Newton step, step-length limits ==============
         const double tau = fmax2(0.99, 1.0 - mu);
         double a_pr = 1.0, a_du = 1.0;
-        {
-            double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
-            for (int k = 0; k < N; ++k) {
-                double du0 = w.ld(S_KF + 0, k) + w.ld(S_KX + 0, k) * d0 + w.ld(S_KX + 1, k) * d1 + w.ld(S_KX + 2, k) * d2 +
-                             w.ld(S_KX + 3, k) * d3;
-                double du1 = w.ld(S_KF + 1, k) + w.ld(S_KX + 4, k) * d0 + w.ld(S_KX + 5, k) * d1 + w.ld(S_KX + 6, k) * d2 +
-                             w.ld(S_KX + 7, k) * d3;
-                if (k >= 1) {
-                    const double kp00 = w.ld(S_KP + 0, k), kp01 = w.ld(S_KP + 1, k), kp11 = w.ld(S_KP + 2, k);
-                    du0 += kp00 * dp0 + kp01 * dp1;
-                    du1 += kp01 * dp0 + kp11 * dp1;
-                }
-                w.st(S_DUL + 0, k, du0);
-                w.st(S_DUL + 1, k, du1);
-                const double v = w.ld(CB + B_X + 3, k);
-                const double S = w.ld(CB + B_DYN + 0, k), C = w.ld(CB + B_DYN + 1, k);
-                const double sb = w.ld(CB + B_DYN + 2, k), cbeta = w.ld(CB + B_DYN + 3, k);
-                const double bp = w.ld(CB + B_DYN + 4, k);
-                const double a02 = -dt * v * S, a03 = dt * C, a12 = dt * v * C, a13 = dt * S,
-                             a23 = dt * sb * kInvWheelbase;
-                const double b01 = -dt * v * S * bp, b11 = dt * v * C * bp, b21 = dt * v * kInvWheelbase * cbeta * bp;
-                const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
-                const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
-                const double n2 = d2 + a23 * d3 + b21 * du1;
-                const double n3 = d3 + dt * du0;
-                d0 = n0; d1 = n1; d2 = n2; d3 = n3;
-                dp0 = du0; dp1 = du1;
-                w.st(S_DXL + 0, k + 1, d0);
-                w.st(S_DXL + 1, k + 1, d1);
-                w.st(S_DXL + 2, k + 1, d2);
-                w.st(S_DXL + 3, k + 1, d3);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const double ui = w.ld(CB + B_U + i, k), d = (i == 0) ? du0 : du1;
-                    const double sl = ui - ulo_r(i), su = uhi_r(i) - ui;
-                    const double zl = w.ld(S_ZUL + i, k), zu = w.ld(S_ZUU + i, k);
-                    if (d < 0) a_pr = fmin2(a_pr, -tau * sl / d);
-                    if (d > 0) a_pr = fmin2(a_pr, tau * su / d);
-                    const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
-                    if (dzl < 0) a_du = fmin2(a_du, -tau * zl / dzl);
-                    if (dzu < 0) a_du = fmin2(a_du, -tau * zu / dzu);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const double xi = w.ld(CB + B_X + i, k + 1), d = (i == 0) ? d0 : (i == 1) ? d1 : (i == 2) ? d2 : d3;
-                    const double sl = xi - xlo_r(i), su = xhi_r(i) - xi;
-                    const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
-                    if (d < 0) a_pr = fmin2(a_pr, -tau * sl / d);
-                    if (d > 0) a_pr = fmin2(a_pr, tau * su / d);
-                    const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
-                    if (dzl < 0) a_du = fmin2(a_du, -tau * zl / dzl);
-                    if (dzu < 0) a_du = fmin2(a_du, -tau * zu / dzu);
-                }
-            }
-        }
+        linear_sweep<false>(P, w, cur, cur, mu, tau, a_pr, a_du);
 
         // =========================== nonlinear rollout + Armijo on the barrier objective ================
         const double phi0 = Jcur + mu * barcur;
@@ -705,7 +723,8 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         double alpha = a_pr, Jn = 0.0, barn = 0.0;
         bool accepted = false;
         for (int nls = 0; nls < 30; ++nls, alpha *= 0.5) {
-            if (!rollout(P, w, cur, tb, false, alpha, 0.5 * (1.0 - tau), sf, ws_, wc_, wd_, wcoll, x0, Jn, barn)) continue;
+            if (!rollout<CC>(P, w, cur, tb, false, alpha, 0.5 * (1.0 - tau), sf, ws_, wc_, wd_, wcoll, x0, Jn, barn))
+                continue;
             const double phi1 = Jn + mu * barn;
             if (phi1 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
                 accepted = true;
@@ -713,33 +732,25 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
             }
         }
         // =========================== dual step (own fraction-to-the-boundary length), accept ============
-        const int NB = (accepted ? tb : cur) * BUF_SLOTS;
-        for (int k = 0; k < N; ++k) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const double ui = w.ld(CB + B_U + i, k), d = w.ld(S_DUL + i, k), un = w.ld(NB + B_U + i, k);
-                const double sl = ui - ulo_r(i), su = uhi_r(i) - ui;
-                const double zl = w.ld(S_ZUL + i, k), zu = w.ld(S_ZUU + i, k);
-                const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
-                const double sln = un - ulo_r(i), sun = uhi_r(i) - un;
-                w.st(S_ZUL + i, k, fmax2(fmin2(zl + a_du * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
-                w.st(S_ZUU + i, k, fmax2(fmin2(zu + a_du * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const double xi = w.ld(CB + B_X + i, k + 1), d = w.ld(S_DXL + i, k + 1), xn = w.ld(NB + B_X + i, k + 1);
-                const double sl = xi - xlo_r(i), su = xhi_r(i) - xi;
-                const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
-                const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
-                const double sln = xn - xlo_r(i), sun = xhi_r(i) - xn;
-                w.st(S_ZXL + i, k + 1, fmax2(fmin2(zl + a_du * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
-                w.st(S_ZXU + i, k + 1, fmax2(fmin2(zu + a_du * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
-            }
-        }
+        linear_sweep<true>(P, w, cur, accepted ? tb : cur, mu, tau, a_pr, a_du);
         if (accepted) {
             cur = tb;
             Jcur = Jn;
             barcur = barn;
+        } else if (CC) {
+            // the rejected rollouts overwrote the cached distance-potential derivatives: restore them
+            for (int k = 1; k < N; ++k) {
+                double d8[8];
+                dist_cost(P, w, k, w.ld(CB + B_X + 0, k), w.ld(CB + B_X + 1, k), d8);
+                w.st(S_LX + 0, k, sf * d8[0]);
+                w.st(S_LX + 1, k, sf * d8[1]);
+                w.st(S_Q + 0, k, sf * d8[2]);
+                w.st(S_Q + 1, k, sf * d8[3]);
+                w.st(S_Q + 2, k, sf * d8[4]);
+                w.st(S_QG + 0, k, sf * d8[5]);
+                w.st(S_QG + 1, k, sf * d8[6]);
+                w.st(S_QG + 2, k, sf * d8[7]);
+            }
         }
     }
     iters_out = iter;

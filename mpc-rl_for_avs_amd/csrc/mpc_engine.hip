@@ -1,13 +1,13 @@
-// mpc_engine.hip - gfx950 kernels and the C ABI (include/mpc_mi355x.h) of the batched MPC solve engine.
+// mpc_engine.hip - gfx950 kernel and the C ABI (include/mpc_mi355x.h) of the batched MPC solve engine.
 //
-// Data layout in HBM (per handle, sized for the largest batch seen):
-//   work   [STAGE_SLOTS][N+1][Bp] double   per-stage solver state, instance index fastest (Bp = B rounded
-//                                          up to 64): a wave's 64 lanes read/write 512 contiguous bytes
-//   oth    [V][4][Bp]            double    other vehicles: x, y, per-stage displacement dx, dy
-//   ref    [M][6]                double    reference path x, y, v, heading, sin(heading), cos(heading);
-//                                          staged into LDS once per workgroup (gathered by ego_index + k)
-// One wave64 lane solves one instance start to finish (mpc_core.hpp); a workgroup is one wave so that the
-// 256 CUs / 8 XCDs are covered as soon as B >= 16384 and nothing is ever exchanged between lanes.
+// Execution model.  One wave64 lane solves one MPC instance start to finish (mpc_core.hpp); lanes never
+// exchange data.  The solver's per-stage state (iterates, multipliers, adjoint, Riccati gains: 46-54 doubles
+// per stage) lives in LDS, laid out [slot][stage][instance] so the active lanes of a wave read consecutive
+// doubles (bank-conflict free ds_read_b64); the 85-point reference path is staged into LDS once per
+// workgroup and gathered by ego_index + k.  HBM is touched only for the inputs (~0.9 KB per instance, read
+// once) and the outputs.  With ~9 KB of LDS per instance a CU (160 KB) holds 16 instances; a workgroup is
+// one wave carrying IPW of them (IPW = 1, 4 or 16 chosen from the batch size so that the workgroups cover
+// all 256 CUs / 8 XCDs before any CU gets a second one).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -34,67 +34,86 @@ int fail(int code, const std::string &msg) {
             return fail(MPC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
-struct GlobalWS {
-    double *base;         // work + lane
-    const double *obase;  // oth + lane
-    size_t Bp;
-    int N1;
-    __device__ __forceinline__ double ld(int slot, int k) const { return base[((size_t)slot * N1 + k) * Bp]; }
-    __device__ __forceinline__ void st(int slot, int k, double v) { base[((size_t)slot * N1 + k) * Bp] = v; }
-    __device__ __forceinline__ double oth(int j, int c) const { return obase[((size_t)j * 4 + c) * Bp]; }
-};
-
 constexpr int kBlock = 64;  // one wave64 per workgroup
 
-__global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
-    mpc::SolveParams P, int B, size_t Bp, double *__restrict__ work, double *__restrict__ oth,
-    const double *__restrict__ ref6, int M, const double *__restrict__ state, const int32_t *__restrict__ ego_index,
-    const double *__restrict__ vref, const double *__restrict__ weights, const uint8_t *__restrict__ is_collide,
-    const double *__restrict__ others, int Vin, double w_collision, double *__restrict__ u0_out,
-    double *__restrict__ U_out, double *__restrict__ X_out, int32_t *__restrict__ status_out,
-    int32_t *__restrict__ iters_out) {
-    extern __shared__ double s_ref[];  // [M][6]
-    for (int i = threadIdx.x; i < M * 6; i += kBlock) s_ref[i] = ref6[i];
-    __syncthreads();
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= B) return;
-
-    const int N = P.N;
-    GlobalWS w{work + b, oth + b, Bp, N + 1};
-    double x0[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x0[i] = state[(size_t)b * 4 + i];
-    const int e0 = ego_index[b];
-    for (int k = 0; k <= N; ++k) {
+// LDS-resident workspace of one lane: element (slot, stage k) of this instance
+template <int IPW>
+struct LdsWS {
+    double *base;         // work + lane
+    const double *obase;  // others + lane
+    const double *table;  // [M][REF_COLS]
+    int N1, e0, M;
+    __device__ __forceinline__ double ld(int slot, int k) const { return base[(slot * N1 + k) * IPW]; }
+    __device__ __forceinline__ void st(int slot, int k, double v) { base[(slot * N1 + k) * IPW] = v; }
+    __device__ __forceinline__ double oth(int j, int c) const { return obase[(j * 4 + c) * IPW]; }
+    __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
         idx = idx > M - 1 ? M - 1 : idx;
         idx = idx < 0 ? 0 : idx;
-        const double *r = s_ref + idx * 6;
-        w.st(mpc::S_REF + 0, k, r[0]);
-        w.st(mpc::S_REF + 1, k, r[1]);
-        w.st(mpc::S_REF + 2, k, vref ? vref[(size_t)b * (N + 1) + k] : r[2]);
-        w.st(mpc::S_REF + 3, k, r[3]);
-        w.st(mpc::S_REF + 4, k, r[4]);
-        w.st(mpc::S_REF + 5, k, r[5]);
+        return table[idx * mpc::REF_COLS + c];
+    }
+};
+
+__host__ __device__ constexpr int stage_slots(bool cc) { return cc ? mpc::STAGE_SLOTS_CC : mpc::STAGE_SLOTS; }
+
+// LDS bytes of one workgroup: path table + IPW workspaces + IPW other-vehicle blocks
+size_t lds_bytes(bool cc, int ipw, int N, int M, int V) {
+    return ((size_t)M * mpc::REF_COLS + (size_t)stage_slots(cc) * (N + 1) * ipw + (size_t)(cc ? V : 0) * 4 * ipw) *
+           sizeof(double);
+}
+
+template <bool CC, int IPW>
+__global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
+    mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
+    const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
+    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin, double w_collision,
+    double *__restrict__ u0_out, double *__restrict__ U_out, double *__restrict__ X_out,
+    int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
+    extern __shared__ double smem[];
+    const int N = P.N;
+    double *s_table = smem;                                     // [M][REF_COLS]
+    double *s_work = s_table + M * mpc::REF_COLS;               // [slots][N+1][IPW]
+    double *s_oth = s_work + stage_slots(CC) * (N + 1) * IPW;   // [V][4][IPW]
+    for (int i = threadIdx.x; i < M * mpc::REF_COLS; i += kBlock) s_table[i] = ref5[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * IPW + lane;
+    if (lane >= IPW || b >= B) return;
+
+    LdsWS<IPW> w{s_work + lane, s_oth + lane, s_table, N + 1, ego_index[b], M};
+    double x0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x0[i] = state[(size_t)b * 4 + i];
+    for (int k = 0; k <= N; ++k) {
+        double rv;
+        if (vref) {
+            rv = vref[(size_t)b * (N + 1) + k];
+        } else {
+            int idx = w.e0 + k;
+            idx = idx > M - 1 ? M - 1 : idx;
+            idx = idx < 0 ? 0 : idx;
+            rv = ref5[M * mpc::REF_COLS + idx];  // speed column is appended after the table
+        }
+        w.st(mpc::S_RV, k, rv);
     }
     const bool collide = is_collide[b] != 0;
-    if (P.collision_cost) {
+    if (CC) {
         for (int j = 0; j < P.V; ++j) {
             const double *ov = others + ((size_t)b * Vin + j) * 4;
             const double sp = ov[2] * P.dt, hh = ov[3];
-            oth[((size_t)j * 4 + 0) * Bp + b] = ov[0];
-            oth[((size_t)j * 4 + 1) * Bp + b] = ov[1];
-            oth[((size_t)j * 4 + 2) * Bp + b] = sp * cos(hh);
-            oth[((size_t)j * 4 + 3) * Bp + b] = sp * sin(hh);
+            s_oth[(j * 4 + 0) * IPW + lane] = ov[0];
+            s_oth[(j * 4 + 1) * IPW + lane] = ov[1];
+            s_oth[(j * 4 + 2) * IPW + lane] = sp * cos(hh);
+            s_oth[(j * 4 + 3) * IPW + lane] = sp * sin(hh);
         }
     }
     const double ws_ = collide ? 100.0 : weights[(size_t)b * 3 + 0];  // agents/pure_mpc.py:143-147
     const double wc_ = weights[(size_t)b * 3 + 1], wd_ = weights[(size_t)b * 3 + 2];
-    const double wcoll = (P.collision_cost && collide) ? 3000.0 * w_collision : 0.0;
+    const double wcoll = (CC && collide) ? 3000.0 * w_collision : 0.0;
 
     int status, iters, cur;
     double kkt;
-    mpc::solve_instance(P, w, x0, ws_, wc_, wd_, wcoll, status, iters, cur, kkt);
+    mpc::solve_instance<CC>(P, w, x0, ws_, wc_, wd_, wcoll, status, iters, cur, kkt);
 
     const int CB = cur * mpc::BUF_SLOTS;
     u0_out[(size_t)b * 2 + 0] = w.ld(CB + mpc::B_U + 0, 0);
@@ -117,12 +136,10 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 struct mpc_handle {
     mpc_config cfg;
     int device = 0;
-    double *d_ref = nullptr;  // [M][6]
+    double *d_ref = nullptr;  // [M][REF_COLS] x y heading sin cos, followed by the speed column [M]
     int M = 0;
-    double *d_work = nullptr;
-    size_t work_doubles = 0;
-    double *d_oth = nullptr;
-    size_t oth_doubles = 0;
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
     // staging buffers for host-pointer calls
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -132,13 +149,38 @@ namespace {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
-int ensure_buffer(double **p, size_t *have, size_t need) {
-    if (*have >= need) return MPC_OK;
-    if (*p) HIP_TRY(hipFree(*p));
-    *p = nullptr;
-    *have = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), need * sizeof(double)));
-    *have = need;
+// instances per wave: the largest batch slice that still leaves every CU at least one workgroup,
+// limited by what the CU's LDS can hold
+int choose_ipw(const mpc_handle *h, bool cc, int B, int N, int V) {
+    const char *env = getenv("MPC_IPW");
+    const int cands[3] = {1, 4, 16};
+    if (env) {
+        const int f = atoi(env);
+        for (int c : cands)
+            if (c == f && lds_bytes(cc, c, N, h->M, V) <= h->lds_per_cu) return c;
+    }
+    int best = 1;
+    for (int c : cands) {
+        if (lds_bytes(cc, c, N, h->M, V) > h->lds_per_cu) break;
+        best = c;
+        // enough workgroups of this size to give every SIMD of every CU one wave?
+        if ((long long)B <= (long long)c * h->num_cu * 4) break;
+    }
+    return best;
+}
+
+template <bool CC, int IPW>
+int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
+           const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
+           const uint8_t *d_coll, const double *d_others, double *d_u0, double *d_U, double *d_X,
+           int32_t *d_status, int32_t *d_iters) {
+    auto kern = mpc_solve_kernel<CC, IPW>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    const unsigned grid = (unsigned)((B + IPW - 1) / IPW);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego, d_vref,
+                       d_weights, d_coll, d_others, V, h->cfg.w_collision, d_u0, d_U, d_X, d_status, d_iters);
+    HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
 
@@ -183,6 +225,13 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
     if (!h) return fail(MPC_ERR_HIP, "mpc_create: out of host memory");
     h->cfg = *cfg;
     h->device = cfg->device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount;
+            if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+        }
+    }
     *out = h;
     g_last_error.clear();
     return MPC_OK;
@@ -192,8 +241,6 @@ void mpc_destroy(mpc_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->d_ref) (void)hipFree(h->d_ref);
-    if (h->d_work) (void)hipFree(h->d_work);
-    if (h->d_oth) (void)hipFree(h->d_oth);
     if (h->d_stage) (void)hipFree(h->d_stage);
     delete h;
 }
@@ -201,15 +248,15 @@ void mpc_destroy(mpc_handle *h) {
 int mpc_set_reference(mpc_handle *h, const double *ref, int32_t M) {
     if (!h || !ref || M < 1 || M > 4096) return fail(MPC_ERR_INVALID_ARG, "mpc_set_reference: bad argument");
     HIP_TRY(hipSetDevice(h->device));
-    std::string buf((size_t)M * 6 * sizeof(double), '\0');
+    std::string buf((size_t)M * (mpc::REF_COLS + 1) * sizeof(double), '\0');
     double *r6 = reinterpret_cast<double *>(&buf[0]);
     for (int i = 0; i < M; ++i) {
-        r6[i * 6 + 0] = ref[i * 4 + 0];
-        r6[i * 6 + 1] = ref[i * 4 + 1];
-        r6[i * 6 + 2] = ref[i * 4 + 2];
-        r6[i * 6 + 3] = ref[i * 4 + 3];
-        r6[i * 6 + 4] = sin(ref[i * 4 + 3]);
-        r6[i * 6 + 5] = cos(ref[i * 4 + 3]);
+        r6[i * mpc::REF_COLS + mpc::R_X] = ref[i * 4 + 0];
+        r6[i * mpc::REF_COLS + mpc::R_Y] = ref[i * 4 + 1];
+        r6[i * mpc::REF_COLS + mpc::R_H] = ref[i * 4 + 3];
+        r6[i * mpc::REF_COLS + mpc::R_SIN] = sin(ref[i * 4 + 3]);
+        r6[i * mpc::REF_COLS + mpc::R_COS] = cos(ref[i * 4 + 3]);
+        r6[M * mpc::REF_COLS + i] = ref[i * 4 + 2];
     }
     if (h->d_ref) HIP_TRY(hipFree(h->d_ref));
     h->d_ref = nullptr;
@@ -220,10 +267,10 @@ int mpc_set_reference(mpc_handle *h, const double *ref, int32_t M) {
 }
 
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V) {
-    if (!h || B < 0 || V < 0) return -1;
-    const size_t Bp = round_up((size_t)(B > 0 ? B : 1), kBlock);
-    const size_t N1 = (size_t)h->cfg.horizon + 1;
-    return (int64_t)(((size_t)mpc::STAGE_SLOTS * N1 + (size_t)V * 4) * Bp * sizeof(double));
+    if (!h || B < 0 || V < 0 || V > MPC_MAX_OTHERS) return -1;
+    const bool cc = V > 0;
+    const int ipw = choose_ipw(h, cc, B > 0 ? B : 1, h->cfg.horizon, V);
+    return (int64_t)lds_bytes(cc, ipw, h->cfg.horizon, h->M > 0 ? h->M : 85, V);
 }
 
 int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t *ego_index, const double *vref,
@@ -242,12 +289,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int N = h->cfg.horizon;
     const size_t N1 = (size_t)N + 1;
-    const size_t Bp = round_up((size_t)B, kBlock);
     const int Vuse = cc ? V : 0;
-    int rc = ensure_buffer(&h->d_work, &h->work_doubles, (size_t)mpc::STAGE_SLOTS * N1 * Bp);
-    if (rc) return rc;
-    rc = ensure_buffer(&h->d_oth, &h->oth_doubles, (size_t)(Vuse > 0 ? Vuse : 1) * 4 * Bp);
-    if (rc) return rc;
 
     // ---- device views of the arguments
     const double *d_state = state, *d_vref = vref, *d_weights = weights, *d_others = others;
@@ -308,18 +350,30 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     P.N = N;
     P.V = Vuse;
     P.max_iter = h->cfg.max_iter;
-    P.collision_cost = cc ? 1 : 0;
     P.dt = h->cfg.dt;
     P.tol = h->cfg.tol;
     P.mu_init = 0.1;
     P.w_distance = h->cfg.w_distance;
 
-    const unsigned grid = (unsigned)(Bp / kBlock);
-    const size_t lds = (size_t)h->M * 6 * sizeof(double);
-    hipLaunchKernelGGL(mpc_solve_kernel, dim3(grid), dim3(kBlock), lds, stream, P, (int)B, Bp, h->d_work, h->d_oth,
-                       h->d_ref, h->M, d_state, d_ego, d_vref, d_weights, d_coll, d_others, (int)V,
-                       h->cfg.w_collision, d_u0, d_U, d_X, d_status, d_iters);
-    HIP_TRY(hipGetLastError());
+    const int ipw = choose_ipw(h, cc, B, N, Vuse);
+    const size_t lds = lds_bytes(cc, ipw, N, h->M, Vuse);
+    if (lds > h->lds_per_cu)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: horizon/others/reference too large for the LDS workspace");
+    int rc;
+#define MPC_LAUNCH(CCV, IPWV)                                                                                   \
+    rc = launch<CCV, IPWV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, \
+                           d_u0, d_U, d_X, d_status, d_iters)
+    if (cc) {
+        if (ipw == 16) MPC_LAUNCH(true, 16);
+        else if (ipw == 4) MPC_LAUNCH(true, 4);
+        else MPC_LAUNCH(true, 1);
+    } else {
+        if (ipw == 16) MPC_LAUNCH(false, 16);
+        else if (ipw == 4) MPC_LAUNCH(false, 4);
+        else MPC_LAUNCH(false, 1);
+    }
+#undef MPC_LAUNCH
+    if (rc) return rc;
 
     if (!dev) {
         char *sb = static_cast<char *>(h->d_stage);

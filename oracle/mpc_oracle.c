@@ -51,6 +51,7 @@ typedef struct {
     double ws, wc, wd;
     double ox[VMAX], oy[VMAX], osx[VMAX], osy[VMAX];
     double wdist, wcoll; /* wcoll already multiplied by 3000*is_collide */
+    int i0;              /* first bounded state component: 0 = all (reference NLP), 2 = theta, v only */
     double sf;           /* objective scale factor (IPOPT-style gradient-based scaling), 1 = unscaled */
 } prob_t;
 
@@ -183,7 +184,7 @@ static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
         for (int i = 0; i < 2; ++i) bar -= log(u[i] - ulo_r(i)) + log(uhi_r(i) - u[i]);
     }
     for (int k = 1; k <= N; ++k)
-        for (int i = 0; i < 4; ++i) bar -= log(it->x[k][i] - xlo_r(i)) + log(xhi_r(i) - it->x[k][i]);
+        for (int i = p->i0; i < 4; ++i) bar -= log(it->x[k][i] - xlo_r(i)) + log(xhi_r(i) - it->x[k][i]);
     return J + mu * bar;
 }
 
@@ -215,10 +216,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
         dyn_eval(it->x[k], it->u[k], &d);
         for (int i = 0; i < 4; ++i) it->x[k + 1][i] = it->x[k][i] + dt * d.f[i];
         for (int i = 0; i < 2; ++i) it->zul[k][i] = it->zuu[k][i] = 1.0;
-        for (int i = 0; i < 4; ++i) it->zxl[k + 1][i] = it->zxu[k + 1][i] = 1.0;
+        for (int i = p->i0; i < 4; ++i) it->zxl[k + 1][i] = it->zxu[k + 1][i] = 1.0;
     }
     for (int k = 1; k <= N; ++k)
-        for (int i = 0; i < 4; ++i)
+        for (int i = p->i0; i < 4; ++i)
             if (!(it->x[k][i] > xlo_r(i)) || !(it->x[k][i] < xhi_r(i))) {
                 *iters_out = 0;
                 if (kkt_out) *kkt_out = INFINITY;
@@ -293,7 +294,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             }
             for (int i = 0; i < 4; ++i) {
                 sum_lam += fabs(y[i]);
-                sum_z += it->zxl[k + 1][i] + it->zxu[k + 1][i];
+                if (i >= p->i0) sum_z += it->zxl[k + 1][i] + it->zxu[k + 1][i];
             }
             if (k >= 1)
                 for (int i = 0; i < 4; ++i) {
@@ -314,7 +315,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             Wdd[k] = dt * v * (g * d.bp * d.bp + h * d.bpp) +
                      dt * y[2] * v / WHEELBASE * (-d.sb * d.bp * d.bp + d.cb * d.bpp);
         }
-        const int nvar = 6 * N, ncon = 4 * N;
+        const int nvar = 6 * N, ncon = 4 * N; /* counts of the reference NLP, independent of i0 */
         double s_d = fmax(100.0, (sum_lam + sum_z) / (nvar + ncon)) / 100.0;
         double s_c = fmax(100.0, sum_z / nvar) / 100.0;
         double err_c0 = 0.0;
@@ -322,7 +323,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             double ec = 0.0;
             err_c0 = 0.0;
             for (int k = 1; k <= N; ++k)
-                for (int i = 0; i < 4; ++i) {
+                for (int i = p->i0; i < 4; ++i) {
                     double cl = (it->x[k][i] - xlo_r(i)) * it->zxl[k][i], cu = (xhi_r(i) - it->x[k][i]) * it->zxu[k][i];
                     ec = fmax(ec, fmax(fabs(cl - mu), fabs(cu - mu)));
                     err_c0 = fmax(err_c0, fmax(cl, cu));
@@ -363,8 +364,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             memset(Pxp, 0, sizeof(Pxp));
             for (int i = 0; i < 4; ++i) {
                 double sl = it->x[N][i] - xlo_r(i), su = xhi_r(i) - it->x[N][i];
-                Pxx[i][i] = it->zxl[N][i] / sl + it->zxu[N][i] / su + delta_w;
-                px[i] = -mu / sl + mu / su;
+                Pxx[i][i] = (i >= p->i0 ? it->zxl[N][i] / sl + it->zxu[N][i] / su : 0.0) + delta_w;
+                px[i] = (i >= p->i0) ? -mu / sl + mu / su : 0.0;
             }
             for (int k = N - 1; k >= 0; --k) {
                 const double rdk = (k >= 1) ? rd_full : 0.0;
@@ -376,8 +377,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                     for (int i = 0; i < 4; ++i) {
                         for (int j = 0; j < 4; ++j) Lxx[i][j] = gn ? Qgs[k][i][j] : Qs[k][i][j];
                         double sl = it->x[k][i] - xlo_r(i), su = xhi_r(i) - it->x[k][i];
-                        Lxx[i][i] += it->zxl[k][i] / sl + it->zxu[k][i] / su + delta_w;
-                        lx[i] = lxs[k][i] - mu / sl + mu / su;
+                        Lxx[i][i] += (i >= p->i0 ? it->zxl[k][i] / sl + it->zxu[k][i] / su : 0.0) + delta_w;
+                        lx[i] = lxs[k][i] + (i >= p->i0 ? -mu / sl + mu / su : 0.0);
                     }
                     if (!gn) {
                         Lxx[2][2] += Wtt[k];
@@ -517,7 +518,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                 if (dzul[k][i] < 0) a_du = fmin(a_du, -tau * it->zul[k][i] / dzul[k][i]);
                 if (dzuu[k][i] < 0) a_du = fmin(a_du, -tau * it->zuu[k][i] / dzuu[k][i]);
             }
-            for (int i = 0; i < 4; ++i) {
+            for (int i = p->i0; i < 4; ++i) {
                 double sl = it->x[k + 1][i] - xlo_r(i), su = xhi_r(i) - it->x[k + 1][i], d = dxl[k + 1][i];
                 if (d < 0) a_pr = fmin(a_pr, -tau * sl / d);
                 if (d > 0) a_pr = fmin(a_pr, tau * su / d);
@@ -549,6 +550,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                 dyn_eval(trial.x[k], trial.u[k], &d);
                 for (int i = 0; i < 4; ++i) {
                     trial.x[k + 1][i] = trial.x[k][i] + dt * d.f[i];
+                    if (i < p->i0) continue;
                     if (trial.x[k + 1][i] - xlo_r(i) < 0.5 * (1.0 - tau) * (it->x[k + 1][i] - xlo_r(i)) ||
                         xhi_r(i) - trial.x[k + 1][i] < 0.5 * (1.0 - tau) * (xhi_r(i) - it->x[k + 1][i]))
                         feas = 0;
@@ -567,7 +569,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
         if (!accepted) trial = *it; /* keep the primal point; the dual step below still moves z */
         /* ---------------- dual step with its own fraction-to-the-boundary length ---------------- */
         for (int k = 1; k <= N; ++k)
-            for (int i = 0; i < 4; ++i) {
+            for (int i = p->i0; i < 4; ++i) {
                 double sln = trial.x[k][i] - xlo_r(i), sun = xhi_r(i) - trial.x[k][i];
                 double zl = it->zxl[k][i] + a_du * dzxl[k][i], zu = it->zxu[k][i] + a_du * dzxu[k][i];
                 trial.zxl[k][i] = fmax(fmin(zl, 1e10 * mu / sln), mu / (1e10 * sln));
@@ -592,7 +594,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
  * batch entry point (same argument meaning as include/mpc_mi355x.h : mpc_solve_batch)
  *   ref_table [M,4] x,y,v,heading; state [B,4]; ego_index [B]; vref [B,N+1] or NULL (table speeds);
  *   weights [B,3] speed,control,input_diff; is_collide [B]; others [B,V,4] x,y,speed,heading.
- *   flags bit0: collision-cost term on.
+ *   flags bit0: collision-cost term on; bit1: drop the (never active) |x|,|y| <= 500 bounds, as the GPU kernel does.
  * outputs: u0 [B,2]; U [B,N,2] / X [B,N+1,4] / lam [B,N+1,4] optional (NULL to skip);
  *   status [B]; iters [B]; kkt [B] optional.
  * ------------------------------------------------------------------------------------------ */
@@ -637,6 +639,7 @@ int oracle_solve_batch(int B, int N, double dt, const double *ref_table, int M, 
             p.osx[j] = ov[2] * dt * cos(ov[3]);
             p.osy[j] = ov[2] * dt * sin(ov[3]);
         }
+        p.i0 = (flags & 2u) ? 2 : 0;
         p.wdist = w_distance;
         p.wcoll = (p.cc && is_collide[b]) ? 3000.0 * w_collision : 0.0;
         iter_t *it = (iter_t *)malloc(sizeof(iter_t));

@@ -43,8 +43,13 @@ def _p(a, ty):
 
 
 def solve_batch(ref_table, state, ego_index, weights, is_collide, vref=None, others=None, N=20, dt=0.1,
-                collision_cost=False, w_distance=10.0, w_collision=1.0, tol=1e-8, max_iter=200, nthreads=0):
-    """Solve B instances on the CPU. Returns dict(u0, U, X, lam, status, iters, kkt)."""
+                collision_cost=False, w_distance=10.0, w_collision=1.0, tol=1e-8, max_iter=200, nthreads=0,
+                xy_bounds=True):
+    """Solve B instances on the CPU. Returns dict(u0, U, X, lam, status, iters, kkt).
+
+    xy_bounds=False drops the |x|,|y| <= 500 bounds of the reference NLP (agents/pure_mpc.py:272-274), which
+    can never be active for a horizon of N*dt seconds starting inside the intersection; the GPU kernel does
+    the same, tests/ check that both settings give the same controls."""
     lib = _load()
     ref_table = np.ascontiguousarray(ref_table, dtype=np.float64)
     state = np.ascontiguousarray(state, dtype=np.float64)
@@ -64,7 +69,8 @@ def solve_batch(ref_table, state, ego_index, weights, is_collide, vref=None, oth
     rc = lib.oracle_solve_batch(
         B, N, dt, _p(ref_table, ctypes.c_double), ref_table.shape[0], _p(state, ctypes.c_double),
         _p(ego_index, ctypes.c_int32), _p(vref, ctypes.c_double), _p(weights, ctypes.c_double),
-        _p(is_collide, ctypes.c_uint8), _p(others, ctypes.c_double), V, 1 if collision_cost else 0,
+        _p(is_collide, ctypes.c_uint8), _p(others, ctypes.c_double), V,
+        (1 if collision_cost else 0) | (0 if xy_bounds else 2),
         w_distance, w_collision, tol, max_iter, _p(u0, ctypes.c_double), _p(U, ctypes.c_double),
         _p(X, ctypes.c_double), _p(lam, ctypes.c_double), _p(status, ctypes.c_int32),
         _p(iters, ctypes.c_int32), _p(kkt, ctypes.c_double), nthreads)

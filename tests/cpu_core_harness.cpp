@@ -12,11 +12,18 @@ namespace {
 struct HostWS {
     double *base;
     const double *obase;
+    const double *table;  // [M][REF_COLS]
     size_t Bp;
-    int N1;
+    int N1, e0, M;
     double ld(int slot, int k) const { return base[((size_t)slot * N1 + k) * Bp]; }
     void st(int slot, int k, double v) { base[((size_t)slot * N1 + k) * Bp] = v; }
     double oth(int j, int c) const { return obase[((size_t)j * 4 + c) * Bp]; }
+    double ref(int k, int c) const {
+        int idx = e0 + k;
+        idx = idx > M - 1 ? M - 1 : idx;
+        idx = idx < 0 ? 0 : idx;
+        return table[idx * mpc::REF_COLS + c];
+    }
 };
 }  // namespace
 
@@ -28,23 +35,26 @@ extern "C" int core_solve_batch(int B, int N, double dt, const double *ref_table
     const size_t Bp = (size_t)((B + 63) / 64) * 64;
     const int cc = (flags & 1u) ? 1 : 0;
     const int Vuse = cc ? V : 0;
-    std::vector<double> work((size_t)mpc::STAGE_SLOTS * (N + 1) * Bp, NAN);
+    std::vector<double> work((size_t)mpc::STAGE_SLOTS_CC * (N + 1) * Bp, NAN);
     std::vector<double> oth((size_t)(Vuse > 0 ? Vuse : 1) * 4 * Bp, NAN);
+    std::vector<double> table((size_t)M * mpc::REF_COLS);
+    for (int i = 0; i < M; ++i) {
+        table[i * mpc::REF_COLS + mpc::R_X] = ref_table[i * 4 + 0];
+        table[i * mpc::REF_COLS + mpc::R_Y] = ref_table[i * 4 + 1];
+        table[i * mpc::REF_COLS + mpc::R_H] = ref_table[i * 4 + 3];
+        table[i * mpc::REF_COLS + mpc::R_SIN] = std::sin(ref_table[i * 4 + 3]);
+        table[i * mpc::REF_COLS + mpc::R_COS] = std::cos(ref_table[i * 4 + 3]);
+    }
     mpc::SolveParams P;
-    P.N = N; P.V = Vuse; P.max_iter = max_iter; P.collision_cost = cc; P.dt = dt; P.tol = tol; P.mu_init = 0.1;
+    P.N = N; P.V = Vuse; P.max_iter = max_iter; P.dt = dt; P.tol = tol; P.mu_init = 0.1;
     P.w_distance = w_distance;
     for (int b = 0; b < B; ++b) {
-        HostWS w{work.data() + b, oth.data() + b, Bp, N + 1};
+        HostWS w{work.data() + b, oth.data() + b, table.data(), Bp, N + 1, ego_index[b], M};
         for (int k = 0; k <= N; ++k) {
             int idx = ego_index[b] + k;
             idx = idx > M - 1 ? M - 1 : idx;
             idx = idx < 0 ? 0 : idx;
-            w.st(mpc::S_REF + 0, k, ref_table[idx * 4 + 0]);
-            w.st(mpc::S_REF + 1, k, ref_table[idx * 4 + 1]);
-            w.st(mpc::S_REF + 2, k, vref ? vref[(size_t)b * (N + 1) + k] : ref_table[idx * 4 + 2]);
-            w.st(mpc::S_REF + 3, k, ref_table[idx * 4 + 3]);
-            w.st(mpc::S_REF + 4, k, std::sin(ref_table[idx * 4 + 3]));
-            w.st(mpc::S_REF + 5, k, std::cos(ref_table[idx * 4 + 3]));
+            w.st(mpc::S_RV, k, vref ? vref[(size_t)b * (N + 1) + k] : ref_table[idx * 4 + 2]);
         }
         for (int j = 0; j < Vuse; ++j) {
             const double *ov = others + ((size_t)b * V + j) * 4;
@@ -58,8 +68,12 @@ extern "C" int core_solve_batch(int B, int N, double dt, const double *ref_table
         const double wcoll = (cc && collide) ? 3000.0 * w_collision : 0.0;
         int st, it, cur;
         double e;
-        mpc::solve_instance(P, w, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll, st, it,
-                            cur, e);
+        if (cc)
+            mpc::solve_instance<true>(P, w, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2],
+                                      wcoll, st, it, cur, e);
+        else
+            mpc::solve_instance<false>(P, w, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2],
+                                       wcoll, st, it, cur, e);
         const int CB = cur * mpc::BUF_SLOTS;
         u0[2 * b + 0] = w.ld(CB + mpc::B_U + 0, 0);
         u0[2 * b + 1] = w.ld(CB + mpc::B_U + 1, 0);

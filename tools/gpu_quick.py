@@ -11,7 +11,7 @@ eng = engine.MPCEngine(horizon=20, max_iter=100)
 for (B, V, cc) in [(512, 4, 0), (512, 8, 1)]:
     inp = synth.solver_inputs(B, V, seed=3)
     out = O.solve_batch(ref, inp['state'], inp['ego_index'], inp['weights'], inp['is_collide'], vref=inp['vref'],
-                        others=inp['others'], collision_cost=bool(cc), max_iter=100)
+                        others=inp['others'], collision_cost=bool(cc), max_iter=100, xy_bounds=False)
     g = eng.solve_batch(inp['state'], inp['ego_index'], inp['weights'], inp['is_collide'], vref=inp['vref'],
                         others=inp['others'], collision_cost=bool(cc))
     good = (out['status'] == 0) & (g['status'] == 0)
@@ -22,20 +22,25 @@ for (B, V, cc) in [(512, 4, 0), (512, 8, 1)]:
 
 import torch
 dev = torch.device('cuda:0')
-for (B, V, cc) in [(1024, 4, 0), (4096, 8, 1), (4096, 4, 0), (16384, 8, 1), (65536, 8, 1)]:
+for (B, V, cc) in [(1024, 4, 0), (4096, 4, 0), (4096, 8, 1)]:
     inp = synth.solver_inputs(B, V, seed=0)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
     args = dict(state=t(inp['state'], torch.float64), ego_index=t(inp['ego_index'], torch.int32),
                 weights=t(inp['weights'], torch.float64), is_collide=t(inp['is_collide'], torch.uint8),
                 vref=t(inp['vref'], torch.float64), others=t(inp['others'], torch.float64), collision_cost=bool(cc))
-    out = eng.solve_batch_torch(**args, sync=True)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(5):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); eng.solve_batch_torch(**args, out=out); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    it = out['iters'].cpu().numpy(); st = out['status'].cpu().numpy()
-    ms = np.median(ts)
-    print(f"B={B} V={V} cc={cc}: {ms:.3f} ms -> {B/ms*1e3:.0f} solves/s; iters mean {it.mean():.1f} max {it.max()} "
-          f"status {np.bincount(st)}; ws {eng.workspace_bytes(B, V)/2**20:.1f} MiB", flush=True)
+    for max_iter in (0, 5, 10, 20, 40, 100):
+        e = engine.MPCEngine(horizon=20, max_iter=max_iter)
+        for ipw in (1, 4, 16):
+            os.environ['MPC_IPW'] = str(ipw)
+            out = e.solve_batch_torch(**args, sync=True)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); e.solve_batch_torch(**args, out=out); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            it = out['iters'].cpu().numpy(); st = out['status'].cpu().numpy()
+            ms = np.median(ts)
+            print(f"B={B} V={V} cc={cc} max_iter={max_iter} ipw={ipw}: {ms:.3f} ms -> {B/ms*1e3:.0f} solves/s; iters mean {it.mean():.1f} "
+                  f"status {np.bincount(st)}", flush=True)
+        e.close()
