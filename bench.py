@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py - MPC solves/sec of the MI355X engine on BASELINE.json's headline configuration.
+
+A "step" is one pass of the hot path (`mpc_solve_batch`) over one batch of synthetic instances that is already
+resident in HBM: configs[2] of BASELINE.json = batch 4096, horizon 20, 8 other vehicles, collision cost on.
+With N GPUs every rank owns its own 4096 instances (weak scaling) and the step ends with the RCCL all-gather of
+the actions, the path's only exchange.  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 4096
+HORIZON = 20
+V = 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_SOLVE = 756 + 32 * V   # inputs + u0/status/iters, FP64
+
+
+def cpu_baseline(inp, sample: int):
+    """The CPU oracle (a from-scratch port of the same NLP + algorithm, oracle/mpc_oracle.c) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    from mpc_rl_for_avs_amd.reference_path import reference_states
+    cores = os.cpu_count() or 1
+    sl = slice(0, sample)
+    args = dict(vref=inp["vref"][sl], others=inp["others"][sl], collision_cost=True, max_iter=100,
+                xy_bounds=False, nthreads=cores)
+    ref = reference_states()
+    oracle_lib.solve_batch(ref, inp["state"][:64], inp["ego_index"][:64], inp["weights"][:64], inp["is_collide"][:64],
+                           vref=inp["vref"][:64], others=inp["others"][:64], collision_cost=True, max_iter=100,
+                           xy_bounds=False, nthreads=cores)  # warm-up (library load, thread pool)
+    t0 = time.perf_counter()
+    out = oracle_lib.solve_batch(ref, inp["state"][sl], inp["ego_index"][sl], inp["weights"][sl],
+                                 inp["is_collide"][sl], **args)
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
+                sample=f"first {sample} instances of the same batch, oracle/mpc_oracle.c (OpenMP over instances), "
+                       f"{dt:.2f} s wall, mean {float(out['iters'].mean()):.1f} iterations"), out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mpc_rl_for_avs_amd import engine, synth, sharding
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    inp = synth.solver_inputs(BATCH, V, seed=rank, N=HORIZON)
+    t = lambda x, dt_: torch.as_tensor(np.ascontiguousarray(x), dtype=dt_, device=dev)
+    args = dict(state=t(inp["state"], torch.float64), ego_index=t(inp["ego_index"], torch.int32),
+                weights=t(inp["weights"], torch.float64), is_collide=t(inp["is_collide"], torch.uint8),
+                vref=t(inp["vref"], torch.float64), others=t(inp["others"], torch.float64), collision_cost=True)
+    eng = engine.MPCEngine(horizon=HORIZON, max_iter=100, device=local_rank)
+    out = dict(u0=torch.empty((BATCH, 2), dtype=torch.float64, device=dev),
+               status=torch.empty(BATCH, dtype=torch.int32, device=dev),
+               iters=torch.empty(BATCH, dtype=torch.int32, device=dev))
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        eng.solve_batch_torch(**args, out=out)          # enqueued on torch's current stream
+        if world > 1:
+            gathered = sharding.all_gather_actions(out["u0"])
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    # kernel-only events (same stream the kernel is launched on = torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        eng.solve_batch_torch(**args, out=out)
+        ev[i][1].record()
+        if world > 1:
+            gathered = sharding.all_gather_actions(out["u0"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    status = out["status"].cpu().numpy()
+    iters = out["iters"].cpu().numpy()
+
+    if rank == 0:
+        value = world * BATCH * a.steps / elapsed
+        achieved = BATCH * ALG_BYTES_PER_SOLVE / (kern_ms * 1e-3) / 1e9
+        res = {
+            "metric": "MPC solves/sec (horizon=20, batch=4096)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch=4096 pure_mpc horizon=20, 8 other vehicles, "
+                                   "collision cost on, cold start, tol 1e-8, max_iter 100; per-GPU batch fixed",
+                       "batch_per_gpu": BATCH, "horizon": HORIZON, "n_vehicles": V, "seed": "rank",
+                       "parallelism": f"instance-sharded x{world}, all-gather of actions"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mpc_solve_kernel<CC=1,IPW=16,N=20>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
+                         "note": "path is FP64-issue-latency bound with an LDS-resident working set; "
+                                 "HBM carries only inputs/outputs (DESIGN.md section 4)"},
+            "solver": {"converged_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
+                       "iters_max": int(iters.max())},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb, oref = cpu_baseline(inp, sample=BATCH)
+            res["cpu_baseline"] = cb
+            u0 = out["u0"].cpu().numpy()
+            both = (status == 0) & (oref["status"] == 0)
+            err = np.abs(u0 - oref["u0"]).max(axis=1) / np.maximum(1.0, np.abs(oref["u0"]).max(axis=1))
+            res["parity"] = {"both_converged": int(both.sum()), "u0_rel_linf_max": float(err[both].max()),
+                             "u0_rel_linf_p99": float(np.percentile(err[both], 99)),
+                             "frac_within_1e-4": float((err[both] <= 1e-4).mean())}
+        print(json.dumps(res), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,20 +84,75 @@ MPC_HD double uhi_r(int i) { return i == 0 ? 5.0 + 5e-8 : (MPC_PI / 3.0) + 1e-8 
 
 constexpr double kInvWheelbase = 1.0 / 2.5;  // Vehicle.LENGTH, agents/utils.py:18
 
-// kinematic bicycle model (agents/pure_mpc.py:220-228): beta = atan(LENGTH_REAR/LENGTH * tan(delta))
-MPC_HD void dyn_eval(double theta, double delta, double &S, double &C, double &sb, double &cb) {
-    const double beta = atan(0.5 * tan(delta));
-    sb = sin(beta);
-    cb = cos(beta);
-    S = sin(theta + beta);
-    C = cos(theta + beta);
+// ---- lean FP64 math -------------------------------------------------------------------------------
+// The solver is bound by instruction issue / instruction-cache footprint, not by memory, so the generic
+// libm expansions (large-argument trig reduction, IEEE division with denormal fix-ups) are replaced by
+// bounded-range versions.  All arguments here are bounded by the NLP itself: |theta| <= pi(1+1e-8),
+// |delta| <= pi/3(1+1e-8), slacks and determinants are positive normal numbers.
+MPC_HD double frcp(double x) {  // 1/x for positive normal x
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+#else
+    return 1.0 / x;
+#endif
 }
-// beta' = d beta / d delta and beta'' from sin/cos(beta):  tan(delta) = 2 tan(beta)
+MPC_HD double frsqrt(double x) {  // 1/sqrt(x) for positive normal x
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);           // 1 - x y^2
+    y = fma(y * e, fma(0.375, e, 0.5), y);    // third-order step
+    e = fma(-x * y, y, 1.0);
+    return fma(y * e, 0.5, y);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+// sin and cos of |x| <= ~2 pi: two-constant Cody-Waite reduction to |r| <= pi/4, fdlibm kernel polynomials
+MPC_HD void sincos_b(double x, double &s, double &c) {
+    const double n = rint(x * 6.36619772367581382433e-01);  // x * 2/pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                              2.75573137070700676789e-06),
+                                       -1.98412698298579493134e-04),
+                                8.33333333332248946124e-03),
+                         -1.66666666666666324348e-01);
+    const double sr = fma(z * r, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                              -2.75573143513906633035e-07),
+                                       2.48015872894767294178e-05),
+                                -1.38888888888741095749e-03),
+                         4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = ((int)n) & 3;
+    const double sa = (q & 1) ? cr : sr, ca = (q & 1) ? sr : cr;
+    s = (q & 2) ? -sa : sa;
+    c = ((q + 1) & 2) ? -ca : ca;
+}
+
+// kinematic bicycle model (agents/pure_mpc.py:220-228): beta = atan(LENGTH_REAR/LENGTH * tan(delta)).
+// tan and atan are eliminated algebraically: with q = (4 cos^2 delta + sin^2 delta)^-1/2,
+//   cos(beta) = 2 cos(delta) q,  sin(beta) = sin(delta) q,  sin/cos(theta+beta) by the addition theorems.
+MPC_HD void dyn_eval(double theta, double delta, double &S, double &C, double &sb, double &cb) {
+    double sd, cd, st, ct;
+    sincos_b(delta, sd, cd);
+    sincos_b(theta, st, ct);
+    const double q = frsqrt(fma(3.0 * cd, cd, 1.0));
+    cb = 2.0 * cd * q;
+    sb = sd * q;
+    S = fma(st, cb, ct * sb);
+    C = fma(ct, cb, -st * sb);
+}
+// beta' = 2 q^2 and beta'' = 12 sin(delta) cos(delta) q^4 expressed through sin/cos(beta): q^2 = sb^2 + cb^2/4
 MPC_HD void beta_derivs(double sb, double cb, double &bp, double &bpp) {
-    const double t = 2.0 * sb / cb;
-    const double t2 = t * t, den = 4.0 + t2;
-    bp = 2.0 * (1.0 + t2) / den;
-    bpp = 12.0 * t * (1.0 + t2) / (den * den);
+    const double q2 = fma(sb, sb, 0.25 * cb * cb);
+    bp = 2.0 * q2;
+    bpp = 6.0 * sb * cb * q2;
 }
 
 // Quadratic tracking part of the stage cost at node k (agents/pure_mpc.py:134-156, multiplier 10 of :206):
@@ -133,16 +188,17 @@ MPC_HD double dist_cost(const SolveParams &P, const WS &w, int k, double x0, dou
     for (int j = 0; j < P.V; ++j) {
         const double px = x0 - (w.oth(j, 0) + k * w.oth(j, 2));
         const double py = x1 - (w.oth(j, 1) + k * w.oth(j, 3));
-        const double d = sqrt(px * px + py * py);
+        const double d2 = fma(px, px, py * py);
+        const double rd = frsqrt(d2), d = d2 * rd;
         const double cst = (d < 1.0 ? 1000.0 : 100.0) * P.w_distance;
-        const double de = d + 1e-6;
-        const double inv2 = 1.0 / (de * de);
+        const double rde = frcp(d + 1e-6);
+        const double inv2 = rde * rde;
         J += cst * inv2;
         if (d8) {
-            const double dpsi = -2.0 * cst * inv2 / de;
-            const double nx = px / d, ny = py / d;
+            const double dpsi = -2.0 * cst * inv2 * rde;
+            const double nx = px * rd, ny = py * rd;
             const double d2psi = 6.0 * cst * inv2 * inv2;
-            const double tt = dpsi / d;
+            const double tt = dpsi * rd;
             g0 += dpsi * nx;
             g1 += dpsi * ny;
             h00 += d2psi * nx * nx + tt * (1.0 - nx * nx);
@@ -186,7 +242,7 @@ MPC_HD void cost_grad(const WS &w, int CB, int k, double sf, double ws_, double 
 template <bool CC, class WS>
 MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, double alpha, double frac, double sf,
                     double ws_, double wc_, double wd_, double wcoll, const double *x0, double &Jout, double &barout) {
-    const int N = P.N;
+    const int N = WS::kN > 0 ? WS::kN : P.N;  // compile-time horizon turns LDS offsets into immediates
     const double dt = P.dt;
     const int CB = cb * BUF_SLOTS, TB = tb * BUF_SLOTS;
     double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
@@ -231,8 +287,7 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
             const double d0 = u0 - up0, d1 = u1 - up1;
             J += 0.01 * sf * wd_ * (d0 * d0 + d1 * d1);
         }
-        bar -= log(u0 - ulo_r(0)) + log(uhi_r(0) - u0);
-        bar -= log(u1 - ulo_r(1)) + log(uhi_r(1) - u1);
+        const double slack_u = ((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1));
         up0 = u0;
         up1 = u1;
         double S, C, sb, cbeta;
@@ -257,8 +312,8 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
         x_1 = n1;
         x_2 = n2;
         x_3 = n3;
-        bar -= log(x_2 - xlo_r(0)) + log(xhi_r(0) - x_2);
-        bar -= log(x_3 - xlo_r(1)) + log(xhi_r(1) - x_3);
+        // one log per stage: the 8 slacks are bounded away from under/overflow (1e-12 .. 1e2 each)
+        bar -= log(slack_u * (((x_2 - xlo_r(0)) * (xhi_r(0) - x_2)) * ((x_3 - xlo_r(1)) * (xhi_r(1) - x_3))));
         if (k + 1 < N) {
             J += sf * track_cost(w, k + 1, ws_, x_0, x_1, x_2, x_3, (double *)nullptr);
             if (CC) {
@@ -290,11 +345,13 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
 template <bool APPLY, class WS>
 MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu, double tau, double &a_pr,
                          double &a_du) {
-    const int N = P.N;
+    const int N = WS::kN > 0 ? WS::kN : P.N;  // compile-time horizon turns LDS offsets into immediates
     const double dt = P.dt;
     const int CB = cb * BUF_SLOTS, NB = nb * BUF_SLOTS;
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
-    double apr = 1.0, adu = APPLY ? a_du : 1.0;
+    // step limits without divisions: primal ratio rp = max |d|/s ; dual ratio (-dz)/z kept as a fraction
+    double rp = 0.0, rdn = 0.0, rdd = 1.0;
+    const double adu = a_du;
     for (int k = 0; k < N; ++k) {
         double du0 = w.ld(S_KF + 0, k) + w.ld(S_KX + 0, k) * d0 + w.ld(S_KX + 1, k) * d1 + w.ld(S_KX + 2, k) * d2 +
                      w.ld(S_KX + 3, k) * d3;
@@ -319,45 +376,33 @@ MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu,
         d0 = n0; d1 = n1; d2 = n2; d3 = n3;
         dp0 = du0; dp1 = du1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double ui = w.ld(CB + B_U + i, k), d = (i == 0) ? du0 : du1;
-            const double sl = ui - ulo_r(i), su = uhi_r(i) - ui;
-            const double zl = w.ld(S_ZUL + i, k), zu = w.ld(S_ZUU + i, k);
-            const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
+        for (int i = 0; i < 4; ++i) {  // i = 0,1: controls of node k;  i = 2,3: theta, v of node k+1
+            const bool isu = i < 2;
+            const int j = isu ? i : i - 2;
+            const double lo = isu ? ulo_r(j) : xlo_r(j), hi = isu ? uhi_r(j) : xhi_r(j);
+            const int kk = isu ? k : k + 1;
+            const int sv = isu ? (CB + B_U + j) : (CB + B_X + 2 + j);
+            const int szl = isu ? (S_ZUL + j) : (S_ZXL + j), szu = isu ? (S_ZUU + j) : (S_ZXU + j);
+            const double val = w.ld(sv, kk), d = (i == 0) ? du0 : (i == 1) ? du1 : (i == 2) ? d2 : d3;
+            const double rsl = frcp(val - lo), rsu = frcp(hi - val);
+            const double zl = w.ld(szl, kk), zu = w.ld(szu, kk);
+            const double dzl = (mu - zl * d) * rsl - zl, dzu = (mu + zu * d) * rsu - zu;
             if (!APPLY) {
-                if (d < 0) apr = fmin2(apr, -tau * sl / d);
-                if (d > 0) apr = fmin2(apr, tau * su / d);
-                if (dzl < 0) adu = fmin2(adu, -tau * zl / dzl);
-                if (dzu < 0) adu = fmin2(adu, -tau * zu / dzu);
+                rp = fmax2(rp, fmax2(-d * rsl, d * rsu));
+                if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
+                if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
             } else {
-                const double un = w.ld(NB + B_U + i, k);
-                const double sln = un - ulo_r(i), sun = uhi_r(i) - un;
-                w.st(S_ZUL + i, k, fmax2(fmin2(zl + adu * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
-                w.st(S_ZUU + i, k, fmax2(fmin2(zu + adu * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double xi = w.ld(CB + B_X + 2 + i, k + 1), d = (i == 0) ? d2 : d3;
-            const double sl = xi - xlo_r(i), su = xhi_r(i) - xi;
-            const double zl = w.ld(S_ZXL + i, k + 1), zu = w.ld(S_ZXU + i, k + 1);
-            const double dzl = (mu - zl * d) / sl - zl, dzu = (mu + zu * d) / su - zu;
-            if (!APPLY) {
-                if (d < 0) apr = fmin2(apr, -tau * sl / d);
-                if (d > 0) apr = fmin2(apr, tau * su / d);
-                if (dzl < 0) adu = fmin2(adu, -tau * zl / dzl);
-                if (dzu < 0) adu = fmin2(adu, -tau * zu / dzu);
-            } else {
-                const double xn = w.ld(NB + B_X + 2 + i, k + 1);
-                const double sln = xn - xlo_r(i), sun = xhi_r(i) - xn;
-                w.st(S_ZXL + i, k + 1, fmax2(fmin2(zl + adu * dzl, 1e10 * mu / sln), mu / (1e10 * sln)));
-                w.st(S_ZXU + i, k + 1, fmax2(fmin2(zu + adu * dzu, 1e10 * mu / sun), mu / (1e10 * sun)));
+                const int nv = isu ? (NB + B_U + j) : (NB + B_X + 2 + j);
+                const double vn = w.ld(nv, kk);
+                const double ml = mu * frcp(vn - lo), mh = mu * frcp(hi - vn);
+                w.st(szl, kk, fmax2(fmin2(zl + adu * dzl, 1e10 * ml), 1e-10 * ml));
+                w.st(szu, kk, fmax2(fmin2(zu + adu * dzu, 1e10 * mh), 1e-10 * mh));
             }
         }
     }
     if (!APPLY) {
-        a_pr = apr;
-        a_du = adu;
+        a_pr = (rp * 1.0 > tau) ? tau / rp : 1.0;
+        a_du = (rdn * 1.0 > tau * rdd) ? tau * rdd / rdn : 1.0;
     }
 }
 
@@ -370,7 +415,7 @@ MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu,
 template <bool CC, class WS>
 MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double ws_, double wc_, double wd_,
                            double wcoll, int &status_out, int &iters_out, int &cur_out, double &kkt_out) {
-    const int N = P.N;
+    const int N = WS::kN > 0 ? WS::kN : P.N;  // compile-time horizon turns LDS offsets into immediates
     const double dt = P.dt;
     int cur = 0;
     status_out = 1;
@@ -538,14 +583,14 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
             double pp00 = 0, pp01 = 0, pp11 = 0, px0 = 0.0, px1 = 0.0, px2, px3, ppv0 = 0, ppv1 = 0;
             {
                 double xi = w.ld(CB + B_X + 2, N);
-                double sl = xi - xlo_r(0), su = xhi_r(0) - xi;
-                p22 = w.ld(S_ZXL + 0, N) / sl + w.ld(S_ZXU + 0, N) / su + delta_w;
-                px2 = -mu / sl + mu / su;
+                double rl = frcp(xi - xlo_r(0)), ru = frcp(xhi_r(0) - xi);
+                p22 = w.ld(S_ZXL + 0, N) * rl + w.ld(S_ZXU + 0, N) * ru + delta_w;
+                px2 = mu * (ru - rl);
                 xi = w.ld(CB + B_X + 3, N);
-                sl = xi - xlo_r(1);
-                su = xhi_r(1) - xi;
-                p33 = w.ld(S_ZXL + 1, N) / sl + w.ld(S_ZXU + 1, N) / su + delta_w;
-                px3 = -mu / sl + mu / su;
+                rl = frcp(xi - xlo_r(1));
+                ru = frcp(xhi_r(1) - xi);
+                p33 = w.ld(S_ZXL + 1, N) * rl + w.ld(S_ZXU + 1, N) * ru + delta_w;
+                px3 = mu * (ru - rl);
             }
             for (int k = N - 1; k >= 0; --k) {
                 const double rdk = (k >= 1) ? rd_full : 0.0;
@@ -592,13 +637,14 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     }
                     lx0 = lx[0];
                     lx1 = lx[1];
-                    double xi = w.ld(CB + B_X + 2, k), sl = xi - xlo_r(0), su = xhi_r(0) - xi;
-                    l22 += qtt + w.ld(S_ZXL + 0, k) / sl + w.ld(S_ZXU + 0, k) / su + delta_w;
-                    lx2 = lx[2] - mu / sl + mu / su;
-                    sl = v - xlo_r(1);
-                    su = xhi_r(1) - v;
-                    l33 = q33 + w.ld(S_ZXL + 1, k) / sl + w.ld(S_ZXU + 1, k) / su + delta_w;
-                    lx3 = lx[3] - mu / sl + mu / su;
+                    const double xi = w.ld(CB + B_X + 2, k);
+                    double rl = frcp(xi - xlo_r(0)), ru = frcp(xhi_r(0) - xi);
+                    l22 += qtt + w.ld(S_ZXL + 0, k) * rl + w.ld(S_ZXU + 0, k) * ru + delta_w;
+                    lx2 = lx[2] + mu * (ru - rl);
+                    rl = frcp(v - xlo_r(1));
+                    ru = frcp(xhi_r(1) - v);
+                    l33 = q33 + w.ld(S_ZXL + 1, k) * rl + w.ld(S_ZXU + 1, k) * ru + delta_w;
+                    lx3 = lx[3] + mu * (ru - rl);
                 }
                 double luu00, luu11, lu0, lu1, lp0 = 0.0, lp1 = 0.0;
                 {
@@ -607,13 +653,13 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                         um0 = w.ld(CB + B_U + 0, k - 1);
                         um1 = w.ld(CB + B_U + 1, k - 1);
                     }
-                    double sl = u0 - ulo_r(0), su = uhi_r(0) - u0;
-                    luu00 = rc + rdk + w.ld(S_ZUL + 0, k) / sl + w.ld(S_ZUU + 0, k) / su + delta_w;
-                    lu0 = rc * u0 + rdk * (u0 - um0) - mu / sl + mu / su;
-                    sl = u1 - ulo_r(1);
-                    su = uhi_r(1) - u1;
-                    luu11 = rc + rdk + w.ld(S_ZUL + 1, k) / sl + w.ld(S_ZUU + 1, k) / su + delta_w + wdd;
-                    lu1 = rc * u1 + rdk * (u1 - um1) - mu / sl + mu / su;
+                    double rl = frcp(u0 - ulo_r(0)), ru = frcp(uhi_r(0) - u0);
+                    luu00 = rc + rdk + w.ld(S_ZUL + 0, k) * rl + w.ld(S_ZUU + 0, k) * ru + delta_w;
+                    lu0 = rc * u0 + rdk * (u0 - um0) + mu * (ru - rl);
+                    rl = frcp(u1 - ulo_r(1));
+                    ru = frcp(uhi_r(1) - u1);
+                    luu11 = rc + rdk + w.ld(S_ZUL + 1, k) * rl + w.ld(S_ZUU + 1, k) * ru + delta_w + wdd;
+                    lu1 = rc * u1 + rdk * (u1 - um1) + mu * (ru - rl);
                     lp0 = -rdk * (u0 - um0);
                     lp1 = -rdk * (u1 - um1);
                 }
@@ -657,7 +703,8 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                     ok = false;
                     break;
                 }
-                const double i00 = hc / det, i01 = -hb / det, i11 = ha / det;
+                const double idet = frcp(det);
+                const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
                 // gains
                 const double kx00 = -(i00 * hxu00 + i01 * hxu01), kx01 = -(i00 * hxu10 + i01 * hxu11);
                 const double kx02 = -(i00 * hxu20 + i01 * hxu21), kx03 = -(i00 * hxu30 + i01 * hxu31);

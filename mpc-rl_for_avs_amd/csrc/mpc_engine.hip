@@ -37,14 +37,17 @@ int fail(int code, const std::string &msg) {
 constexpr int kBlock = 64;  // one wave64 per workgroup
 
 // LDS-resident workspace of one lane: element (slot, stage k) of this instance
-template <int IPW>
+// (NC > 0: horizon known at compile time, so slot offsets fold into the ds_read/ds_write immediates)
+template <int IPW, int NC>
 struct LdsWS {
+    static constexpr int kN = NC;
     double *base;         // work + lane
     const double *obase;  // others + lane
     const double *table;  // [M][REF_COLS]
-    int N1, e0, M;
-    __device__ __forceinline__ double ld(int slot, int k) const { return base[(slot * N1 + k) * IPW]; }
-    __device__ __forceinline__ void st(int slot, int k, double v) { base[(slot * N1 + k) * IPW] = v; }
+    int N1r, e0, M;
+    __device__ __forceinline__ int n1() const { return NC > 0 ? NC + 1 : N1r; }
+    __device__ __forceinline__ double ld(int slot, int k) const { return base[(slot * n1() + k) * IPW]; }
+    __device__ __forceinline__ void st(int slot, int k, double v) { base[(slot * n1() + k) * IPW] = v; }
     __device__ __forceinline__ double oth(int j, int c) const { return obase[(j * 4 + c) * IPW]; }
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
@@ -62,7 +65,7 @@ size_t lds_bytes(bool cc, int ipw, int N, int M, int V) {
            sizeof(double);
 }
 
-template <bool CC, int IPW>
+template <bool CC, int IPW, int NC>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     double *__restrict__ u0_out, double *__restrict__ U_out, double *__restrict__ X_out,
     int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
     extern __shared__ double smem[];
-    const int N = P.N;
+    const int N = NC > 0 ? NC : P.N;
     double *s_table = smem;                                     // [M][REF_COLS]
     double *s_work = s_table + M * mpc::REF_COLS;               // [slots][N+1][IPW]
     double *s_oth = s_work + stage_slots(CC) * (N + 1) * IPW;   // [V][4][IPW]
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     const int b = blockIdx.x * IPW + lane;
     if (lane >= IPW || b >= B) return;
 
-    LdsWS<IPW> w{s_work + lane, s_oth + lane, s_table, N + 1, ego_index[b], M};
+    LdsWS<IPW, NC> w{s_work + lane, s_oth + lane, s_table, N + 1, ego_index[b], M};
     double x0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) x0[i] = state[(size_t)b * 4 + i];
@@ -149,8 +152,10 @@ namespace {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
-// instances per wave: the largest batch slice that still leaves every CU at least one workgroup,
-// limited by what the CU's LDS can hold
+// Instances per wave.  Measured on MI355X (tools/gpu_quick.py): the solve is bound by the dependent-issue
+// latency of a wave, and waves that share a CU slow each other down, so one wave per CU is the sweet spot:
+// take the smallest slice that keeps the number of workgroups within the number of CUs, capped by what the
+// CU's LDS can hold (16 instances).  MPC_IPW=1|4|16 overrides (for experiments).
 int choose_ipw(const mpc_handle *h, bool cc, int B, int N, int V) {
     const char *env = getenv("MPC_IPW");
     const int cands[3] = {1, 4, 16};
@@ -163,18 +168,17 @@ int choose_ipw(const mpc_handle *h, bool cc, int B, int N, int V) {
     for (int c : cands) {
         if (lds_bytes(cc, c, N, h->M, V) > h->lds_per_cu) break;
         best = c;
-        // enough workgroups of this size to give every SIMD of every CU one wave?
-        if ((long long)B <= (long long)c * h->num_cu * 4) break;
+        if ((long long)B <= (long long)c * h->num_cu) break;
     }
     return best;
 }
 
-template <bool CC, int IPW>
+template <bool CC, int IPW, int NC>
 int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
            const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
            const uint8_t *d_coll, const double *d_others, double *d_u0, double *d_U, double *d_X,
            int32_t *d_status, int32_t *d_iters) {
-    auto kern = mpc_solve_kernel<CC, IPW>;
+    auto kern = mpc_solve_kernel<CC, IPW, NC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const unsigned grid = (unsigned)((B + IPW - 1) / IPW);
@@ -360,9 +364,15 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     if (lds > h->lds_per_cu)
         return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: horizon/others/reference too large for the LDS workspace");
     int rc;
+#define MPC_LAUNCH_N(CCV, IPWV, NCV)                                                                           \
+    rc = launch<CCV, IPWV, NCV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll,   \
+                                d_others, d_u0, d_U, d_X, d_status, d_iters)
 #define MPC_LAUNCH(CCV, IPWV)                                                                                   \
-    rc = launch<CCV, IPWV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, \
-                           d_u0, d_U, d_X, d_status, d_iters)
+    do {                                                                                                        \
+        if (N == 20) MPC_LAUNCH_N(CCV, IPWV, 20);       /* BASELINE horizon */                                  \
+        else if (N == 16) MPC_LAUNCH_N(CCV, IPWV, 16);  /* reference cfg.yaml default */                        \
+        else MPC_LAUNCH_N(CCV, IPWV, 0);                                                                        \
+    } while (0)
     if (cc) {
         if (ipw == 16) MPC_LAUNCH(true, 16);
         else if (ipw == 4) MPC_LAUNCH(true, 4);
@@ -373,6 +383,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
         else MPC_LAUNCH(false, 1);
     }
 #undef MPC_LAUNCH
+#undef MPC_LAUNCH_N
     if (rc) return rc;
 
     if (!dev) {

@@ -1,0 +1,47 @@
+"""Batch sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+MPC instances are independent (one per parallel RL env), so the batch is cut into contiguous blocks, every
+rank solves its block with its own engine, and the only exchange is the all-gather of the resulting actions
+(`[B/G, 2]` float64 per rank, 8 KiB at B = 4096 and G = 8 - latency-bound on xGMI) so that every learner
+sees all actions, as `a2c_mpc` / `ppo_mpc` need (reference agents/ppo_mpc.py:422-432 steps every env with its
+MPC action).  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of `total` instances owned by `rank` (blocks differ by at most one)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_actions(local_u0, group=None):
+    """Gather equally sized per-rank action blocks [b, 2] into [world*b, 2] on every rank (one collective)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local_u0.shape[0],) + tuple(local_u0.shape[1:]), dtype=local_u0.dtype,
+                      device=local_u0.device)
+    dist.all_gather_into_tensor(out, local_u0.contiguous(), group=group)
+    return out
+
+
+def all_gather_ragged(local_u0, total: int, group=None):
+    """Gather blocks made by `shard_range` (sizes may differ by one) into the full [total, 2] array."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    width = -(-total // world)
+    pad = torch.zeros((width,) + tuple(local_u0.shape[1:]), dtype=local_u0.dtype, device=local_u0.device)
+    pad[: local_u0.shape[0]] = local_u0
+    full = all_gather_actions(pad, group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        parts.append(full[r * width: r * width + (hi - lo)])
+    del rank
+    return torch.cat(parts, dim=0)

@@ -10,6 +10,7 @@
 
 namespace {
 struct HostWS {
+    static constexpr int kN = 0;  // runtime horizon
     double *base;
     const double *obase;
     const double *table;  // [M][REF_COLS]

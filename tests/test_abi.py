@@ -1,0 +1,72 @@
+"""The C-ABI shared library: it loads, exports every symbol include/mpc_mi355x.h declares, and refuses to
+run without a GPU (CPU only - no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mpc_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpc_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mpc_rl_for_avs_amd import engine
+    lib = engine.load_library()
+    names = _declared_symbols()
+    assert {"mpc_create", "mpc_destroy", "mpc_set_reference", "mpc_solve_batch", "mpc_last_error",
+            "mpc_version", "mpc_default_config", "mpc_workspace_bytes"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mpc_mi355x.h but not exported"
+    assert lib.mpc_version() == 1
+    assert sorted(engine._EXPORTS) == names
+
+
+def test_default_config_and_argument_checks():
+    from mpc_rl_for_avs_amd import engine
+    lib = engine.load_library()
+    cfg = engine._Config()
+    lib.mpc_default_config(ctypes.byref(cfg))
+    assert (cfg.horizon, cfg.max_iter, cfg.device) == (20, 100, 0)
+    assert cfg.dt == 0.1 and cfg.tol == 1e-8 and cfg.w_distance == 10.0 and cfg.w_collision == 1.0
+    assert cfg.struct_size == ctypes.sizeof(engine._Config)
+    h = ctypes.c_void_p()
+    cfg.horizon = 0
+    assert lib.mpc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1          # MPC_ERR_INVALID_ARG
+    assert b"horizon" in lib.mpc_last_error()
+    cfg.horizon = 20
+    cfg.struct_size = 4
+    assert lib.mpc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert lib.mpc_solve_batch(None, 1, None, None, None, None, None, None, 0, 0, None, None, None, None, None,
+                               None) == -1
+
+
+def test_no_gpu_fails_loudly():
+    """Without a HIP device the engine must raise, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mpc_rl_for_avs_amd import engine
+    with pytest.raises(engine.EngineError, match="no HIP device"):
+        engine.MPCEngine()
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+
+    class Env:
+        config = {"simulation_frequency": 30, "policy_frequency": 10, "observation": {"vehicles_count": 10}}
+    with pytest.raises(engine.EngineError):
+        PureMPC_Agent(Env(), dict(horizon=20, render=False, weight_speed=1, weight_control=1, weight_input_diff=1))
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference the oracle (test infrastructure) anywhere."""
+    pkg = os.path.join(ROOT, "mpc-rl_for_avs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in text and "nlp_spec" not in text and "mpc_oracle" not in text, f

@@ -1,0 +1,67 @@
+"""Multi-process path on CPU: world_size 2 over gloo.  Each rank solves its contiguous shard (here with the CPU
+oracle standing in for the GPU engine - the sharding / gather logic is what is under test) and the all-gather
+of the actions must reproduce the single-process result on every rank."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpc_rl_for_avs_amd import sharding, synth
+    from mpc_rl_for_avs_amd.reference_path import reference_states
+    import oracle_lib
+    inp = synth.solver_inputs(total, 4, seed=21)
+    lo, hi = sharding.shard_range(total, rank, world)
+    out = oracle_lib.solve_batch(reference_states(), inp["state"][lo:hi], inp["ego_index"][lo:hi],
+                                 inp["weights"][lo:hi], inp["is_collide"][lo:hi], vref=inp["vref"][lo:hi],
+                                 max_iter=60, nthreads=1)
+    full = sharding.all_gather_ragged(torch.from_numpy(out["u0"]), total)
+    q.put((rank, full.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [16, 15])
+def test_sharded_solve_gathers_to_single_process_result(total, oracle, ref_table):
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(total, 4, seed=21)
+    want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
+                              vref=inp["vref"], max_iter=60, nthreads=1)["u0"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + total
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert got[r].shape == (total, 2)
+        assert np.array_equal(got[r], want)
+
+
+def test_shard_range_partitions():
+    from mpc_rl_for_avs_amd.sharding import shard_range
+    for total in (0, 1, 7, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference interface (pure_mpc.py) against golden vectors produced by the reference's
+own numpy code (tests/golden/make_golden.py), plus the hand-derived geometry KATs that replace shapely (CPU only).
+The solve itself is stubbed by a recording fake engine here - the real engine needs a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+class Env:
+    config = {"simulation_frequency": 30, "policy_frequency": 10, "observation": {"vehicles_count": 10}}
+
+
+CFG = dict(horizon=20, render=False, ttc_threshold=3, weight_speed=1, weight_control=1, weight_input_diff=1,
+           speed_override=0)
+
+
+class FakeEngine:
+    def __init__(self):
+        self.calls = []
+
+    def solve_batch(self, state, ego_index, weights, is_collide, vref=None, others=None, collision_cost=False,
+                    want_trajectories=True):
+        self.calls.append(dict(state=state.copy(), ego_index=ego_index.copy(), weights=weights.copy(),
+                               is_collide=is_collide.copy(), vref=vref.copy(), others=others,
+                               collision_cost=collision_cost))
+        B = state.shape[0]
+        return dict(u0=np.tile([0.5, -0.1], (B, 1)), status=np.zeros(B, np.int32), iters=np.zeros(B, np.int32))
+
+
+@pytest.fixture()
+def agent():
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    return PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "reference_numpy.npz"))
+
+
+def test_parse_obs_matches_reference(agent, gold):
+    obs = gold["parse_obs_in"]
+    for b in range(obs.shape[0]):
+        agent._parse_obs(obs[b])
+        e = agent.ego_vehicle
+        got = np.array([e.position[0], e.position[1], e.heading, e.speed, agent.observed_vehicles_count], np.float64)
+        assert np.array_equal(got, gold["parse_ego"][b])
+        oth = np.zeros((9, 4))
+        for j, v in enumerate(agent.agent_vehicles):
+            oth[j] = (v.position[0], v.position[1], v.speed, v.heading)
+        assert np.array_equal(oth, gold["parse_others"][b])
+    with pytest.raises(TypeError):
+        agent._parse_obs([[0.0] * 8] * 10)
+    with pytest.raises(ValueError):
+        agent._parse_obs(np.zeros((9, 8), np.float32))
+    with pytest.raises(ValueError):
+        agent.predict_batch(np.zeros((3, 9, 8), np.float32))
+    got = np.array([agent.normalize_angle(a) for a in gold["normalize_in"]])
+    assert np.array_equal(got, gold["normalize_out"])
+
+
+def test_update_reference_states_matches_reference(agent, gold):
+    agent._parse_obs(gold["parse_obs_in"][0])
+    st = agent._states[0]
+    for row, want in zip(gold["update_ref_in"], gold["update_ref_speed_out"]):
+        ego_index, is_collide, mem, rl, speed, c0, c1 = row
+        conflict = [None if c < 0 else int(c) for c in (c0, c1)]
+        st.ego_index, st.is_collide, st.collision_memory = int(ego_index), bool(is_collide), int(mem)
+        st.conflict_index = conflict
+        st.memorized_conflict_indices = conflict if mem > 0 else None
+        st.last_valid_stop_point = None
+        rs = None if np.isnan(rl) else np.array([[rl]])
+        ref = agent.update_reference_states(0, rs, st, speed)
+        assert np.array_equal(ref[:, 2], want), row
+        assert np.array_equal(ref[:, [0, 1, 3]], gold["reference_states"][:, [0, 1, 3]])
+
+
+def test_future_position_predictors_match_reference(agent, gold):
+    for (x, y, sp, vref), want, n in zip(gold["ego_future_in"], gold["ego_future_out"], gold["ego_future_len"]):
+        fut = agent.predict_ego_future_positions(np.array([x, y], np.float32), sp, -1.5, 3.5, 0.1, 30, vref)
+        assert len(fut) == n
+        got = np.asarray([np.asarray(p, dtype=np.float64) for p in fut])
+        np.testing.assert_allclose(got, want[:n], rtol=0, atol=1e-12)
+    fut = agent.predict_future_positions(np.array([-20.0, 2.0], np.float32), np.float32(8.0), np.float32(0.1), 0.1, 30)
+    np.testing.assert_allclose(np.asarray(fut, np.float64), gold["agent_future_out"], rtol=0, atol=1e-12)
+
+
+def test_path_crossing_kats():
+    """Hand-derived replacements for shapely's LineString.intersection cases (agents/pure_mpc.py:615-633)."""
+    from mpc_rl_for_avs_amd.pure_mpc import first_path_crossing
+    ego = np.array([[0.0, 0.0], [0.0, 1.0], [0.0, 2.0], [1.0, 3.0]])
+    # transversal crossing -> the Point
+    np.testing.assert_allclose(first_path_crossing(ego, np.array([[-1.0, 0.5], [1.0, 0.5]])), [0.0, 0.5])
+    # no crossing
+    assert first_path_crossing(ego, np.array([[2.0, 0.0], [3.0, 0.0]])) is None
+    # touching at a vertex
+    np.testing.assert_allclose(first_path_crossing(ego, np.array([[-1.0, 2.0], [0.0, 2.0]])), [0.0, 2.0])
+    # two crossings -> the first one along the ego path
+    p = first_path_crossing(np.array([[0.0, 0.0], [2.0, 0.0], [2.0, 2.0]]), np.array([[1.0, -1.0], [3.0, 1.0]]))
+    np.testing.assert_allclose(p, [2.0, 0.0])          # the line passes through the corner vertex first
+    # collinear overlap -> a vertex in the middle of the overlapping stretch
+    p = first_path_crossing(ego, np.array([[0.0, 0.5], [0.0, 1.5]]))
+    assert p[0] == 0.0 and 0.5 <= p[1] <= 1.5
+    # degenerate agent (standing still) on the path
+    np.testing.assert_allclose(first_path_crossing(ego, np.array([[0.0, 1.0], [0.0, 1.0]])), [0.0, 1.0])
+
+
+def test_collision_state_machine_and_solver_inputs(agent):
+    """Crossing vehicle -> is_collide with a 10-step memory, speed profile ramps to zero before the conflict
+    point, speed weight forced to 100 is left to the engine (is_collide flag)."""
+    obs = np.zeros((10, 8), np.float32)
+    obs[0] = [1, 2.0, 30.0, 0.0, -10.0, -np.pi / 2, -1.0, 0.0]      # ego driving down the approach lane
+    obs[1] = [1, -15.0, 12.0, 8.0, 0.0, 0.0, 0.0, 1.0]              # crosses the ego path at (2, 12) ahead
+    act = agent.predict(obs)
+    assert act.shape == (2,) and np.allclose(act, [0.5, -0.1])
+    call = agent._engine.calls[-1]
+    assert agent.is_collide and call["is_collide"][0] == 1
+    assert agent.collision_memory == 10
+    assert call["ego_index"][0] == 19 and agent.ego_index == 19
+    assert agent.conflict_index[0] == 37                              # reference point nearest to (2, 12)
+    stop = 37 - 5
+    want = np.r_[np.linspace(10.0, 0.0, stop - 19), np.zeros(21 - (stop - 19))]
+    np.testing.assert_allclose(call["vref"][0], want, atol=1e-6)
+    assert np.allclose(agent.stop_point, agent.reference_trajectory[stop])
+    # vehicle gone: the memory keeps the collision state for 10 more steps, then clears
+    obs[1] = 0
+    for i in range(10):
+        agent.predict(obs)
+        assert agent.is_collide and agent.collision_memory == 9 - i
+    agent.predict(obs)
+    assert not agent.is_collide and agent._engine.calls[-1]["is_collide"][0] == 0
+    assert np.allclose(agent._engine.calls[-1]["vref"][0], 10.0)
+    # RL overrides: reference speed (v0 agents) and weights (v1 agents)
+    agent.predict(obs, ref_speed=np.array([[0.7]]))
+    assert np.allclose(agent._engine.calls[-1]["vref"][0], 0.7)
+    agent.predict(obs, weights_from_RL=np.array([[0.2, 0.3, 0.4]]))
+    assert np.allclose(agent._engine.calls[-1]["weights"][0], [0.2, 0.3, 0.4])
+    assert agent.predict(obs, return_numpy=False).acceleration == 0.5
+
+
+def test_predict_batch_equals_looped_predict():
+    from mpc_rl_for_avs_amd import synth
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    obs = synth.make_obs_batch(12, 4, seed=9)
+    a = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
+    a.predict_batch(obs)
+    batch = a._engine.calls[-1]
+    for b in range(12):
+        s = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
+        s.predict(obs[b])
+        one = s._engine.calls[-1]
+        for k in ("state", "ego_index", "weights", "is_collide", "vref"):
+            assert np.array_equal(batch[k][b], one[k][0]), (b, k)
+
+
+def test_synth_generator_shapes():
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(33, 8, seed=0)
+    assert inp["state"].shape == (33, 4) and inp["vref"].shape == (33, 21) and inp["others"].shape == (33, 8, 4)
+    assert inp["ego_index"].dtype == np.int32 and inp["is_collide"].dtype == np.uint8
+    assert np.all(inp["weights"] >= 0) and np.all(np.abs(inp["state"][:, 2]) <= np.pi)
+    again = synth.solver_inputs(33, 8, seed=0)
+    assert all(np.array_equal(inp[k], again[k]) for k in ("state", "vref", "others", "weights"))

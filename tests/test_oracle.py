@@ -1,0 +1,118 @@
+"""The CPU oracle against its pins: analytic known answers, independent KKT certificates, an independent
+solver, the committed golden solutions (CPU only)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_u0_err
+import nlp_spec as S
+
+
+def _solve(oracle, ref, **kw):
+    return oracle.solve_batch(ref, **kw)
+
+
+def test_reference_table_matches_reference_golden(ref_table):
+    g = np.load(os.path.join(GOLDEN, "reference_numpy.npz"))
+    assert np.array_equal(S.reference_states(0.1), g["reference_states"])       # oracle restatement
+    assert np.array_equal(ref_table, g["reference_states"])                     # product table
+    assert ref_table.shape == (85, 4)
+    np.testing.assert_allclose(ref_table[40], [1.921541, 9.003083, 10, -1.649336], atol=1e-6)
+
+
+def test_kat_on_reference_zero_controls(oracle, ref_table):
+    """Ego exactly on the straight reference at 10 m/s: J* = 0, u* = 0 (SURVEY 8c pin 3)."""
+    out = _solve(oracle, ref_table, state=np.array([[2.0, 45.0, -np.pi / 2, 10.0]]), ego_index=np.array([4]),
+                 weights=np.ones((1, 3)), is_collide=np.zeros(1, np.uint8))
+    assert out["status"][0] == 0
+    assert np.abs(out["U"]).max() < 1e-7
+    np.testing.assert_allclose(out["X"][0, :, 3], 10.0, atol=1e-7)
+
+
+def test_kat_speed_override_saturates_braking(oracle, ref_table):
+    """RL reference speed 0.7 m/s at 10 m/s: the first action is full braking a_0 = -5 (SURVEY 8c pin 3)."""
+    out = _solve(oracle, ref_table, state=np.array([[2.0, 45.0, -np.pi / 2, 10.0]]), ego_index=np.array([4]),
+                 weights=np.ones((1, 3)), is_collide=np.zeros(1, np.uint8), vref=np.full((1, 21), 0.7))
+    assert out["status"][0] == 0
+    assert abs(out["u0"][0, 0] + 5.0) < 1e-6 and abs(out["u0"][0, 1]) < 1e-6
+
+
+@pytest.mark.parametrize("V,cc,seed", [(4, False, 1), (8, True, 1)])
+def test_kkt_certificates(oracle, ref_table, V, cc, seed):
+    """Every converged oracle solution satisfies the KKT conditions of the ORIGINAL NLP (nlp_spec restates
+    agents/pure_mpc.py:128-280 independently of the solver; multipliers are re-fitted, not taken from it)."""
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(24, V, seed=seed)
+    out = _solve(oracle, ref_table, state=inp["state"], ego_index=inp["ego_index"], weights=inp["weights"],
+                 is_collide=inp["is_collide"], vref=inp["vref"], others=inp["others"], collision_cost=cc)
+    assert (out["status"] == 0).mean() >= 0.8
+    for b in np.nonzero(out["status"] == 0)[0]:
+        p = S.Problem.build(20, 0.1, inp["state"][b], inp["ego_index"][b], ref_table.copy(), inp["weights"][b],
+                            inp["is_collide"][b], collision_cost=cc, others=inp["others"][b])
+        p.ref[:, 2] = inp["vref"][b]
+        c = S.kkt_certificate(p, out["X"][b], out["U"][b], act_tol=1e-5)
+        g = max(1.0, np.abs(S.pack(*S.cost_grad(p, out["X"][b], out["U"][b]))).max())
+        assert c["feasibility"] < 1e-10                    # dynamics + initial condition
+        assert c["bound_violation"] < 1e-7                 # within IPOPT's bound_relax_factor
+        assert c["stationarity"] / g < 1e-5, (b, c["stationarity"], g)
+        assert c["min_bound_mult"] >= -1e-6 * g
+
+
+def test_scipy_crosscheck(oracle, ref_table):
+    """An independent solver (SLSQP) never finds a lower objective and agrees on u0 where it is accurate."""
+    import scipy_crosscheck as X
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(16, 4, seed=2)
+    pick = [1, 5, 6, 12, 13]                       # instances on which SLSQP itself converges tightly
+    out = _solve(oracle, ref_table, state=inp["state"], ego_index=inp["ego_index"], weights=inp["weights"],
+                 is_collide=inp["is_collide"], vref=inp["vref"])
+    for b in pick:
+        p = S.Problem.build(20, 0.1, inp["state"][b], inp["ego_index"][b], ref_table.copy(), inp["weights"][b],
+                            inp["is_collide"][b])
+        p.ref[:, 2] = inp["vref"][b]
+        r = X.solve_slsqp(p)
+        J = S.cost(p, out["X"][b], out["U"][b])
+        assert J <= r["fun"] + 1e-6 * max(1.0, abs(J))
+        assert np.abs(r["U"][0] - out["u0"][b]).max() < 1e-5
+
+
+def test_golden_solutions_reproduce(oracle, ref_table):
+    g = np.load(os.path.join(GOLDEN, "oracle_solutions.npz"))
+    for name, cc in (("cfg2", False), ("cfg3", True)):
+        out = _solve(oracle, ref_table, state=g[f"{name}_state"], ego_index=g[f"{name}_ego_index"],
+                     weights=g[f"{name}_weights"], is_collide=g[f"{name}_is_collide"], vref=g[f"{name}_vref"],
+                     others=g[f"{name}_others"], collision_cost=cc)
+        ok = g[f"{name}_status"] == 0
+        assert np.array_equal(out["status"] == 0, ok)
+        assert rel_u0_err(out["u0"], g[f"{name}_u0"])[ok].max() < 1e-9
+        assert np.nanmax(g[f"{name}_kkt_rel_stationarity"]) < 1e-5      # certificates stored with the fixture
+
+
+def test_xy_bounds_never_matter(oracle, ref_table):
+    """|x|,|y| <= 500 (agents/pure_mpc.py:272-274) cannot be active: dropping them (as the GPU kernel does)
+    leaves the controls unchanged except on a few ill-posed, multi-modal instances."""
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(256, 4, seed=5)
+    kw = dict(state=inp["state"], ego_index=inp["ego_index"], weights=inp["weights"], is_collide=inp["is_collide"],
+              vref=inp["vref"], max_iter=100)
+    a = _solve(oracle, ref_table, **kw)
+    b = _solve(oracle, ref_table, xy_bounds=False, **kw)
+    both = (a["status"] == 0) & (b["status"] == 0)
+    err = rel_u0_err(b["u0"], a["u0"])[both]
+    assert np.median(err) < 1e-9 and (err < 1e-6).mean() > 0.97
+    assert np.abs(a["X"][:, :, :2]).max() < 100.0
+
+
+def test_edge_cases(oracle, ref_table):
+    # standing start, ego at the end of the table, v above the reference, horizon 16
+    st = np.array([[2.0, 45.0, -np.pi / 2, 0.0], [-36.0, -2.2, -3.1, 9.0], [2.2, 30.0, -1.5, 14.0]])
+    out = _solve(oracle, ref_table, state=st, ego_index=np.array([4, 84, 19]), weights=np.ones((3, 3)),
+                 is_collide=np.array([0, 0, 1], np.uint8), N=16)
+    assert out["U"].shape == (3, 16, 2)
+    assert np.all(np.isfinite(out["u0"]))
+    assert out["status"][0] == 0 and out["u0"][0, 0] > 4.9          # full throttle from standstill
+    # state outside the bounds -> flagged, zero controls
+    out = _solve(oracle, ref_table, state=np.array([[2.0, 45.0, -np.pi / 2, 31.0]]), ego_index=np.array([4]),
+                 weights=np.ones((1, 3)), is_collide=np.zeros(1, np.uint8))
+    assert out["status"][0] == 3
