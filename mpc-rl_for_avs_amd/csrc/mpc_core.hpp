@@ -249,6 +249,7 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
     double J = 0.0, bar = 0.0;
     double up0 = 0.0, up1 = 0.0;    // previous new control
     double dup0 = 0.0, dup1 = 0.0;  // previous control change
+    const double fracu = 2.0 * frac;  // = 1 - tau for the controls; the states keep half of that as slack
     for (int k = 0; k < N; ++k) {
         double u0, u1;
         if (first) {
@@ -267,13 +268,12 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
                 s0 += kp00 * dup0 + kp01 * dup1;
                 s1 += kp01 * dup0 + kp11 * dup1;
             }
-            u0 = c0 + s0;
-            u1 = c1 + s1;
-            dup0 = s0;
-            dup1 = s1;
-            if (u0 - ulo_r(0) < frac * (c0 - ulo_r(0)) || uhi_r(0) - u0 < frac * (uhi_r(0) - c0) ||
-                u1 - ulo_r(1) < frac * (c1 - ulo_r(1)) || uhi_r(1) - u1 < frac * (uhi_r(1) - c1))
-                return false;
+            // control bounds: clamp each component to the fraction-to-the-boundary box instead of shortening
+            // the whole step (saturated accelerations would otherwise jam every iteration)
+            u0 = fmin2(fmax2(c0 + s0, ulo_r(0) + fracu * (c0 - ulo_r(0))), uhi_r(0) - fracu * (uhi_r(0) - c0));
+            u1 = fmin2(fmax2(c1 + s1, ulo_r(1) + fracu * (c1 - ulo_r(1))), uhi_r(1) - fracu * (uhi_r(1) - c1));
+            dup0 = u0 - c0;
+            dup1 = u1 - c1;
             w.st(TB + B_U + 0, k, u0);
             w.st(TB + B_U + 1, k, u1);
         }
@@ -388,15 +388,16 @@ MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu,
             const double zl = w.ld(szl, kk), zu = w.ld(szu, kk);
             const double dzl = (mu - zl * d) * rsl - zl, dzu = (mu + zu * d) * rsu - zu;
             if (!APPLY) {
-                rp = fmax2(rp, fmax2(-d * rsl, d * rsu));
+                if (!isu) rp = fmax2(rp, fmax2(-d * rsl, d * rsu));  // controls are clamped in the rollout instead
                 if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
                 if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
             } else {
                 const int nv = isu ? (NB + B_U + j) : (NB + B_X + 2 + j);
                 const double vn = w.ld(nv, kk);
                 const double ml = mu * frcp(vn - lo), mh = mu * frcp(hi - vn);
-                w.st(szl, kk, fmax2(fmin2(zl + adu * dzl, 1e10 * ml), 1e-10 * ml));
-                w.st(szu, kk, fmax2(fmin2(zu + adu * dzu, 1e10 * mh), 1e-10 * mh));
+                // multipliers that shrink share the fraction-to-the-boundary length, growing ones take the full step
+                w.st(szl, kk, fmax2(fmin2(zl + (dzl > 0.0 ? 1.0 : adu) * dzl, 1e10 * ml), 1e-10 * ml));
+                w.st(szu, kk, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : adu) * dzu, 1e10 * mh), 1e-10 * mh));
             }
         }
     }
@@ -573,7 +574,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         double dV1 = 0.0, delta_w = 0.0;
         int nmod = 0;
         bool ok = false, gn = false;
-        for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
+        for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
             ok = true;
             dV1 = 0.0;
             double need = 0.0;
@@ -745,7 +746,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 ++nmod;
                 if (gn) {
                     delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
-                } else if (err_d / s_d > 1.0 || nmod > 12) {
+                } else if (err_d / s_d > 1.0 || nmod > 2) {
                     gn = true;
                     delta_w = 0.0;
                 } else {
@@ -769,7 +770,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         const int tb = cur ^ 1;
         double alpha = a_pr, Jn = 0.0, barn = 0.0;
         bool accepted = false;
-        for (int nls = 0; nls < 30; ++nls, alpha *= 0.5) {
+        for (int nls = 0; nls < 6; ++nls, alpha *= 0.25) {  // at most 6 trials, backtracking factor 1/4
             if (!rollout<CC>(P, w, cur, tb, false, alpha, 0.5 * (1.0 - tau), sf, ws_, wc_, wd_, wcoll, x0, Jn, barn))
                 continue;
             const double phi1 = Jn + mu * barn;

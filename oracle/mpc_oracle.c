@@ -152,6 +152,9 @@ static double stage_cost_raw(const prob_t *p, int k, const double *x, double *lx
     return J;
 }
 
+/* optional work counters (ORACLE_COUNT=1, single thread): iterations, backward sweeps, rollouts */
+static long g_cnt_iter, g_cnt_sweep, g_cnt_roll;
+
 typedef struct {
     double tol, mu_init;
     int max_iter;
@@ -197,6 +200,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
     double mu = o->mu_init;
     const double mu_min = o->tol / 10.0;
     int status = 1, iter = 0;
+    const double KSIG = 1e10; /* IPOPT kappa_Sigma */
+    const int MAXLS = 6;      /* line-search trials per iteration */
+    const double BTF = 0.25;  /* backtracking factor */
+    const int MAXDW = 2;      /* shifted-Hessian retries before falling back to the Gauss-Newton model */
     const double kap_eps = getenv("ORACLE_KEPS") ? atof(getenv("ORACLE_KEPS")) : 10.0;
     const double kap_mu = getenv("ORACLE_KMU") ? atof(getenv("ORACLE_KMU")) : 0.2;
 
@@ -356,7 +363,9 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
         double dV1 = 0.0, delta_w = 0.0;
         int nmod = 0, ok = 0, gn = 0;
         double need = 0.0;
+        ++g_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
+            ++g_cnt_sweep;
             ok = 1;
             dV1 = 0.0;
             double Pxx[4][4], Pxp[4][2], Ppp[2][2] = {{0, 0}, {0, 0}}, px[4], pp[2] = {0, 0};
@@ -475,7 +484,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                 ++nmod;
                 if (gn) {
                     delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
-                } else if (err_d / s_d > 1.0 || nmod > 12) {
+                } else if (err_d / s_d > 1.0 || nmod > MAXDW) {
                     gn = 1;
                     delta_w = 0.0;
                 } else {
@@ -511,8 +520,6 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             }
             for (int i = 0; i < 2; ++i) {
                 double sl = it->u[k][i] - ulo_r(i), su = uhi_r(i) - it->u[k][i], d = dul[k][i];
-                if (d < 0) a_pr = fmin(a_pr, -tau * sl / d);
-                if (d > 0) a_pr = fmin(a_pr, tau * su / d);
                 dzul[k][i] = (mu - it->zul[k][i] * d) / sl - it->zul[k][i];
                 dzuu[k][i] = (mu + it->zuu[k][i] * d) / su - it->zuu[k][i];
                 if (dzul[k][i] < 0) a_du = fmin(a_du, -tau * it->zul[k][i] / dzul[k][i]);
@@ -532,8 +539,9 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
         /* ---------------- nonlinear rollout with feedback, Armijo on the barrier objective ------------- */
         double phi0 = barrier_objective(p, it, mu), alpha = a_pr, phi1 = phi0;
         int accepted = 0, nls = 0;
-        for (nls = 0; nls < 30; ++nls, alpha *= 0.5) {
+        for (nls = 0; nls < MAXLS; ++nls, alpha *= BTF) {
             int feas = 1;
+            ++g_cnt_roll;
             trial = *it;
             for (int k = 0; k < N && feas; ++k) {
                 for (int i = 0; i < 2; ++i) {
@@ -542,9 +550,11 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                     if (k >= 1)
                         for (int j = 0; j < 2; ++j) s += Kp[k][i][j] * (trial.u[k - 1][j] - it->u[k - 1][j]);
                     trial.u[k][i] = it->u[k][i] + s;
-                    if (trial.u[k][i] - ulo_r(i) < 0.5 * (1.0 - tau) * (it->u[k][i] - ulo_r(i)) ||
-                        uhi_r(i) - trial.u[k][i] < 0.5 * (1.0 - tau) * (uhi_r(i) - it->u[k][i]))
-                        feas = 0;
+                    /* control bounds: clamp each component to the fraction-to-the-boundary box instead of
+                     * shortening the whole step (saturated accelerations would otherwise jam every iteration) */
+                    double lo_c = ulo_r(i) + (1.0 - tau) * (it->u[k][i] - ulo_r(i));
+                    double hi_c = uhi_r(i) - (1.0 - tau) * (uhi_r(i) - it->u[k][i]);
+                    trial.u[k][i] = fmin(fmax(trial.u[k][i], lo_c), hi_c);
                 }
                 dyn_t d;
                 dyn_eval(trial.x[k], trial.u[k], &d);
@@ -567,20 +577,21 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
                     iter, nmod, gn, mu, delta_w, err_d, err_c0, E0, a_pr, alpha, a_du, nls, dV1, phi0, phi1, accepted);
         if (!accepted) trial = *it; /* keep the primal point; the dual step below still moves z */
-        /* ---------------- dual step with its own fraction-to-the-boundary length ---------------- */
+        /* ---------------- dual step: multipliers that shrink share one fraction-to-the-boundary length, multipliers
+         *                  that grow (no positivity issue) take the full Newton step ---------------- */
         for (int k = 1; k <= N; ++k)
             for (int i = p->i0; i < 4; ++i) {
                 double sln = trial.x[k][i] - xlo_r(i), sun = xhi_r(i) - trial.x[k][i];
-                double zl = it->zxl[k][i] + a_du * dzxl[k][i], zu = it->zxu[k][i] + a_du * dzxu[k][i];
-                trial.zxl[k][i] = fmax(fmin(zl, 1e10 * mu / sln), mu / (1e10 * sln));
-                trial.zxu[k][i] = fmax(fmin(zu, 1e10 * mu / sun), mu / (1e10 * sun));
+                double zl = it->zxl[k][i] + (dzxl[k][i] > 0 ? 1.0 : a_du) * dzxl[k][i], zu = it->zxu[k][i] + (dzxu[k][i] > 0 ? 1.0 : a_du) * dzxu[k][i];
+                trial.zxl[k][i] = fmax(fmin(zl, KSIG * mu / sln), mu / (KSIG * sln));
+                trial.zxu[k][i] = fmax(fmin(zu, KSIG * mu / sun), mu / (KSIG * sun));
             }
         for (int k = 0; k < N; ++k)
             for (int i = 0; i < 2; ++i) {
                 double sln = trial.u[k][i] - ulo_r(i), sun = uhi_r(i) - trial.u[k][i];
-                double zl = it->zul[k][i] + a_du * dzul[k][i], zu = it->zuu[k][i] + a_du * dzuu[k][i];
-                trial.zul[k][i] = fmax(fmin(zl, 1e10 * mu / sln), mu / (1e10 * sln));
-                trial.zuu[k][i] = fmax(fmin(zu, 1e10 * mu / sun), mu / (1e10 * sun));
+                double zl = it->zul[k][i] + (dzul[k][i] > 0 ? 1.0 : a_du) * dzul[k][i], zu = it->zuu[k][i] + (dzuu[k][i] > 0 ? 1.0 : a_du) * dzuu[k][i];
+                trial.zul[k][i] = fmax(fmin(zl, KSIG * mu / sln), mu / (KSIG * sln));
+                trial.zuu[k][i] = fmax(fmin(zu, KSIG * mu / sun), mu / (KSIG * sun));
             }
         *it = trial;
     }
@@ -605,6 +616,7 @@ int oracle_solve_batch(int B, int N, double dt, const double *ref_table, int M, 
                        double *U, double *X, double *lam, int32_t *status, int32_t *iters, double *kkt,
                        int nthreads) {
     if (N < 1 || N > NMAX || V < 0 || V > VMAX || M < 1) return -1;
+    g_cnt_iter = g_cnt_sweep = g_cnt_roll = 0;
     opts_t o = {tol, getenv("ORACLE_MU0") ? atof(getenv("ORACLE_MU0")) : 0.1, max_iter};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -664,5 +676,7 @@ int oracle_solve_batch(int B, int N, double dt, const double *ref_table, int M, 
         if (kkt) kkt[b] = e;
         free(it);
     }
+    if (getenv("ORACLE_COUNT"))
+        fprintf(stderr, "oracle work: %ld iterations, %ld backward sweeps, %ld rollouts\n", g_cnt_iter, g_cnt_sweep, g_cnt_roll);
     return 0;
 }
