@@ -37,13 +37,15 @@ def cpu_baseline(inp, sample: int):
     oracle_lib.solve_batch(ref, inp["state"][:64], inp["ego_index"][:64], inp["weights"][:64], inp["is_collide"][:64],
                            vref=inp["vref"][:64], others=inp["others"][:64], collision_cost=True, max_iter=100,
                            xy_bounds=False, nthreads=cores)  # warm-up (library load, thread pool)
-    t0 = time.perf_counter()
-    out = oracle_lib.solve_batch(ref, inp["state"][sl], inp["ego_index"][sl], inp["weights"][sl],
-                                 inp["is_collide"][sl], **args)
-    dt = time.perf_counter() - t0
+    dt = float("inf")
+    for _ in range(3):                                   # best of 3: the first OpenMP team start-up is slow
+        t0 = time.perf_counter()
+        out = oracle_lib.solve_batch(ref, inp["state"][sl], inp["ego_index"][sl], inp["weights"][sl],
+                                     inp["is_collide"][sl], **args)
+        dt = min(dt, time.perf_counter() - t0)
     return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
                 sample=f"first {sample} instances of the same batch, oracle/mpc_oracle.c (OpenMP over instances), "
-                       f"{dt:.2f} s wall, mean {float(out['iters'].mean()):.1f} iterations"), out
+                       f"best of 3 runs {dt:.2f} s wall, mean {float(out['iters'].mean()):.1f} iterations"), out
 
 
 def main():

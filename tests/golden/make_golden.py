@@ -120,7 +120,7 @@ def oracle_vectors():
     for name, V, cc, seed in (("cfg2", 4, False, 101), ("cfg3", 8, True, 202)):
         inp = synth.solver_inputs(32, V, seed=seed)
         sol = oracle_lib.solve_batch(ref, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
-                                     vref=inp["vref"], others=inp["others"], collision_cost=cc, max_iter=200)
+                                     vref=inp["vref"], others=inp["others"], collision_cost=cc, max_iter=100)
         stat = np.full(32, np.nan)
         for b in range(32):
             if sol["status"][b] != 0:
