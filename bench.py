@@ -48,6 +48,21 @@ def cpu_baseline(inp, sample: int):
                        f"best of 3 runs {dt:.2f} s wall, mean {float(out['iters'].mean()):.1f} iterations"), out
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
+    same command, profiles/r*_pmc_summary.csv, KB units). The loads are 8-byte strided, outside the access widths
+    MI355X_MICROARCH.md calibrates, so the raw counters are used (no x2 correction)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None
+    vals = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(open(files[-1]))}
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
+    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +143,7 @@ def main():
                        "batch_per_gpu": BATCH, "horizon": HORIZON, "n_vehicles": V, "seed": "rank",
                        "parallelism": f"instance-sharded x{world}, all-gather of actions"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
                          "kernel": "mpc_solve_kernel<CC=1,IPW=16,N=20>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "path is FP64-issue-latency bound with an LDS-resident working set; "
