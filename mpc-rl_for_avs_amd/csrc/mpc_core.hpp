@@ -71,8 +71,9 @@ struct SolveParams {
     double w_distance;  // weight_distance
 };
 
-MPC_HD double fmax2(double a, double b) { return a > b ? a : b; }
-MPC_HD double fmin2(double a, double b) { return a < b ? a : b; }
+// single v_max_f64 / v_min_f64 on the device (a compare + two v_cndmask otherwise)
+MPC_HD double fmax2(double a, double b) { return __builtin_fmax(a, b); }
+MPC_HD double fmin2(double a, double b) { return __builtin_fmin(a, b); }
 
 // bounds of the reference NLP (agents/pure_mpc.py:272-280), relaxed like IPOPT's bound_relax_factor 1e-8.
 // State bounds: index 0 = theta in [-pi, pi], 1 = v in [0, 30]  (|x|,|y| <= 500 can never be active here).

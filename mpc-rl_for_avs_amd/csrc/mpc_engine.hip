@@ -38,16 +38,27 @@ constexpr int kBlock = 64;  // one wave64 per workgroup
 
 // LDS-resident workspace of one lane: element (slot, stage k) of this instance
 // (NC > 0: horizon known at compile time, so slot offsets fold into the ds_read/ds_write immediates)
-template <int IPW, int NC>
+typedef __attribute__((address_space(3))) double lds_double;  // keeps ds_read/ds_write through the opaque asm
+
+template <int IPW, int NC, bool CCW>
 struct LdsWS {
     static constexpr int kN = NC;
-    double *base;         // work + lane
-    const double *obase;  // others + lane
-    const double *table;  // [M][REF_COLS]
+    lds_double *base;         // work + lane
+    const lds_double *obase;  // others + lane
+    const lds_double *table;  // [M][REF_COLS]
     int N1r, e0, M;
-    __device__ __forceinline__ int n1() const { return NC > 0 ? NC + 1 : N1r; }
-    __device__ __forceinline__ double ld(int slot, int k) const { return base[(slot * n1() + k) * IPW]; }
-    __device__ __forceinline__ void st(int slot, int k, double v) { base[(slot * n1() + k) * IPW] = v; }
+    // [stage][slot][instance]: one address register per stage, every slot (and the neighbouring stages) is
+    // then within the 16-bit immediate offset of ds_read_b64 / ds_write_b64
+    static constexpr int kSlots = CCW ? mpc::STAGE_SLOTS_CC : mpc::STAGE_SLOTS;
+    // The stage base is made opaque to the optimiser (an empty, CSE-able asm): otherwise loop strength reduction
+    // re-bases the addresses on constants > 64 KB and every access pays its own v_add_u32.
+    __device__ __forceinline__ lds_double *stage(int k) const {
+        lds_double *p = base + k * (kSlots * IPW);
+        asm("" : "+v"(p));
+        return p;
+    }
+    __device__ __forceinline__ double ld(int slot, int k) const { return stage(k)[slot * IPW]; }
+    __device__ __forceinline__ void st(int slot, int k, double v) { stage(k)[slot * IPW] = v; }
     __device__ __forceinline__ double oth(int j, int c) const { return obase[(j * 4 + c) * IPW]; }
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     double *s_table = smem;                                     // [M][REF_COLS]
-    double *s_work = s_table + M * mpc::REF_COLS;               // [slots][N+1][IPW]
+    double *s_work = s_table + M * mpc::REF_COLS;               // [N+1][slots][IPW]
     double *s_oth = s_work + stage_slots(CC) * (N + 1) * IPW;   // [V][4][IPW]
     for (int i = threadIdx.x; i < M * mpc::REF_COLS; i += kBlock) s_table[i] = ref5[i];
     __syncthreads();
@@ -83,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     const int b = blockIdx.x * IPW + lane;
     if (lane >= IPW || b >= B) return;
 
-    LdsWS<IPW, NC> w{s_work + lane, s_oth + lane, s_table, N + 1, ego_index[b], M};
+    LdsWS<IPW, NC, CC> w{(lds_double *)(s_work + lane), (const lds_double *)(s_oth + lane),
+                         (const lds_double *)s_table, N + 1, ego_index[b], M};
     double x0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) x0[i] = state[(size_t)b * 4 + i];
