@@ -83,9 +83,11 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     inp = synth.solver_inputs(BATCH, V, seed=rank, N=HORIZON)
     t = lambda x, dt_: torch.as_tensor(np.ascontiguousarray(x), dtype=dt_, device=dev)
@@ -101,13 +103,13 @@ def main():
     def step():
         nonlocal gathered
         eng.solve_batch_torch(**args, out=out)          # enqueued on torch's current stream
-        if world > 1:
+        if use_dist:
             gathered = sharding.all_gather_actions(out["u0"])
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     # kernel-only events (same stream the kernel is launched on = torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -117,13 +119,14 @@ def main():
         ev[i][0].record()
         eng.solve_batch_torch(**args, out=out)
         ev[i][1].record()
-        if world > 1:
+        if use_dist:
             gathered = sharding.all_gather_actions(out["u0"])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
+        assert gathered.shape == (world * BATCH, 2)
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -162,7 +165,7 @@ def main():
                              "frac_within_1e-4": float((err[both] <= 1e-4).mean())}
         print(json.dumps(res), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

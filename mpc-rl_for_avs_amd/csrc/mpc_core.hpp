@@ -216,6 +216,21 @@ MPC_HD double dist_cost(const SolveParams &P, const WS &w, int k, double x0, dou
     return J;
 }
 
+// collision-cost variant: derivatives of the distance potential at node k of trajectory buffer CB -> cache
+template <class WS>
+MPC_HD void cache_dist_derivs(const SolveParams &P, WS &w, int CB, int k, double sf) {
+    double d8[8];
+    dist_cost(P, w, k, w.ld(CB + B_X + 0, k), w.ld(CB + B_X + 1, k), d8);
+    w.st(S_LX + 0, k, sf * d8[0]);
+    w.st(S_LX + 1, k, sf * d8[1]);
+    w.st(S_Q + 0, k, sf * d8[2]);
+    w.st(S_Q + 1, k, sf * d8[3]);
+    w.st(S_Q + 2, k, sf * d8[4]);
+    w.st(S_QG + 0, k, sf * d8[5]);
+    w.st(S_QG + 1, k, sf * d8[6]);
+    w.st(S_QG + 2, k, sf * d8[7]);
+}
+
 // scaled stage-cost gradient at node k (1 <= k < N) of the current trajectory
 template <bool CC, class WS>
 MPC_HD void cost_grad(const WS &w, int CB, int k, double sf, double ws_, double wcoll, double *lx) {
@@ -238,8 +253,8 @@ MPC_HD void cost_grad(const WS &w, int CB, int k, double sf, double ws_, double 
 // written into buffer `tb` (reading the current iterate from buffer `cb`); with first==true the controls of
 // `tb` are taken as they are (cold start).  Returns false when a bound would be crossed
 // (fraction-to-the-boundary rule with parameter `frac`).  J / bar receive the scaled objective and the
-// log-barrier sum of the new trajectory.  The collision-cost variant also caches the derivatives of the
-// distance potential along the new trajectory (S_LX / S_Q / S_QG).
+// log-barrier sum of the new trajectory.  (Trial rollouts need only the VALUE of the distance potential; its
+// derivatives are computed once per iteration, in the adjoint sweep of the accepted trajectory.)
 template <bool CC, class WS>
 MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, double alpha, double frac, double sf,
                     double ws_, double wc_, double wd_, double wcoll, const double *x0, double &Jout, double &barout) {
@@ -317,18 +332,7 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
         bar -= log(slack_u * (((x_2 - xlo_r(0)) * (xhi_r(0) - x_2)) * ((x_3 - xlo_r(1)) * (xhi_r(1) - x_3))));
         if (k + 1 < N) {
             J += sf * track_cost(w, k + 1, ws_, x_0, x_1, x_2, x_3, (double *)nullptr);
-            if (CC) {
-                double d8[8];
-                J += sf * (dist_cost(P, w, k + 1, x_0, x_1, d8) + wcoll * x_3 * x_3);
-                w.st(S_LX + 0, k + 1, sf * d8[0]);
-                w.st(S_LX + 1, k + 1, sf * d8[1]);
-                w.st(S_Q + 0, k + 1, sf * d8[2]);
-                w.st(S_Q + 1, k + 1, sf * d8[3]);
-                w.st(S_Q + 2, k + 1, sf * d8[4]);
-                w.st(S_QG + 0, k + 1, sf * d8[5]);
-                w.st(S_QG + 1, k + 1, sf * d8[6]);
-                w.st(S_QG + 2, k + 1, sf * d8[7]);
-            }
+            if (CC) J += sf * (dist_cost(P, w, k + 1, x_0, x_1, (double *)nullptr) + wcoll * x_3 * x_3);
         }
     }
     w.st(TB + B_X + 0, N, x_0);
@@ -449,22 +453,13 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         double gmax = 0.0;
         for (int k = 1; k < N; ++k) {
             double lx[4];
+            if (CC) cache_dist_derivs(P, w, 0, k, 1.0);
             cost_grad<CC>(w, 0, k, 1.0, ws_, wcoll, lx);
             gmax = fmax2(gmax, fmax2(fmax2(fabs(lx[0]), fabs(lx[1])), fmax2(fabs(lx[2]), fabs(lx[3]))));
         }
         gmax = fmax2(gmax, 0.02 * (wc_ + wd_) * fabs(w.ld(S_BUF0 + B_U + 0, 0)));
         sf = 100.0 / fmin2(fmax2(100.0, gmax), 1e4);
         Jcur *= sf;
-        if (CC)
-            for (int k = 1; k < N; ++k) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) w.st(S_LX + i, k, sf * w.ld(S_LX + i, k));
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    w.st(S_Q + i, k, sf * w.ld(S_Q + i, k));
-                    w.st(S_QG + i, k, sf * w.ld(S_QG + i, k));
-                }
-            }
     }
     const double rd_full = 0.02 * sf * wd_, rc = 0.02 * sf * wc_, qtt = 10.0 * sf;
     const double q33 = sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0));
@@ -533,6 +528,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 }
                 if (k >= 1) {
                     double lx[4];
+                    if (CC) cache_dist_derivs(P, w, CB, k, sf);
                     cost_grad<CC>(w, CB, k, sf, ws_, wcoll, lx);
                     const double t0 = lx[0] + y0;
                     const double t1 = lx[1] + y1;
@@ -786,20 +782,6 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
             cur = tb;
             Jcur = Jn;
             barcur = barn;
-        } else if (CC) {
-            // the rejected rollouts overwrote the cached distance-potential derivatives: restore them
-            for (int k = 1; k < N; ++k) {
-                double d8[8];
-                dist_cost(P, w, k, w.ld(CB + B_X + 0, k), w.ld(CB + B_X + 1, k), d8);
-                w.st(S_LX + 0, k, sf * d8[0]);
-                w.st(S_LX + 1, k, sf * d8[1]);
-                w.st(S_Q + 0, k, sf * d8[2]);
-                w.st(S_Q + 1, k, sf * d8[3]);
-                w.st(S_Q + 2, k, sf * d8[4]);
-                w.st(S_QG + 0, k, sf * d8[5]);
-                w.st(S_QG + 1, k, sf * d8[6]);
-                w.st(S_QG + 2, k, sf * d8[7]);
-            }
         }
     }
     iters_out = iter;
