@@ -46,6 +46,8 @@ extern "C" {
 #define MPC_STATUS_MAX_ITER 1       /* last iterate returned, like the reference (agents/pure_mpc.py:303-305) */
 #define MPC_STATUS_FACTORIZATION 2
 #define MPC_STATUS_INFEASIBLE_START 3 /* the initial state violates the state bounds of agents/pure_mpc.py:272-274 */
+#define MPC_STATUS_STALLED 4          /* no acceptable step in 3 consecutive iterations (non-smooth point of the
+                                         collision cost); last iterate returned */
 
 typedef struct mpc_handle mpc_handle;
 

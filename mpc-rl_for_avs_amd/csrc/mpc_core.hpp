@@ -465,7 +465,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
     const double q33 = sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0));
     double mu = P.mu_init;
     const double mu_min = P.tol / 10.0;
-    int iter = 0;
+    int iter = 0, nfail = 0;
 
     for (iter = 0; iter <= P.max_iter; ++iter) {
         const int CB = cur * BUF_SLOTS;
@@ -565,16 +565,13 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         if (iter == P.max_iter) break;
 
         // =========================== Riccati / DDP factorisation sweep ================================
-        // exact Lagrangian Hessian first; if a control block is not positive definite: far from a stationary
-        // point fall back to the convex Gauss-Newton model, close to one keep the exact Hessian shifted by
-        // delta_w sized from the offending eigenvalue.
+        // exact Lagrangian Hessian first; if a control block is not positive definite the sweep is redone with
+        // the convex Gauss-Newton model (at most one retry in practice).
         double dV1 = 0.0, delta_w = 0.0;
-        int nmod = 0;
         bool ok = false, gn = false;
         for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
             ok = true;
             dV1 = 0.0;
-            double need = 0.0;
             // value function of node k+1: Pxx (sym 4x4), Pxp (4x2), Ppp (sym 2x2), px, pp
             double p00 = delta_w, p01 = 0, p02 = 0, p03 = 0, p11 = delta_w, p12 = 0, p13 = 0, p22, p23 = 0, p33;
             double e00 = 0, e01 = 0, e10 = 0, e11 = 0, e20 = 0, e21 = 0, e30 = 0, e31 = 0;
@@ -696,8 +693,6 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 const double ha = huu00, hb = 0.5 * (huu01a + huu10a), hc = huu11;
                 const double det = ha * hc - hb * hb;
                 if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
-                    const double hm = 0.5 * (ha + hc), hd = sqrt(0.25 * (ha - hc) * (ha - hc) + hb * hb);
-                    need = fmax2(-(hm - hd), 0.0);
                     ok = false;
                     break;
                 }
@@ -740,14 +735,10 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
                 ppv1 = lp1 - rdk * kf1;
             }
             if (!ok) {
-                ++nmod;
-                if (gn) {
-                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
-                } else if (err_d / s_d > 1.0 || nmod > 2) {
-                    gn = true;
-                    delta_w = 0.0;
+                if (!gn) {
+                    gn = true;  // convex Gauss-Newton model for this iteration
                 } else {
-                    delta_w = fmax2(2.0 * delta_w, delta_w + 1.5 * need + 1e-6);
+                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;  // numerically singular even so
                 }
                 if (delta_w > 1e40) break;
             }
@@ -782,6 +773,13 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
             cur = tb;
             Jcur = Jn;
             barcur = barn;
+            nfail = 0;
+        } else if (++nfail >= 3) {
+            // three consecutive iterations without an acceptable step: the primal point cannot move any more
+            // (a kink of the collision cost at d = 1, or numerical stationarity) - stop instead of burning the budget
+            status_out = 4;
+            ++iter;
+            break;
         }
     }
     iters_out = iter;

@@ -22,6 +22,7 @@ STATUS_CONVERGED = 0
 STATUS_MAX_ITER = 1
 STATUS_FACTORIZATION = 2
 STATUS_INFEASIBLE_START = 3
+STATUS_STALLED = 4
 
 
 class EngineError(RuntimeError):

@@ -192,18 +192,18 @@ static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
 }
 
 /* solve one instance.
- * status: 0 converged, 1 max_iter reached, 2 factorisation failure, 3 start not strictly feasible */
+ * status: 0 converged, 1 max_iter reached, 2 factorisation failure, 3 start not strictly feasible,
+ *         4 stalled (no acceptable step in three consecutive iterations) */
 static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, double *kkt_out) {
     const int N = p->N;
     const double dt = p->dt;
     double rd_full = 0.02 * p->wd, rc = 0.02 * p->wc;
     double mu = o->mu_init;
     const double mu_min = o->tol / 10.0;
-    int status = 1, iter = 0;
+    int status = 1, iter = 0, nfail = 0;
     const double KSIG = 1e10; /* IPOPT kappa_Sigma */
     const int MAXLS = 6;      /* line-search trials per iteration */
     const double BTF = 0.25;  /* backtracking factor */
-    const int MAXDW = 2;      /* shifted-Hessian retries before falling back to the Gauss-Newton model */
     const double kap_eps = getenv("ORACLE_KEPS") ? atof(getenv("ORACLE_KEPS")) : 10.0;
     const double kap_mu = getenv("ORACLE_KMU") ? atof(getenv("ORACLE_KMU")) : 0.2;
 
@@ -362,7 +362,6 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
          * convexified QP exactly, stays a descent direction, and no re-factorisation is needed. */
         double dV1 = 0.0, delta_w = 0.0;
         int nmod = 0, ok = 0, gn = 0;
-        double need = 0.0;
         ++g_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
             ++g_cnt_sweep;
@@ -451,7 +450,6 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                 (void)l1;
                 if (!(ha > 0.0) || !(hc > 0.0) || !(ha * hc - hb * hb > 1e-12 * ha * hc)) {
                     ok = 0;
-                    need = fmax(-l2, 0.0);
                     break;
                 }
                 double det = ha * hc - hb * hb;
@@ -478,17 +476,13 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                 memcpy(pp, nppv, sizeof(pp));
             }
             if (!ok) {
-                /* Far from a stationary point the convex Gauss-Newton model is the better fallback; close to
-                 * one (scaled dual residual <= 1) an indefinite Hessian is a property of the problem and the
-                 * exact Hessian is kept, shifted by delta_w sized from the offending eigenvalue. */
+                /* exact Hessian not positive definite on the null space: use the convex Gauss-Newton model for this
+                 * iteration; if even that is numerically singular, add a small multiple of the identity */
                 ++nmod;
-                if (gn) {
-                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
-                } else if (err_d / s_d > 1.0 || nmod > MAXDW) {
+                if (!gn) {
                     gn = 1;
-                    delta_w = 0.0;
                 } else {
-                    delta_w = fmax(2.0 * delta_w, delta_w + 1.5 * need + 1e-6);
+                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
                 }
                 if (delta_w > 1e40) break;
             }
@@ -577,6 +571,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
             fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
                     iter, nmod, gn, mu, delta_w, err_d, err_c0, E0, a_pr, alpha, a_du, nls, dV1, phi0, phi1, accepted);
         if (!accepted) trial = *it; /* keep the primal point; the dual step below still moves z */
+        nfail = accepted ? 0 : nfail + 1;
         /* ---------------- dual step: multipliers that shrink share one fraction-to-the-boundary length, multipliers
          *                  that grow (no positivity issue) take the full Newton step ---------------- */
         for (int k = 1; k <= N; ++k)
@@ -594,6 +589,13 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
                 trial.zuu[k][i] = fmax(fmin(zu, KSIG * mu / sun), mu / (KSIG * sun));
             }
         *it = trial;
+        /* three consecutive iterations without an acceptable step: the primal point cannot move any more (a kink of
+         * the collision cost at d = 1, or numerical stationarity) - stop instead of burning the iteration budget */
+        if (nfail >= 3) {
+            status = 4;
+            ++iter;
+            break;
+        }
     }
     for (int k = 1; k <= N; ++k)
         for (int i = 0; i < 4; ++i) it->lam[k][i] = -yv[k][i] / p->sf;
