@@ -102,7 +102,9 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
                     uint32_t flags, double *u0, double *U, double *X, int32_t *status, int32_t *iters,
                     void *stream);
 
-/* Bytes of device workspace the engine holds for batches up to B (diagnostics / capacity planning). */
+/* LDS bytes one workgroup of the solve kernel uses for a batch of B instances with V other vehicles in the
+ * collision-cost term (V = 0: term off): path table + instances-per-wave x per-instance solver state.  The
+ * engine keeps no per-instance state in HBM.  (diagnostics / capacity planning) */
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);
 
 #ifdef __cplusplus

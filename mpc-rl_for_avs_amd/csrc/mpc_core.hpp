@@ -31,7 +31,7 @@ namespace mpc {
 // fit the 160 KB LDS of one CU.  What is cheap to recompute is not stored: the reference geometry comes
 // from the shared path table by index, beta'/beta'' from sin/cos(beta), the quadratic tracking cost and its
 // derivatives from the state (only the collision-cost variant caches them), the linearised step is
-// re-run in the dual-update pass, and the never-active |x|,|y| <= 500 bounds carry no multipliers.
+// parked in the adjoint slots for the dual update, and the never-active |x|,|y| <= 500 bounds carry no multipliers.
 // Two trajectory buffers (current / trial) are swapped on accept.
 // ---------------------------------------------------------------------------------------------------
 enum : int {
@@ -262,7 +262,7 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
     const double dt = P.dt;
     const int CB = cb * BUF_SLOTS, TB = tb * BUF_SLOTS;
     double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
-    double J = 0.0, bar = 0.0;
+    double J = 0.0, bar = 0.0, slack_acc = 1.0;
     double up0 = 0.0, up1 = 0.0;    // previous new control
     double dup0 = 0.0, dup1 = 0.0;  // previous control change
     const double fracu = 2.0 * frac;  // = 1 - tau for the controls; the states keep half of that as slack
@@ -328,8 +328,12 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
         x_1 = n1;
         x_2 = n2;
         x_3 = n3;
-        // one log per stage: the 8 slacks are bounded away from under/overflow (1e-12 .. 1e2 each)
-        bar -= log(slack_u * (((x_2 - xlo_r(0)) * (xhi_r(0) - x_2)) * ((x_3 - xlo_r(1)) * (xhi_r(1) - x_3))));
+        // one log per TWO stages: 16 slacks, each within 1e-12 .. 1e2, cannot under/overflow a double
+        slack_acc *= slack_u * (((x_2 - xlo_r(0)) * (xhi_r(0) - x_2)) * ((x_3 - xlo_r(1)) * (xhi_r(1) - x_3)));
+        if ((k & 1) || k + 1 == N) {
+            bar -= log(slack_acc);
+            slack_acc = 1.0;
+        }
         if (k + 1 < N) {
             J += sf * track_cost(w, k + 1, ws_, x_0, x_1, x_2, x_3, (double *)nullptr);
             if (CC) J += sf * (dist_cost(P, w, k + 1, x_0, x_1, (double *)nullptr) + wcoll * x_3 * x_3);
@@ -344,19 +348,18 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
     return true;
 }
 
-// Linearised forward sweep of the Newton step along the current trajectory.
-//   APPLY == false: step-length limits a_pr (primal) and a_du (dual) by the fraction-to-the-boundary rule.
-//   APPLY == true : the dual step  z += a_du*dz  with the slacks of buffer `nb`, clamped like IPOPT (kappa_Sigma 1e10).
-template <bool APPLY, class WS>
-MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu, double tau, double &a_pr,
-                         double &a_du) {
+// Linearised forward sweep of the Newton step along the current trajectory: step-length limits a_pr (primal,
+// state bounds only - controls are clamped in the rollout) and a_du (dual) by the fraction-to-the-boundary
+// rule.  The bounded components of the step (du, d theta, d v) are parked in the adjoint slots S_Y, which are
+// free until the next iteration, for the dual update.
+template <class WS>
+MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, double mu, double tau, double &a_pr, double &a_du) {
     const int N = WS::kN > 0 ? WS::kN : P.N;  // compile-time horizon turns LDS offsets into immediates
     const double dt = P.dt;
-    const int CB = cb * BUF_SLOTS, NB = nb * BUF_SLOTS;
+    const int CB = cb * BUF_SLOTS;
     double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
     // step limits without divisions: primal ratio rp = max |d|/s ; dual ratio (-dz)/z kept as a fraction
     double rp = 0.0, rdn = 0.0, rdd = 1.0;
-    const double adu = a_du;
     for (int k = 0; k < N; ++k) {
         double du0 = w.ld(S_KF + 0, k) + w.ld(S_KX + 0, k) * d0 + w.ld(S_KX + 1, k) * d1 + w.ld(S_KX + 2, k) * d2 +
                      w.ld(S_KX + 3, k) * d3;
@@ -380,6 +383,10 @@ MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu,
         const double n3 = d3 + dt * du0;
         d0 = n0; d1 = n1; d2 = n2; d3 = n3;
         dp0 = du0; dp1 = du1;
+        w.st(S_Y + 0, k, du0);
+        w.st(S_Y + 1, k, du1);
+        w.st(S_Y + 2, k + 1, d2);
+        w.st(S_Y + 3, k + 1, d3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {  // i = 0,1: controls of node k;  i = 2,3: theta, v of node k+1
             const bool isu = i < 2;
@@ -392,23 +399,39 @@ MPC_HD void linear_sweep(const SolveParams &P, WS &w, int cb, int nb, double mu,
             const double rsl = frcp(val - lo), rsu = frcp(hi - val);
             const double zl = w.ld(szl, kk), zu = w.ld(szu, kk);
             const double dzl = (mu - zl * d) * rsl - zl, dzu = (mu + zu * d) * rsu - zu;
-            if (!APPLY) {
-                if (!isu) rp = fmax2(rp, fmax2(-d * rsl, d * rsu));  // controls are clamped in the rollout instead
-                if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
-                if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
-            } else {
-                const int nv = isu ? (NB + B_U + j) : (NB + B_X + 2 + j);
-                const double vn = w.ld(nv, kk);
-                const double ml = mu * frcp(vn - lo), mh = mu * frcp(hi - vn);
-                // multipliers that shrink share the fraction-to-the-boundary length, growing ones take the full step
-                w.st(szl, kk, fmax2(fmin2(zl + (dzl > 0.0 ? 1.0 : adu) * dzl, 1e10 * ml), 1e-10 * ml));
-                w.st(szu, kk, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : adu) * dzu, 1e10 * mh), 1e-10 * mh));
-            }
+            if (!isu) rp = fmax2(rp, fmax2(-d * rsl, d * rsu));
+            if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
+            if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
         }
     }
-    if (!APPLY) {
-        a_pr = (rp * 1.0 > tau) ? tau / rp : 1.0;
-        a_du = (rdn * 1.0 > tau * rdd) ? tau * rdd / rdn : 1.0;
+    a_pr = (rp > tau) ? tau / rp : 1.0;
+    a_du = (rdn > tau * rdd) ? tau * rdd / rdn : 1.0;
+}
+
+// Dual step  z += a*dz  (dz from the parked Newton step): multipliers that shrink share the
+// fraction-to-the-boundary length a_du, growing ones take the full step; clamped like IPOPT (kappa_Sigma 1e10)
+// around mu / (new slack) with the slacks of buffer `nb`.
+template <class WS>
+MPC_HD void dual_update(const SolveParams &P, WS &w, int cb, int nb, double mu, double a_du) {
+    const int N = WS::kN > 0 ? WS::kN : P.N;  // compile-time horizon turns LDS offsets into immediates
+    const int CB = cb * BUF_SLOTS, NB = nb * BUF_SLOTS;
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool isu = i < 2;
+            const int j = isu ? i : i - 2;
+            const double lo = isu ? ulo_r(j) : xlo_r(j), hi = isu ? uhi_r(j) : xhi_r(j);
+            const int kk = isu ? k : k + 1;
+            const int sv = isu ? (B_U + j) : (B_X + 2 + j);
+            const int szl = isu ? (S_ZUL + j) : (S_ZXL + j), szu = isu ? (S_ZUU + j) : (S_ZXU + j);
+            const double val = w.ld(CB + sv, kk), d = w.ld(S_Y + i, kk);
+            const double zl = w.ld(szl, kk), zu = w.ld(szu, kk);
+            const double dzl = (mu - zl * d) * frcp(val - lo) - zl, dzu = (mu + zu * d) * frcp(hi - val) - zu;
+            const double vn = w.ld(NB + sv, kk);
+            const double ml = mu * frcp(vn - lo), mh = mu * frcp(hi - vn);
+            w.st(szl, kk, fmax2(fmin2(zl + (dzl > 0.0 ? 1.0 : a_du) * dzl, 1e10 * ml), 1e-10 * ml));
+            w.st(szu, kk, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : a_du) * dzu, 1e10 * mh), 1e-10 * mh));
+        }
     }
 }
 
@@ -751,7 +774,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         // =========================== linear forward sweep: Newton step, step-length limits ==============
         const double tau = fmax2(0.99, 1.0 - mu);
         double a_pr = 1.0, a_du = 1.0;
-        linear_sweep<false>(P, w, cur, cur, mu, tau, a_pr, a_du);
+        linear_sweep(P, w, cur, mu, tau, a_pr, a_du);
 
         // =========================== nonlinear rollout + Armijo on the barrier objective ================
         const double phi0 = Jcur + mu * barcur;
@@ -768,7 +791,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
             }
         }
         // =========================== dual step (own fraction-to-the-boundary length), accept ============
-        linear_sweep<true>(P, w, cur, accepted ? tb : cur, mu, tau, a_pr, a_du);
+        dual_update(P, w, cur, accepted ? tb : cur, mu, a_du);
         if (accepted) {
             cur = tb;
             Jcur = Jn;

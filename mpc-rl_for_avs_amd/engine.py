@@ -117,6 +117,7 @@ class MPCEngine:
         self._check(self._lib.mpc_set_reference(self._h, _ptr(ref), ref.shape[0]), "mpc_set_reference")
 
     def workspace_bytes(self, B, V=0):
+        """LDS bytes per workgroup for a batch of B (V > 0: collision-cost variant with V vehicles)."""
         return int(self._lib.mpc_workspace_bytes(self._h, int(B), int(V)))
 
     # ------------------------------------------------------------------ host (numpy) path
