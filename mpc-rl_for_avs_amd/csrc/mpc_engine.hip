@@ -90,9 +90,14 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     double *s_oth = s_work + stage_slots(CC) * (N + 1) * IPW;   // [V][4][IPW]
     for (int i = threadIdx.x; i < M * mpc::REF_COLS; i += kBlock) s_table[i] = ref5[i];
     __syncthreads();
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x * IPW + lane;
-    if (lane >= IPW || b >= B) return;
+    // All 64 lanes stay active: lane l works on instance l % IPW, i.e. every instance is computed by 64/IPW
+    // replica lanes that read and write the same LDS words with the same values.  Measured on MI355X
+    // (tools/ubench/ubench_waves.hip): FP64 VALU ops of a wave with < 16 active lanes are serialised across the
+    // whole CU (~5 cycles each, CU-wide), and 16-lane waves reach the full per-SIMD rate only when >= 64 lanes
+    // are active on the CU; a full wave always runs at 4 cycles per instruction on its own SIMD.
+    const int lane = threadIdx.x % IPW;
+    int b = blockIdx.x * IPW + lane;
+    b = b < B ? b : B - 1;  // ragged last workgroup: surplus lanes mirror the last instance
 
     LdsWS<IPW, NC, CC> w{(lds_double *)(s_work + lane), (const lds_double *)(s_oth + lane),
                          (const lds_double *)s_table, N + 1, ego_index[b], M};
