@@ -253,9 +253,10 @@ MPC_HD void cost_grad(const WS &w, int CB, int k, double sf, double ws_, double 
 // written into buffer `tb` (reading the current iterate from buffer `cb`); with first==true the controls of
 // `tb` are taken as they are (cold start).  Returns false when a bound would be crossed
 // (fraction-to-the-boundary rule with parameter `frac`).  J / bar receive the scaled objective and the
-// log-barrier sum of the new trajectory.  (Trial rollouts need only the VALUE of the distance potential; its
+// log-barrier sum of the new trajectory; STORE = false evaluates a trial without writing anything (used by the
+// replica lanes of the parallel line search).  (Trial rollouts need only the VALUE of the distance potential; its
 // derivatives are computed once per iteration, in the adjoint sweep of the accepted trajectory.)
-template <bool CC, class WS>
+template <bool CC, bool STORE, class WS>
 MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, double alpha, double frac, double sf,
                     double ws_, double wc_, double wd_, double wcoll, const double *x0, double &Jout, double &barout) {
     const int N = WS::kN > 0 ? WS::kN : P.N;  // compile-time horizon turns LDS offsets into immediates
@@ -290,13 +291,13 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
             u1 = fmin2(fmax2(c1 + s1, ulo_r(1) + fracu * (c1 - ulo_r(1))), uhi_r(1) - fracu * (uhi_r(1) - c1));
             dup0 = u0 - c0;
             dup1 = u1 - c1;
-            w.st(TB + B_U + 0, k, u0);
-            w.st(TB + B_U + 1, k, u1);
+            if (STORE) w.st(TB + B_U + 0, k, u0);
+            if (STORE) w.st(TB + B_U + 1, k, u1);
         }
-        w.st(TB + B_X + 0, k, x_0);
-        w.st(TB + B_X + 1, k, x_1);
-        w.st(TB + B_X + 2, k, x_2);
-        w.st(TB + B_X + 3, k, x_3);
+        if (STORE) w.st(TB + B_X + 0, k, x_0);
+        if (STORE) w.st(TB + B_X + 1, k, x_1);
+        if (STORE) w.st(TB + B_X + 2, k, x_2);
+        if (STORE) w.st(TB + B_X + 3, k, x_3);
         // control costs  (agents/pure_mpc.py:161-165)
         J += 0.01 * sf * wc_ * (u0 * u0 + u1 * u1);
         if (k >= 1) {
@@ -308,10 +309,10 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
         up1 = u1;
         double S, C, sb, cbeta;
         dyn_eval(x_2, u1, S, C, sb, cbeta);
-        w.st(TB + B_DYN + 0, k, S);
-        w.st(TB + B_DYN + 1, k, C);
-        w.st(TB + B_DYN + 2, k, sb);
-        w.st(TB + B_DYN + 3, k, cbeta);
+        if (STORE) w.st(TB + B_DYN + 0, k, S);
+        if (STORE) w.st(TB + B_DYN + 1, k, C);
+        if (STORE) w.st(TB + B_DYN + 2, k, sb);
+        if (STORE) w.st(TB + B_DYN + 3, k, cbeta);
         const double n0 = x_0 + dt * (x_3 * C);
         const double n1 = x_1 + dt * (x_3 * S);
         const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
@@ -339,10 +340,10 @@ MPC_HD bool rollout(const SolveParams &P, WS &w, int cb, int tb, bool first, dou
             if (CC) J += sf * (dist_cost(P, w, k + 1, x_0, x_1, (double *)nullptr) + wcoll * x_3 * x_3);
         }
     }
-    w.st(TB + B_X + 0, N, x_0);
-    w.st(TB + B_X + 1, N, x_1);
-    w.st(TB + B_X + 2, N, x_2);
-    w.st(TB + B_X + 3, N, x_3);
+    if (STORE) w.st(TB + B_X + 0, N, x_0);
+    if (STORE) w.st(TB + B_X + 1, N, x_1);
+    if (STORE) w.st(TB + B_X + 2, N, x_2);
+    if (STORE) w.st(TB + B_X + 3, N, x_3);
     Jout = J;
     barout = bar;
     return true;
@@ -467,7 +468,7 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
     }
     if (x0[3] < 0.01) w.st(S_BUF0 + B_U + 0, 0, (0.01 - x0[3]) / dt);
     double sf = 1.0, Jcur = 0.0, barcur = 0.0;
-    if (!rollout<CC>(P, w, 0, 0, true, 0.0, 0.0, 1.0, ws_, wc_, wd_, wcoll, x0, Jcur, barcur)) {
+    if (!rollout<CC, true>(P, w, 0, 0, true, 0.0, 0.0, 1.0, ws_, wc_, wd_, wcoll, x0, Jcur, barcur)) {
         status_out = 3;
         return;
     }
@@ -779,15 +780,46 @@ MPC_HD void solve_instance(const SolveParams &P, WS &w, const double *x0, double
         // =========================== nonlinear rollout + Armijo on the barrier objective ================
         const double phi0 = Jcur + mu * barcur;
         const int tb = cur ^ 1;
+        // Trial k uses alpha = a_pr * 4^-k, k = 0..5, and the first k that passes Armijo is accepted.  Trial 0 is
+        // run (and stored) by all lanes; when it fails, the R = WS::kReplicas replica lanes of this instance evaluate
+        // R further trials at once without storing, and the winner is re-run with stores - the same result as the
+        // sequential search, in at most 3-4 rollouts instead of 6 for the instances that backtrack deep.
         double alpha = a_pr, Jn = 0.0, barn = 0.0;
         bool accepted = false;
-        for (int nls = 0; nls < 6; ++nls, alpha *= 0.25) {  // at most 6 trials, backtracking factor 1/4
-            if (!rollout<CC>(P, w, cur, tb, false, alpha, 0.5 * (1.0 - tau), sf, ws_, wc_, wd_, wcoll, x0, Jn, barn))
-                continue;
-            const double phi1 = Jn + mu * barn;
-            if (phi1 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
-                accepted = true;
-                break;
+        const double frac = 0.5 * (1.0 - tau);
+        auto armijo = [&](double a, double Jt, double bt) {
+            return Jt + mu * bt <= phi0 + 1e-4 * a * 2.0 * dV1 + 1e-12 * fabs(phi0);
+        };
+        if (rollout<CC, true>(P, w, cur, tb, false, alpha, frac, sf, ws_, wc_, wd_, wcoll, x0, Jn, barn) &&
+            armijo(alpha, Jn, barn)) {
+            accepted = true;
+        } else {
+            constexpr int R = WS::kReplicas;
+            int k = 1;
+            while (k < 6 && !accepted) {
+                if (R > 1) {
+                    const int myk = k + w.replica();
+                    double a = a_pr;
+                    for (int q = 0; q < myk; ++q) a *= 0.25;
+                    double Jt = 0.0, bt = 0.0;
+                    const bool pass = myk < 6 &&
+                                      rollout<CC, false>(P, w, cur, tb, false, a, frac, sf, ws_, wc_, wd_, wcoll, x0, Jt, bt) &&
+                                      armijo(a, Jt, bt);
+                    const int r = w.first_passing(pass);  // smallest replica index of this instance that passed
+                    if (r >= 0) {
+                        alpha = a_pr;
+                        for (int q = 0; q < k + r; ++q) alpha *= 0.25;
+                        rollout<CC, true>(P, w, cur, tb, false, alpha, frac, sf, ws_, wc_, wd_, wcoll, x0, Jn, barn);
+                        accepted = true;
+                    }
+                    k += R;
+                } else {
+                    alpha *= 0.25;
+                    if (rollout<CC, true>(P, w, cur, tb, false, alpha, frac, sf, ws_, wc_, wd_, wcoll, x0, Jn, barn) &&
+                        armijo(alpha, Jn, barn))
+                        accepted = true;
+                    ++k;
+                }
             }
         }
         // =========================== dual step (own fraction-to-the-boundary length), accept ============

@@ -43,6 +43,7 @@ typedef __attribute__((address_space(3))) double lds_double;  // keeps ds_read/d
 template <int IPW, int NC, bool CCW>
 struct LdsWS {
     static constexpr int kN = NC;
+    static constexpr int kReplicas = kBlock / IPW;  // lanes l, l+IPW, l+2*IPW, ... work on the same instance
     lds_double *base;         // work + lane
     const lds_double *obase;  // others + lane
     const lds_double *table;  // [M][REF_COLS]
@@ -60,6 +61,17 @@ struct LdsWS {
     __device__ __forceinline__ double ld(int slot, int k) const { return stage(k)[slot * IPW]; }
     __device__ __forceinline__ void st(int slot, int k, double v) { stage(k)[slot * IPW] = v; }
     __device__ __forceinline__ double oth(int j, int c) const { return obase[(j * 4 + c) * IPW]; }
+    __device__ __forceinline__ int replica() const { return (int)threadIdx.x / IPW; }
+    // smallest replica index of this lane's instance whose `pass` is true, or -1 (one wave-wide ballot)
+    __device__ __forceinline__ int first_passing(bool pass) const {
+        const unsigned long long m = __ballot(pass);
+        const int inst = (int)threadIdx.x % IPW;
+        int r = -1;
+#pragma unroll
+        for (int q = kReplicas - 1; q >= 0; --q)
+            if ((m >> (inst + q * IPW)) & 1ull) r = q;
+        return r;
+    }
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
         idx = idx > M - 1 ? M - 1 : idx;

@@ -11,6 +11,9 @@
 namespace {
 struct HostWS {
     static constexpr int kN = 0;  // runtime horizon
+    static constexpr int kReplicas = 1;  // no replica lanes on the host: sequential line search
+    int replica() const { return 0; }
+    int first_passing(bool pass) const { return pass ? 0 : -1; }
     double *base;
     const double *obase;
     const double *table;  // [M][REF_COLS]
