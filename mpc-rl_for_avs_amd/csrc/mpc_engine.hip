@@ -17,6 +17,7 @@
 
 #include "../../include/mpc_mi355x.h"
 #include "mpc_core.hpp"
+#include "mpc_wave.hpp"
 
 namespace {
 
@@ -163,6 +164,94 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     if (iters_out) iters_out[b] = iters;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
+// ---------------------------------------------------------------------------------------------------
+template <int NC>
+struct WaveCtx {
+    static constexpr int kN = NC;
+    lds_double *L;        // this instance's LDS words
+    const double *table;  // [M][REF_COLS] in global memory (wave-uniform index in the serial parts -> scalar loads)
+    int e0, M;
+    __device__ __forceinline__ double ld(int i) const { return L[i]; }
+    __device__ __forceinline__ void st(int i, double v) { L[i] = v; }
+    template <class F>
+    __device__ __forceinline__ void phase(F &&f) {
+        f((int)threadIdx.x);
+        __syncthreads();  // single-wave workgroup: orders the LDS traffic of the phase before what follows
+    }
+    __device__ __forceinline__ double ref(int k, int c) const {
+        int idx = e0 + k;
+        idx = idx > M - 1 ? M - 1 : idx;
+        idx = idx < 0 ? 0 : idx;
+        return table[idx * mpc::REF_COLS + c];
+    }
+};
+
+template <bool CC, int NC>
+__global__ __launch_bounds__(kBlock, 4) void mpc_solve_wave_kernel(
+    mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
+    const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
+    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin, double w_collision,
+    double *__restrict__ u0_out, double *__restrict__ U_out, double *__restrict__ X_out,
+    int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
+    extern __shared__ double smem[];
+    const int N = NC > 0 ? NC : P.N;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    constexpr int SL = mpc::wave::stage_slots(CC);
+    WaveCtx<NC> ctx{(lds_double *)smem, ref5, ego_index[b], M};
+    const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
+    // inputs -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j)
+    if (lane <= N) {
+        double rv;
+        if (vref) {
+            rv = vref[(size_t)b * (N + 1) + lane];
+        } else {
+            int idx = ctx.e0 + lane;
+            idx = idx > M - 1 ? M - 1 : idx;
+            idx = idx < 0 ? 0 : idx;
+            rv = ref5[M * mpc::REF_COLS + idx];
+        }
+        ctx.st(lane * SL + mpc::wave::W_RV, rv);
+    }
+    if (CC && lane < P.V) {
+        const double *ov = others + ((size_t)b * Vin + lane) * 4;
+        const double sp = ov[2] * P.dt, hh = ov[3];
+        ctx.st(OTH + lane * 4 + 0, ov[0]);
+        ctx.st(OTH + lane * 4 + 1, ov[1]);
+        ctx.st(OTH + lane * 4 + 2, sp * cos(hh));
+        ctx.st(OTH + lane * 4 + 3, sp * sin(hh));
+    }
+    __syncthreads();
+    double x0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x0[i] = state[(size_t)b * 4 + i];
+    const bool collide = is_collide[b] != 0;
+    const double ws_ = collide ? 100.0 : weights[(size_t)b * 3 + 0];  // agents/pure_mpc.py:143-147
+    const double wcoll = (CC && collide) ? 3000.0 * w_collision : 0.0;
+    mpc::wave::Solver<CC, WaveCtx<NC>> solver(P, ctx, x0, ws_, weights[(size_t)b * 3 + 1], weights[(size_t)b * 3 + 2],
+                                             wcoll);
+    int status, iters, cur;
+    double kkt;
+    solver.solve(status, iters, cur, kkt);
+    __syncthreads();
+    const int CB = cur * 6;
+    if (lane < 2) u0_out[(size_t)b * 2 + lane] = ctx.ld(CB + mpc::wave::W_U + lane);
+    if (U_out && lane < N) {
+        U_out[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 0);
+        U_out[((size_t)b * N + lane) * 2 + 1] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 1);
+    }
+    if (X_out && lane <= N)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            X_out[((size_t)b * (N + 1) + lane) * 4 + i] = ctx.ld(lane * SL + CB + mpc::wave::W_X + i);
+    if (lane == 0) {
+        if (status_out) status_out[b] = status;
+        if (iters_out) iters_out[b] = iters;
+    }
+}
+
 }  // namespace
 
 struct mpc_handle {
@@ -215,6 +304,28 @@ int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t 
                        d_weights, d_coll, d_others, V, h->cfg.w_collision, d_u0, d_U, d_X, d_status, d_iters);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
+}
+
+template <bool CC, int NC>
+int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
+                const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
+                const uint8_t *d_coll, const double *d_others, double *d_u0, double *d_U, double *d_X,
+                int32_t *d_status, int32_t *d_iters) {
+    auto kern = mpc_solve_wave_kernel<CC, NC>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
+                       d_vref, d_weights, d_coll, d_others, V, h->cfg.w_collision, d_u0, d_U, d_X, d_status, d_iters);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+// Which kernel: the wave-cooperative one (one wave per instance) whenever the horizon fits its reduction buffers;
+// MPC_KERNEL=lane|wave overrides (experiments, A/B tests).
+bool use_wave_kernel(int N) {
+    const char *env = getenv("MPC_KERNEL");
+    if (env && !strcmp(env, "lane")) return false;
+    return N <= 20;
 }
 
 }  // namespace
@@ -388,11 +499,28 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     P.mu_init = 0.1;
     P.w_distance = h->cfg.w_distance;
 
+    int rc;
+    if (use_wave_kernel(N)) {
+        const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
+#define MPC_LAUNCH_W(CCV, NCV)                                                                                  \
+    rc = launch_wave<CCV, NCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights, d_coll,    \
+                               d_others, d_u0, d_U, d_X, d_status, d_iters)
+        if (cc) {
+            if (N == 20) MPC_LAUNCH_W(true, 20);
+            else if (N == 16) MPC_LAUNCH_W(true, 16);
+            else MPC_LAUNCH_W(true, 0);
+        } else {
+            if (N == 20) MPC_LAUNCH_W(false, 20);
+            else if (N == 16) MPC_LAUNCH_W(false, 16);
+            else MPC_LAUNCH_W(false, 0);
+        }
+#undef MPC_LAUNCH_W
+        if (rc) return rc;
+    } else {
     const int ipw = choose_ipw(h, cc, B, N, Vuse);
     const size_t lds = lds_bytes(cc, ipw, N, h->M, Vuse);
     if (lds > h->lds_per_cu)
         return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: horizon/others/reference too large for the LDS workspace");
-    int rc;
 #define MPC_LAUNCH_N(CCV, IPWV, NCV)                                                                           \
     rc = launch<CCV, IPWV, NCV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll,   \
                                 d_others, d_u0, d_U, d_X, d_status, d_iters)
@@ -414,6 +542,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
 #undef MPC_LAUNCH
 #undef MPC_LAUNCH_N
     if (rc) return rc;
+    }
 
     if (!dev) {
         char *sb = static_cast<char *>(h->d_stage);

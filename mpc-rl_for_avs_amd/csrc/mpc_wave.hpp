@@ -1,0 +1,767 @@
+// mpc_wave.hpp - wave-cooperative interior-point DDP solver: ONE wave64 per MPC instance.
+//
+// Same NLP and same algorithm as mpc_core.hpp (which assigns one lane per instance), reorganised so that the
+// 64 lanes of a wave work on a single instance:
+//   * everything that is independent per stage (trig of the dynamics, cost and collision-potential values and
+//     derivatives, barrier terms, complementarity, dual residual, step-length ratios, dual update) runs
+//     stage-parallel, lane k = stage k, with reductions through LDS;
+//   * the Riccati / DDP factorisation stage is a lane-per-matrix-entry computation on the 8x8 stage KKT block
+//     [Hxx Hxp Hxu; . Hpp Hpu; . . Huu] (state 4 + previous control 2 + control 2) staged in LDS:
+//     T = P F (6x8), H = L + F'T (8x8), 2x2 solve, gains (2x6), P' = Hxx' + Hx'u K (6x6), four LDS exchanges;
+//   * only the true recursions (dynamics rollout, adjoint, linearised step) stay serial; they are executed
+//     redundantly by all lanes on wave-uniform values.
+// Why: measured on MI355X the one-lane-per-instance kernel is bound by the serial FP64 instruction stream of
+// its slowest instance (~47 k instructions per iteration at ~6-10 cycles each, Riccati stage = 770 of them),
+// with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state (8-9 KB) has to sit in
+// LDS.  One wave per instance keeps the same LDS footprint (16 waves per CU, 4 per SIMD, which hide each
+// other's LDS latencies) and cuts the serial stream to ~14 k instructions per iteration.
+//
+// The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
+// (f(lane) per lane, followed by a wave barrier); tests/cpu_wave_harness.cpp runs the phases as loops over the
+// 64 lanes, so the same source is validated on the CPU against the oracle.
+#pragma once
+
+#include "mpc_core.hpp"
+
+namespace mpc {
+namespace wave {
+
+constexpr int kLanes = 64;
+
+// per-stage slots in LDS (doubles); trajectory buffer b lives at b*6
+enum : int {
+    W_X = 0,     // 4 (buffer 0; buffer 1 at +6)
+    W_U = 4,     // 2
+    W_DYN = 12,  // 4  sin/cos(theta+beta), sin/cos(beta) of the current trajectory
+    W_ZXL = 16,  // 2
+    W_ZXU = 18,  // 2
+    W_ZUL = 20,  // 2
+    W_ZUU = 22,  // 2
+    W_Y = 24,    // 4  adjoint; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
+    W_KX = 28,   // 8
+    W_KP = 36,   // 3
+    W_KF = 39,   // 2
+    W_RV = 41,   // 1
+    W_SLOTS = 42,
+    W_LX = 42,   // 2  (collision-cost variant)
+    W_Q = 44,    // 3
+    W_QG = 47,   // 3
+    W_SLOTS_CC = 50
+};
+// scratch behind the stage arrays
+enum : int {
+    SC_P = 0,     // 36  value-function Hessian over (x, p), row-major 6x6
+    SC_PV = 36,   // 6   value-function gradient
+    SC_T = 42,    // 64  T = P F (6x8) during a Riccati stage; reduction buffer (3 x 21) elsewhere; gains K
+    SC_H = 106,   // 64  stage KKT block H (8x8)
+    SC_HV = 170,  // 8   its gradient
+    SC_SIG = 178, // 8   barrier curvature / gradient of the 4 bounded variables of the stage
+    SC_SIZE = 186
+};
+constexpr int SC_K = SC_T;        // gains (2x6) + feed-forward (2) reuse the T area once H is complete
+constexpr int SC_RED = SC_T;      // reductions: 3 arrays of 21
+
+MPC_HD constexpr int stage_slots(bool cc) { return cc ? W_SLOTS_CC : W_SLOTS; }
+// doubles of LDS one instance needs: stage arrays + scratch + other vehicles
+MPC_HD constexpr int lds_doubles(bool cc, int N, int V) { return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0); }
+
+// entry (m, j) of F = [A B; 0 I] (6 x 8: rows x+ (4), p+ (2); columns x (4), p (2), u (2)) from the stage scalars
+struct StageLin {
+    double a02, a03, a12, a13, a23, b01, b11, b21, dt;
+};
+MPC_HD double F_entry(const StageLin &s, int m, int j) {
+    // branch-free select chain; m, j are lane-dependent
+    double v = 0.0;
+    v = (m == j && j < 4) ? 1.0 : v;                    // identity of A
+    v = (m == 0 && j == 2) ? s.a02 : v;
+    v = (m == 0 && j == 3) ? s.a03 : v;
+    v = (m == 1 && j == 2) ? s.a12 : v;
+    v = (m == 1 && j == 3) ? s.a13 : v;
+    v = (m == 2 && j == 3) ? s.a23 : v;
+    v = (m == 3 && j == 6) ? s.dt : v;                  // B
+    v = (m == 0 && j == 7) ? s.b01 : v;
+    v = (m == 1 && j == 7) ? s.b11 : v;
+    v = (m == 2 && j == 7) ? s.b21 : v;
+    v = ((m == 4 && j == 6) || (m == 5 && j == 7)) ? 1.0 : v;  // p+ = u
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CTX (one per wave / instance) provides
+//   double ld(int i), void st(int i, double v)   LDS words of this instance
+//   void phase(F f)                              f(lane) for the 64 lanes, then a barrier
+//   double ref(int k, int c)                     reference path column c at stage k
+//   static constexpr int kN                      compile-time horizon or 0
+// The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
+// ---------------------------------------------------------------------------------------------------
+template <bool CC, class CTX>
+struct Solver {
+    const SolveParams &P;
+    CTX &c;
+    const int N, SL, SCR, OTH;
+    const double dt;
+    double x0[4];
+    double ws_, wc_, wd_, wcoll;
+    double sf = 1.0;
+
+    MPC_HD Solver(const SolveParams &P_, CTX &c_, const double *x0_, double ws, double wc, double wd, double wcl)
+        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
+          dt(P_.dt), ws_(ws), wc_(wc), wd_(wd), wcoll(wcl) {
+        x0[0] = x0_[0]; x0[1] = x0_[1]; x0[2] = x0_[2]; x0[3] = x0_[3];
+    }
+    MPC_HD double S(int k, int slot) const { return c.ld(k * SL + slot); }
+    MPC_HD void S(int k, int slot, double v) { c.st(k * SL + slot, v); }
+    MPC_HD double sc(int i) const { return c.ld(SCR + i); }
+    MPC_HD void sc(int i, double v) { c.st(SCR + i, v); }
+    MPC_HD double oth(int j, int q) const { return c.ld(OTH + j * 4 + q); }
+
+    // ---- cost pieces (same formulas as mpc_core.hpp) ------------------------------------------------
+    MPC_HD double track(int k, double x_0, double x_1, double x_2, double x_3, double *g) const {
+        const double s = c.ref(k, R_SIN), cc = c.ref(k, R_COS);
+        const double dx = x_0 - c.ref(k, R_X), dy = x_1 - c.ref(k, R_Y);
+        const double perp = dx * s - dy * cc, para = dx * cc + dy * s;
+        const double dv = x_3 - S(k, W_RV), dth = x_2 - c.ref(k, R_H);
+        if (g) {
+            g[0] = 10.0 * (8.0 * perp * s + 4.0 * para * cc);
+            g[1] = 10.0 * (-8.0 * perp * cc + 4.0 * para * s);
+            g[2] = 10.0 * dth;
+            g[3] = 20.0 * ws_ * dv;
+        }
+        return 10.0 * (4.0 * perp * perp + 2.0 * para * para + ws_ * dv * dv + 0.5 * dth * dth);
+    }
+    MPC_HD double dist(int k, double x_0, double x_1, double *d8) const {
+        double J = 0.0, g0 = 0, g1 = 0, h00 = 0, h01 = 0, h11 = 0, c00 = 0, c01 = 0, c11 = 0;
+        for (int j = 0; j < P.V; ++j) {
+            const double px = x_0 - (oth(j, 0) + k * oth(j, 2));
+            const double py = x_1 - (oth(j, 1) + k * oth(j, 3));
+            const double d2 = fma(px, px, py * py);
+            const double rd = frsqrt(d2), d = d2 * rd;
+            const double cst = (d < 1.0 ? 1000.0 : 100.0) * P.w_distance;
+            const double rde = frcp(d + 1e-6);
+            const double inv2 = rde * rde;
+            J += cst * inv2;
+            if (d8) {
+                const double dpsi = -2.0 * cst * inv2 * rde;
+                const double nx = px * rd, ny = py * rd;
+                const double d2psi = 6.0 * cst * inv2 * inv2;
+                const double tt = dpsi * rd;
+                g0 += dpsi * nx;
+                g1 += dpsi * ny;
+                h00 += d2psi * nx * nx + tt * (1.0 - nx * nx);
+                h01 += (d2psi - tt) * nx * ny;
+                h11 += d2psi * ny * ny + tt * (1.0 - ny * ny);
+                c00 += d2psi * nx * nx;
+                c01 += d2psi * nx * ny;
+                c11 += d2psi * ny * ny;
+            }
+        }
+        if (d8) {
+            d8[0] = g0; d8[1] = g1; d8[2] = h00; d8[3] = h01; d8[4] = h11; d8[5] = c00; d8[6] = c01; d8[7] = c11;
+        }
+        return J;
+    }
+    // scaled stage-cost gradient at node k of trajectory buffer cb
+    MPC_HD void cost_grad(int cb, int k, double *lx) const {
+        const int B = cb * 6;
+        const double x_3 = S(k, B + W_X + 3);
+        double g[4];
+        track(k, S(k, B + W_X + 0), S(k, B + W_X + 1), S(k, B + W_X + 2), x_3, g);
+        lx[0] = sf * g[0];
+        lx[1] = sf * g[1];
+        lx[2] = sf * g[2];
+        lx[3] = sf * g[3];
+        if (CC) {
+            lx[0] += S(k, W_LX + 0);
+            lx[1] += S(k, W_LX + 1);
+            lx[3] += sf * 2.0 * wcoll * x_3;
+        }
+    }
+
+    // ---- rollout: serial dynamics (uniform) + stage-parallel cost ----------------------------------------
+    // trial controls u_k = ucur_k + alpha kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1}), clamped to the
+    // fraction-to-the-boundary box; with first == true the controls already in buffer tb are used.
+    MPC_HD bool rollout(int cb, int tb, bool first, double alpha, double frac, double &Jout, double &barout) {
+        const int CB = cb * 6, TB = tb * 6;
+        const double fracu = 2.0 * frac;
+        double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
+        double dup0 = 0.0, dup1 = 0.0;
+        bool feas = true;
+#pragma unroll 1
+        for (int k = 0; k < N; ++k) {
+            double u0, u1;
+            if (first) {
+                u0 = S(k, TB + W_U + 0);
+                u1 = S(k, TB + W_U + 1);
+            } else {
+                const double e0 = x_0 - S(k, CB + W_X + 0), e1 = x_1 - S(k, CB + W_X + 1);
+                const double e2 = x_2 - S(k, CB + W_X + 2), e3 = x_3 - S(k, CB + W_X + 3);
+                const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
+                double s0 = alpha * S(k, W_KF + 0) + S(k, W_KX + 0) * e0 + S(k, W_KX + 1) * e1 + S(k, W_KX + 2) * e2 +
+                            S(k, W_KX + 3) * e3;
+                double s1 = alpha * S(k, W_KF + 1) + S(k, W_KX + 4) * e0 + S(k, W_KX + 5) * e1 + S(k, W_KX + 6) * e2 +
+                            S(k, W_KX + 7) * e3;
+                if (k >= 1) {
+                    const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);
+                    s0 += kp00 * dup0 + kp01 * dup1;
+                    s1 += kp01 * dup0 + kp11 * dup1;
+                }
+                u0 = fmin2(fmax2(c0 + s0, ulo_r(0) + fracu * (c0 - ulo_r(0))), uhi_r(0) - fracu * (uhi_r(0) - c0));
+                u1 = fmin2(fmax2(c1 + s1, ulo_r(1) + fracu * (c1 - ulo_r(1))), uhi_r(1) - fracu * (uhi_r(1) - c1));
+                dup0 = u0 - c0;
+                dup1 = u1 - c1;
+                S(k, TB + W_U + 0, u0);
+                S(k, TB + W_U + 1, u1);
+            }
+            S(k, TB + W_X + 0, x_0);
+            S(k, TB + W_X + 1, x_1);
+            S(k, TB + W_X + 2, x_2);
+            S(k, TB + W_X + 3, x_3);
+            double Sn, Cn, sb, cb_;
+            dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+            const double n0 = x_0 + dt * (x_3 * Cn);
+            const double n1 = x_1 + dt * (x_3 * Sn);
+            const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+            const double n3 = x_3 + dt * u0;
+            if (!first) {
+                const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+                if (n2 - xlo_r(0) < frac * (o2 - xlo_r(0)) || xhi_r(0) - n2 < frac * (xhi_r(0) - o2) ||
+                    n3 - xlo_r(1) < frac * (o3 - xlo_r(1)) || xhi_r(1) - n3 < frac * (xhi_r(1) - o3)) {
+                    feas = false;
+                    break;
+                }
+            } else if (!(n2 > xlo_r(0)) || !(n2 < xhi_r(0)) || !(n3 > xlo_r(1)) || !(n3 < xhi_r(1))) {
+                feas = false;
+                break;
+            }
+            x_0 = n0;
+            x_1 = n1;
+            x_2 = n2;
+            x_3 = n3;
+        }
+        if (!feas) return false;
+        S(N, TB + W_X + 0, x_0);
+        S(N, TB + W_X + 1, x_1);
+        S(N, TB + W_X + 2, x_2);
+        S(N, TB + W_X + 3, x_3);
+        // stage-parallel: control cost of stage k, tracking / collision cost and barrier of node k+1
+        c.phase([&](int lane) {
+            if (lane >= N) return;
+            const int k = lane;
+            const double u0 = S(k, TB + W_U + 0), u1 = S(k, TB + W_U + 1);
+            double J = 0.01 * sf * wc_ * (u0 * u0 + u1 * u1);
+            if (k >= 1) {
+                const double d0 = u0 - S(k - 1, TB + W_U + 0), d1 = u1 - S(k - 1, TB + W_U + 1);
+                J += 0.01 * sf * wd_ * (d0 * d0 + d1 * d1);
+            }
+            const double y0 = S(k + 1, TB + W_X + 0), y1 = S(k + 1, TB + W_X + 1);
+            const double y2 = S(k + 1, TB + W_X + 2), y3 = S(k + 1, TB + W_X + 3);
+            const double slack = (((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1))) *
+                                 (((y2 - xlo_r(0)) * (xhi_r(0) - y2)) * ((y3 - xlo_r(1)) * (xhi_r(1) - y3)));
+            if (k + 1 < N) {
+                J += sf * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
+                if (CC) J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
+            }
+            sc(SC_RED + lane, J);
+            sc(SC_RED + 21 + lane, -log(slack));
+        });
+        double J = 0.0, bar = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < N; ++k) {
+            J += sc(SC_RED + k);
+            bar += sc(SC_RED + 21 + k);
+        }
+        Jout = J;
+        barout = bar;
+        return true;
+    }
+
+    // ---- the solve --------------------------------------------------------------------------------------
+    MPC_HD void solve(int &status_out, int &iters_out, int &cur_out, double &kkt_out) {
+        int cur = 0;
+        status_out = 1;
+        iters_out = 0;
+        cur_out = 0;
+        kkt_out = INFINITY;
+        // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
+        c.phase([&](int lane) {
+            if (lane >= N) return;
+            S(lane, W_U + 0, 0.0);
+            S(lane, W_U + 1, 0.0);
+            for (int i = 0; i < 2; ++i) {
+                S(lane, W_ZUL + i, 1.0);
+                S(lane, W_ZUU + i, 1.0);
+                S(lane + 1, W_ZXL + i, 1.0);
+                S(lane + 1, W_ZXU + i, 1.0);
+            }
+        });
+        if (x0[3] < 0.01) S(0, W_U + 0, (0.01 - x0[3]) / dt);
+        double Jcur = 0.0, barcur = 0.0;
+        if (!rollout(0, 0, true, 0.0, 0.0, Jcur, barcur)) {
+            status_out = 3;
+            return;
+        }
+        // objective scaling: sf = 100 / clamp(|grad f|_inf at the start, 100, 1e4)
+        {
+            c.phase([&](int lane) {
+                double g = 0.0;
+                if (lane >= 1 && lane < N) {
+                    if (CC) {
+                        double d8[8];
+                        dist(lane, S(lane, W_X + 0), S(lane, W_X + 1), d8);
+                        S(lane, W_LX + 0, d8[0]);
+                        S(lane, W_LX + 1, d8[1]);
+                    }
+                    double lx[4];
+                    cost_grad(0, lane, lx);
+                    g = fmax2(fmax2(fabs(lx[0]), fabs(lx[1])), fmax2(fabs(lx[2]), fabs(lx[3])));
+                }
+                if (lane < 21) sc(SC_RED + lane, g);
+            });
+            double gmax = 0.02 * (wc_ + wd_) * fabs(S(0, W_U + 0));
+#pragma unroll 1
+            for (int k = 1; k < N && k < 21; ++k) gmax = fmax2(gmax, sc(SC_RED + k));
+            sf = 100.0 / fmin2(fmax2(100.0, gmax), 1e4);
+            Jcur *= sf;
+        }
+        const double rd_full = 0.02 * sf * wd_, rc = 0.02 * sf * wc_, qtt = 10.0 * sf;
+        const double q33 = sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0));
+        double mu = P.mu_init;
+        const double mu_min = P.tol / 10.0;
+        int iter = 0, nfail = 0;
+
+        for (iter = 0; iter <= P.max_iter; ++iter) {
+            const int CB = cur * 6;
+            // ============ stage-parallel preparation: dynamics trig, collision-potential derivatives,
+            //              complementarity products
+            c.phase([&](int lane) {
+                if (lane >= N) return;
+                const int k = lane;
+                const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
+                double Sn, Cn, sb, cb_;
+                dyn_eval(S(k, CB + W_X + 2), u1, Sn, Cn, sb, cb_);
+                S(k, W_DYN + 0, Sn);
+                S(k, W_DYN + 1, Cn);
+                S(k, W_DYN + 2, sb);
+                S(k, W_DYN + 3, cb_);
+                if (CC && k >= 1) {
+                    double d8[8];
+                    dist(k, S(k, CB + W_X + 0), S(k, CB + W_X + 1), d8);
+                    S(k, W_LX + 0, sf * d8[0]);
+                    S(k, W_LX + 1, sf * d8[1]);
+                    S(k, W_Q + 0, sf * d8[2]);
+                    S(k, W_Q + 1, sf * d8[3]);
+                    S(k, W_Q + 2, sf * d8[4]);
+                    S(k, W_QG + 0, sf * d8[5]);
+                    S(k, W_QG + 1, sf * d8[6]);
+                    S(k, W_QG + 2, sf * d8[7]);
+                }
+                const double zul0 = S(k, W_ZUL + 0), zul1 = S(k, W_ZUL + 1), zuu0 = S(k, W_ZUU + 0), zuu1 = S(k, W_ZUU + 1);
+                double cmx, cmn, sz = zul0 + zul1 + zuu0 + zuu1;
+                {
+                    const double c0 = (u0 - ulo_r(0)) * zul0, c1 = (uhi_r(0) - u0) * zuu0;
+                    const double c2 = (u1 - ulo_r(1)) * zul1, c3 = (uhi_r(1) - u1) * zuu1;
+                    cmx = fmax2(fmax2(c0, c1), fmax2(c2, c3));
+                    cmn = fmin2(fmin2(c0, c1), fmin2(c2, c3));
+                }
+                for (int i = 0; i < 2; ++i) {
+                    const double xi = S(k + 1, CB + W_X + 2 + i);
+                    const double zl = S(k + 1, W_ZXL + i), zu = S(k + 1, W_ZXU + i);
+                    const double c0 = (xi - xlo_r(i)) * zl, c1 = (xhi_r(i) - xi) * zu;
+                    cmx = fmax2(cmx, fmax2(c0, c1));
+                    cmn = fmin2(cmn, fmin2(c0, c1));
+                    sz += zl + zu;
+                }
+                sc(SC_RED + lane, cmx);
+                sc(SC_RED + 21 + lane, cmn);
+                sc(SC_RED + 42 + lane, sz);
+            });
+            double cmax = 0.0, cmin = INFINITY, sum_z = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) {
+                cmax = fmax2(cmax, sc(SC_RED + k));
+                cmin = fmin2(cmin, sc(SC_RED + 21 + k));
+                sum_z += sc(SC_RED + 42 + k);
+            }
+            // ============ adjoint recursion (serial): y_k = dL/dx_k
+            double sum_lam = 0.0;
+            {
+                double y0 = 0.0, y1 = 0.0;
+                double y2 = -S(N, W_ZXL + 0) + S(N, W_ZXU + 0);
+                double y3 = -S(N, W_ZXL + 1) + S(N, W_ZXU + 1);
+#pragma unroll 1
+                for (int k = N - 1; k >= 0; --k) {
+                    S(k + 1, W_Y + 0, y0);
+                    S(k + 1, W_Y + 1, y1);
+                    S(k + 1, W_Y + 2, y2);
+                    S(k + 1, W_Y + 3, y3);
+                    sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
+                    if (k >= 1) {
+                        const double v = S(k, CB + W_X + 3);
+                        const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2);
+                        const double a02 = -dt * v * Sn, a03 = dt * Cn, a12 = dt * v * Cn, a13 = dt * Sn,
+                                     a23 = dt * sb * kInvWheelbase;
+                        double lx[4];
+                        cost_grad(cur, k, lx);
+                        const double t0 = lx[0] + y0;
+                        const double t1 = lx[1] + y1;
+                        const double t2 = lx[2] - S(k, W_ZXL + 0) + S(k, W_ZXU + 0) + a02 * y0 + a12 * y1 + y2;
+                        const double t3 = lx[3] - S(k, W_ZXL + 1) + S(k, W_ZXU + 1) + a03 * y0 + a13 * y1 + a23 * y2 + y3;
+                        y0 = t0;
+                        y1 = t1;
+                        y2 = t2;
+                        y3 = t3;
+                    }
+                }
+            }
+            // ============ dual residual of the controls (stage-parallel)
+            c.phase([&](int lane) {
+                if (lane >= N) return;
+                const int k = lane;
+                const double rdk = (k >= 1) ? rd_full : 0.0;
+                const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
+                double um0 = 0.0, um1 = 0.0;
+                if (k >= 1) {
+                    um0 = S(k - 1, CB + W_U + 0);
+                    um1 = S(k - 1, CB + W_U + 1);
+                }
+                double r0 = rc * u0 + rdk * (u0 - um0) - S(k, W_ZUL + 0) + S(k, W_ZUU + 0);
+                double r1 = rc * u1 + rdk * (u1 - um1) - S(k, W_ZUL + 1) + S(k, W_ZUU + 1);
+                if (k + 1 < N) {
+                    r0 -= rd_full * (S(k + 1, CB + W_U + 0) - u0);
+                    r1 -= rd_full * (S(k + 1, CB + W_U + 1) - u1);
+                }
+                const double v = S(k, CB + W_X + 3);
+                const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
+                double bp, bpp;
+                beta_derivs(sb, cb_, bp, bpp);
+                const double b01 = -dt * v * Sn * bp, b11 = dt * v * Cn * bp, b21 = dt * v * kInvWheelbase * cb_ * bp;
+                r0 += dt * S(k + 1, W_Y + 3);
+                r1 += b01 * S(k + 1, W_Y + 0) + b11 * S(k + 1, W_Y + 1) + b21 * S(k + 1, W_Y + 2);
+                sc(SC_RED + lane, fmax2(fabs(r0), fabs(r1)));
+            });
+            double err_d = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) err_d = fmax2(err_d, sc(SC_RED + k));
+            const double s_d = fmax2(100.0, (sum_lam + sum_z) / (10.0 * N)) / 100.0;
+            const double s_c = fmax2(100.0, sum_z / (6.0 * N)) / 100.0;
+            for (;;) {
+                const double ec = fmax2(cmax - mu, mu - cmin);
+                const double E_mu = fmax2(err_d / s_d, ec / s_c);
+                if (E_mu <= 10.0 * mu && mu > mu_min) {
+                    mu = fmax2(mu_min, fmin2(0.2 * mu, mu * sqrt(mu)));
+                    continue;
+                }
+                break;
+            }
+            const double E0 = fmax2(err_d / s_d, cmax / s_c);
+            kkt_out = E0;
+            if (E0 <= P.tol) {
+                status_out = 0;
+                break;
+            }
+            if (iter == P.max_iter) break;
+
+            // ============ Riccati / DDP factorisation: lane (i, j) = entry of the 8x8 stage block ============
+            double dV1 = 0.0, delta_w = 0.0;
+            bool ok = false, gn = false;
+            for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
+                ok = true;
+                dV1 = 0.0;
+                // terminal value function: barrier terms of (theta, v)_N
+                c.phase([&](int lane) {
+                    if (lane < 36) sc(SC_P + lane, ((lane % 7) == 0 && lane < 28) ? delta_w : 0.0);
+                    if (lane >= 36 && lane < 42) sc(SC_PV + lane - 36, 0.0);
+                });
+                for (int i = 0; i < 2; ++i) {
+                    const double xi = S(N, CB + W_X + 2 + i);
+                    const double rl = frcp(xi - xlo_r(i)), ru = frcp(xhi_r(i) - xi);
+                    sc(SC_P + (2 + i) * 7, S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w);
+                    sc(SC_PV + 2 + i, mu * (ru - rl));
+                }
+#pragma unroll 1
+                for (int k = N - 1; k >= 0; --k) {
+                    const double rdk = (k >= 1) ? rd_full : 0.0;
+                    const double v = S(k, CB + W_X + 3);
+                    const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
+                    double bp, bpp;
+                    beta_derivs(sb, cb_, bp, bpp);
+                    StageLin sl;
+                    sl.a02 = -dt * v * Sn; sl.a03 = dt * Cn; sl.a12 = dt * v * Cn; sl.a13 = dt * Sn;
+                    sl.a23 = dt * sb * kInvWheelbase;
+                    sl.b01 = -dt * v * Sn * bp; sl.b11 = dt * v * Cn * bp; sl.b21 = dt * v * kInvWheelbase * cb_ * bp;
+                    sl.dt = dt;
+                    // ---- level 1: T = P F (6x8); clear H; barrier curvature / gradient of the 4 bounded variables
+                    c.phase([&](int lane) {
+                        const int i = lane >> 3, j = lane & 7;
+                        if (lane < 48) {
+                            double t = 0.0;
+                            for (int m = 0; m < 6; ++m) t = fma(sc(SC_P + i * 6 + m), F_entry(sl, m, j), t);
+                            sc(SC_T + lane, t);
+                        } else if (lane < 52) {
+                            const int q = lane - 48;  // 0: theta_k, 1: v_k, 2: a_k, 3: delta_k
+                            const bool isx = q < 2;
+                            const int b = isx ? q : q - 2;
+                            const double val = isx ? S(k, CB + W_X + 2 + b) : S(k, CB + W_U + b);
+                            const double lo = isx ? xlo_r(b) : ulo_r(b), hi = isx ? xhi_r(b) : uhi_r(b);
+                            const double zl = isx ? S(k, W_ZXL + b) : S(k, W_ZUL + b);
+                            const double zu = isx ? S(k, W_ZXU + b) : S(k, W_ZUU + b);
+                            const double rl = frcp(val - lo), ru = frcp(hi - val);
+                            sc(SC_SIG + q, zl * rl + zu * ru);
+                            sc(SC_SIG + 4 + q, mu * (ru - rl));
+                        }
+                        sc(SC_H + lane, 0.0);
+                        if (lane < 8) sc(SC_HV + lane, 0.0);
+                    });
+                    // ---- stage cost Hessian / gradient L (uniform): written into H, HV
+                    const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
+                    double wdd = 0.0;
+                    if (!gn) {
+                        const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
+                        const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
+                        wdd = dt * v * (g * bp * bp + h * bpp) + dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
+                        if (k >= 1) {
+                            sc(SC_H + 2 * 8 + 2, dt * v * g);                // theta-theta
+                            sc(SC_H + 2 * 8 + 3, dt * h);                    // theta-v
+                            sc(SC_H + 3 * 8 + 2, dt * h);
+                            const double wtd = dt * v * g * bp;
+                            const double wvd = dt * h * bp + dt * yy2 * cb_ * bp * kInvWheelbase;
+                            sc(SC_H + 2 * 8 + 7, wtd);
+                            sc(SC_H + 7 * 8 + 2, wtd);
+                            sc(SC_H + 3 * 8 + 7, wvd);
+                            sc(SC_H + 7 * 8 + 3, wvd);
+                        }
+                    }
+                    if (k >= 1) {
+                        double lx[4];
+                        cost_grad(cur, k, lx);
+                        const double s = c.ref(k, R_SIN), cc = c.ref(k, R_COS);
+                        double l00 = sf * 10.0 * (8.0 * s * s + 4.0 * cc * cc) + delta_w;
+                        double l01 = sf * 10.0 * (-8.0 * s * cc + 4.0 * cc * s);
+                        double l11 = sf * 10.0 * (8.0 * cc * cc + 4.0 * s * s) + delta_w;
+                        if (CC) {
+                            const int QS = gn ? W_QG : W_Q;
+                            l00 += S(k, QS + 0);
+                            l01 += S(k, QS + 1);
+                            l11 += S(k, QS + 2);
+                        }
+                        sc(SC_H + 0, l00);
+                        sc(SC_H + 1, l01);
+                        sc(SC_H + 8, l01);
+                        sc(SC_H + 9, l11);
+                        sc(SC_H + 2 * 8 + 2, sc(SC_H + 2 * 8 + 2) + qtt + sc(SC_SIG + 0) + delta_w);
+                        sc(SC_H + 3 * 8 + 3, q33 + sc(SC_SIG + 1) + delta_w);
+                        sc(SC_HV + 0, lx[0]);
+                        sc(SC_HV + 1, lx[1]);
+                        sc(SC_HV + 2, lx[2] + sc(SC_SIG + 4));
+                        sc(SC_HV + 3, lx[3] + sc(SC_SIG + 5));
+                        sc(SC_H + 4 * 8 + 4, rdk);
+                        sc(SC_H + 5 * 8 + 5, rdk);
+                        sc(SC_H + 4 * 8 + 6, -rdk);
+                        sc(SC_H + 6 * 8 + 4, -rdk);
+                        sc(SC_H + 5 * 8 + 7, -rdk);
+                        sc(SC_H + 7 * 8 + 5, -rdk);
+                    }
+                    {
+                        double um0 = 0.0, um1 = 0.0;
+                        if (k >= 1) {
+                            um0 = S(k - 1, CB + W_U + 0);
+                            um1 = S(k - 1, CB + W_U + 1);
+                        }
+                        sc(SC_H + 6 * 8 + 6, rc + rdk + sc(SC_SIG + 2) + delta_w);
+                        sc(SC_H + 7 * 8 + 7, rc + rdk + sc(SC_SIG + 3) + delta_w + wdd);
+                        sc(SC_HV + 6, rc * u0 + rdk * (u0 - um0) + sc(SC_SIG + 6));
+                        sc(SC_HV + 7, rc * u1 + rdk * (u1 - um1) + sc(SC_SIG + 7));
+                        sc(SC_HV + 4, -rdk * (u0 - um0));
+                        sc(SC_HV + 5, -rdk * (u1 - um1));
+                    }
+                    // ---- level 2: H += F' T, HV += F' PV
+                    c.phase([&](int lane) {
+                        const int i = lane >> 3, j = lane & 7;
+                        double h = sc(SC_H + lane);
+                        for (int m = 0; m < 6; ++m) h = fma(F_entry(sl, m, i), sc(SC_T + m * 8 + j), h);
+                        sc(SC_H + lane, h);
+                        if (lane < 8) {
+                            double g = sc(SC_HV + lane);
+                            for (int m = 0; m < 6; ++m) g = fma(F_entry(sl, m, lane), sc(SC_PV + m), g);
+                            sc(SC_HV + lane, g);
+                        }
+                    });
+                    // ---- 2x2 control block (uniform)
+                    const double ha = sc(SC_H + 6 * 8 + 6), hb = 0.5 * (sc(SC_H + 6 * 8 + 7) + sc(SC_H + 7 * 8 + 6)),
+                                 hc = sc(SC_H + 7 * 8 + 7);
+                    const double det = ha * hc - hb * hb;
+                    if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
+                        ok = false;
+                        break;
+                    }
+                    const double idet = frcp(det);
+                    const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
+                    const double hu0 = sc(SC_HV + 6), hu1 = sc(SC_HV + 7);
+                    const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
+                    dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
+                    S(k, W_KF + 0, kf0);
+                    S(k, W_KF + 1, kf1);
+                    S(k, W_KP + 0, rdk * i00);
+                    S(k, W_KP + 1, rdk * i01);
+                    S(k, W_KP + 2, rdk * i11);
+                    // ---- level 3: gains K = -Huu^-1 Hu. (2x6) into the T area and the stage arrays
+                    c.phase([&](int lane) {
+                        if (lane >= 12) return;
+                        const int a = lane / 6, j = lane % 6;
+                        const double ia0 = a == 0 ? i00 : i01, ia1 = a == 0 ? i01 : i11;
+                        const double kv = -(ia0 * sc(SC_H + 6 * 8 + j) + ia1 * sc(SC_H + 7 * 8 + j));
+                        sc(SC_K + lane, kv);
+                        if (j < 4) S(k, W_KX + a * 4 + j, kv);
+                    });
+                    // ---- level 4: value function of node k: P = sym(Hxx + Hxu K), pv = hx + Hxu kf
+                    c.phase([&](int lane) {
+                        if (lane < 36) {
+                            const int i = lane / 6, j = lane % 6;
+                            const double nij = sc(SC_H + i * 8 + j) + sc(SC_H + i * 8 + 6) * sc(SC_K + j) +
+                                               sc(SC_H + i * 8 + 7) * sc(SC_K + 6 + j);
+                            const double nji = sc(SC_H + j * 8 + i) + sc(SC_H + j * 8 + 6) * sc(SC_K + i) +
+                                               sc(SC_H + j * 8 + 7) * sc(SC_K + 6 + i);
+                            sc(SC_P + lane, 0.5 * (nij + nji));
+                        } else if (lane < 42) {
+                            const int i = lane - 36;
+                            sc(SC_PV + i, sc(SC_HV + i) + sc(SC_H + i * 8 + 6) * kf0 + sc(SC_H + i * 8 + 7) * kf1);
+                        }
+                    });
+                }
+                if (!ok) {
+                    if (!gn) {
+                        gn = true;
+                    } else {
+                        delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
+                    }
+                    if (delta_w > 1e40) break;
+                }
+            }
+            if (!ok) {
+                status_out = 2;
+                break;
+            }
+
+            // ============ linearised Newton step (serial recursion), parked in the adjoint slots
+            const double tau = fmax2(0.99, 1.0 - mu);
+            {
+                double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
+#pragma unroll 1
+                for (int k = 0; k < N; ++k) {
+                    double du0 = S(k, W_KF + 0) + S(k, W_KX + 0) * d0 + S(k, W_KX + 1) * d1 + S(k, W_KX + 2) * d2 +
+                                 S(k, W_KX + 3) * d3;
+                    double du1 = S(k, W_KF + 1) + S(k, W_KX + 4) * d0 + S(k, W_KX + 5) * d1 + S(k, W_KX + 6) * d2 +
+                                 S(k, W_KX + 7) * d3;
+                    if (k >= 1) {
+                        const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);
+                        du0 += kp00 * dp0 + kp01 * dp1;
+                        du1 += kp01 * dp0 + kp11 * dp1;
+                    }
+                    const double v = S(k, CB + W_X + 3);
+                    const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
+                    double bp, bpp;
+                    beta_derivs(sb, cb_, bp, bpp);
+                    const double a02 = -dt * v * Sn, a03 = dt * Cn, a12 = dt * v * Cn, a13 = dt * Sn,
+                                 a23 = dt * sb * kInvWheelbase;
+                    const double b01 = -dt * v * Sn * bp, b11 = dt * v * Cn * bp, b21 = dt * v * kInvWheelbase * cb_ * bp;
+                    const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
+                    const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
+                    const double n2 = d2 + a23 * d3 + b21 * du1;
+                    const double n3 = d3 + dt * du0;
+                    d0 = n0; d1 = n1; d2 = n2; d3 = n3;
+                    dp0 = du0; dp1 = du1;
+                    S(k, W_Y + 0, du0);
+                    S(k, W_Y + 1, du1);
+                    S(k + 1, W_Y + 2, d2);
+                    S(k + 1, W_Y + 3, d3);
+                }
+            }
+            // ============ step-length limits (stage-parallel)
+            c.phase([&](int lane) {
+                if (lane >= N) return;
+                const int k = lane;
+                double rp = 0.0, rdn = 0.0, rdd = 1.0;
+                for (int i = 0; i < 4; ++i) {
+                    const bool isu = i < 2;
+                    const int j = isu ? i : i - 2;
+                    const double lo = isu ? ulo_r(j) : xlo_r(j), hi = isu ? uhi_r(j) : xhi_r(j);
+                    const int kk = isu ? k : k + 1;
+                    const double val = isu ? S(kk, CB + W_U + j) : S(kk, CB + W_X + 2 + j);
+                    const double d = S(kk, W_Y + i);
+                    const double zl = isu ? S(kk, W_ZUL + j) : S(kk, W_ZXL + j);
+                    const double zu = isu ? S(kk, W_ZUU + j) : S(kk, W_ZXU + j);
+                    const double rsl = frcp(val - lo), rsu = frcp(hi - val);
+                    const double dzl = (mu - zl * d) * rsl - zl, dzu = (mu + zu * d) * rsu - zu;
+                    if (!isu) rp = fmax2(rp, fmax2(-d * rsl, d * rsu));
+                    if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
+                    if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
+                }
+                sc(SC_RED + lane, rp);
+                sc(SC_RED + 21 + lane, rdn);
+                sc(SC_RED + 42 + lane, rdd);
+            });
+            double a_pr, a_du;
+            {
+                double rp = 0.0, rdn = 0.0, rdd = 1.0;
+#pragma unroll 1
+                for (int k = 0; k < N; ++k) {
+                    rp = fmax2(rp, sc(SC_RED + k));
+                    const double n = sc(SC_RED + 21 + k), d = sc(SC_RED + 42 + k);
+                    if (n * rdd > rdn * d) { rdn = n; rdd = d; }
+                }
+                a_pr = (rp > tau) ? tau / rp : 1.0;
+                a_du = (rdn > tau * rdd) ? tau * rdd / rdn : 1.0;
+            }
+            // ============ line search on the barrier objective (Armijo, <= 6 trials, factor 1/4)
+            const double phi0 = Jcur + mu * barcur;
+            const int tb = cur ^ 1;
+            double alpha = a_pr, Jn = 0.0, barn = 0.0;
+            bool accepted = false;
+            for (int nls = 0; nls < 6; ++nls, alpha *= 0.25) {
+                if (!rollout(cur, tb, false, alpha, 0.5 * (1.0 - tau), Jn, barn)) continue;
+                if (Jn + mu * barn <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                    accepted = true;
+                    break;
+                }
+            }
+            // ============ dual update (stage-parallel)
+            {
+                const int NB = (accepted ? tb : cur) * 6;
+                c.phase([&](int lane) {
+                    if (lane >= N) return;
+                    const int k = lane;
+                    for (int i = 0; i < 4; ++i) {
+                        const bool isu = i < 2;
+                        const int j = isu ? i : i - 2;
+                        const double lo = isu ? ulo_r(j) : xlo_r(j), hi = isu ? uhi_r(j) : xhi_r(j);
+                        const int kk = isu ? k : k + 1;
+                        const int sv = isu ? (W_U + j) : (W_X + 2 + j);
+                        const int szl = isu ? (W_ZUL + j) : (W_ZXL + j), szu = isu ? (W_ZUU + j) : (W_ZXU + j);
+                        const double val = S(kk, CB + sv), d = S(kk, W_Y + i);
+                        const double zl = S(kk, szl), zu = S(kk, szu);
+                        const double dzl = (mu - zl * d) * frcp(val - lo) - zl, dzu = (mu + zu * d) * frcp(hi - val) - zu;
+                        const double vn = S(kk, NB + sv);
+                        const double ml = mu * frcp(vn - lo), mh = mu * frcp(hi - vn);
+                        S(kk, szl, fmax2(fmin2(zl + (dzl > 0.0 ? 1.0 : a_du) * dzl, 1e10 * ml), 1e-10 * ml));
+                        S(kk, szu, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : a_du) * dzu, 1e10 * mh), 1e-10 * mh));
+                    }
+                });
+            }
+            if (accepted) {
+                cur = tb;
+                Jcur = Jn;
+                barcur = barn;
+                nfail = 0;
+            } else if (++nfail >= 3) {
+                status_out = 4;
+                ++iter;
+                break;
+            }
+        }
+        iters_out = iter;
+        cur_out = cur;
+    }
+};
+
+}  // namespace wave
+}  // namespace mpc
