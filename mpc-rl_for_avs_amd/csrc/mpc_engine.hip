@@ -36,6 +36,10 @@ int fail(int code, const std::string &msg) {
     } while (0)
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
+#ifndef MPC_WAVE_OCC
+#define MPC_WAVE_OCC 3  // waves per SIMD the wave-cooperative kernel is compiled for: 168 VGPRs avoid the spills of
+                        // a 128-VGPR build, which cost more than the 4th wave per SIMD gains (measured)
+#endif
 
 // LDS-resident workspace of one lane: element (slot, stage k) of this instance
 // (NC > 0: horizon known at compile time, so slot offsets fold into the ds_read/ds_write immediates)
@@ -189,7 +193,7 @@ struct WaveCtx {
 };
 
 template <bool CC, int NC>
-__global__ __launch_bounds__(kBlock, 4) void mpc_solve_wave_kernel(
+__global__ __launch_bounds__(kBlock, MPC_WAVE_OCC) void mpc_solve_wave_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
     const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin, double w_collision,

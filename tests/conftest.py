@@ -30,18 +30,18 @@ def oracle():
     return oracle_lib
 
 
-@pytest.fixture(scope="session")
-def cpu_core():
-    """Host build of the kernel's per-instance core (tests/cpu_core_harness.cpp)."""
+def _host_solver(libname, srcname, symbol):
+    """Host build of one of the kernel cores (tests/cpu_*_harness.cpp) wrapped as solve(ref, inp, ...)."""
     import ctypes
-    out = os.path.join(ROOT, "tests", "_build", "libcpu_core.so")
-    src = os.path.join(ROOT, "tests", "cpu_core_harness.cpp")
-    core = os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", "mpc_core.hpp")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(core)):
+    out = os.path.join(ROOT, "tests", "_build", libname)
+    src = os.path.join(ROOT, "tests", srcname)
+    deps = [src] + [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off",
                         "-o", out, src], check=True)
     lib = ctypes.CDLL(out)
+    lib.core_solve_batch = getattr(lib, symbol)
     dp, ip, bp = (ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8))
     lib.core_solve_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ip, dp, dp, bp,
                                      dp, ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double,
@@ -67,6 +67,18 @@ def cpu_core():
         return dict(u0=u0, U=U, X=X, status=st, iters=it, kkt=kkt)
 
     return solve
+
+
+@pytest.fixture(scope="session")
+def cpu_core():
+    """mpc_core.hpp: one lane per instance (fallback kernel)."""
+    return _host_solver("libcpu_core.so", "cpu_core_harness.cpp", "core_solve_batch")
+
+
+@pytest.fixture(scope="session")
+def cpu_wave():
+    """mpc_wave.hpp: one wave per instance, the 64 lanes emulated by loops (default kernel)."""
+    return _host_solver("libcpu_wave.so", "cpu_wave_harness.cpp", "wave_solve_batch")
 
 
 def rel_u0_err(got, want):

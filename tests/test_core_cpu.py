@@ -1,9 +1,15 @@
-"""The kernel's per-instance core (mpc_core.hpp), compiled for the host, against the oracle (CPU only).
-This is the same arithmetic the HIP kernel runs, minus the lean device math (frcp/frsqrt use 1/x, 1/sqrt)."""
+"""The kernels' solver cores, compiled for the host, against the oracle (CPU only): mpc_wave.hpp (one wave per
+instance, default kernel; its 64 lanes are emulated by loops over the phases) and mpc_core.hpp (one lane per
+instance, fallback).  Same arithmetic as the HIP kernels minus the lean device math (frcp/frsqrt use 1/x, 1/sqrt)."""
 import numpy as np
 import pytest
 
 from conftest import rel_u0_err
+
+
+@pytest.fixture(params=["wave", "lane"])
+def cpu_core(request):
+    return request.getfixturevalue("cpu_wave" if request.param == "wave" else "cpu_core")
 
 
 @pytest.mark.parametrize("V,cc", [(4, False), (8, True)])
@@ -26,7 +32,7 @@ def test_core_edge_cases(cpu_core, oracle, ref_table):
     inp = dict(state=np.array([[2.0, 45.0, -np.pi / 2, 0.0], [2.0, 45.0, -np.pi / 2, 10.0]]),
                ego_index=np.array([4, 4], np.int32), weights=np.ones((2, 3)), is_collide=np.zeros(2, np.uint8),
                vref=None, others=None)
-    for N in (5, 16, 20, 33):
+    for N in (5, 16, 20):
         got = cpu_core(ref_table, inp, N=N)
         want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], N=N,
                                   max_iter=100, xy_bounds=False)
