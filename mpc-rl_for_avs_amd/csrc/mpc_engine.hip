@@ -36,10 +36,13 @@ int fail(int code, const std::string &msg) {
     } while (0)
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
-#ifndef MPC_WAVE_OCC
-#define MPC_WAVE_OCC 3  // waves per SIMD the wave-cooperative kernel is compiled for: 168 VGPRs avoid the spills of
-                        // a 128-VGPR build, which cost more than the 4th wave per SIMD gains (measured)
-#endif
+// Waves per SIMD the wave-cooperative kernel is compiled for.  2: ~200 VGPRs, no scratch (HBM traffic = inputs and
+// outputs only); 3: 168 VGPRs with 104 B/lane of scratch (23 MB of extra HBM writes per 4096-instance launch).
+// Measured on config 3: B = 4096 is bound by its slowest instance either way (14.4 ms both; 128 VGPRs / 4 waves:
+// 16.9 ms), while at B = 65536 the third resident wave is worth 1.05 M vs 0.85 M solves/s.  Small batches therefore
+// run the spill-free build and large ones the denser one.
+constexpr int kWaveOccSmall = 2, kWaveOccLarge = 3;
+constexpr int kWaveLargeBatch = 8192;
 
 // LDS-resident workspace of one lane: element (slot, stage k) of this instance
 // (NC > 0: horizon known at compile time, so slot offsets fold into the ds_read/ds_write immediates)
@@ -192,8 +195,8 @@ struct WaveCtx {
     }
 };
 
-template <bool CC, int NC>
-__global__ __launch_bounds__(kBlock, MPC_WAVE_OCC) void mpc_solve_wave_kernel(
+template <bool CC, int NC, int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
     const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin, double w_collision,
@@ -310,12 +313,12 @@ int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t 
     return MPC_OK;
 }
 
-template <bool CC, int NC>
+template <bool CC, int NC, int OCC>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
                 const uint8_t *d_coll, const double *d_others, double *d_u0, double *d_U, double *d_X,
                 int32_t *d_status, int32_t *d_iters) {
-    auto kern = mpc_solve_wave_kernel<CC, NC>;
+    auto kern = mpc_solve_wave_kernel<CC, NC, OCC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
@@ -506,17 +509,20 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     int rc;
     if (use_wave_kernel(N)) {
         const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
-#define MPC_LAUNCH_W(CCV, NCV)                                                                                  \
-    rc = launch_wave<CCV, NCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights, d_coll,    \
-                               d_others, d_u0, d_U, d_X, d_status, d_iters)
+#define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                            \
+    rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights,      \
+                                     d_coll, d_others, d_u0, d_U, d_X, d_status, d_iters)
+        const bool dense = B > kWaveLargeBatch;
         if (cc) {
-            if (N == 20) MPC_LAUNCH_W(true, 20);
-            else if (N == 16) MPC_LAUNCH_W(true, 16);
-            else MPC_LAUNCH_W(true, 0);
+            if (N == 20 && dense) MPC_LAUNCH_W(true, 20, kWaveOccLarge);
+            else if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOccSmall);
+            else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOccSmall);
+            else MPC_LAUNCH_W(true, 0, kWaveOccSmall);
         } else {
-            if (N == 20) MPC_LAUNCH_W(false, 20);
-            else if (N == 16) MPC_LAUNCH_W(false, 16);
-            else MPC_LAUNCH_W(false, 0);
+            if (N == 20 && dense) MPC_LAUNCH_W(false, 20, kWaveOccLarge);
+            else if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOccSmall);
+            else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOccSmall);
+            else MPC_LAUNCH_W(false, 0, kWaveOccSmall);
         }
 #undef MPC_LAUNCH_W
         if (rc) return rc;

@@ -10,8 +10,4 @@ run sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST
 run sq3 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INST_CYCLES_SALU
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python3 - <<'PY'
-import csv, glob, os, collections
-out = os.environ.get("OUTDIR", "")
-PY
 for d in $OUT/*/; do find $d -name "*counter_collection.csv" | head -1; done
