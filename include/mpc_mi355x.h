@@ -102,6 +102,45 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
                     uint32_t flags, double *u0, double *U, double *X, int32_t *status, int32_t *iters,
                     void *stream);
 
+/*
+ * Observation-level entry: everything PureMPC_Agent.predict() does (agents/pure_mpc.py:68-78) for B parallel
+ * environments, on the device: observation parsing (agents/base_agent.py:81-116), the path-crossing collision
+ * detector with its 10-step memory (agents/pure_mpc.py:552-676), the rewrite of the reference speed profile
+ * (agents/pure_mpc.py:678-724) and the solve.  Environment b of the call owns state record b inside the handle
+ * (records are created fresh on first use and persist across calls; see mpc_reset_env_state).
+ *   obs            [B][vehicles_count][8] float32: presence, x, y, vx, vy, heading, sin_h, cos_h, absolute values,
+ *                  row 0 = ego (config/config.py:4-26); present rows are contiguous (agents/base_agent.py:106-114)
+ *   vehicles_count rows per observation, 1..MPC_MAX_OTHERS+1 (cfg `observation.vehicles_count`, 10)
+ *   weights        [B][3] weight_speed, weight_control, weight_input_diff (RL action or the cfg defaults)
+ *   ref_speed      [B] RL reference-speed override (agents/pure_mpc.py:683-688) or NULL
+ *   flags          MPC_FLAG_COLLISION_COST: distance/collision terms over the observed vehicles; MPC_FLAG_DEVICE_PTRS,
+ *                  MPC_FLAG_NO_SYNC as for mpc_solve_batch
+ *   act            [B][2] acceleration, steer;  status/iters [B] optional
+ */
+int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicles_count, const double *weights,
+                      const double *ref_speed, uint32_t flags, double *act, int32_t *status, int32_t *iters,
+                      void *stream);
+
+/* Episode boundaries: forget collision memory / stop point of the listed environments (host array of n ids);
+ * env_ids == NULL or n < 0 resets all.  Replaces constructing a new PureMPC_Agent (agents/pure_mpc.py:38-43,63). */
+int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *stream);
+
+/* Same, from a done-mask: environment b is reset where done[b] != 0 (device pointer with MPC_FLAG_DEVICE_PTRS;
+ * with MPC_FLAG_NO_SYNC the reset is only enqueued). */
+int mpc_reset_env_mask(mpc_handle *h, int32_t B, const uint8_t *done, uint32_t flags, void *stream);
+
+/* Detector state of environments 0..B-1 after the last mpc_predict_batch (host arrays, any may be NULL; synchronises):
+ * is_collide, ego_index, collision_memory, stop_index (-1 = none) [B]; conflict_index [B][MPC_MAX_OTHERS] (-1 = none).
+ * Serves the attributes callers read from the agent (agents/pure_mpc.py:38-43: is_collide, conflict_index, stop_point). */
+int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *ego_index, int32_t *collision_memory,
+                      int32_t *stop_index, int32_t *conflict_index);
+
+/* Problem data the last mpc_predict_batch derived from the observations (host arrays, any may be NULL; synchronises):
+ * state [B][4], ego_index [B], vref [B][N+1], is_collide [B], others [B][max(vehicles_count-1,1)][4], nveh [B].
+ * Diagnostics / tests: these are exactly the arguments mpc_solve_batch would take. */
+int mpc_get_last_inputs(mpc_handle *h, int32_t B, double *state, int32_t *ego_index, double *vref,
+                        uint8_t *is_collide, double *others, int32_t *nveh);
+
 /* LDS bytes one workgroup of the solve kernel uses for a batch of B instances with V other vehicles in the
  * collision-cost term (V = 0: term off): path table + instances-per-wave x per-instance solver state.  The
  * engine keeps no per-instance state in HBM.  (diagnostics / capacity planning) */

@@ -14,10 +14,12 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/mpc_mi355x.h"
 #include "mpc_core.hpp"
 #include "mpc_wave.hpp"
+#include "mpc_preamble.hpp"
 
 namespace {
 
@@ -100,9 +102,9 @@ template <bool CC, int IPW, int NC>
 __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
-    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin, double w_collision,
-    double *__restrict__ u0_out, double *__restrict__ U_out, double *__restrict__ X_out,
-    int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
+    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
+    const int32_t *__restrict__ nveh, double w_collision, double *__restrict__ u0_out, double *__restrict__ U_out,
+    double *__restrict__ X_out, int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     double *s_table = smem;                                     // [M][REF_COLS]
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
         w.st(mpc::S_RV, k, rv);
     }
     const bool collide = is_collide[b] != 0;
+    if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     if (CC) {
         for (int j = 0; j < P.V; ++j) {
             const double *ov = others + ((size_t)b * Vin + j) * 4;
@@ -199,12 +202,13 @@ template <bool CC, int NC, int OCC>
 __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
-    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin, double w_collision,
-    double *__restrict__ u0_out, double *__restrict__ U_out, double *__restrict__ X_out,
-    int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
+    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
+    const int32_t *__restrict__ nveh, double w_collision, double *__restrict__ u0_out, double *__restrict__ U_out,
+    double *__restrict__ X_out, int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     const int b = blockIdx.x;
+    if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     const int lane = threadIdx.x;
     constexpr int SL = mpc::wave::stage_slots(CC);
     WaveCtx<NC> ctx{(lds_double *)smem, ref5, ego_index[b], M};
@@ -259,6 +263,42 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// observation -> problem data (mpc_preamble.hpp), one thread per environment.  ~2.5 KB of private arrays per
+// thread (two 31-point polylines and the overlap work list); the kernel is < 2 % of a solve.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
+    int B, const float *__restrict__ obs, int rows, const double *__restrict__ ref5, int M, int N, double dt,
+    const double *__restrict__ ref_speed, mpc::pre::EnvState *__restrict__ env, double *__restrict__ state,
+    int32_t *__restrict__ ego_index, double *__restrict__ vref, uint8_t *__restrict__ is_collide,
+    double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const mpc::pre::RefTable R{ref5, M};
+    mpc::pre::EnvState st = env[b];
+    double *oth = others + (size_t)b * Vslots * 4;
+    int32_t e = 0, nv = 0;
+    uint8_t c = 0;
+    mpc::pre::preamble_env(obs + (size_t)b * rows * mpc::pre::kObsCols, rows, R, N, dt,
+                           ref_speed ? ref_speed + b : nullptr, st, state + (size_t)b * 4, e,
+                           vref + (size_t)b * (N + 1), c, oth, nv);
+    for (int j = nv; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
+    ego_index[b] = e;
+    is_collide[b] = c;
+    nveh[b] = nv;
+    env[b] = st;
+}
+
+__global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, const uint8_t *__restrict__ mask,
+                                     mpc::pre::EnvState *__restrict__ env, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = ids ? ids[i] : i;
+    if (b < 0 || b >= cap) return;
+    if (mask && !mask[i]) return;
+    env[b] = mpc::pre::EnvState{};
+}
+
 }  // namespace
 
 struct mpc_handle {
@@ -271,6 +311,16 @@ struct mpc_handle {
     // staging buffers for host-pointer calls
     void *d_stage = nullptr;
     size_t stage_bytes = 0;
+    // observation-level path (mpc_predict_batch): per-environment detector state and the problem data the
+    // preamble kernel writes for the solve kernel
+    mpc::pre::EnvState *d_env = nullptr;
+    int env_cap = 0;
+    void *d_pre = nullptr;
+    size_t pre_bytes = 0;
+    int pre_B = 0, pre_V = 0;   // shape of the last preamble output (for mpc_get_last_inputs)
+    double *p_state = nullptr, *p_vref = nullptr, *p_others = nullptr;
+    int32_t *p_ego = nullptr, *p_nveh = nullptr;
+    uint8_t *p_coll = nullptr;
 };
 
 namespace {
@@ -301,14 +351,15 @@ int choose_ipw(const mpc_handle *h, bool cc, int B, int N, int V) {
 template <bool CC, int IPW, int NC>
 int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
            const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
-           const uint8_t *d_coll, const double *d_others, double *d_u0, double *d_U, double *d_X,
-           int32_t *d_status, int32_t *d_iters) {
+           const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, double *d_u0, double *d_U,
+           double *d_X, int32_t *d_status, int32_t *d_iters) {
     auto kern = mpc_solve_kernel<CC, IPW, NC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     const unsigned grid = (unsigned)((B + IPW - 1) / IPW);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego, d_vref,
-                       d_weights, d_coll, d_others, V, h->cfg.w_collision, d_u0, d_U, d_X, d_status, d_iters);
+                       d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_u0, d_U, d_X, d_status,
+                       d_iters);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
@@ -316,13 +367,14 @@ int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t 
 template <bool CC, int NC, int OCC>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
-                const uint8_t *d_coll, const double *d_others, double *d_u0, double *d_U, double *d_X,
-                int32_t *d_status, int32_t *d_iters) {
+                const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, double *d_u0, double *d_U,
+                double *d_X, int32_t *d_status, int32_t *d_iters) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
-                       d_vref, d_weights, d_coll, d_others, V, h->cfg.w_collision, d_u0, d_U, d_X, d_status, d_iters);
+                       d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_u0, d_U, d_X, d_status,
+                       d_iters);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
@@ -333,6 +385,74 @@ bool use_wave_kernel(int N) {
     const char *env = getenv("MPC_KERNEL");
     if (env && !strcmp(env, "lane")) return false;
     return N <= 20;
+}
+
+// Kernel choice + launch for B instances whose data already sits in device memory (shared by mpc_solve_batch and
+// mpc_predict_batch).  d_nveh: vehicles present per instance or nullptr (= V for all).
+int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t stream, const double *d_state,
+                   const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
+                   const double *d_others, const int32_t *d_nveh, double *d_u0, double *d_U, double *d_X,
+                   int32_t *d_status, int32_t *d_iters) {
+    const int N = h->cfg.horizon;
+    const int Vuse = cc ? V : 0;
+    mpc::SolveParams P;
+    P.N = N;
+    P.V = Vuse;
+    P.max_iter = h->cfg.max_iter;
+    P.dt = h->cfg.dt;
+    P.tol = h->cfg.tol;
+    P.mu_init = 0.1;
+    P.w_distance = h->cfg.w_distance;
+
+    int rc;
+    if (use_wave_kernel(N)) {
+        const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
+#define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                            \
+    rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights,      \
+                                     d_coll, d_others, d_nveh, d_u0, d_U, d_X, d_status, d_iters)
+        const bool dense = B > kWaveLargeBatch;
+        if (cc) {
+            if (N == 20 && dense) MPC_LAUNCH_W(true, 20, kWaveOccLarge);
+            else if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOccSmall);
+            else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOccSmall);
+            else MPC_LAUNCH_W(true, 0, kWaveOccSmall);
+        } else {
+            if (N == 20 && dense) MPC_LAUNCH_W(false, 20, kWaveOccLarge);
+            else if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOccSmall);
+            else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOccSmall);
+            else MPC_LAUNCH_W(false, 0, kWaveOccSmall);
+        }
+#undef MPC_LAUNCH_W
+        if (rc) return rc;
+    } else {
+    const int ipw = choose_ipw(h, cc, B, N, Vuse);
+    const size_t lds = lds_bytes(cc, ipw, N, h->M, Vuse);
+    if (lds > h->lds_per_cu)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: horizon/others/reference too large for the LDS workspace");
+#define MPC_LAUNCH_N(CCV, IPWV, NCV)                                                                           \
+    rc = launch<CCV, IPWV, NCV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll,   \
+                                d_others, d_nveh, d_u0, d_U, d_X, d_status, d_iters)
+#define MPC_LAUNCH(CCV, IPWV)                                                                                   \
+    do {                                                                                                        \
+        if (N == 20) MPC_LAUNCH_N(CCV, IPWV, 20);       /* BASELINE horizon */                                  \
+        else if (N == 16) MPC_LAUNCH_N(CCV, IPWV, 16);  /* reference cfg.yaml default */                        \
+        else MPC_LAUNCH_N(CCV, IPWV, 0);                                                                        \
+    } while (0)
+    if (cc) {
+        if (ipw == 16) MPC_LAUNCH(true, 16);
+        else if (ipw == 4) MPC_LAUNCH(true, 4);
+        else MPC_LAUNCH(true, 1);
+    } else {
+        if (ipw == 16) MPC_LAUNCH(false, 16);
+        else if (ipw == 4) MPC_LAUNCH(false, 4);
+        else MPC_LAUNCH(false, 1);
+    }
+#undef MPC_LAUNCH
+#undef MPC_LAUNCH_N
+    if (rc) return rc;
+    }
+
+    return MPC_OK;
 }
 
 }  // namespace
@@ -393,6 +513,8 @@ void mpc_destroy(mpc_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->d_ref) (void)hipFree(h->d_ref);
     if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->d_env) (void)hipFree(h->d_env);
+    if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
 }
 
@@ -497,62 +619,9 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
         d_iters = reinterpret_cast<int32_t *>(sb + off_it);
     }
 
-    mpc::SolveParams P;
-    P.N = N;
-    P.V = Vuse;
-    P.max_iter = h->cfg.max_iter;
-    P.dt = h->cfg.dt;
-    P.tol = h->cfg.tol;
-    P.mu_init = 0.1;
-    P.w_distance = h->cfg.w_distance;
-
-    int rc;
-    if (use_wave_kernel(N)) {
-        const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
-#define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                            \
-    rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights,      \
-                                     d_coll, d_others, d_u0, d_U, d_X, d_status, d_iters)
-        const bool dense = B > kWaveLargeBatch;
-        if (cc) {
-            if (N == 20 && dense) MPC_LAUNCH_W(true, 20, kWaveOccLarge);
-            else if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOccSmall);
-            else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOccSmall);
-            else MPC_LAUNCH_W(true, 0, kWaveOccSmall);
-        } else {
-            if (N == 20 && dense) MPC_LAUNCH_W(false, 20, kWaveOccLarge);
-            else if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOccSmall);
-            else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOccSmall);
-            else MPC_LAUNCH_W(false, 0, kWaveOccSmall);
-        }
-#undef MPC_LAUNCH_W
-        if (rc) return rc;
-    } else {
-    const int ipw = choose_ipw(h, cc, B, N, Vuse);
-    const size_t lds = lds_bytes(cc, ipw, N, h->M, Vuse);
-    if (lds > h->lds_per_cu)
-        return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: horizon/others/reference too large for the LDS workspace");
-#define MPC_LAUNCH_N(CCV, IPWV, NCV)                                                                           \
-    rc = launch<CCV, IPWV, NCV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll,   \
-                                d_others, d_u0, d_U, d_X, d_status, d_iters)
-#define MPC_LAUNCH(CCV, IPWV)                                                                                   \
-    do {                                                                                                        \
-        if (N == 20) MPC_LAUNCH_N(CCV, IPWV, 20);       /* BASELINE horizon */                                  \
-        else if (N == 16) MPC_LAUNCH_N(CCV, IPWV, 16);  /* reference cfg.yaml default */                        \
-        else MPC_LAUNCH_N(CCV, IPWV, 0);                                                                        \
-    } while (0)
-    if (cc) {
-        if (ipw == 16) MPC_LAUNCH(true, 16);
-        else if (ipw == 4) MPC_LAUNCH(true, 4);
-        else MPC_LAUNCH(true, 1);
-    } else {
-        if (ipw == 16) MPC_LAUNCH(false, 16);
-        else if (ipw == 4) MPC_LAUNCH(false, 4);
-        else MPC_LAUNCH(false, 1);
-    }
-#undef MPC_LAUNCH
-#undef MPC_LAUNCH_N
-    if (rc) return rc;
-    }
+    if (int rc = dispatch_solve(h, B, cc, V, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, nullptr,
+                                d_u0, d_U, d_X, d_status, d_iters))
+        return rc;
 
     if (!dev) {
         char *sb = static_cast<char *>(h->d_stage);
@@ -565,6 +634,221 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     } else if (!(flags & MPC_FLAG_NO_SYNC)) {
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    return MPC_OK;
+}
+
+// grow the per-environment state array to at least B records (new records start as fresh episodes)
+static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
+    if (B <= h->env_cap) return MPC_OK;
+    int cap = h->env_cap > 0 ? h->env_cap : 256;
+    while (cap < B) cap *= 2;
+    mpc::pre::EnvState *n = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&n), (size_t)cap * sizeof(mpc::pre::EnvState)));
+    HIP_TRY(hipMemsetAsync(n, 0, (size_t)cap * sizeof(mpc::pre::EnvState), stream));
+    if (h->d_env) {
+        HIP_TRY(hipMemcpyAsync(n, h->d_env, (size_t)h->env_cap * sizeof(mpc::pre::EnvState),
+                               hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipFree(h->d_env));
+    }
+    h->d_env = n;
+    h->env_cap = cap;
+    return MPC_OK;
+}
+
+int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicles_count, const double *weights,
+                      const double *ref_speed, uint32_t flags, double *act, int32_t *status, int32_t *iters,
+                      void *stream_) {
+    if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: null handle");
+    if (B < 0 || !obs || !weights || !act)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: null required pointer or negative batch");
+    if (vehicles_count < 1 || vehicles_count > MPC_MAX_OTHERS + 1)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: vehicles_count out of range");
+    if (!h->d_ref) return fail(MPC_ERR_NO_REFERENCE, "mpc_predict_batch: call mpc_set_reference first");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int N = h->cfg.horizon, rows = vehicles_count, V = vehicles_count - 1;
+    const size_t N1 = (size_t)N + 1;
+    const bool cc = (flags & MPC_FLAG_COLLISION_COST) != 0 && V > 0;
+    const bool dev = (flags & MPC_FLAG_DEVICE_PTRS) != 0;
+    if (int rc = ensure_env(h, B, stream)) return rc;
+
+    // problem-data buffers written by the preamble kernel
+    {
+        size_t off = 0;
+        auto seg = [&](size_t bytes) {
+            size_t o = off;
+            off += round_up(bytes, 16);
+            return o;
+        };
+        const size_t o_state = seg((size_t)B * 4 * 8), o_vref = seg((size_t)B * N1 * 8);
+        const size_t o_oth = seg((size_t)B * (V > 0 ? V : 1) * 4 * 8), o_ego = seg((size_t)B * 4);
+        const size_t o_nv = seg((size_t)B * 4), o_c = seg((size_t)B);
+        if (h->pre_bytes < off) {
+            if (h->d_pre) HIP_TRY(hipFree(h->d_pre));
+            h->d_pre = nullptr;
+            h->pre_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_pre, off));
+            h->pre_bytes = off;
+        }
+        char *pb = static_cast<char *>(h->d_pre);
+        h->p_state = reinterpret_cast<double *>(pb + o_state);
+        h->p_vref = reinterpret_cast<double *>(pb + o_vref);
+        h->p_others = reinterpret_cast<double *>(pb + o_oth);
+        h->p_ego = reinterpret_cast<int32_t *>(pb + o_ego);
+        h->p_nveh = reinterpret_cast<int32_t *>(pb + o_nv);
+        h->p_coll = reinterpret_cast<uint8_t *>(pb + o_c);
+        h->pre_B = B;
+        h->pre_V = V;
+    }
+
+    const float *d_obs = obs;
+    const double *d_weights = weights, *d_rs = ref_speed;
+    double *d_act = act;
+    int32_t *d_status = status, *d_iters = iters;
+    size_t off_act = 0, off_st = 0, off_it = 0;
+    if (!dev) {
+        size_t off = 0;
+        auto seg = [&](size_t bytes) {
+            size_t o = off;
+            off += round_up(bytes, 16);
+            return o;
+        };
+        const size_t o_obs = seg((size_t)B * rows * mpc::pre::kObsCols * 4), o_w = seg((size_t)B * 3 * 8);
+        const size_t o_rs = ref_speed ? seg((size_t)B * 8) : 0;
+        off_act = seg((size_t)B * 2 * 8);
+        off_st = seg((size_t)B * 4);
+        off_it = seg((size_t)B * 4);
+        if (h->stage_bytes < off) {
+            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
+            h->d_stage = nullptr;
+            h->stage_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_stage, off));
+            h->stage_bytes = off;
+        }
+        char *sb = static_cast<char *>(h->d_stage);
+        HIP_TRY(hipMemcpyAsync(sb + o_obs, obs, (size_t)B * rows * mpc::pre::kObsCols * 4, hipMemcpyHostToDevice,
+                               stream));
+        HIP_TRY(hipMemcpyAsync(sb + o_w, weights, (size_t)B * 3 * 8, hipMemcpyHostToDevice, stream));
+        d_obs = reinterpret_cast<float *>(sb + o_obs);
+        d_weights = reinterpret_cast<double *>(sb + o_w);
+        if (ref_speed) {
+            HIP_TRY(hipMemcpyAsync(sb + o_rs, ref_speed, (size_t)B * 8, hipMemcpyHostToDevice, stream));
+            d_rs = reinterpret_cast<double *>(sb + o_rs);
+        }
+        d_act = reinterpret_cast<double *>(sb + off_act);
+        d_status = reinterpret_cast<int32_t *>(sb + off_st);
+        d_iters = reinterpret_cast<int32_t *>(sb + off_it);
+    }
+
+    hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       (int)B, d_obs, rows, h->d_ref, h->M, N, h->cfg.dt, d_rs, h->d_env, h->p_state, h->p_ego,
+                       h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh);
+    HIP_TRY(hipGetLastError());
+    if (int rc = dispatch_solve(h, B, cc, V, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
+                                h->p_others, h->p_nveh, d_act, nullptr, nullptr, d_status, d_iters))
+        return rc;
+
+    if (!dev) {
+        char *sb = static_cast<char *>(h->d_stage);
+        HIP_TRY(hipMemcpyAsync(act, sb + off_act, (size_t)B * 2 * 8, hipMemcpyDeviceToHost, stream));
+        if (status) HIP_TRY(hipMemcpyAsync(status, sb + off_st, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        if (iters) HIP_TRY(hipMemcpyAsync(iters, sb + off_it, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    } else if (!(flags & MPC_FLAG_NO_SYNC)) {
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return MPC_OK;
+}
+
+int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *stream_) {
+    if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_reset_env_state: null handle");
+    if (!h->d_env) return MPC_OK;   // nothing allocated yet: every environment is fresh
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!env_ids || n < 0) {
+        HIP_TRY(hipMemsetAsync(h->d_env, 0, (size_t)h->env_cap * sizeof(mpc::pre::EnvState), stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MPC_OK;
+    }
+    if (n == 0) return MPC_OK;
+    int32_t *d_ids = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_ids), (size_t)n * 4));
+    hipError_t e = hipMemcpyAsync(d_ids, env_ids, (size_t)n * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int)n, d_ids,
+                           (const uint8_t *)nullptr, h->d_env, h->env_cap);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_ids);
+    if (e != hipSuccess) return fail(MPC_ERR_HIP, std::string("mpc_reset_env_state: ") + hipGetErrorString(e));
+    return MPC_OK;
+}
+
+int mpc_reset_env_mask(mpc_handle *h, int32_t B, const uint8_t *done, uint32_t flags, void *stream_) {
+    if (!h || B < 0 || !done) return fail(MPC_ERR_INVALID_ARG, "mpc_reset_env_mask: bad argument");
+    if (!h->d_env || B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const uint8_t *d_done = done;
+    uint8_t *tmp = nullptr;
+    if (!(flags & MPC_FLAG_DEVICE_PTRS)) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), (size_t)B));
+        hipError_t e = hipMemcpyAsync(tmp, done, (size_t)B, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) {
+            (void)hipFree(tmp);
+            return fail(MPC_ERR_HIP, std::string("mpc_reset_env_mask: ") + hipGetErrorString(e));
+        }
+        d_done = tmp;
+    }
+    const int n = B < h->env_cap ? B : h->env_cap;
+    hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n,
+                       (const int32_t *)nullptr, d_done, h->d_env, h->env_cap);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && (tmp || !(flags & MPC_FLAG_NO_SYNC))) e = hipStreamSynchronize(stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(MPC_ERR_HIP, std::string("mpc_reset_env_mask: ") + hipGetErrorString(e));
+    return MPC_OK;
+}
+
+int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *ego_index, int32_t *collision_memory,
+                      int32_t *stop_index, int32_t *conflict_index) {
+    if (!h || B < 0) return fail(MPC_ERR_INVALID_ARG, "mpc_get_env_state: bad argument");
+    if (B == 0) return MPC_OK;
+    if (!h->d_env || B > h->env_cap) return fail(MPC_ERR_INVALID_ARG, "mpc_get_env_state: no such environments");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<mpc::pre::EnvState> host((size_t)B);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host.data(), h->d_env, (size_t)B * sizeof(mpc::pre::EnvState), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+        const mpc::pre::EnvState &s = host[(size_t)b];
+        if (is_collide) is_collide[b] = s.is_collide;
+        if (ego_index) ego_index[b] = s.ego_index;
+        if (collision_memory) collision_memory[b] = s.collision_memory;
+        if (stop_index) stop_index[b] = s.stop_index1 - 1;
+        if (conflict_index)
+            for (int j = 0; j < MPC_MAX_OTHERS; ++j)
+                conflict_index[(size_t)b * MPC_MAX_OTHERS + j] = j < s.n_conflict ? s.conflict[j] : -1;
+    }
+    return MPC_OK;
+}
+
+int mpc_get_last_inputs(mpc_handle *h, int32_t B, double *state, int32_t *ego_index, double *vref,
+                        uint8_t *is_collide, double *others, int32_t *nveh) {
+    if (!h || B < 0) return fail(MPC_ERR_INVALID_ARG, "mpc_get_last_inputs: bad argument");
+    if (B == 0) return MPC_OK;
+    if (!h->d_pre || B > h->pre_B) return fail(MPC_ERR_INVALID_ARG, "mpc_get_last_inputs: no preamble output of that size");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N1 = (size_t)h->cfg.horizon + 1, V = (size_t)(h->pre_V > 0 ? h->pre_V : 1);
+    if (state) HIP_TRY(hipMemcpy(state, h->p_state, (size_t)B * 4 * 8, hipMemcpyDeviceToHost));
+    if (ego_index) HIP_TRY(hipMemcpy(ego_index, h->p_ego, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (vref) HIP_TRY(hipMemcpy(vref, h->p_vref, (size_t)B * N1 * 8, hipMemcpyDeviceToHost));
+    if (is_collide) HIP_TRY(hipMemcpy(is_collide, h->p_coll, (size_t)B, hipMemcpyDeviceToHost));
+    if (others) HIP_TRY(hipMemcpy(others, h->p_others, (size_t)B * V * 4 * 8, hipMemcpyDeviceToHost));
+    if (nveh) HIP_TRY(hipMemcpy(nveh, h->p_nveh, (size_t)B * 4, hipMemcpyDeviceToHost));
     return MPC_OK;
 }
 

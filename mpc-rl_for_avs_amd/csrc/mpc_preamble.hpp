@@ -1,0 +1,461 @@
+// mpc_preamble.hpp - everything PureMPC_Agent.predict() does BEFORE the NLP solve, for one environment:
+//   a2  observation parsing                     agents/base_agent.py:81-116   (Vehicle: agents/utils.py:16-40)
+//   a4  path-crossing "collision" detector       agents/pure_mpc.py:552-676    with its 10-step memory
+//       ego path prediction along the reference  agents/pure_mpc.py:459-527
+//       constant-velocity prediction of others   agents/pure_mpc.py:529-550
+//   a5  rewrite of the reference speed profile   agents/pure_mpc.py:678-724
+//   a6  problem data of the solve                agents/pure_mpc.py:95-117
+// written once for host and device (MPC_HD): the HIP kernel runs one thread per environment, the CPU test harness
+// (tests/cpu_preamble_harness.cpp) loops over environments.  The per-environment state of the detector lives in
+// `EnvState` records inside the engine handle.
+//
+// Arithmetic fidelity.  The reference runs on numpy 2.1 (requirements.txt), whose promotion rules keep float32
+// scalars float32 when they meet Python floats, so parts of its preamble are float32 arithmetic on the float32
+// observation: heading wrap, speed = |v|, the other vehicles' predicted polylines, the ego speed ramp and the first
+// metres of its arc length, and np.linspace of the stop profile.  Those places use `float` with explicitly unfused
+// operations here; everything else is double like the reference.  What the reference delegates to shapely
+// (LineString.intersection, agents/pure_mpc.py:608-633) is the segment arithmetic of `first_crossing` below, the
+// same construction as the host mirror `pure_mpc.first_path_crossing`.
+#pragma once
+
+#include <stdint.h>
+
+#include "mpc_core.hpp"
+
+namespace mpc {
+namespace pre {
+
+constexpr int kPredHorizon = 30;     // agents/pure_mpc.py:554
+constexpr int kTimeThreshold = 30;   // agents/pure_mpc.py:555
+constexpr int kMemorySteps = 10;     // agents/pure_mpc.py:39
+constexpr int kSafetyBuffer = 5;     // agents/pure_mpc.py:681
+constexpr double kMaxSpeed = 30.0;   // agents/pure_mpc.py:680
+constexpr int kMaxOthers = 16;       // MPC_MAX_OTHERS
+constexpr int kObsCols = 8;          // presence, x, y, vx, vy, heading, sin_h, cos_h  (config/config.py:13)
+constexpr double kPi = 3.141592653589793;
+
+// persistent detector state of one environment (agents/pure_mpc.py:38-43,63); all-zero = fresh episode
+struct EnvState {
+    int32_t collision_memory;
+    int32_t has_memorized;    // memorized_conflict_indices is not None
+    int32_t n_memorized;
+    int32_t n_conflict;       // entries of conflict[] (= vehicles seen by the last full detection)
+    int32_t is_collide;
+    int32_t ego_index;
+    int32_t stop_index1;      // stop_point as reference index + 1 (0 = None)
+    int32_t last_valid_stop1; // last_valid_stop_point, same encoding
+    int32_t conflict[kMaxOthers];   // conflict_index per vehicle, -1 = None
+    int32_t memorized[kMaxOthers];
+};
+
+// ---- operations that must round one by one like numpy's (no FMA contraction, also after inlining) -----------
+// hipcc contracts a*b+c by default and HIP's __fmul_rn/__fadd_rn are plain operators, so the pragma is what counts;
+// the host harness is additionally compiled with -ffp-contract=off.  Float division and sqrtf are correctly rounded
+// by hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt.
+MPC_HD float f32mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+MPC_HD float f32add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+MPC_HD double f64mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+MPC_HD double f64add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+MPC_HD double f64sub(double a, double b) { return f64add(a, -b); }
+
+struct P2 {
+    double x, y;
+};
+MPC_HD double dist2d(double ax, double ay, double bx, double by) {
+    const double dx = f64sub(ax, bx), dy = f64sub(ay, by);
+    return sqrt(f64add(f64mul(dx, dx), f64mul(dy, dy)));
+}
+
+// reference table: [M][REF_COLS] (x, y, heading, sin, cos) followed by the speed column [M]
+struct RefTable {
+    const double *t;
+    int M;
+    MPC_HD double x(int i) const { return t[i * REF_COLS + R_X]; }
+    MPC_HD double y(int i) const { return t[i * REF_COLS + R_Y]; }
+    MPC_HD double v(int i) const { return t[M * REF_COLS + i]; }
+    // argmin_i |ref_i - p| (first minimum), agents/pure_mpc.py:106-109, 567-570, 651-653
+    MPC_HD int nearest(double px, double py) const {
+        int best = 0;
+        double bd = dist2d(x(0), y(0), px, py);
+        for (int i = 1; i < M; ++i) {
+            const double d = dist2d(x(i), y(i), px, py);
+            if (d < bd) {
+                bd = d;
+                best = i;
+            }
+        }
+        return best;
+    }
+};
+
+// ---- a4: ego polyline, agents/pure_mpc.py:459-527 ------------------------------------------------------------
+// Returns the number of points written to out (<= kPredHorizon + 1).
+MPC_HD int ego_future(const RefTable &R, float px, float py, float speed, double reference_speed, double dt, P2 *out) {
+    out[0] = P2{(double)px, (double)py};
+    int n = 1;
+    const int start = R.nearest((double)px, (double)py);
+    const int npts = R.M - start;
+    if (npts < 2) return n;
+    // current_speed / current_distance start as float32 (the observation's dtype) and become double once the ramp
+    // reaches the float64 reference speed
+    bool s32 = true, d32 = true;
+    float cs_f = speed, cd_f = 0.0f;
+    double cs_d = 0.0, cd_d = 0.0;
+    const float acc_dt_f = (float)(3.5 * dt);   // Vehicle.max_acceleration * dt, weakly typed -> float32
+    const float dt_f = (float)dt;
+    // cumulative arc length from ref[start], recomputed incrementally while searching
+    for (int step = 0; step < kPredHorizon; ++step) {
+        const double cs_now = s32 ? (double)cs_f : cs_d;
+        if (cs_now < reference_speed) {
+            if (s32) {
+                const float t = f32add(cs_f, acc_dt_f);
+                if (reference_speed < (double)t) {      // min(t, reference_speed) returns the float64 reference
+                    s32 = false;
+                    cs_d = reference_speed;
+                } else {
+                    cs_f = t;
+                }
+            } else {
+                const double t = f64add(cs_d, 3.5 * dt);
+                cs_d = reference_speed < t ? reference_speed : t;
+            }
+        } else {
+            s32 = false;
+            cs_d = reference_speed;
+        }
+        if (s32) {
+            const float inc = f32mul(cs_f, dt_f);
+            if (d32) cd_f = f32add(cd_f, inc);
+            else cd_d = f64add(cd_d, (double)inc);
+        } else {
+            const double inc = f64mul(cs_d, dt);
+            if (d32) {
+                cd_d = f64add((double)cd_f, inc);
+                d32 = false;
+            } else {
+                cd_d = f64add(cd_d, inc);
+            }
+        }
+        const double cd = d32 ? (double)cd_f : cd_d;
+        // next_idx = searchsorted(cumulative, cd) (left): first index with cumulative[idx] >= cd
+        int idx = 0;
+        double cum = 0.0, prev = 0.0;
+        while (idx < npts && cum < cd) {
+            ++idx;
+            if (idx < npts) {
+                prev = cum;
+                cum = f64add(cum, dist2d(R.x(start + idx), R.y(start + idx), R.x(start + idx - 1), R.y(start + idx - 1)));
+            }
+        }
+        if (idx >= npts) break;
+        if (idx == 0) {
+            out[n++] = P2{R.x(start), R.y(start)};
+        } else {
+            double alpha = (cum != prev) ? f64sub(cd, prev) / f64sub(cum, prev) : 1.0;
+            alpha = alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+            const double ax = R.x(start + idx - 1), ay = R.y(start + idx - 1);
+            out[n++] = P2{f64add(ax, f64mul(alpha, f64sub(R.x(start + idx), ax))),
+                          f64add(ay, f64mul(alpha, f64sub(R.y(start + idx), ay)))};
+        }
+    }
+    if (n <= 1) {                                   // agents/pure_mpc.py:524-526
+        for (int i = 0; i < kPredHorizon; ++i) out[i] = P2{(double)px, (double)py};
+        return kPredHorizon;
+    }
+    return n;
+}
+
+// ---- segment intersection (what shapely does for the reference) ----------------------------------------------
+struct Hit {
+    double t;
+    P2 p;
+};
+MPC_HD bool close2(P2 a, P2 b) {   // np.allclose(a, b, atol=1e-12) with the default rtol 1e-5
+    return fabs(a.x - b.x) <= 1e-12 + 1e-5 * fabs(b.x) && fabs(a.y - b.y) <= 1e-12 + 1e-5 * fabs(b.y);
+}
+MPC_HD double clamp01(double t) { return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t); }
+// hits of segment p-q with segment a-b: 0, 1 or 2 (collinear overlap ends); same arithmetic as
+// pure_mpc._seg_intersections
+MPC_HD int seg_intersections(P2 p, P2 q, P2 a, P2 b, Hit *h) {
+    const double eps = 1e-12;
+    const double rx = q.x - p.x, ry = q.y - p.y, sx = b.x - a.x, sy = b.y - a.y;
+    const double rxs = f64sub(f64mul(rx, sy), f64mul(ry, sx));
+    const double apx = a.x - p.x, apy = a.y - p.y;
+    double m = 1.0;
+    m = fmax(m, fmax(fabs(rx), fabs(ry)));
+    m = fmax(m, fmax(fabs(sx), fabs(sy)));
+    const double scale = m * m;
+    if (fabs(rxs) > eps * scale) {
+        const double t = f64sub(f64mul(apx, sy), f64mul(apy, sx)) / rxs;
+        const double u = f64sub(f64mul(apx, ry), f64mul(apy, rx)) / rxs;
+        if (-1e-12 <= t && t <= 1 + 1e-12 && -1e-12 <= u && u <= 1 + 1e-12) {
+            const double tc = clamp01(t);
+            h[0] = Hit{tc, P2{f64add(p.x, f64mul(tc, rx)), f64add(p.y, f64mul(tc, ry))}};
+            return 1;
+        }
+        return 0;
+    }
+    if (fabs(f64sub(f64mul(apx, ry), f64mul(apy, rx))) > eps * scale) return 0;   // parallel, not collinear
+    const double rr = f64add(f64mul(rx, rx), f64mul(ry, ry));
+    if (rr == 0.0) {                                                             // p-q is a point
+        const double ss = f64add(f64mul(sx, sx), f64mul(sy, sy));
+        if (ss == 0.0) {
+            // np.allclose(p, a): rtol 1e-5, atol 1e-8
+            const bool same = fabs(p.x - a.x) <= 1e-8 + 1e-5 * fabs(a.x) && fabs(p.y - a.y) <= 1e-8 + 1e-5 * fabs(a.y);
+            if (same) {
+                h[0] = Hit{0.0, p};
+                return 1;
+            }
+            return 0;
+        }
+        const double u = f64add(f64mul(p.x - a.x, sx), f64mul(p.y - a.y, sy)) / ss;
+        if (-1e-12 <= u && u <= 1 + 1e-12) {
+            h[0] = Hit{0.0, p};
+            return 1;
+        }
+        return 0;
+    }
+    const double t0 = f64add(f64mul(apx, rx), f64mul(apy, ry)) / rr;
+    const double t1 = f64add(f64mul(b.x - p.x, rx), f64mul(b.y - p.y, ry)) / rr;
+    const double lo = fmax(0.0, fmin(t0, t1)), hi = fmin(1.0, fmax(t0, t1));
+    if (lo > hi) return 0;
+    h[0] = Hit{lo, P2{f64add(p.x, f64mul(lo, rx)), f64add(p.y, f64mul(lo, ry))}};
+    if (hi - lo < 1e-15) return 1;
+    h[1] = Hit{hi, P2{f64add(p.x, f64mul(hi, rx)), f64add(p.y, f64mul(hi, ry))}};
+    return 2;
+}
+
+// First intersection of the ego polyline with the (straight) agent polyline ag[0..na-1], ordered along the ego path;
+// a collinear overlap yields the middle vertex of the overlapping stretch (agents/pure_mpc.py:615-633 on shapely's
+// result).  Returns false if they do not meet.
+MPC_HD bool first_crossing(const P2 *ego, int ne, const P2 *ag, int na, P2 &out) {
+    if (ne < 2 || na < 2) return false;
+    const P2 a = ag[0], b = ag[na - 1];
+    for (int i = 0; i < ne - 1; ++i) {
+        Hit h[2];
+        const int nh = seg_intersections(ego[i], ego[i + 1], a, b, h);
+        if (nh == 0) continue;
+        if (nh == 1) {
+            out = h[0].p;
+            return true;
+        }
+        // collinear overlap starting on ego segment i
+        constexpr int kMaxPts = 2 + kPredHorizon + kPredHorizon + 1;
+        P2 pts[kMaxPts];
+        double key[kMaxPts];
+        int np = 0;
+        pts[np++] = h[0].p;
+        pts[np++] = h[1].p;
+        for (int j = i + 1; j < ne - 1; ++j) {
+            Hit h2[2];
+            if (seg_intersections(ego[j], ego[j + 1], a, b, h2) != 2) break;
+            pts[np++] = h2[1].p;
+        }
+        const double sx = b.x - a.x, sy = b.y - a.y;
+        const double ss = f64add(f64mul(sx, sx), f64mul(sy, sy));
+        const P2 pf = pts[0], pl = pts[np - 1];
+        const double k0 = f64add(f64mul(pf.x - a.x, sx), f64mul(pf.y - a.y, sy));
+        const double k1 = f64add(f64mul(pl.x - a.x, sx), f64mul(pl.y - a.y, sy));
+        const double klo = fmin(k0, k1) - 1e-12, khi = fmax(k0, k1) + 1e-12;
+        for (int m = 0; m < na && np < kMaxPts; ++m) {
+            const double kv = f64add(f64mul(ag[m].x - a.x, sx), f64mul(ag[m].y - a.y, sy));
+            if (ss > 0 && klo <= kv && kv <= khi) pts[np++] = ag[m];
+        }
+        const double dx = ego[i + 1].x - ego[i].x, dy = ego[i + 1].y - ego[i].y;
+        for (int m = 0; m < np; ++m) key[m] = f64add(f64mul(pts[m].x - ego[i].x, dx), f64mul(pts[m].y - ego[i].y, dy));
+        // sort by (key, x, y): insertion sort, <= 63 entries
+        for (int m = 1; m < np; ++m) {
+            const double km = key[m];
+            const P2 pm = pts[m];
+            int q = m - 1;
+            while (q >= 0 && (key[q] > km || (key[q] == km && (pts[q].x > pm.x || (pts[q].x == pm.x && pts[q].y > pm.y))))) {
+                key[q + 1] = key[q];
+                pts[q + 1] = pts[q];
+                --q;
+            }
+            key[q + 1] = km;
+            pts[q + 1] = pm;
+        }
+        int nu = 0;
+        for (int m = 0; m < np; ++m)
+            if (nu == 0 || !close2(pts[nu - 1], pts[m])) pts[nu++] = pts[m];
+        out = pts[nu / 2];
+        return true;
+    }
+    return false;
+}
+
+MPC_HD int argmin_dist(const P2 *pts, int n, P2 p) {
+    int best = 0;
+    double bd = dist2d(pts[0].x, pts[0].y, p.x, p.y);
+    for (int i = 1; i < n; ++i) {
+        const double d = dist2d(pts[i].x, pts[i].y, p.x, p.y);
+        if (d < bd) {
+            bd = d;
+            best = i;
+        }
+    }
+    return best;
+}
+
+// float32 |v| like np.linalg.norm of a float32 pair (agents/utils.py:36)
+MPC_HD float speed_f32(float vx, float vy) { return sqrtf(f32add(f32mul(vx, vx), f32mul(vy, vy))); }
+
+// heading wrap of the ego row (agents/base_agent.py:156-170) on a float32 scalar: the subtraction stays float32
+MPC_HD float normalize_angle_f32(float a) {
+    const float two_pi = (float)(2.0 * kPi);
+    while ((double)a > kPi) a = f32add(a, -two_pi);
+    while ((double)a < -kPi) a = f32add(a, two_pi);
+    return a;
+}
+
+// ---- the whole preamble for one environment -------------------------------------------------------------------
+// obs: [rows][8] float32.  Outputs: state[4], vref[N+1], others[(rows-1)][4] (x, y, speed, heading; absent slots are
+// not written), nveh, ego_index, is_collide.  ref_speed: RL override or nullptr.
+MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, double dt, const double *ref_speed,
+                         EnvState &st, double *state, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
+                         double *others, int32_t &nveh_out) {
+    // ---- a2: parse (agents/base_agent.py:81-116)
+    int present = 0;
+    for (int r = 0; r < rows; ++r) present += (obs[r * kObsCols + 0] == 1.0f) ? 1 : 0;
+    int observed = present - 1;
+    observed = observed < 0 ? 0 : observed;
+    observed = observed > kMaxOthers ? kMaxOthers : observed;
+    const float ex = obs[1], ey = obs[2];
+    const float eh = normalize_angle_f32(obs[5]);
+    const float ev = speed_f32(obs[3], obs[4]);
+    state[0] = (double)ex;
+    state[1] = (double)ey;
+    state[2] = (double)eh;
+    state[3] = (double)ev;
+    for (int j = 0; j < observed; ++j) {
+        const float *o = obs + (j + 1) * kObsCols;
+        others[j * 4 + 0] = (double)o[1];
+        others[j * 4 + 1] = (double)o[2];
+        others[j * 4 + 2] = (double)speed_f32(o[3], o[4]);
+        others[j * 4 + 3] = (double)o[5];             // not wrapped (agents/base_agent.py:112)
+    }
+    nveh_out = observed;
+
+    // ---- a4: collision detector (agents/pure_mpc.py:552-676)
+    if (st.collision_memory > 0 && st.has_memorized) {
+        st.n_conflict = st.n_memorized;
+        for (int j = 0; j < kMaxOthers; ++j) st.conflict[j] = st.memorized[j];
+        st.is_collide = 1;
+        st.collision_memory -= 1;
+    } else {
+        st.ego_index = R.nearest((double)ex, (double)ey);
+        P2 ego[kPredHorizon + 1];
+        const int ne = ego_future(R, ex, ey, ev, R.v(st.ego_index), dt, ego);
+        bool any = false;
+        st.n_conflict = observed;
+        for (int j = 0; j < kMaxOthers; ++j) st.conflict[j] = -1;
+        for (int j = 0; j < observed; ++j) {
+            const float *o = obs + (j + 1) * kObsCols;
+            // agents/pure_mpc.py:529-550 in float32: step = speed * dt * [cos h, sin h], positions accumulate
+            const float sp = speed_f32(o[3], o[4]);
+            const float sdt = f32mul(sp, (float)dt);
+            const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
+            P2 ag[kPredHorizon + 1];
+            float ax = o[1], ay = o[2];
+            ag[0] = P2{(double)ax, (double)ay};
+            for (int m = 1; m <= kPredHorizon; ++m) {
+                ax = f32add(ax, stx);
+                ay = f32add(ay, sty);
+                ag[m] = P2{(double)ax, (double)ay};
+            }
+            P2 pt;
+            if (!first_crossing(ego, ne, ag, kPredHorizon + 1, pt)) continue;
+            const int ego_time = argmin_dist(ego, ne, pt);
+            const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
+            int dtm = ego_time - agent_time;
+            dtm = dtm < 0 ? -dtm : dtm;
+            if (dtm < kTimeThreshold) {
+                any = true;
+                st.conflict[j] = R.nearest(pt.x, pt.y);
+            }
+        }
+        st.is_collide = any ? 1 : 0;
+        if (any) {
+            st.collision_memory = kMemorySteps;
+            st.has_memorized = 1;
+            st.n_memorized = st.n_conflict;
+            for (int j = 0; j < kMaxOthers; ++j) st.memorized[j] = st.conflict[j];
+        } else if (st.collision_memory > 0) {
+            st.collision_memory -= 1;
+            st.is_collide = 1;
+        } else {
+            st.has_memorized = 0;
+        }
+    }
+
+    // ---- a6: ego_index is refreshed by _solve in every call (agents/pure_mpc.py:106-109)
+    const int e = R.nearest((double)ex, (double)ey);
+    st.ego_index = e;
+    ego_index_out = e;
+    collide_out = st.is_collide ? 1 : 0;
+
+    // ---- a5: speed profile over the horizon window (agents/pure_mpc.py:678-724)
+    const int M = R.M;
+    if (ref_speed) {
+        const double v = *ref_speed < 0.0 ? 0.0 : (*ref_speed > kMaxSpeed ? kMaxSpeed : *ref_speed);
+        for (int k = 0; k <= N; ++k) vref[k] = v;
+        return;
+    }
+    int stop = -1, pts = 0;
+    if (st.is_collide) {
+        const int32_t *ci = (st.collision_memory > 0 && st.has_memorized) ? st.memorized : st.conflict;
+        const int nc = (st.collision_memory > 0 && st.has_memorized) ? st.n_memorized : st.n_conflict;
+        int mn = -1;
+        for (int j = 0; j < nc; ++j)
+            if (ci[j] >= 0 && (mn < 0 || ci[j] < mn)) mn = ci[j];
+        if (mn >= 0) {
+            stop = mn - kSafetyBuffer;
+            stop = stop < e + 1 ? e + 1 : stop;
+            stop = stop > M - 1 ? M - 1 : stop;
+            pts = stop - e;
+            if (pts > 0) {
+                st.stop_index1 = stop + 1;
+                st.last_valid_stop1 = stop + 1;
+            } else if (st.last_valid_stop1 > 0) {
+                st.stop_index1 = st.last_valid_stop1;
+            }
+        }
+    }
+    // np.linspace(ego_speed, 0, pts) in float32 (start is a float32 scalar)
+    const float fstep = pts > 1 ? (-ev) / (float)(pts - 1) : 0.0f;
+    for (int k = 0; k <= N; ++k) {
+        int idx = e + k;
+        idx = idx > M - 1 ? M - 1 : idx;
+        double v = R.v(idx);
+        if (pts > 0) {
+            if (idx >= stop) {
+                v = 0.0;
+            } else {
+                const int i = idx - e;
+                float y;
+                if (pts == 1) y = ev;                               // div = 0: y = 0 * delta + start
+                else if (i == pts - 1) y = 0.0f;                    // endpoint is set exactly
+                else if (fstep == 0.0f) y = f32add(f32mul((float)i / (float)(pts - 1), -ev), ev);
+                else y = f32add(f32mul((float)i, fstep), ev);
+                v = (double)y;
+            }
+        }
+        vref[k] = v;
+    }
+}
+
+}  // namespace pre
+}  // namespace mpc

@@ -36,7 +36,9 @@ class _Config(ctypes.Structure):
 
 
 _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_create", "mpc_destroy",
-            "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes"]
+            "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
+            "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs"]
+MAX_OTHERS = 16
 _lib = None
 
 
@@ -79,6 +81,16 @@ def load_library(path: str | None = None):
     lib.mpc_solve_batch.restype = ctypes.c_int
     lib.mpc_workspace_bytes.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     lib.mpc_workspace_bytes.restype = ctypes.c_int64
+    lib.mpc_predict_batch.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, dp, dp, ctypes.c_uint32, dp, ip, ip, vp]
+    lib.mpc_predict_batch.restype = ctypes.c_int
+    lib.mpc_reset_env_state.argtypes = [vp, ip, ctypes.c_int32, vp]
+    lib.mpc_reset_env_state.restype = ctypes.c_int
+    lib.mpc_reset_env_mask.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_uint32, vp]
+    lib.mpc_reset_env_mask.restype = ctypes.c_int
+    lib.mpc_get_env_state.argtypes = [vp, ctypes.c_int32, ip, ip, ip, ip, ip]
+    lib.mpc_get_env_state.restype = ctypes.c_int
+    lib.mpc_get_last_inputs.argtypes = [vp, ctypes.c_int32, dp, ip, dp, vp, dp, ip]
+    lib.mpc_get_last_inputs.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -184,6 +196,91 @@ class MPCEngine:
                                        p(out["status"]), p(out["iters"]), stream)
         self._check(rc, "mpc_solve_batch")
         return out
+
+    # ------------------------------------------------------------------ observation-level path
+    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False):
+        """obs[B, vehicles_count, 8] float32 -> dict(act[B, 2], status, iters): parsing, collision detector (with the
+        per-environment memory kept inside the engine), speed-profile rewrite and solve, all on the device."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        if obs.ndim != 3 or obs.shape[2] != 8:
+            raise ValueError(f"obs must be [B, vehicles_count, 8], got {obs.shape}")
+        B, rows = obs.shape[:2]
+        weights = np.ascontiguousarray(weights, dtype=np.float64).reshape(B, 3)
+        rs = None if ref_speed is None else np.ascontiguousarray(ref_speed, dtype=np.float64).reshape(B)
+        act = np.empty((B, 2))
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        flags = FLAG_COLLISION_COST if collision_cost else 0
+        rc = self._lib.mpc_predict_batch(self._h, B, _ptr(obs), rows, _ptr(weights), _ptr(rs), flags, _ptr(act),
+                                         _ptr(status), _ptr(iters), None)
+        self._check(rc, "mpc_predict_batch")
+        return dict(act=act, status=status, iters=iters)
+
+    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False):
+        """Zero-copy variant on torch device tensors (obs float32 [B, R, 8], weights float64 [B, 3], ref_speed float64
+        [B] or None), enqueued on torch's current stream.  Returns dict(act, status, iters) of device tensors."""
+        import torch
+        B, rows = int(obs.shape[0]), int(obs.shape[1])
+        dev = obs.device
+        for name, t, dt_ in (("obs", obs, torch.float32), ("weights", weights, torch.float64),
+                             ("ref_speed", ref_speed, torch.float64)):
+            if t is None:
+                continue
+            if t.dtype != dt_ or not t.is_contiguous() or t.device != dev or not t.is_cuda:
+                raise ValueError(f"{name}: expected contiguous {dt_} tensor on {dev}")
+        if obs.dim() != 3 or obs.shape[2] != 8 or tuple(weights.shape) != (B, 3):
+            raise ValueError("obs must be [B, vehicles_count, 8] and weights [B, 3]")
+        if out is None:
+            out = dict(act=torch.empty((B, 2), dtype=torch.float64, device=dev),
+                       status=torch.empty(B, dtype=torch.int32, device=dev),
+                       iters=torch.empty(B, dtype=torch.int32, device=dev))
+        flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.mpc_predict_batch(self._h, B, p(obs), rows, p(weights), p(ref_speed), flags, p(out["act"]),
+                                         p(out["status"]), p(out["iters"]), stream)
+        self._check(rc, "mpc_predict_batch")
+        return out
+
+    def reset_env_state(self, env_ids=None):
+        """Episode boundaries: fresh detector state for the given environments (None = all)."""
+        if env_ids is None:
+            rc = self._lib.mpc_reset_env_state(self._h, None, -1, None)
+        else:
+            ids = np.ascontiguousarray(env_ids, dtype=np.int32).reshape(-1)
+            rc = self._lib.mpc_reset_env_state(self._h, _ptr(ids), ids.size, None)
+        self._check(rc, "mpc_reset_env_state")
+
+    def reset_env_mask_torch(self, done):
+        """Same from a uint8 device mask [B], enqueued on torch's current stream."""
+        import torch
+        if done.dtype != torch.uint8 or not done.is_contiguous() or not done.is_cuda:
+            raise ValueError("done: expected contiguous uint8 device tensor")
+        stream = ctypes.c_void_p(torch.cuda.current_stream(done.device).cuda_stream)
+        rc = self._lib.mpc_reset_env_mask(self._h, int(done.numel()), ctypes.c_void_p(done.data_ptr()),
+                                          FLAG_DEVICE_PTRS | FLAG_NO_SYNC, stream)
+        self._check(rc, "mpc_reset_env_mask")
+
+    def env_state(self, B):
+        """Detector state of environments 0..B-1 (host copies): is_collide, ego_index, collision_memory, stop_index,
+        conflict_index[B, 16] (-1 = none)."""
+        o = dict(is_collide=np.empty(B, np.int32), ego_index=np.empty(B, np.int32),
+                 collision_memory=np.empty(B, np.int32), stop_index=np.empty(B, np.int32),
+                 conflict_index=np.empty((B, MAX_OTHERS), np.int32))
+        rc = self._lib.mpc_get_env_state(self._h, B, _ptr(o["is_collide"]), _ptr(o["ego_index"]),
+                                         _ptr(o["collision_memory"]), _ptr(o["stop_index"]), _ptr(o["conflict_index"]))
+        self._check(rc, "mpc_get_env_state")
+        return o
+
+    def last_inputs(self, B, vehicles_count):
+        """The problem data the last predict_batch derived from its observations (host copies)."""
+        N, V = self.horizon, max(int(vehicles_count) - 1, 1)
+        o = dict(state=np.empty((B, 4)), ego_index=np.empty(B, np.int32), vref=np.empty((B, N + 1)),
+                 is_collide=np.empty(B, np.uint8), others=np.empty((B, V, 4)), nveh=np.empty(B, np.int32))
+        rc = self._lib.mpc_get_last_inputs(self._h, B, _ptr(o["state"]), _ptr(o["ego_index"]), _ptr(o["vref"]),
+                                           _ptr(o["is_collide"]), _ptr(o["others"]), _ptr(o["nveh"]))
+        self._check(rc, "mpc_get_last_inputs")
+        return o
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -5,9 +5,14 @@
 (agents/ppo_mpc.py:197-200,422-427; agents/a2c_mpc.py:103-106,145-150) and the run scripts work unchanged,
 and adds `predict_batch()` for many parallel environments.  What happens where:
 
-  host (this file, numpy)   observation parsing, path-crossing "collision" detection with its 10-step memory,
-                            rewrite of the reference speed profile       (agents/pure_mpc.py:552-724)
-  MI355X (engine.py)        the NLP solve itself                          (agents/pure_mpc.py:80-318)
+  predict() / _solve()      one environment, the reference's call sequence: observation parsing, path-crossing
+                            "collision" detection with its 10-step memory and the rewrite of the reference speed
+                            profile (agents/pure_mpc.py:552-724) run here in numpy so that the attributes the
+                            reference exposes (ego_vehicle, agent_vehicles, conflict_points, ...) exist as objects;
+                            the NLP solve (agents/pure_mpc.py:80-318) runs on the MI355X
+  predict_batch()           B environments: the same preamble runs on the device (csrc/mpc_preamble.hpp, one
+                            thread per environment, detector memory inside the engine) followed by the solve -
+                            one C-ABI call, `mpc_predict_batch`
 
 There is no CPU solve path: without the HIP library / a GPU the constructor raises `EngineError`.
 Plotting (`plot`, `visualize_predictions`) is not part of the hot path and is a no-op here.
@@ -134,9 +139,9 @@ def first_path_crossing(ego_path, agent_path):
             j += 1
         s = b - a
         ss = float(s @ s)
+        k0, k1 = float((pts[0] - a) @ s), float((pts[-1] - a) @ s)
         for v in ag:                        # the agent's own vertices inside the overlap are nodes too
-            if ss > 0 and min(float((pts[0] - a) @ s), float((pts[-1] - a) @ s)) - 1e-12 <= float((v - a) @ s) <= \
-                    max(float((pts[0] - a) @ s), float((pts[-1] - a) @ s)) + 1e-12:
+            if ss > 0 and min(k0, k1) - 1e-12 <= float((v - a) @ s) <= max(k0, k1) + 1e-12:
                 pts.append(v)
         d = ego[i + 1] - ego[i]
         keyed = sorted(((float((pt - ego[i]) @ d), tuple(pt)) for pt in pts))
@@ -230,10 +235,14 @@ class PureMPC_Agent:
             [np.cos(other_vehicle.heading), np.sin(other_vehicle.heading)])
 
     def reset_env_state(self, env_ids=None):
-        """Forget the collision memory of the given environments (episode boundaries)."""
+        """Forget the collision memory of the given environments (episode boundaries), in the engine
+        (`predict_batch`) and in the host-side states (`predict`, `predict_batch_host`)."""
         ids = range(len(self._states)) if env_ids is None else env_ids
         for i in ids:
-            self._states[i] = _EnvState()
+            if i < len(self._states):
+                self._states[i] = _EnvState()
+        if hasattr(self._engine, "reset_env_state"):
+            self._engine.reset_env_state(env_ids)
 
     # ------------------------------------------------------------------ reference API
     def predict(self, obs, return_numpy=True, weights_from_RL=None, ref_speed=None):
@@ -279,11 +288,29 @@ class PureMPC_Agent:
 
         `weights_from_RL` is [B, 3] (speed, control, input_diff) or None, `ref_speed` [B, 1] or None;
         environment b keeps its own collision memory across calls (same B every call, `reset_env_state` at
-        episode ends).  Equivalent to looping `predict` over the environments."""
-        if not isinstance(obs, np.ndarray):
-            raise TypeError(f"Expect observation type np.ndarray, but got {type(obs)}.")
-        if obs.ndim != 3 or obs.shape[1:] != (self.total_vehicles_count, 8):
-            raise ValueError(f"Expect observations of shape (B, {self.total_vehicles_count}, 8), but got {obs.shape}")
+        episode ends).  Equivalent to looping `predict` over the environments; everything runs on the device
+        (`mpc_predict_batch`)."""
+        obs, w, rs = self._check_batch_args(obs, weights_from_RL, ref_speed)
+        B = obs.shape[0]
+        if w is None:
+            w = np.tile([float(self.default_weights[f"weight_{k}"]) for k in PureMPC_Agent.weight_components], (B, 1))
+        out = self._engine.predict_batch(obs, w, None if rs is None else rs[:, 0], collision_cost=self.collision_cost)
+        self.last_solve = out
+        bad = int(np.count_nonzero(out["status"]))
+        if bad:                                             # agents/pure_mpc.py:303-305
+            print(f"NOTICE: Not found solution ({bad} of {B} instances)")
+        return out["act"]
+
+    def batch_env_state(self, B):
+        """is_collide / ego_index / collision_memory / stop_index / conflict_index of environments 0..B-1 after
+        `predict_batch` (the batched counterpart of the attributes `predict` leaves on the agent)."""
+        return self._engine.env_state(B)
+
+    def predict_batch_host(self, obs, weights_from_RL=None, ref_speed=None) -> np.ndarray:
+        """`predict` looped over the environments with one batched solve: the preamble of every environment runs in
+        numpy on the host (the single-environment code path), the solve on the device.  Kept as the cross-check of
+        `predict_batch`; it has its own per-environment states, separate from the engine's."""
+        obs, w, rs = self._check_batch_args(obs, weights_from_RL, ref_speed)
         B = obs.shape[0]
         while len(self._states) < B:
             self._states.append(_EnvState())
@@ -293,12 +320,20 @@ class PureMPC_Agent:
             self._check_collision_env(self._states[b], e, o)
             egos.append(e)
             others.append(o)
-        w = None if weights_from_RL is None else np.asarray(weights_from_RL, dtype=np.float64).reshape(B, -1)[:, :3]
-        rs = None if ref_speed is None else np.asarray(ref_speed, dtype=np.float64).reshape(B, 1)
         act = self._solve_envs(self._states[:B], egos, others, w, rs)
         for b in range(B):
             self._states[b].last_acc = act[b, 0]
         return act
+
+    def _check_batch_args(self, obs, weights_from_RL, ref_speed):
+        if not isinstance(obs, np.ndarray):
+            raise TypeError(f"Expect observation type np.ndarray, but got {type(obs)}.")
+        if obs.ndim != 3 or obs.shape[1:] != (self.total_vehicles_count, 8):
+            raise ValueError(f"Expect observations of shape (B, {self.total_vehicles_count}, 8), but got {obs.shape}")
+        B = obs.shape[0]
+        w = None if weights_from_RL is None else np.asarray(weights_from_RL, dtype=np.float64).reshape(B, -1)[:, :3]
+        rs = None if ref_speed is None else np.asarray(ref_speed, dtype=np.float64).reshape(B, 1)
+        return obs, w, rs
 
     # ------------------------------------------------------------------ preamble pieces
     def _nearest_ref_index(self, position):
@@ -455,6 +490,7 @@ class PureMPC_Agent:
 
     def _solve_envs(self, states, egos, others, weights_from_RL, ref_speed):
         inp = self.build_solver_inputs(states, egos, others, weights_from_RL, ref_speed)
+        self.last_inputs = inp
         out = self._engine.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
                                        vref=inp["vref"], others=inp["others"],
                                        collision_cost=self.collision_cost and inp["others"] is not None,

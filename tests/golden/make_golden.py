@@ -103,6 +103,38 @@ def reference_vectors():
     out["ego_future_in"] = np.array(ego_in)
     out["ego_future_out"] = np.stack(ego_out)
     out["ego_future_len"] = np.array(ego_len)
+    # the same predictor driven the way `_check_collision` drives it: float32 position and float32 speed straight
+    # from a parsed observation (numpy 2 keeps the speed ramp and the first metres of arc length in float32)
+    obs32 = synth.make_obs_batch(24, 2, seed=77)
+    e32_in, e32_out, e32_len = [], [], []
+    for b in range(24):
+        ag._parse_obs(obs32[b])
+        ego = ag.ego_vehicle
+        idx = int(np.argmin(np.linalg.norm(ag.reference_trajectory - ego.position, axis=1)))
+        vref = ag.global_reference_states[idx, 2] if b % 6 else 0.5 * float(ego.speed)
+        fut = ag.predict_ego_future_positions(ego.position, ego.speed, ego.heading, ego.max_acceleration, ag.dt, 30, vref)
+        arr = np.full((31, 2), np.nan)
+        arr[:len(fut)] = np.asarray([np.asarray(p, dtype=np.float64) for p in fut])
+        e32_in.append([ego.position[0], ego.position[1], ego.speed, vref])
+        e32_out.append(arr)
+        e32_len.append(len(fut))
+    out["ego_future32_in"] = np.array(e32_in, dtype=np.float64)      # float32 values, exactly representable
+    out["ego_future32_out"] = np.stack(e32_out)
+    out["ego_future32_len"] = np.array(e32_len)
+    # stop profile with a float32 ego speed (np.linspace then runs in float32)
+    ag._parse_obs(obs32[0])
+    lin_in, lin_out = [], []
+    for (ego_index, conflict, speed) in [(10, [30], np.float32(9.3)), (3, [40, 12], np.float32(3.3)),
+                                         (50, [52], np.float32(11.7)), (20, [27], np.float32(0.0))]:
+        ag.ego_index, ag.is_collide, ag.conflict_index, ag.collision_memory = ego_index, True, conflict, 0
+        ag.memorized_conflict_indices = None
+        ag.ego_vehicle.speed = speed
+        ag.last_valid_stop_point = None
+        ref = ag.update_reference_states(speed_override=0, speed_overide_from_RL=None)
+        lin_in.append([ego_index, min(conflict), float(speed)])
+        lin_out.append(ref[:, 2].copy())
+    out["stop_profile32_in"] = np.array(lin_in, dtype=np.float64)
+    out["stop_profile32_out"] = np.stack(lin_out)
     fut = ag.predict_future_positions(np.array([-20.0, 2.0], dtype=np.float32), np.float32(8.0), np.float32(0.1), 0.1, 30)
     out["agent_future_out"] = np.asarray(fut, dtype=np.float64)
     del rng
@@ -142,4 +174,5 @@ def oracle_vectors():
 
 if __name__ == "__main__":
     reference_vectors()
-    oracle_vectors()
+    if "--reference-only" not in sys.argv:
+        oracle_vectors()

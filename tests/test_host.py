@@ -86,6 +86,21 @@ def test_future_position_predictors_match_reference(agent, gold):
         np.testing.assert_allclose(got, want[:n], rtol=0, atol=1e-12)
     fut = agent.predict_future_positions(np.array([-20.0, 2.0], np.float32), np.float32(8.0), np.float32(0.1), 0.1, 30)
     np.testing.assert_allclose(np.asarray(fut, np.float64), gold["agent_future_out"], rtol=0, atol=1e-12)
+    # driven with the float32 position / speed of a parsed observation, as _check_collision does
+    for (x, y, sp, vref), want, n in zip(gold["ego_future32_in"], gold["ego_future32_out"], gold["ego_future32_len"]):
+        fut = agent.predict_ego_future_positions(np.array([x, y], np.float32), np.float32(sp), -1.5, 3.5, 0.1, 30, vref)
+        assert len(fut) == n
+        got = np.asarray([np.asarray(q, dtype=np.float64) for q in fut])
+        assert np.array_equal(got, want[:n])
+
+
+def test_stop_profile_with_float32_speed_matches_reference(agent, gold):
+    from mpc_rl_for_avs_amd.pure_mpc import _EnvState
+    for (ego_index, conflict, speed), want in zip(gold["stop_profile32_in"], gold["stop_profile32_out"]):
+        st = _EnvState()
+        st.ego_index, st.is_collide, st.conflict_index = int(ego_index), True, [int(conflict)]
+        ref = agent.update_reference_states(0, None, st, np.float32(speed))
+        assert np.array_equal(ref[:, 2], want)
 
 
 def test_path_crossing_kats():
@@ -141,12 +156,12 @@ def test_collision_state_machine_and_solver_inputs(agent):
     assert agent.predict(obs, return_numpy=False).acceleration == 0.5
 
 
-def test_predict_batch_equals_looped_predict():
+def test_predict_batch_host_equals_looped_predict():
     from mpc_rl_for_avs_amd import synth
     from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
     obs = synth.make_obs_batch(12, 4, seed=9)
     a = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
-    a.predict_batch(obs)
+    a.predict_batch_host(obs)
     batch = a._engine.calls[-1]
     for b in range(12):
         s = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
