@@ -1,0 +1,324 @@
+"""MPC-in-the-loop rollout collection for many parallel environments (BASELINE configs 4-5).
+
+The reference collects experience with ONE environment and one MPC solve per step:
+    policy(obs) -> clip -> mpc_agent.predict(obs, weights_from_RL | ref_speed) -> env.step(mpc_action) -> buffer.add
+(`PPO_MPC.collect_rollouts` agents/ppo_mpc.py:353-483, `A2C_MPC.collect_rollouts` agents/a2c_mpc.py:111-180, both
+copies of stable-baselines3's on-policy loop with the MPC call spliced in).  `BatchedCollector` is that loop for B
+environments at once with every tensor resident on the GPU: the policy is a torch module, the MPC call is
+`MPCEngine.predict_batch_torch` (one C-ABI call: device preamble + solve, zero-copy on torch's stream), the
+environment steps as vectorised torch ops, and the buffer is a set of device tensors.  With `torch.distributed`
+initialised the environments are sharded over the ranks and the MPC actions are all-gathered (RCCL) every step,
+the path's only exchange.
+
+highway-env, gymnasium and stable-baselines3 are not available offline, so
+  * `SyntheticIntersectionEnv` is a stand-in with the reference's observation layout (config/config.py:10-26:
+    10 rows x [presence, x, y, vx, vy, heading, sin_h, cos_h], absolute, sorted by distance), its ego route (the
+    reference path of agents/base_agent.py:118-154), the MPC's own vehicle model for the ego (agents/pure_mpc.py:
+    220-228), constant-velocity traffic on the four approach lanes, and the reward / termination *shape* of
+    envs/intersection_env_Feb2025_v1.py:80-155 (collision, speed, arrival, lane centring, off-road; crash or arrival
+    terminates, 200 steps truncate).  It is scaffolding for throughput measurements, not a re-implementation of
+    highway-env.
+  * `ActorCritic` has the shape of SB3's default `MlpPolicy` used by the reference's `create_ppo_policy /
+    create_a2c_policy` (trainers/trainer_utils.py:6-45): flattened 80-d observation, separate 64-64 tanh towers
+    for policy and value, diagonal Gaussian over a Box(-1, 1)^dim action (dim 1 = reference speed "v0",
+    dim 3 = cost weights "v1", trainers/trainer.py:422-428).
+  * `RolloutBuffer.compute_returns_and_advantage` is generalised advantage estimation as SB3 defines it.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .reference_path import reference_states
+
+VEHICLES_COUNT = 10        # config/cfg.yaml:2
+EPISODE_STEPS = 200        # duration 10 s + 10 s at 10 Hz (envs/intersection_env_Feb2025_v1.py:153-155, config.py:41)
+REWARD = dict(collision=-200.0, high_speed=15.0, arrived=50.0, center_bonus=5.0, off_road=-50.0)  # env :47-52,:96-107
+LANE_HALF_WIDTH = 2.0
+CRASH_DISTANCE = 2.5
+WHEELBASE = 2.5
+
+
+class SyntheticIntersectionEnv:
+    """B independent intersection episodes stepped together on one device (auto-reset like an SB3 VecEnv)."""
+
+    def __init__(self, num_envs: int, device="cpu", seed: int = 0, n_others: int = 4, dt: float = 0.1,
+                 spawn_probability: float = 0.3):
+        assert 0 <= n_others <= VEHICLES_COUNT - 1
+        self.num_envs, self.K, self.dt = int(num_envs), int(n_others), float(dt)
+        self.device = torch.device(device)
+        self.spawn_probability = float(spawn_probability)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        ref = reference_states(dt)
+        self.ref_xy = torch.as_tensor(ref[:, :2], dtype=torch.float64, device=self.device)
+        self.M = ref.shape[0]
+        B, K = self.num_envs, max(self.K, 1)
+        self.ego = torch.zeros((B, 4), dtype=torch.float64, device=self.device)      # x, y, heading, speed
+        self.opos = torch.zeros((B, K, 2), dtype=torch.float64, device=self.device)
+        self.ospeed = torch.zeros((B, K), dtype=torch.float64, device=self.device)
+        self.ohead = torch.zeros((B, K), dtype=torch.float64, device=self.device)
+        self.oactive = torch.zeros((B, K), dtype=torch.bool, device=self.device)
+        self.t = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._lane_h = torch.tensor([0.0, math.pi / 2, math.pi, -math.pi / 2], dtype=torch.float64, device=self.device)
+
+    # ---- random helpers ------------------------------------------------------------------------------------
+    def _u(self, shape, lo, hi):
+        return lo + (hi - lo) * torch.rand(shape, generator=self.gen, device=self.device, dtype=torch.float64)
+
+    def _spawn_others(self, shape, dlo, dhi):
+        """Vehicles on the four approach lanes driving towards the centre (right-hand traffic, lane offset 2 m)."""
+        lane = torch.randint(0, 4, shape, generator=self.gen, device=self.device)
+        h = self._lane_h[lane]
+        d = self._u(shape, dlo, dhi)
+        x = -d * torch.cos(h) + torch.where(lane == 1, -2.0, 0.0) + torch.where(lane == 3, 2.0, 0.0)
+        y = -d * torch.sin(h) + torch.where(lane == 0, 2.0, 0.0) + torch.where(lane == 2, -2.0, 0.0)
+        sp = torch.clamp(8.0 + torch.randn(shape, generator=self.gen, device=self.device, dtype=torch.float64), min=0.0)
+        return torch.stack([x, y], dim=-1), sp, h
+
+    def _reset_where(self, mask):
+        B, K = self.num_envs, max(self.K, 1)
+        ego = torch.zeros((B, 4), dtype=torch.float64, device=self.device)
+        ego[:, 0] = 2.0
+        ego[:, 1] = 45.0 + self._u((B,), -5.0, 5.0)          # envs/intersection_env_Feb2025_v1.py:397-410
+        ego[:, 2] = -math.pi / 2
+        ego[:, 3] = 10.0
+        pos, sp, h = self._spawn_others((B, K), 5.0, 60.0)
+        m1, m2 = mask[:, None], mask[:, None, None]
+        self.ego = torch.where(m1, ego, self.ego)
+        self.opos = torch.where(m2, pos, self.opos)
+        self.ospeed = torch.where(m1, sp, self.ospeed)
+        self.ohead = torch.where(m1, h, self.ohead)
+        active = torch.ones((B, K), dtype=torch.bool, device=self.device) if self.K > 0 else \
+            torch.zeros((B, K), dtype=torch.bool, device=self.device)
+        self.oactive = torch.where(m1, active, self.oactive)
+        self.t = torch.where(mask, torch.zeros_like(self.t), self.t)
+
+    # ---- observation (config/config.py:10-26) ------------------------------------------------------------------
+    def observe(self) -> torch.Tensor:
+        B, K = self.num_envs, max(self.K, 1)
+        obs = torch.zeros((B, VEHICLES_COUNT, 8), dtype=torch.float32, device=self.device)
+        x, y, th, v = self.ego.unbind(dim=1)
+        obs[:, 0, 0] = 1.0
+        obs[:, 0, 1], obs[:, 0, 2] = x.float(), y.float()
+        obs[:, 0, 3], obs[:, 0, 4] = (v * torch.cos(th)).float(), (v * torch.sin(th)).float()
+        obs[:, 0, 5], obs[:, 0, 6], obs[:, 0, 7] = th.float(), torch.sin(th).float(), torch.cos(th).float()
+        if self.K > 0:
+            d = torch.linalg.norm(self.opos - self.ego[:, None, :2], dim=-1)
+            d = torch.where(self.oactive, d, torch.full_like(d, float("inf")))
+            order = torch.argsort(d, dim=1, stable=True)                  # `order: sorted`: nearest first, absent last
+            g = lambda t: torch.gather(t, 1, order)
+            act = g(self.oactive)
+            px = torch.gather(self.opos[..., 0], 1, order)
+            py = torch.gather(self.opos[..., 1], 1, order)
+            sp, hh = g(self.ospeed), g(self.ohead)
+            rows = torch.stack([torch.ones_like(px), px, py, sp * torch.cos(hh), sp * torch.sin(hh), hh, torch.sin(hh),
+                                torch.cos(hh)], dim=-1)
+            rows = torch.where(act[..., None], rows, torch.zeros_like(rows))
+            obs[:, 1:1 + K] = rows.float()
+        return obs
+
+    def reset(self) -> torch.Tensor:
+        self._reset_where(torch.ones(self.num_envs, dtype=torch.bool, device=self.device))
+        return self.observe()
+
+    # ---- one policy step ---------------------------------------------------------------------------------------
+    def step(self, action: torch.Tensor):
+        """action[B, 2] = acceleration [m/s^2], steering angle [rad] (what the RL wrappers hand to env.step,
+        agents/ppo_mpc.py:430-432).  Returns obs, reward, done, info like an SB3 VecEnv with auto-reset:
+        info = dict(terminal_obs, truncated, crashed, arrived)."""
+        a = torch.clamp(action[:, 0].to(torch.float64), -5.0, 5.0)                      # config/config.py:31
+        delta = torch.clamp(action[:, 1].to(torch.float64), -math.pi / 4, math.pi / 4)  # config/config.py:30
+        x, y, th, v = self.ego.unbind(dim=1)
+        beta = torch.atan(0.5 * torch.tan(delta))
+        dt = self.dt
+        nx = x + v * torch.cos(th + beta) * dt
+        ny = y + v * torch.sin(th + beta) * dt
+        nth = th + v / WHEELBASE * torch.sin(beta) * dt
+        nv = torch.clamp(v + a * dt, 0.0, 30.0)
+        self.ego = torch.stack([nx, ny, nth, nv], dim=1)
+        if self.K > 0:
+            step = (self.ospeed * dt)[..., None] * torch.stack([torch.cos(self.ohead), torch.sin(self.ohead)], dim=-1)
+            self.opos = self.opos + step
+            gone = (self.opos.abs().amax(dim=-1) > 65.0) | ~self.oactive
+            self.oactive = self.oactive & ~gone
+            respawn = gone & (torch.rand(gone.shape, generator=self.gen, device=self.device) < self.spawn_probability)
+            pos, sp, h = self._spawn_others(gone.shape, 40.0, 60.0)
+            self.opos = torch.where(respawn[..., None], pos, self.opos)
+            self.ospeed = torch.where(respawn, sp, self.ospeed)
+            self.ohead = torch.where(respawn, h, self.ohead)
+            self.oactive = self.oactive | respawn
+            dist = torch.linalg.norm(self.opos - self.ego[:, None, :2], dim=-1)
+            crashed = ((dist < CRASH_DISTANCE) & self.oactive).any(dim=1)
+        else:
+            crashed = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        dref = torch.linalg.norm(self.ref_xy[None] - self.ego[:, None, :2], dim=-1)
+        lateral, idx = dref.min(dim=1)
+        on_road = lateral <= LANE_HALF_WIDTH
+        arrived = (idx >= self.M - 3) & on_road
+        centering = 1.0 - torch.clamp(lateral / LANE_HALF_WIDTH, max=1.0)
+        reward = (REWARD["collision"] * crashed + REWARD["high_speed"] * (self.ego[:, 3] / 10.0) +
+                  REWARD["arrived"] * arrived + torch.where(on_road, REWARD["center_bonus"] * centering,
+                                                            torch.full_like(centering, REWARD["off_road"])))
+        self.t = self.t + 1
+        terminated = crashed | arrived
+        truncated = (self.t >= EPISODE_STEPS) & ~terminated
+        done = terminated | truncated
+        terminal_obs = self.observe()
+        self._reset_where(done)
+        obs = torch.where(done[:, None, None], self.observe(), terminal_obs)
+        return obs, reward.float(), done, dict(terminal_obs=terminal_obs, truncated=truncated, crashed=crashed,
+                                               arrived=arrived)
+
+
+class ActorCritic(torch.nn.Module):
+    """SB3 `MlpPolicy`-shaped actor-critic: 80 -> 64 -> 64 (tanh) twice, Gaussian head of `action_dim`."""
+
+    def __init__(self, action_dim: int, obs_dim: int = VEHICLES_COUNT * 8, hidden: int = 64):
+        super().__init__()
+        mk = lambda: torch.nn.Sequential(torch.nn.Linear(obs_dim, hidden), torch.nn.Tanh(),
+                                         torch.nn.Linear(hidden, hidden), torch.nn.Tanh())
+        self.pi, self.vf = mk(), mk()
+        self.action_net = torch.nn.Linear(hidden, action_dim)
+        self.value_net = torch.nn.Linear(hidden, 1)
+        self.log_std = torch.nn.Parameter(torch.zeros(action_dim))
+        self.action_dim = action_dim
+
+    def _dist(self, obs):
+        mean = self.action_net(self.pi(obs.flatten(1)))
+        # validate_args=False: the default argument checks read a device boolean back on the host (a sync per step)
+        return torch.distributions.Normal(mean, self.log_std.exp().expand_as(mean), validate_args=False)
+
+    def forward(self, obs, deterministic: bool = False, generator=None):
+        d = self._dist(obs)
+        if deterministic:
+            actions = d.mean
+        else:
+            actions = d.mean + d.stddev * torch.randn(d.mean.shape, generator=generator, device=d.mean.device,
+                                                      dtype=d.mean.dtype)
+        return actions, self.predict_values(obs), d.log_prob(actions).sum(dim=1)
+
+    def predict_values(self, obs):
+        return self.value_net(self.vf(obs.flatten(1)))[:, 0]
+
+    def evaluate_actions(self, obs, actions):
+        d = self._dist(obs)
+        return self.predict_values(obs), d.log_prob(actions).sum(dim=1), d.entropy().sum(dim=1)
+
+
+class RolloutBuffer:
+    """[n_steps, B, ...] device tensors + GAE (the arithmetic of SB3's RolloutBuffer, which the reference uses as is)."""
+
+    def __init__(self, n_steps, num_envs, action_dim, device, gamma=0.99, gae_lambda=0.95):
+        T, B = int(n_steps), int(num_envs)
+        z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=device)
+        self.obs = z(T, B, VEHICLES_COUNT, 8)
+        self.actions = z(T, B, action_dim)
+        self.rewards, self.values, self.log_probs = z(T, B), z(T, B), z(T, B)
+        self.episode_starts = z(T, B)
+        self.advantages, self.returns = z(T, B), z(T, B)
+        self.mpc_actions = z(T, B, 2, dt=torch.float64)
+        self.gamma, self.gae_lambda, self.n_steps, self.pos = float(gamma), float(gae_lambda), T, 0
+
+    def reset(self):
+        self.pos = 0
+
+    def add(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions=None):
+        i = self.pos
+        self.obs[i], self.actions[i], self.rewards[i] = obs, actions, rewards
+        self.episode_starts[i], self.values[i], self.log_probs[i] = episode_starts, values, log_probs
+        if mpc_actions is not None:
+            self.mpc_actions[i] = mpc_actions
+        self.pos += 1
+
+    def compute_returns_and_advantage(self, last_values, dones):
+        last_gae = torch.zeros_like(last_values)
+        dones = dones.to(last_values.dtype)
+        for step in reversed(range(self.n_steps)):
+            if step == self.n_steps - 1:
+                next_non_terminal, next_values = 1.0 - dones, last_values
+            else:
+                next_non_terminal, next_values = 1.0 - self.episode_starts[step + 1], self.values[step + 1]
+            delta = self.rewards[step] + self.gamma * next_values * next_non_terminal - self.values[step]
+            last_gae = delta + self.gamma * self.gae_lambda * next_non_terminal * last_gae
+            self.advantages[step] = last_gae
+        self.returns = self.advantages + self.values
+
+
+class BatchedCollector:
+    """`collect_rollouts` of the reference for B environments (see module docstring).
+
+    version "v0": the policy's 1-d action is the reference-speed override (agents/ppo_mpc.py:410-414);
+    version "v1": its first three components are the cost weights (agents/ppo_mpc.py:416-420).
+    algorithm "ppo" clips the action to the Box(-1, 1) bounds before use and bootstraps truncated episodes with the
+    value of the terminal observation (agents/ppo_mpc.py:399-407, 451-461); "a2c" does neither
+    (agents/a2c_mpc.py:138-144).
+    reset_mpc_on_done=False mirrors the reference, whose single MPC agent keeps its collision memory across
+    episode boundaries; True forgets it (`mpc_reset_env_mask`) when an environment restarts.
+    """
+
+    def __init__(self, env, policy: ActorCritic, engine, version: str = "v0", algorithm: str = "ppo",
+                 n_steps: int = 64, gamma: float = 0.99, gae_lambda: float = 0.95,
+                 default_weights=(1.0, 1.0, 1.0), collision_cost: bool = False, reset_mpc_on_done: bool = False,
+                 gather_actions: bool = False, seed: int = 0):
+        if version not in ("v0", "v1") or algorithm not in ("ppo", "a2c"):
+            raise ValueError("version must be v0|v1 and algorithm ppo|a2c")
+        if version == "v1" and policy.action_dim < 3:
+            raise ValueError("v1 needs an action of at least 3 components (speed, control, input_diff weights)")
+        self.env, self.policy, self.engine = env, policy, engine
+        self.version, self.algorithm = version, algorithm
+        self.collision_cost, self.reset_mpc_on_done, self.gather_actions = collision_cost, reset_mpc_on_done, gather_actions
+        dev = env.device
+        B = env.num_envs
+        self.buffer = RolloutBuffer(n_steps, B, policy.action_dim, dev, gamma, gae_lambda)
+        self.default_weights = torch.tensor(default_weights, dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(int(seed))
+        self._last_obs = env.reset()
+        self._last_episode_starts = torch.ones(B, dtype=torch.float32, device=dev)
+        self.num_timesteps = 0
+        self.last_mpc = None
+        self.gathered_actions = None
+
+    def mpc_inputs(self, actions):
+        """RL action -> (weights[B,3] float64, ref_speed[B] float64 or None) as the reference maps them."""
+        clipped = torch.clamp(actions, -1.0, 1.0) if self.algorithm == "ppo" else actions
+        if self.version == "v0":
+            return self.default_weights, clipped[:, 0].to(torch.float64).contiguous()
+        return clipped[:, :3].to(torch.float64).contiguous(), None
+
+    @torch.no_grad()
+    def collect_rollouts(self, n_rollout_steps: int | None = None):
+        n = self.buffer.n_steps if n_rollout_steps is None else int(n_rollout_steps)
+        assert n == self.buffer.n_steps
+        self.policy.eval()
+        self.buffer.reset()
+        ep_done = crashed = arrived = 0
+        dones = torch.zeros(self.env.num_envs, dtype=torch.bool, device=self.env.device)
+        for _ in range(n):
+            obs = self._last_obs
+            actions, values, log_probs = self.policy(obs, generator=self.gen)
+            weights, ref_speed = self.mpc_inputs(actions)
+            self.last_mpc = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost)
+            mpc_action = self.last_mpc["act"]
+            if self.gather_actions:
+                from . import sharding
+                self.gathered_actions = sharding.all_gather_actions(mpc_action)
+            new_obs, rewards, dones, info = self.env.step(mpc_action)
+            self.num_timesteps += self.env.num_envs
+            if self.algorithm == "ppo":                      # agents/ppo_mpc.py:451-461
+                tv = self.policy.predict_values(info["terminal_obs"])
+                rewards = rewards + self.buffer.gamma * tv * info["truncated"].to(tv.dtype)
+            if self.reset_mpc_on_done:
+                self.engine.reset_env_mask_torch(dones.to(torch.uint8))
+            self.buffer.add(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
+            self._last_obs = new_obs
+            self._last_episode_starts = dones.to(torch.float32)
+            ep_done = ep_done + dones.sum()
+            crashed = crashed + info["crashed"].sum()
+            arrived = arrived + info["arrived"].sum()
+        last_values = self.policy.predict_values(self._last_obs)
+        self.buffer.compute_returns_and_advantage(last_values, dones)
+        return dict(steps=n * self.env.num_envs, episodes=int(ep_done), crashed=int(crashed), arrived=int(arrived))

@@ -65,3 +65,53 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+class _RankEngine:
+    """MPC stub whose action encodes the global environment id, so the gathered tensor can be checked."""
+
+    def __init__(self, offset):
+        self.offset = offset
+
+    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False):
+        B = obs.shape[0]
+        act = torch.zeros((B, 2), dtype=torch.float64)
+        act[:, 0] = -1.0
+        act[:, 1] = 1e-3 * (self.offset + torch.arange(B, dtype=torch.float64))
+        return dict(act=act, status=torch.zeros(B, dtype=torch.int32), iters=torch.zeros(B, dtype=torch.int32))
+
+
+def _rollout_worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpc_rl_for_avs_amd import rollout, sharding
+    lo, hi = sharding.shard_range(total, rank, world)
+    torch.manual_seed(0)
+    env = rollout.SyntheticIntersectionEnv(hi - lo, seed=100 + rank, n_others=2)
+    col = rollout.BatchedCollector(env, rollout.ActorCritic(1), _RankEngine(lo), version="v0", n_steps=3,
+                                   gather_actions=True)
+    col.collect_rollouts()
+    q.put((rank, col.gathered_actions.numpy(), col.buffer.mpc_actions[-1].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_rollout_gathers_every_ranks_actions():
+    """Config-5 shape: environments sharded over ranks, MPC actions all-gathered each step (gloo stands in for RCCL)."""
+    total = 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rollout_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (g, l) for r, g, l in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([np.full(total, -1.0), 1e-3 * np.arange(total)], axis=1)
+    for r in range(2):
+        assert np.array_equal(got[r][0], want)
+        assert np.array_equal(got[r][1], want[r * 6:(r + 1) * 6])

@@ -1,0 +1,119 @@
+"""Rollout collector logic on the CPU (torch CPU tensors, the MPC call stubbed): action mapping of the two agent
+versions, PPO clipping / time-limit bootstrap, buffer contents, generalised advantage estimation against plain
+loops, and the synthetic environment's contract (observation layout the MPC preamble expects, auto-reset)."""
+import numpy as np
+import pytest
+import torch
+
+from mpc_rl_for_avs_amd import rollout
+
+
+class StubEngine:
+    """Stands in for MPCEngine.predict_batch_torch: brakes gently, steers along the lane."""
+
+    def __init__(self):
+        self.calls = []
+
+    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False):
+        self.calls.append(dict(obs=obs.clone(), weights=weights.clone(),
+                               ref_speed=None if ref_speed is None else ref_speed.clone()))
+        B = obs.shape[0]
+        act = torch.zeros((B, 2), dtype=torch.float64)
+        act[:, 0] = -0.5
+        return dict(act=act, status=torch.zeros(B, dtype=torch.int32), iters=torch.zeros(B, dtype=torch.int32))
+
+    def reset_env_mask_torch(self, done):
+        self.calls.append(dict(reset=done.clone()))
+
+
+def _gae_loops(rewards, values, episode_starts, last_values, dones, gamma, lam):
+    T, B = rewards.shape
+    adv = np.zeros((T, B))
+    for b in range(B):
+        last = 0.0
+        for t in reversed(range(T)):
+            if t == T - 1:
+                nnt, nv = 1.0 - float(dones[b]), last_values[b]
+            else:
+                nnt, nv = 1.0 - episode_starts[t + 1, b], values[t + 1, b]
+            delta = rewards[t, b] + gamma * nv * nnt - values[t, b]
+            last = delta + gamma * lam * nnt * last
+            adv[t, b] = last
+    return adv
+
+
+def test_env_observation_contract_and_autoreset():
+    env = rollout.SyntheticIntersectionEnv(64, seed=1, n_others=5)
+    obs = env.reset()
+    assert obs.shape == (64, 10, 8) and obs.dtype == torch.float32
+    assert torch.all(obs[:, 0, 0] == 1) and torch.all(obs[:, 0, 1] == 2.0)
+    pres = obs[:, :, 0]
+    assert torch.all(pres[:, 1:6] == 1) and torch.all(pres[:, 6:] == 0)          # present rows contiguous
+    d = torch.linalg.norm(obs[:, 1:6, 1:3] - obs[:, :1, 1:3], dim=-1)
+    assert torch.all(d[:, 1:] >= d[:, :-1])                                       # sorted by distance
+    assert torch.allclose(obs[:, :6, 6], torch.sin(obs[:, :6, 5]), atol=1e-6)
+    # drive straight ahead at full throttle: everyone crashes, arrives or runs out of time, and restarts
+    total_done = 0
+    for _ in range(260):
+        act = torch.zeros((64, 2), dtype=torch.float64)
+        obs, rew, done, info = env.step(act)
+        total_done += int(done.sum())
+        assert torch.all(obs[done][:, 0, 1] == 2.0)                               # fresh episode after done
+        assert torch.all(info["terminal_obs"][~done] == obs[~done])
+        assert not (info["crashed"] & info["arrived"] & info["truncated"]).any()
+        assert rew.shape == (64,) and torch.isfinite(rew).all()
+    assert total_done >= 64
+    again = rollout.SyntheticIntersectionEnv(64, seed=1, n_others=5).reset()
+    assert torch.equal(again, rollout.SyntheticIntersectionEnv(64, seed=1, n_others=5).reset())
+
+
+@pytest.mark.parametrize("version,algo,dim", [("v0", "ppo", 1), ("v1", "ppo", 3), ("v1", "a2c", 4), ("v0", "a2c", 1)])
+def test_collector_maps_actions_like_the_reference(version, algo, dim):
+    torch.manual_seed(0)
+    env = rollout.SyntheticIntersectionEnv(8, seed=3, n_others=3)
+    pol = rollout.ActorCritic(dim)
+    with torch.no_grad():
+        pol.log_std.fill_(1.0)                        # wide exploration so that clipping matters
+    eng = StubEngine()
+    col = rollout.BatchedCollector(env, pol, eng, version=version, algorithm=algo, n_steps=6,
+                                   default_weights=(1.0, 2.0, 3.0))
+    stats = col.collect_rollouts()
+    assert stats["steps"] == 48 and col.num_timesteps == 48 and len(eng.calls) == 6
+    buf = col.buffer
+    for t, call in enumerate(eng.calls):
+        a = buf.actions[t]
+        used = torch.clamp(a, -1, 1) if algo == "ppo" else a
+        assert torch.equal(call["obs"], buf.obs[t])
+        if version == "v0":
+            assert torch.equal(call["ref_speed"], used[:, 0].double())
+            assert torch.equal(call["weights"], torch.tensor([[1.0, 2.0, 3.0]]).double().repeat(8, 1))
+        else:
+            assert call["ref_speed"] is None and torch.equal(call["weights"], used[:, :3].double())
+    assert torch.all(buf.episode_starts[0] == 1)
+    assert torch.all(buf.mpc_actions[:, :, 0] == -0.5)
+    adv = _gae_loops(buf.rewards.numpy(), buf.values.numpy(), buf.episode_starts.numpy(),
+                     pol.predict_values(col._last_obs).detach().numpy(), col._last_episode_starts.numpy(), 0.99, 0.95)
+    np.testing.assert_allclose(buf.advantages.numpy(), adv, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(buf.returns.numpy(), adv + buf.values.numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_ppo_bootstraps_truncated_episodes_and_optional_mpc_reset():
+    env = rollout.SyntheticIntersectionEnv(4, seed=5, n_others=0)
+    pol = rollout.ActorCritic(1)
+    eng = StubEngine()
+    col = rollout.BatchedCollector(env, pol, eng, version="v0", algorithm="ppo", n_steps=3, reset_mpc_on_done=True)
+    env.t[:] = rollout.EPISODE_STEPS - 2              # two steps before the time limit
+    col.collect_rollouts()
+    resets = [c["reset"] for c in eng.calls if "reset" in c]
+    assert len(resets) == 3 and resets[1].all() and not resets[0].any()
+    # the truncated step's reward carries gamma * V(terminal observation)
+    env2 = rollout.SyntheticIntersectionEnv(4, seed=5, n_others=0)
+    col2 = rollout.BatchedCollector(env2, pol, StubEngine(), version="v0", algorithm="a2c", n_steps=3)
+    env2.t[:] = rollout.EPISODE_STEPS - 2
+    col2.collect_rollouts()
+    assert torch.equal(col.buffer.obs, col2.buffer.obs)                           # same seeds, same trajectories
+    diff = col.buffer.rewards[1] - col2.buffer.rewards[1]                         # ppo adds gamma * V(terminal obs)
+    assert torch.all(diff.abs() > 1e-6) and torch.equal(col.buffer.rewards[0], col2.buffer.rewards[0])
+    assert torch.equal(col.buffer.episode_starts[2], torch.ones(4))
+    with pytest.raises(ValueError):
+        rollout.BatchedCollector(env, rollout.ActorCritic(1), eng, version="v1")
