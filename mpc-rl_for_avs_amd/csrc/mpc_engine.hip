@@ -264,28 +264,47 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// observation -> problem data (mpc_preamble.hpp), one thread per environment.  ~2.5 KB of private arrays per
-// thread (two 31-point polylines and the overlap work list); the kernel is < 2 % of a solve.
+// observation -> problem data (mpc_preamble.hpp).  16 lanes per environment, 4 environments per wave: lane 0
+// parses, predicts the ego polyline into LDS and runs the detector state machine / speed profile; lane j tests other
+// vehicle j against that polyline (the part that scales with the number of vehicles).
 // ---------------------------------------------------------------------------------------------------
+constexpr int kPreGroup = mpc::pre::kMaxOthers;         // lanes per environment
+constexpr int kPreEnvs = kBlock / kPreGroup;            // environments per workgroup
+
 __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     int B, const float *__restrict__ obs, int rows, const double *__restrict__ ref5, int M, int N, double dt,
     const double *__restrict__ ref_speed, mpc::pre::EnvState *__restrict__ env, double *__restrict__ state,
     int32_t *__restrict__ ego_index, double *__restrict__ vref, uint8_t *__restrict__ is_collide,
     double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const mpc::pre::RefTable R{ref5, M};
-    mpc::pre::EnvState st = env[b];
+    namespace pre = mpc::pre;
+    __shared__ pre::P2 s_ego[kPreEnvs][pre::kPredHorizon + 1];
+    __shared__ int s_ne[kPreEnvs];
+    __shared__ int32_t s_conf[kPreEnvs][pre::kMaxOthers];
+    const int g = threadIdx.x / kPreGroup, l = threadIdx.x % kPreGroup;
+    const int bq = blockIdx.x * kPreEnvs + g;
+    const bool live = bq < B;
+    const int b = live ? bq : B - 1;                    // surplus groups read the last environment, write nothing
+    const pre::RefTable R{ref5, M};
+    const float *ob = obs + (size_t)b * rows * pre::kObsCols;
+    const pre::Parsed p = pre::parse_obs(ob, rows);
+    // surplus groups (live == false) only keep the barriers company: no detector work on possibly changing state
+    const bool replay = !live || (env[b].collision_memory > 0 && env[b].has_memorized);
+    if (!replay && l == 0)
+        s_ne[g] = pre::ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, s_ego[g]);
+    __syncthreads();
+    if (!replay) s_conf[g][l] = l < p.observed ? pre::detect_vehicle(ob + (l + 1) * pre::kObsCols, s_ego[g], s_ne[g], R, dt) : -1;
+    __syncthreads();
+    if (l != 0 || !live) return;
+    pre::EnvState st = env[b];
     double *oth = others + (size_t)b * Vslots * 4;
-    int32_t e = 0, nv = 0;
+    pre::write_vehicles(ob, p, state + (size_t)b * 4, oth);
+    for (int j = p.observed; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
+    int32_t e = 0;
     uint8_t c = 0;
-    mpc::pre::preamble_env(obs + (size_t)b * rows * mpc::pre::kObsCols, rows, R, N, dt,
-                           ref_speed ? ref_speed + b : nullptr, st, state + (size_t)b * 4, e,
-                           vref + (size_t)b * (N + 1), c, oth, nv);
-    for (int j = nv; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
+    pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], st, e, vref + (size_t)b * (N + 1), c);
     ego_index[b] = e;
     is_collide[b] = c;
-    nveh[b] = nv;
+    nveh[b] = p.observed;
     env[b] = st;
 }
 
@@ -742,7 +761,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         d_iters = reinterpret_cast<int32_t *>(sb + off_it);
     }
 
-    hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)((B + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)((B + kPreEnvs - 1) / kPreEnvs)), dim3(kBlock), 0, stream,
                        (int)B, d_obs, rows, h->d_ref, h->M, N, h->cfg.dt, d_rs, h->d_env, h->p_state, h->p_ego,
                        h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh);
     HIP_TRY(hipGetLastError());

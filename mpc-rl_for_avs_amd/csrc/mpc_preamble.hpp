@@ -115,7 +115,10 @@ MPC_HD int ego_future(const RefTable &R, float px, float py, float speed, double
     double cs_d = 0.0, cd_d = 0.0;
     const float acc_dt_f = (float)(3.5 * dt);   // Vehicle.max_acceleration * dt, weakly typed -> float32
     const float dt_f = (float)dt;
-    // cumulative arc length from ref[start], recomputed incrementally while searching
+    // np.searchsorted(cumulative, distance) state: the travelled distance never decreases, so the search resumes
+    // where the previous step stopped (the cumulative sums are formed in the same order as np.cumsum)
+    int idx = 0;
+    double cum = 0.0, prev = 0.0;
     for (int step = 0; step < kPredHorizon; ++step) {
         const double cs_now = s32 ? (double)cs_f : cs_d;
         if (cs_now < reference_speed) {
@@ -150,8 +153,6 @@ MPC_HD int ego_future(const RefTable &R, float px, float py, float speed, double
         }
         const double cd = d32 ? (double)cd_f : cd_d;
         // next_idx = searchsorted(cumulative, cd) (left): first index with cumulative[idx] >= cd
-        int idx = 0;
-        double cum = 0.0, prev = 0.0;
         while (idx < npts && cum < cd) {
             ++idx;
             if (idx < npts) {
@@ -321,71 +322,77 @@ MPC_HD float normalize_angle_f32(float a) {
     return a;
 }
 
-// ---- the whole preamble for one environment -------------------------------------------------------------------
-// obs: [rows][8] float32.  Outputs: state[4], vref[N+1], others[(rows-1)][4] (x, y, speed, heading; absent slots are
-// not written), nveh, ego_index, is_collide.  ref_speed: RL override or nullptr.
-MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, double dt, const double *ref_speed,
-                         EnvState &st, double *state, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
-                         double *others, int32_t &nveh_out) {
-    // ---- a2: parse (agents/base_agent.py:81-116)
+// ---- the preamble of one environment in three parts (the HIP kernel spreads part 2 over lanes) -------------------
+struct Parsed {
+    float ex, ey, eh, ev;   // ego x, y, wrapped heading, speed (float32 like the reference's Vehicle fields)
+    int observed;           // other vehicles present (rows 1..observed)
+};
+
+// part 1 - a2: parse (agents/base_agent.py:81-116)
+MPC_HD Parsed parse_obs(const float *obs, int rows) {
     int present = 0;
     for (int r = 0; r < rows; ++r) present += (obs[r * kObsCols + 0] == 1.0f) ? 1 : 0;
     int observed = present - 1;
     observed = observed < 0 ? 0 : observed;
     observed = observed > kMaxOthers ? kMaxOthers : observed;
-    const float ex = obs[1], ey = obs[2];
-    const float eh = normalize_angle_f32(obs[5]);
-    const float ev = speed_f32(obs[3], obs[4]);
-    state[0] = (double)ex;
-    state[1] = (double)ey;
-    state[2] = (double)eh;
-    state[3] = (double)ev;
-    for (int j = 0; j < observed; ++j) {
+    return Parsed{obs[1], obs[2], normalize_angle_f32(obs[5]), speed_f32(obs[3], obs[4]), observed};
+}
+// problem data that comes straight from the observation: state[4], others[observed][4] (x, y, speed, heading)
+MPC_HD void write_vehicles(const float *obs, const Parsed &p, double *state, double *others) {
+    state[0] = (double)p.ex;
+    state[1] = (double)p.ey;
+    state[2] = (double)p.eh;
+    state[3] = (double)p.ev;
+    for (int j = 0; j < p.observed; ++j) {
         const float *o = obs + (j + 1) * kObsCols;
         others[j * 4 + 0] = (double)o[1];
         others[j * 4 + 1] = (double)o[2];
         others[j * 4 + 2] = (double)speed_f32(o[3], o[4]);
         others[j * 4 + 3] = (double)o[5];             // not wrapped (agents/base_agent.py:112)
     }
-    nveh_out = observed;
+}
+// the detector replays its memory instead of looking at the scene (agents/pure_mpc.py:558-563)
+MPC_HD bool replays_memory(const EnvState &st) { return st.collision_memory > 0 && st.has_memorized; }
 
-    // ---- a4: collision detector (agents/pure_mpc.py:552-676)
-    if (st.collision_memory > 0 && st.has_memorized) {
+// part 2 - a4 for ONE other vehicle (agents/pure_mpc.py:575-660): reference index of the conflict point or -1.
+// o = its observation row; the constant-velocity polyline is float32 arithmetic (agents/pure_mpc.py:529-550:
+// step = speed * dt * [cos h, sin h], positions accumulate).
+MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt) {
+    const float sp = speed_f32(o[3], o[4]);
+    const float sdt = f32mul(sp, (float)dt);
+    const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
+    P2 ag[kPredHorizon + 1];
+    float ax = o[1], ay = o[2];
+    ag[0] = P2{(double)ax, (double)ay};
+    for (int m = 1; m <= kPredHorizon; ++m) {
+        ax = f32add(ax, stx);
+        ay = f32add(ay, sty);
+        ag[m] = P2{(double)ax, (double)ay};
+    }
+    P2 pt;
+    if (!first_crossing(ego, ne, ag, kPredHorizon + 1, pt)) return -1;
+    const int ego_time = argmin_dist(ego, ne, pt);
+    const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
+    int dtm = ego_time - agent_time;
+    dtm = dtm < 0 ? -dtm : dtm;
+    return dtm < kTimeThreshold ? R.nearest(pt.x, pt.y) : -1;
+}
+
+// part 3 - detector state machine (agents/pure_mpc.py:558-563, 661-676), a6 ego index, a5 speed profile
+// (agents/pure_mpc.py:678-724).  conflict: the part-2 results of vehicles 0..observed-1 (unused when replaying).
+MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *ref_speed, const int32_t *conflict,
+                       EnvState &st, int32_t &ego_index_out, double *vref, uint8_t &collide_out) {
+    if (replays_memory(st)) {
         st.n_conflict = st.n_memorized;
         for (int j = 0; j < kMaxOthers; ++j) st.conflict[j] = st.memorized[j];
         st.is_collide = 1;
         st.collision_memory -= 1;
     } else {
-        st.ego_index = R.nearest((double)ex, (double)ey);
-        P2 ego[kPredHorizon + 1];
-        const int ne = ego_future(R, ex, ey, ev, R.v(st.ego_index), dt, ego);
         bool any = false;
-        st.n_conflict = observed;
-        for (int j = 0; j < kMaxOthers; ++j) st.conflict[j] = -1;
-        for (int j = 0; j < observed; ++j) {
-            const float *o = obs + (j + 1) * kObsCols;
-            // agents/pure_mpc.py:529-550 in float32: step = speed * dt * [cos h, sin h], positions accumulate
-            const float sp = speed_f32(o[3], o[4]);
-            const float sdt = f32mul(sp, (float)dt);
-            const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
-            P2 ag[kPredHorizon + 1];
-            float ax = o[1], ay = o[2];
-            ag[0] = P2{(double)ax, (double)ay};
-            for (int m = 1; m <= kPredHorizon; ++m) {
-                ax = f32add(ax, stx);
-                ay = f32add(ay, sty);
-                ag[m] = P2{(double)ax, (double)ay};
-            }
-            P2 pt;
-            if (!first_crossing(ego, ne, ag, kPredHorizon + 1, pt)) continue;
-            const int ego_time = argmin_dist(ego, ne, pt);
-            const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
-            int dtm = ego_time - agent_time;
-            dtm = dtm < 0 ? -dtm : dtm;
-            if (dtm < kTimeThreshold) {
-                any = true;
-                st.conflict[j] = R.nearest(pt.x, pt.y);
-            }
+        st.n_conflict = p.observed;
+        for (int j = 0; j < kMaxOthers; ++j) {
+            st.conflict[j] = j < p.observed ? conflict[j] : -1;
+            any = any || st.conflict[j] >= 0;
         }
         st.is_collide = any ? 1 : 0;
         if (any) {
@@ -401,13 +408,14 @@ MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, d
         }
     }
 
-    // ---- a6: ego_index is refreshed by _solve in every call (agents/pure_mpc.py:106-109)
-    const int e = R.nearest((double)ex, (double)ey);
+    // a6: ego_index is refreshed by _solve in every call (agents/pure_mpc.py:106-109)
+    const float ev = p.ev;
+    const int e = R.nearest((double)p.ex, (double)p.ey);
     st.ego_index = e;
     ego_index_out = e;
     collide_out = st.is_collide ? 1 : 0;
 
-    // ---- a5: speed profile over the horizon window (agents/pure_mpc.py:678-724)
+    // a5: speed profile over the horizon window
     const int M = R.M;
     if (ref_speed) {
         const double v = *ref_speed < 0.0 ? 0.0 : (*ref_speed > kMaxSpeed ? kMaxSpeed : *ref_speed);
@@ -455,6 +463,24 @@ MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, d
         }
         vref[k] = v;
     }
+}
+
+// ---- the three parts in sequence (host harness; the kernel calls the parts itself) -----------------------------
+// obs: [rows][8] float32.  Outputs: state[4], vref[N+1], others[(rows-1)][4] (absent slots are not written), nveh,
+// ego_index, is_collide.  ref_speed: RL override or nullptr.
+MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, double dt, const double *ref_speed,
+                         EnvState &st, double *state, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
+                         double *others, int32_t &nveh_out) {
+    const Parsed p = parse_obs(obs, rows);
+    write_vehicles(obs, p, state, others);
+    nveh_out = p.observed;
+    int32_t conflict[kMaxOthers];
+    if (!replays_memory(st)) {
+        P2 ego[kPredHorizon + 1];
+        const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, ego);
+        for (int j = 0; j < p.observed; ++j) conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt);
+    }
+    finish_env(p, R, N, ref_speed, conflict, st, ego_index_out, vref, collide_out);
 }
 
 }  // namespace pre
