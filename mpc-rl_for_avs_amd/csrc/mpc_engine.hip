@@ -190,6 +190,39 @@ struct WaveCtx {
         f((int)threadIdx.x);
         __syncthreads();  // single-wave workgroup: orders the LDS traffic of the phase before what follows
     }
+    __device__ __forceinline__ void tick(int) const {}  // section timing hook, used by tools/ubench only
+    // wave reductions: xor-butterfly of lane shuffles, every lane ends with the result
+    __device__ __forceinline__ double wave_sum(mpc::wave::PerLane<double> &p) const {
+        double v = p.v;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    }
+    __device__ __forceinline__ double wave_max(mpc::wave::PerLane<double> &p) const {
+        double v = p.v;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) v = mpc::fmax2(v, __shfl_xor(v, off));
+        return v;
+    }
+    __device__ __forceinline__ double wave_min(mpc::wave::PerLane<double> &p) const {
+        double v = p.v;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) v = mpc::fmin2(v, __shfl_xor(v, off));
+        return v;
+    }
+    __device__ __forceinline__ void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd,
+                                                   double &rn, double &rd) const {
+        double n = pn.v, d = pd.v;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const double n2 = __shfl_xor(n, off), d2 = __shfl_xor(d, off);
+            const bool take = mpc::wave::ratio_greater(n2, d2, n, d);
+            n = take ? n2 : n;
+            d = take ? d2 : d;
+        }
+        rn = n;
+        rd = d;
+    }
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
         idx = idx > M - 1 ? M - 1 : idx;

@@ -58,8 +58,16 @@ enum : int {
     SC_SIG = 178, // 8   barrier curvature / gradient of the 4 bounded variables of the stage
     SC_SIZE = 186
 };
-constexpr int SC_K = SC_T;        // gains (2x6) + feed-forward (2) reuse the T area once H is complete
 constexpr int SC_RED = SC_T;      // reductions: 3 arrays of 21
+// compact stage cost Hessian / gradient, assembled for all stages before a sweep into slots that are free during it:
+// the stage's gain slots (overwritten by the gains once the stage is done) and the trial trajectory buffer
+enum : int {
+    A_L00 = W_KX + 0, A_L01 = W_KX + 1, A_L11 = W_KX + 2, A_H22 = W_KX + 3, A_H23 = W_KX + 4, A_H33 = W_KX + 5,
+    A_WTD = W_KX + 6, A_WVD = W_KX + 7, A_H66 = W_KP + 0, A_H77 = W_KP + 1, A_HV6 = W_KP + 2, A_HV7 = W_KF + 0,
+    A_HV4 = W_KF + 1,
+    A_HV0 = W_X,   // + trial buffer offset: hv0..3
+    A_HV5 = W_U    // + trial buffer offset
+};
 
 MPC_HD constexpr int stage_slots(bool cc) { return cc ? W_SLOTS_CC : W_SLOTS; }
 // doubles of LDS one instance needs: stage arrays + scratch + other vehicles
@@ -86,12 +94,65 @@ MPC_HD double F_entry(const StageLin &s, int m, int j) {
     return v;
 }
 
+// section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
+enum : int {
+    T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_ASM, T_RIC_L2, T_RIC_2X2, T_RIC_L3,
+    T_RIC_L4, T_LINEAR, T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD, T_COUNT
+};
+
+// A value that differs per lane and lives across phases: one register per lane on the device; the host emulation,
+// which runs the lanes of a phase one after the other, keeps all 64.
+template <class T>
+struct PerLane {
+#if defined(__HIPCC__)   // both passes of a hipcc compile (the host pass never runs this code)
+    T v;
+    MPC_HD T &at(int) { return v; }
+#else
+    T v[kLanes];
+    MPC_HD T &at(int lane) { return v[lane]; }
+#endif
+};
+
+// (n2/d2 > n1/d1) for positive denominators, division-free; ties keep the first pair.  When both cross products are
+// equal because both numerators are zero the first pair is kept as well.
+MPC_HD bool ratio_greater(double n2, double d2, double n1, double d1) { return n2 * d1 > n1 * d2; }
+
+// Host-side model of the wave reductions the device does with xor-butterflies of lane shuffles (same pairing, so the
+// same rounding): combine(v[l], v[l ^ off]) for off = 32, 16, ..., 1; every lane ends with the full result.
+#if !defined(__HIPCC__)
+template <class T, class OP>
+inline T host_butterfly(PerLane<T> &p, OP op) {
+    for (int off = kLanes / 2; off; off >>= 1) {
+        T nv[kLanes];
+        for (int l = 0; l < kLanes; ++l) nv[l] = op(p.v[l], p.v[l ^ off]);
+        for (int l = 0; l < kLanes; ++l) p.v[l] = nv[l];
+    }
+    return p.v[0];
+}
+#endif
+
+// column j of F as six values; j is lane-dependent, so the entries are blended with 0/1 indicator factors
+// (exact: the other products are +-0) instead of 64-bit select chains
+MPC_HD void F_column(const StageLin &s, int j, double *f) {
+    const double d0 = j == 0 ? 1.0 : 0.0, d1 = j == 1 ? 1.0 : 0.0, d2 = j == 2 ? 1.0 : 0.0, d3 = j == 3 ? 1.0 : 0.0;
+    const double d6 = j == 6 ? 1.0 : 0.0, d7 = j == 7 ? 1.0 : 0.0;
+    f[0] = fma(s.b01, d7, fma(s.a03, d3, fma(s.a02, d2, d0)));
+    f[1] = fma(s.b11, d7, fma(s.a13, d3, fma(s.a12, d2, d1)));
+    f[2] = fma(s.b21, d7, fma(s.a23, d3, d2));
+    f[3] = fma(s.dt, d6, d3);
+    f[4] = d6;
+    f[5] = d7;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // CTX (one per wave / instance) provides
 //   double ld(int i), void st(int i, double v)   LDS words of this instance
 //   void phase(F f)                              f(lane) for the 64 lanes, then a barrier
 //   double ref(int k, int c)                     reference path column c at stage k
 //   static constexpr int kN                      compile-time horizon or 0
+//   void tick(int section)                       attributes the time since the previous tick to `section`
+//   double wave_sum / wave_max / wave_min(PerLane<double>&)   reduction over the 64 lanes, result in every lane
+//   void wave_max_ratio(PerLane<double>& n, PerLane<double>& d, double &rn, double &rd)   pair with the largest n/d
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
 // ---------------------------------------------------------------------------------------------------
 template <bool CC, class CTX>
@@ -114,6 +175,47 @@ struct Solver {
     MPC_HD double sc(int i) const { return c.ld(SCR + i); }
     MPC_HD void sc(int i, double v) { c.st(SCR + i, v); }
     MPC_HD double oth(int j, int q) const { return c.ld(OTH + j * 4 + q); }
+
+    // Lane roles of the Riccati exchanges, fixed for the whole solve (set_lane_roles):
+    //   exchange 2: lane (i, j) of the 8x8 block adds L(i, j) = [slot of the compact stage Hessian or none] + cst * rdk
+    //               lanes 0..7 add the stage gradient from slot hv (+ trial-buffer offset if hvab)
+    //   exchange 3: lanes 0..35 own P(i, j), 36..41 pv(i), 42..53 gain K(a, j), 54 the feed-forward / Kp
+    PerLane<int> r_slot, r_hv, r_hvab, r_i, r_j;
+    PerLane<double> r_cst;
+    PerLane<double> red_a, red_b, red_c;   // per-lane operands of the wave reductions
+    MPC_HD void set_lane_roles() {
+        c.phase([&](int lane) {
+            const int i = lane >> 3, j = lane & 7;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            int slot = -1;
+            double cst = 0.0;
+            switch (lo * 8 + hi) {
+                case 0 * 8 + 0: slot = A_L00; break;
+                case 0 * 8 + 1: slot = A_L01; break;
+                case 1 * 8 + 1: slot = A_L11; break;
+                case 2 * 8 + 2: slot = A_H22; break;
+                case 2 * 8 + 3: slot = A_H23; break;
+                case 3 * 8 + 3: slot = A_H33; break;
+                case 2 * 8 + 7: slot = A_WTD; break;
+                case 3 * 8 + 7: slot = A_WVD; break;
+                case 6 * 8 + 6: slot = A_H66; break;
+                case 7 * 8 + 7: slot = A_H77; break;
+                case 4 * 8 + 4: cst = 1.0; break;
+                case 5 * 8 + 5: cst = 1.0; break;
+                case 4 * 8 + 6: cst = -1.0; break;
+                case 5 * 8 + 7: cst = -1.0; break;
+                default: break;
+            }
+            r_slot.at(lane) = slot;
+            r_cst.at(lane) = cst;
+            const int q = lane & 7;
+            r_hv.at(lane) = q < 4 ? A_HV0 + q : (q == 4 ? A_HV4 : (q == 5 ? A_HV5 : (q == 6 ? A_HV6 : A_HV7)));
+            r_hvab.at(lane) = (q < 4 || q == 5) ? 1 : 0;
+            const int e = lane < 36 ? lane : (lane < 42 ? (lane - 36) * 6 : (lane < 54 ? (lane - 42) % 6 : 0));
+            r_i.at(lane) = e / 6;
+            r_j.at(lane) = e % 6;
+        });
+    }
 
     // ---- cost pieces (same formulas as mpc_core.hpp) ------------------------------------------------
     MPC_HD double track(int k, double x_0, double x_1, double x_2, double x_3, double *g) const {
@@ -238,13 +340,19 @@ struct Solver {
             x_2 = n2;
             x_3 = n3;
         }
-        if (!feas) return false;
+        if (!feas) {
+            c.tick(T_ROLL_DYN);
+            return false;
+        }
         S(N, TB + W_X + 0, x_0);
         S(N, TB + W_X + 1, x_1);
         S(N, TB + W_X + 2, x_2);
         S(N, TB + W_X + 3, x_3);
+        c.tick(T_ROLL_DYN);
         // stage-parallel: control cost of stage k, tracking / collision cost and barrier of node k+1
         c.phase([&](int lane) {
+            red_a.at(lane) = 0.0;
+            red_b.at(lane) = 0.0;
             if (lane >= N) return;
             const int k = lane;
             const double u0 = S(k, TB + W_U + 0), u1 = S(k, TB + W_U + 1);
@@ -261,17 +369,12 @@ struct Solver {
                 J += sf * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
                 if (CC) J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
             }
-            sc(SC_RED + lane, J);
-            sc(SC_RED + 21 + lane, -log(slack));
+            red_a.at(lane) = J;
+            red_b.at(lane) = -log(slack);
         });
-        double J = 0.0, bar = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < N; ++k) {
-            J += sc(SC_RED + k);
-            bar += sc(SC_RED + 21 + k);
-        }
-        Jout = J;
-        barout = bar;
+        Jout = c.wave_sum(red_a);
+        barout = c.wave_sum(red_b);
+        c.tick(T_ROLL_COST);
         return true;
     }
 
@@ -282,6 +385,7 @@ struct Solver {
         iters_out = 0;
         cur_out = 0;
         kkt_out = INFINITY;
+        set_lane_roles();
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;
@@ -315,11 +419,9 @@ struct Solver {
                     cost_grad(0, lane, lx);
                     g = fmax2(fmax2(fabs(lx[0]), fabs(lx[1])), fmax2(fabs(lx[2]), fabs(lx[3])));
                 }
-                if (lane < 21) sc(SC_RED + lane, g);
+                red_a.at(lane) = g;
             });
-            double gmax = 0.02 * (wc_ + wd_) * fabs(S(0, W_U + 0));
-#pragma unroll 1
-            for (int k = 1; k < N && k < 21; ++k) gmax = fmax2(gmax, sc(SC_RED + k));
+            const double gmax = fmax2(0.02 * (wc_ + wd_) * fabs(S(0, W_U + 0)), c.wave_max(red_a));
             sf = 100.0 / fmin2(fmax2(100.0, gmax), 1e4);
             Jcur *= sf;
         }
@@ -331,10 +433,16 @@ struct Solver {
 
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
+            c.tick(T_DUALUPD);
             // ============ stage-parallel preparation: dynamics trig, collision-potential derivatives,
             //              complementarity products
             c.phase([&](int lane) {
-                if (lane >= N) return;
+                if (lane >= N) {
+                    red_a.at(lane) = 0.0;
+                    red_b.at(lane) = INFINITY;
+                    red_c.at(lane) = 0.0;
+                    return;
+                }
                 const int k = lane;
                 const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
                 double Sn, Cn, sb, cb_;
@@ -371,17 +479,12 @@ struct Solver {
                     cmn = fmin2(cmn, fmin2(c0, c1));
                     sz += zl + zu;
                 }
-                sc(SC_RED + lane, cmx);
-                sc(SC_RED + 21 + lane, cmn);
-                sc(SC_RED + 42 + lane, sz);
+                red_a.at(lane) = cmx;
+                red_b.at(lane) = cmn;
+                red_c.at(lane) = sz;
             });
-            double cmax = 0.0, cmin = INFINITY, sum_z = 0.0;
-#pragma unroll 1
-            for (int k = 0; k < N; ++k) {
-                cmax = fmax2(cmax, sc(SC_RED + k));
-                cmin = fmin2(cmin, sc(SC_RED + 21 + k));
-                sum_z += sc(SC_RED + 42 + k);
-            }
+            const double cmax = c.wave_max(red_a), cmin = c.wave_min(red_b), sum_z = c.wave_sum(red_c);
+            c.tick(T_PREP);
             // ============ adjoint recursion (serial): y_k = dL/dx_k
             double sum_lam = 0.0;
             {
@@ -413,9 +516,13 @@ struct Solver {
                     }
                 }
             }
+            c.tick(T_ADJOINT);
             // ============ dual residual of the controls (stage-parallel)
             c.phase([&](int lane) {
-                if (lane >= N) return;
+                if (lane >= N) {
+                    red_a.at(lane) = 0.0;
+                    return;
+                }
                 const int k = lane;
                 const double rdk = (k >= 1) ? rd_full : 0.0;
                 const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
@@ -437,11 +544,9 @@ struct Solver {
                 const double b01 = -dt * v * Sn * bp, b11 = dt * v * Cn * bp, b21 = dt * v * kInvWheelbase * cb_ * bp;
                 r0 += dt * S(k + 1, W_Y + 3);
                 r1 += b01 * S(k + 1, W_Y + 0) + b11 * S(k + 1, W_Y + 1) + b21 * S(k + 1, W_Y + 2);
-                sc(SC_RED + lane, fmax2(fabs(r0), fabs(r1)));
+                red_a.at(lane) = fmax2(fabs(r0), fabs(r1));
             });
-            double err_d = 0.0;
-#pragma unroll 1
-            for (int k = 0; k < N; ++k) err_d = fmax2(err_d, sc(SC_RED + k));
+            const double err_d = c.wave_max(red_a);
             const double s_d = fmax2(100.0, (sum_lam + sum_z) / (10.0 * N)) / 100.0;
             const double s_c = fmax2(100.0, sum_z / (6.0 * N)) / 100.0;
             for (;;) {
@@ -461,16 +566,102 @@ struct Solver {
             }
             if (iter == P.max_iter) break;
 
+            c.tick(T_DUALRES);
             // ============ Riccati / DDP factorisation: lane (i, j) = entry of the 8x8 stage block ============
+            // Everything of a stage that does not depend on the value function (stage cost Hessian / gradient with
+            // the barrier and constraint-curvature terms) is assembled for all stages at once, lane k = stage k, into
+            // slots that are free during the sweep (the stage's gain slots and the trial trajectory buffer); the
+            // sweep then needs three LDS exchanges per stage: T = P F, H = L + F'T, and (inverse, gains, P) together.
+            const int AB = (cur ^ 1) * 6;   // trial buffer: hv0..3 at AB + W_X, hv5 at AB + W_U
             double dV1 = 0.0, delta_w = 0.0;
             bool ok = false, gn = false;
             for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
                 ok = true;
                 dV1 = 0.0;
-                // terminal value function: barrier terms of (theta, v)_N
                 c.phase([&](int lane) {
+                    // terminal value function: barrier terms of (theta, v)_N
                     if (lane < 36) sc(SC_P + lane, ((lane % 7) == 0 && lane < 28) ? delta_w : 0.0);
                     if (lane >= 36 && lane < 42) sc(SC_PV + lane - 36, 0.0);
+                    if (lane >= N) return;
+                    // ---- stage cost Hessian / gradient of stage k = lane (compact: the 10 distinct entries + 8 gradients)
+                    const int k = lane;
+                    const double rdk = (k >= 1) ? rd_full : 0.0;
+                    const double v = S(k, CB + W_X + 3);
+                    const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
+                    double bp, bpp;
+                    beta_derivs(sb, cb_, bp, bpp);
+                    const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
+                    double sig[4], sgr[4];
+                    for (int q = 0; q < 4; ++q) {   // 0: theta_k, 1: v_k, 2: a_k, 3: delta_k
+                        const bool isx = q < 2;
+                        const int b = isx ? q : q - 2;
+                        const double val = isx ? S(k, CB + W_X + 2 + b) : (b == 0 ? u0 : u1);
+                        const double lo = isx ? xlo_r(b) : ulo_r(b), hi = isx ? xhi_r(b) : uhi_r(b);
+                        const double zl = isx ? S(k, W_ZXL + b) : S(k, W_ZUL + b);
+                        const double zu = isx ? S(k, W_ZXU + b) : S(k, W_ZUU + b);
+                        const double rl = frcp(val - lo), ru = frcp(hi - val);
+                        sig[q] = zl * rl + zu * ru;
+                        sgr[q] = mu * (ru - rl);
+                    }
+                    double wdd = 0.0, wtt = 0.0, wtv = 0.0, wtd = 0.0, wvd = 0.0;
+                    if (!gn) {
+                        const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
+                        const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
+                        wdd = dt * v * (g * bp * bp + h * bpp) + dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
+                        wtt = dt * v * g;
+                        wtv = dt * h;
+                        wtd = dt * v * g * bp;
+                        wvd = dt * h * bp + dt * yy2 * cb_ * bp * kInvWheelbase;
+                    }
+                    double l00 = 0.0, l01 = 0.0, l11 = 0.0, h22 = 0.0, h23 = 0.0, h33 = 0.0, hv0 = 0.0, hv1 = 0.0, hv2 = 0.0,
+                           hv3 = 0.0;
+                    if (k >= 1) {
+                        double lx[4];
+                        cost_grad(cur, k, lx);
+                        const double s = c.ref(k, R_SIN), cc = c.ref(k, R_COS);
+                        l00 = sf * 10.0 * (8.0 * s * s + 4.0 * cc * cc) + delta_w;
+                        l01 = sf * 10.0 * (-8.0 * s * cc + 4.0 * cc * s);
+                        l11 = sf * 10.0 * (8.0 * cc * cc + 4.0 * s * s) + delta_w;
+                        if (CC) {
+                            const int QS = gn ? W_QG : W_Q;
+                            l00 += S(k, QS + 0);
+                            l01 += S(k, QS + 1);
+                            l11 += S(k, QS + 2);
+                        }
+                        h22 = wtt + qtt + sig[0] + delta_w;
+                        h23 = wtv;
+                        h33 = q33 + sig[1] + delta_w;
+                        hv0 = lx[0];
+                        hv1 = lx[1];
+                        hv2 = lx[2] + sgr[0];
+                        hv3 = lx[3] + sgr[1];
+                    } else {
+                        wtd = 0.0;
+                        wvd = 0.0;
+                    }
+                    double um0 = 0.0, um1 = 0.0;
+                    if (k >= 1) {
+                        um0 = S(k - 1, CB + W_U + 0);
+                        um1 = S(k - 1, CB + W_U + 1);
+                    }
+                    S(k, A_L00, l00);
+                    S(k, A_L01, l01);
+                    S(k, A_L11, l11);
+                    S(k, A_H22, h22);
+                    S(k, A_H23, h23);
+                    S(k, A_H33, h33);
+                    S(k, A_WTD, wtd);
+                    S(k, A_WVD, wvd);
+                    S(k, A_H66, rc + rdk + sig[2] + delta_w);
+                    S(k, A_H77, rc + rdk + sig[3] + delta_w + wdd);
+                    S(k, AB + A_HV0, hv0);
+                    S(k, AB + A_HV0 + 1, hv1);
+                    S(k, AB + A_HV0 + 2, hv2);
+                    S(k, AB + A_HV0 + 3, hv3);
+                    S(k, A_HV4, -rdk * (u0 - um0));
+                    S(k, AB + A_HV5, -rdk * (u1 - um1));
+                    S(k, A_HV6, rc * u0 + rdk * (u0 - um0) + sgr[2]);
+                    S(k, A_HV7, rc * u1 + rdk * (u1 - um1) + sgr[3]);
                 });
                 for (int i = 0; i < 2; ++i) {
                     const double xi = S(N, CB + W_X + 2 + i);
@@ -478,6 +669,7 @@ struct Solver {
                     sc(SC_P + (2 + i) * 7, S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w);
                     sc(SC_PV + 2 + i, mu * (ru - rl));
                 }
+                c.tick(T_RIC_INIT);
 #pragma unroll 1
                 for (int k = N - 1; k >= 0; --k) {
                     const double rdk = (k >= 1) ? rd_full : 0.0;
@@ -490,143 +682,90 @@ struct Solver {
                     sl.a23 = dt * sb * kInvWheelbase;
                     sl.b01 = -dt * v * Sn * bp; sl.b11 = dt * v * Cn * bp; sl.b21 = dt * v * kInvWheelbase * cb_ * bp;
                     sl.dt = dt;
-                    // ---- level 1: T = P F (6x8); clear H; barrier curvature / gradient of the 4 bounded variables
+                    c.tick(T_RIC_SCALARS);
+                    // ---- exchange 1: T = P F (6x8)
                     c.phase([&](int lane) {
-                        const int i = lane >> 3, j = lane & 7;
-                        if (lane < 48) {
-                            double t = 0.0;
-                            for (int m = 0; m < 6; ++m) t = fma(sc(SC_P + i * 6 + m), F_entry(sl, m, j), t);
-                            sc(SC_T + lane, t);
-                        } else if (lane < 52) {
-                            const int q = lane - 48;  // 0: theta_k, 1: v_k, 2: a_k, 3: delta_k
-                            const bool isx = q < 2;
-                            const int b = isx ? q : q - 2;
-                            const double val = isx ? S(k, CB + W_X + 2 + b) : S(k, CB + W_U + b);
-                            const double lo = isx ? xlo_r(b) : ulo_r(b), hi = isx ? xhi_r(b) : uhi_r(b);
-                            const double zl = isx ? S(k, W_ZXL + b) : S(k, W_ZUL + b);
-                            const double zu = isx ? S(k, W_ZXU + b) : S(k, W_ZUU + b);
-                            const double rl = frcp(val - lo), ru = frcp(hi - val);
-                            sc(SC_SIG + q, zl * rl + zu * ru);
-                            sc(SC_SIG + 4 + q, mu * (ru - rl));
-                        }
-                        sc(SC_H + lane, 0.0);
-                        if (lane < 8) sc(SC_HV + lane, 0.0);
+                        if (lane >= 48) return;
+                        const int i = lane >> 3;
+                        double f[6];
+                        F_column(sl, lane & 7, f);
+                        double t = 0.0;
+                        for (int m = 0; m < 6; ++m) t = fma(sc(SC_P + i * 6 + m), f[m], t);
+                        sc(SC_T + lane, t);
                     });
-                    // ---- stage cost Hessian / gradient L (uniform): written into H, HV
-                    const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
-                    double wdd = 0.0;
-                    if (!gn) {
-                        const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
-                        const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
-                        wdd = dt * v * (g * bp * bp + h * bpp) + dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
-                        if (k >= 1) {
-                            sc(SC_H + 2 * 8 + 2, dt * v * g);                // theta-theta
-                            sc(SC_H + 2 * 8 + 3, dt * h);                    // theta-v
-                            sc(SC_H + 3 * 8 + 2, dt * h);
-                            const double wtd = dt * v * g * bp;
-                            const double wvd = dt * h * bp + dt * yy2 * cb_ * bp * kInvWheelbase;
-                            sc(SC_H + 2 * 8 + 7, wtd);
-                            sc(SC_H + 7 * 8 + 2, wtd);
-                            sc(SC_H + 3 * 8 + 7, wvd);
-                            sc(SC_H + 7 * 8 + 3, wvd);
-                        }
-                    }
-                    if (k >= 1) {
-                        double lx[4];
-                        cost_grad(cur, k, lx);
-                        const double s = c.ref(k, R_SIN), cc = c.ref(k, R_COS);
-                        double l00 = sf * 10.0 * (8.0 * s * s + 4.0 * cc * cc) + delta_w;
-                        double l01 = sf * 10.0 * (-8.0 * s * cc + 4.0 * cc * s);
-                        double l11 = sf * 10.0 * (8.0 * cc * cc + 4.0 * s * s) + delta_w;
-                        if (CC) {
-                            const int QS = gn ? W_QG : W_Q;
-                            l00 += S(k, QS + 0);
-                            l01 += S(k, QS + 1);
-                            l11 += S(k, QS + 2);
-                        }
-                        sc(SC_H + 0, l00);
-                        sc(SC_H + 1, l01);
-                        sc(SC_H + 8, l01);
-                        sc(SC_H + 9, l11);
-                        sc(SC_H + 2 * 8 + 2, sc(SC_H + 2 * 8 + 2) + qtt + sc(SC_SIG + 0) + delta_w);
-                        sc(SC_H + 3 * 8 + 3, q33 + sc(SC_SIG + 1) + delta_w);
-                        sc(SC_HV + 0, lx[0]);
-                        sc(SC_HV + 1, lx[1]);
-                        sc(SC_HV + 2, lx[2] + sc(SC_SIG + 4));
-                        sc(SC_HV + 3, lx[3] + sc(SC_SIG + 5));
-                        sc(SC_H + 4 * 8 + 4, rdk);
-                        sc(SC_H + 5 * 8 + 5, rdk);
-                        sc(SC_H + 4 * 8 + 6, -rdk);
-                        sc(SC_H + 6 * 8 + 4, -rdk);
-                        sc(SC_H + 5 * 8 + 7, -rdk);
-                        sc(SC_H + 7 * 8 + 5, -rdk);
-                    }
-                    {
-                        double um0 = 0.0, um1 = 0.0;
-                        if (k >= 1) {
-                            um0 = S(k - 1, CB + W_U + 0);
-                            um1 = S(k - 1, CB + W_U + 1);
-                        }
-                        sc(SC_H + 6 * 8 + 6, rc + rdk + sc(SC_SIG + 2) + delta_w);
-                        sc(SC_H + 7 * 8 + 7, rc + rdk + sc(SC_SIG + 3) + delta_w + wdd);
-                        sc(SC_HV + 6, rc * u0 + rdk * (u0 - um0) + sc(SC_SIG + 6));
-                        sc(SC_HV + 7, rc * u1 + rdk * (u1 - um1) + sc(SC_SIG + 7));
-                        sc(SC_HV + 4, -rdk * (u0 - um0));
-                        sc(SC_HV + 5, -rdk * (u1 - um1));
-                    }
-                    // ---- level 2: H += F' T, HV += F' PV
+                    c.tick(T_RIC_L1);
+                    // ---- exchange 2: H = L + F' T, HV = l + F' PV
                     c.phase([&](int lane) {
                         const int i = lane >> 3, j = lane & 7;
-                        double h = sc(SC_H + lane);
-                        for (int m = 0; m < 6; ++m) h = fma(F_entry(sl, m, i), sc(SC_T + m * 8 + j), h);
+                        double f[6];
+                        F_column(sl, i, f);
+                        const int ls = r_slot.at(lane);
+                        const double lv = S(k, ls >= 0 ? ls : 0);
+                        double h = (ls >= 0 ? lv : 0.0) + r_cst.at(lane) * rdk;
+                        for (int m = 0; m < 6; ++m) h = fma(f[m], sc(SC_T + m * 8 + j), h);
                         sc(SC_H + lane, h);
                         if (lane < 8) {
-                            double g = sc(SC_HV + lane);
-                            for (int m = 0; m < 6; ++m) g = fma(F_entry(sl, m, lane), sc(SC_PV + m), g);
+                            F_column(sl, lane, f);
+                            double g = S(k, r_hv.at(lane) + (r_hvab.at(lane) ? AB : 0));
+                            for (int m = 0; m < 6; ++m) g = fma(f[m], sc(SC_PV + m), g);
                             sc(SC_HV + lane, g);
                         }
                     });
-                    // ---- 2x2 control block (uniform)
-                    const double ha = sc(SC_H + 6 * 8 + 6), hb = 0.5 * (sc(SC_H + 6 * 8 + 7) + sc(SC_H + 7 * 8 + 6)),
-                                 hc = sc(SC_H + 7 * 8 + 7);
-                    const double det = ha * hc - hb * hb;
-                    if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
+                    c.tick(T_RIC_L2);
+                    // ---- exchange 3: 2x2 control block, gains K = -Huu^-1 Hu., value function of node k
+                    //      P = sym(Hxx + Hxu K), pv = hx + Hxu kf   (every lane inverts the 2x2 block itself)
+                    bool okk = true;
+                    double kf0 = 0.0, kf1 = 0.0, hu0 = 0.0, hu1 = 0.0;
+                    c.phase([&](int lane) {
+                        const double ha = sc(SC_H + 6 * 8 + 6), hb = 0.5 * (sc(SC_H + 6 * 8 + 7) + sc(SC_H + 7 * 8 + 6)),
+                                     hc = sc(SC_H + 7 * 8 + 7);
+                        hu0 = sc(SC_HV + 6);
+                        hu1 = sc(SC_HV + 7);
+                        // operands of this lane, fetched before the block is tested so that all reads are in flight together
+                        const int i = r_i.at(lane), j = r_j.at(lane);
+                        const double hij = sc(SC_H + i * 8 + j), hji = sc(SC_H + j * 8 + i);
+                        const double hi6 = sc(SC_H + i * 8 + 6), hi7 = sc(SC_H + i * 8 + 7);
+                        const double hj6 = sc(SC_H + j * 8 + 6), hj7 = sc(SC_H + j * 8 + 7);
+                        const double h6j = sc(SC_H + 6 * 8 + j), h7j = sc(SC_H + 7 * 8 + j);
+                        const double h6i = sc(SC_H + 6 * 8 + i), h7i = sc(SC_H + 7 * 8 + i);
+                        const double hvi = sc(SC_HV + i);
+                        const double det = ha * hc - hb * hb;
+                        if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
+                            okk = false;
+                            return;
+                        }
+                        const double idet = frcp(det);
+                        const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
+                        kf0 = -(i00 * hu0 + i01 * hu1);
+                        kf1 = -(i01 * hu0 + i11 * hu1);
+                        if (lane < 36) {
+                            const double k0j = -(i00 * h6j + i01 * h7j), k1j = -(i01 * h6j + i11 * h7j);
+                            const double k0i = -(i00 * h6i + i01 * h7i), k1i = -(i01 * h6i + i11 * h7i);
+                            const double nij = hij + hi6 * k0j + hi7 * k1j;
+                            const double nji = hji + hj6 * k0i + hj7 * k1i;
+                            sc(SC_P + lane, 0.5 * (nij + nji));
+                        } else if (lane < 42) {
+                            sc(SC_PV + i, hvi + hi6 * kf0 + hi7 * kf1);
+                        } else if (lane < 54) {
+                            const int a = (lane - 42) / 6;
+                            if (j < 4) {
+                                const double ia0 = a == 0 ? i00 : i01, ia1 = a == 0 ? i01 : i11;
+                                S(k, W_KX + a * 4 + j, -(ia0 * h6j + ia1 * h7j));
+                            }
+                        } else if (lane == 54) {
+                            S(k, W_KF + 0, kf0);
+                            S(k, W_KF + 1, kf1);
+                            S(k, W_KP + 0, rdk * i00);
+                            S(k, W_KP + 1, rdk * i01);
+                            S(k, W_KP + 2, rdk * i11);
+                        }
+                    });
+                    c.tick(T_RIC_L4);
+                    if (!okk) {
                         ok = false;
                         break;
                     }
-                    const double idet = frcp(det);
-                    const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
-                    const double hu0 = sc(SC_HV + 6), hu1 = sc(SC_HV + 7);
-                    const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
                     dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
-                    S(k, W_KF + 0, kf0);
-                    S(k, W_KF + 1, kf1);
-                    S(k, W_KP + 0, rdk * i00);
-                    S(k, W_KP + 1, rdk * i01);
-                    S(k, W_KP + 2, rdk * i11);
-                    // ---- level 3: gains K = -Huu^-1 Hu. (2x6) into the T area and the stage arrays
-                    c.phase([&](int lane) {
-                        if (lane >= 12) return;
-                        const int a = lane / 6, j = lane % 6;
-                        const double ia0 = a == 0 ? i00 : i01, ia1 = a == 0 ? i01 : i11;
-                        const double kv = -(ia0 * sc(SC_H + 6 * 8 + j) + ia1 * sc(SC_H + 7 * 8 + j));
-                        sc(SC_K + lane, kv);
-                        if (j < 4) S(k, W_KX + a * 4 + j, kv);
-                    });
-                    // ---- level 4: value function of node k: P = sym(Hxx + Hxu K), pv = hx + Hxu kf
-                    c.phase([&](int lane) {
-                        if (lane < 36) {
-                            const int i = lane / 6, j = lane % 6;
-                            const double nij = sc(SC_H + i * 8 + j) + sc(SC_H + i * 8 + 6) * sc(SC_K + j) +
-                                               sc(SC_H + i * 8 + 7) * sc(SC_K + 6 + j);
-                            const double nji = sc(SC_H + j * 8 + i) + sc(SC_H + j * 8 + 6) * sc(SC_K + i) +
-                                               sc(SC_H + j * 8 + 7) * sc(SC_K + 6 + i);
-                            sc(SC_P + lane, 0.5 * (nij + nji));
-                        } else if (lane < 42) {
-                            const int i = lane - 36;
-                            sc(SC_PV + i, sc(SC_HV + i) + sc(SC_H + i * 8 + 6) * kf0 + sc(SC_H + i * 8 + 7) * kf1);
-                        }
-                    });
                 }
                 if (!ok) {
                     if (!gn) {
@@ -642,6 +781,7 @@ struct Solver {
                 break;
             }
 
+            c.tick(T_RIC_INIT);
             // ============ linearised Newton step (serial recursion), parked in the adjoint slots
             const double tau = fmax2(0.99, 1.0 - mu);
             {
@@ -676,9 +816,15 @@ struct Solver {
                     S(k + 1, W_Y + 3, d3);
                 }
             }
+            c.tick(T_LINEAR);
             // ============ step-length limits (stage-parallel)
             c.phase([&](int lane) {
-                if (lane >= N) return;
+                if (lane >= N) {
+                    red_a.at(lane) = 0.0;
+                    red_b.at(lane) = 0.0;
+                    red_c.at(lane) = 1.0;
+                    return;
+                }
                 const int k = lane;
                 double rp = 0.0, rdn = 0.0, rdd = 1.0;
                 for (int i = 0; i < 4; ++i) {
@@ -696,22 +842,19 @@ struct Solver {
                     if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
                     if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
                 }
-                sc(SC_RED + lane, rp);
-                sc(SC_RED + 21 + lane, rdn);
-                sc(SC_RED + 42 + lane, rdd);
+                red_a.at(lane) = rp;
+                red_b.at(lane) = rdn;
+                red_c.at(lane) = rdd;
             });
             double a_pr, a_du;
             {
-                double rp = 0.0, rdn = 0.0, rdd = 1.0;
-#pragma unroll 1
-                for (int k = 0; k < N; ++k) {
-                    rp = fmax2(rp, sc(SC_RED + k));
-                    const double n = sc(SC_RED + 21 + k), d = sc(SC_RED + 42 + k);
-                    if (n * rdd > rdn * d) { rdn = n; rdd = d; }
-                }
+                const double rp = c.wave_max(red_a);
+                double rdn, rdd;
+                c.wave_max_ratio(red_b, red_c, rdn, rdd);
                 a_pr = (rp > tau) ? tau / rp : 1.0;
                 a_du = (rdn > tau * rdd) ? tau * rdd / rdn : 1.0;
             }
+            c.tick(T_RATIOS);
             // ============ line search on the barrier objective (Armijo, <= 6 trials, factor 1/4)
             const double phi0 = Jcur + mu * barcur;
             const int tb = cur ^ 1;

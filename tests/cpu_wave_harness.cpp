@@ -20,6 +20,32 @@ struct HostCtx {
     void phase(F &&f) {
         for (int lane = 0; lane < mpc::wave::kLanes; ++lane) f(lane);
     }
+    void tick(int) const {}
+    double wave_sum(mpc::wave::PerLane<double> &p) const {
+        return mpc::wave::host_butterfly(p, [](double a, double b) { return a + b; });
+    }
+    double wave_max(mpc::wave::PerLane<double> &p) const {
+        return mpc::wave::host_butterfly(p, [](double a, double b) { return mpc::fmax2(a, b); });
+    }
+    double wave_min(mpc::wave::PerLane<double> &p) const {
+        return mpc::wave::host_butterfly(p, [](double a, double b) { return mpc::fmin2(a, b); });
+    }
+    void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd, double &rn, double &rd) const {
+        for (int off = mpc::wave::kLanes / 2; off; off >>= 1) {
+            double nn[mpc::wave::kLanes], nd[mpc::wave::kLanes];
+            for (int l = 0; l < mpc::wave::kLanes; ++l) {
+                const bool take = mpc::wave::ratio_greater(pn.v[l ^ off], pd.v[l ^ off], pn.v[l], pd.v[l]);
+                nn[l] = take ? pn.v[l ^ off] : pn.v[l];
+                nd[l] = take ? pd.v[l ^ off] : pd.v[l];
+            }
+            for (int l = 0; l < mpc::wave::kLanes; ++l) {
+                pn.v[l] = nn[l];
+                pd.v[l] = nd[l];
+            }
+        }
+        rn = pn.v[0];
+        rd = pd.v[0];
+    }
     double ref(int k, int c) const {
         int idx = e0 + k;
         idx = idx > M - 1 ? M - 1 : idx;
