@@ -210,6 +210,14 @@ struct WaveCtx {
         for (int off = 32; off; off >>= 1) v = mpc::fmin2(v, __shfl_xor(v, off));
         return v;
     }
+    __device__ __forceinline__ void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
+        double v = p.v;
+#pragma unroll
+        for (int off = 16; off; off >>= 1) v += __shfl_xor(v, off);
+        lo = __shfl(v, 0);
+        hi = __shfl(v, 32);
+    }
+    __device__ __forceinline__ int wave_bcast(mpc::wave::PerLane<int> &p, int lane) const { return __shfl(p.v, lane); }
     __device__ __forceinline__ void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd,
                                                    double &rn, double &rd) const {
         double n = pn.v, d = pd.v;

@@ -27,6 +27,7 @@ namespace mpc {
 namespace wave {
 
 constexpr int kLanes = 64;
+constexpr int kTrials = 6;   // step lengths tried by the line search: a_pr * 4^-t
 
 // per-stage slots in LDS (doubles); trajectory buffer b lives at b*6
 enum : int {
@@ -71,7 +72,11 @@ enum : int {
 
 MPC_HD constexpr int stage_slots(bool cc) { return cc ? W_SLOTS_CC : W_SLOTS; }
 // doubles of LDS one instance needs: stage arrays + scratch + other vehicles
-MPC_HD constexpr int lds_doubles(bool cc, int N, int V) { return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0); }
+// doubles of one line-search trial area: (x 4, u 2) per node
+MPC_HD constexpr int trial_doubles(int N) { return 6 * (N + 1); }
+MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
+    return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0) + (kTrials - 1) * trial_doubles(N);
+}
 
 // entry (m, j) of F = [A B; 0 I] (6 x 8: rows x+ (4), p+ (2); columns x (4), p (2), u (2)) from the stage scalars
 struct StageLin {
@@ -153,20 +158,22 @@ MPC_HD void F_column(const StageLin &s, int j, double *f) {
 //   void tick(int section)                       attributes the time since the previous tick to `section`
 //   double wave_sum / wave_max / wave_min(PerLane<double>&)   reduction over the 64 lanes, result in every lane
 //   void wave_max_ratio(PerLane<double>& n, PerLane<double>& d, double &rn, double &rd)   pair with the largest n/d
+//   void wave_sum2(PerLane<double>&, double &lo, double &hi)   sums over lanes 0..31 and 32..63
+//   int wave_bcast(PerLane<int>&, int lane)                    value of one lane
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
 // ---------------------------------------------------------------------------------------------------
 template <bool CC, class CTX>
 struct Solver {
     const SolveParams &P;
     CTX &c;
-    const int N, SL, SCR, OTH;
+    const int N, SL, SCR, OTH, TRL;
     const double dt;
     double x0[4];
     double ws_, wc_, wd_, wcoll;
     double sf = 1.0;
 
     MPC_HD Solver(const SolveParams &P_, CTX &c_, const double *x0_, double ws, double wc, double wd, double wcl)
-        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
+        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE), TRL(OTH + (CC ? 4 * P_.V : 0)),
           dt(P_.dt), ws_(ws), wc_(wc), wd_(wd), wcoll(wcl) {
         x0[0] = x0_[0]; x0[1] = x0_[1]; x0[2] = x0_[2]; x0[3] = x0_[3];
     }
@@ -183,6 +190,7 @@ struct Solver {
     PerLane<int> r_slot, r_hv, r_hvab, r_i, r_j;
     PerLane<double> r_cst;
     PerLane<double> red_a, red_b, red_c;   // per-lane operands of the wave reductions
+    PerLane<int> ls_feas;                  // line search: lane t = trial t stayed inside the fraction-to-the-boundary box
     MPC_HD void set_lane_roles() {
         c.phase([&](int lane) {
             const int i = lane >> 3, j = lane & 7;
@@ -279,22 +287,86 @@ struct Solver {
         }
     }
 
-    // ---- rollout: serial dynamics (uniform) + stage-parallel cost ----------------------------------------
-    // trial controls u_k = ucur_k + alpha kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1}), clamped to the
-    // fraction-to-the-boundary box; with first == true the controls already in buffer tb are used.
-    MPC_HD bool rollout(int cb, int tb, bool first, double alpha, double frac, double &Jout, double &barout) {
-        const int CB = cb * 6, TB = tb * 6;
-        const double fracu = 2.0 * frac;
+    // ---- objective / barrier terms of one stage of a trajectory stored at L[base + k * stride + e],
+    //      e = 0..3 state of node k, 4..5 control of stage k: control cost of stage k, tracking / collision cost and
+    //      barrier of node k + 1
+    MPC_HD void stage_terms(int base, int stride, int k, double &Jk, double &bark) const {
+        const double u0 = c.ld(base + k * stride + 4), u1 = c.ld(base + k * stride + 5);
+        double J = 0.01 * sf * wc_ * (u0 * u0 + u1 * u1);
+        if (k >= 1) {
+            const double d0 = u0 - c.ld(base + (k - 1) * stride + 4), d1 = u1 - c.ld(base + (k - 1) * stride + 5);
+            J += 0.01 * sf * wd_ * (d0 * d0 + d1 * d1);
+        }
+        const int nb = base + (k + 1) * stride;
+        const double y0 = c.ld(nb + 0), y1 = c.ld(nb + 1), y2 = c.ld(nb + 2), y3 = c.ld(nb + 3);
+        const double slack = (((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1))) *
+                             (((y2 - xlo_r(0)) * (xhi_r(0) - y2)) * ((y3 - xlo_r(1)) * (xhi_r(1) - y3)));
+        if (k + 1 < N) {
+            J += sf * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
+            if (CC) J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
+        }
+        Jk = J;
+        bark = -log(slack);
+    }
+
+    // ---- initial rollout of the controls already in buffer 0: serial dynamics (uniform) + stage-parallel cost
+    MPC_HD bool rollout_init(double &Jout, double &barout) {
         double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
-        double dup0 = 0.0, dup1 = 0.0;
-        bool feas = true;
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
-            double u0, u1;
-            if (first) {
-                u0 = S(k, TB + W_U + 0);
-                u1 = S(k, TB + W_U + 1);
-            } else {
+            const double u0 = S(k, W_U + 0), u1 = S(k, W_U + 1);
+            S(k, W_X + 0, x_0);
+            S(k, W_X + 1, x_1);
+            S(k, W_X + 2, x_2);
+            S(k, W_X + 3, x_3);
+            double Sn, Cn, sb, cb_;
+            dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+            const double n0 = x_0 + dt * (x_3 * Cn);
+            const double n1 = x_1 + dt * (x_3 * Sn);
+            const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+            const double n3 = x_3 + dt * u0;
+            if (!(n2 > xlo_r(0)) || !(n2 < xhi_r(0)) || !(n3 > xlo_r(1)) || !(n3 < xhi_r(1))) return false;
+            x_0 = n0;
+            x_1 = n1;
+            x_2 = n2;
+            x_3 = n3;
+        }
+        S(N, W_X + 0, x_0);
+        S(N, W_X + 1, x_1);
+        S(N, W_X + 2, x_2);
+        S(N, W_X + 3, x_3);
+        c.phase([&](int lane) {
+            red_a.at(lane) = 0.0;
+            red_b.at(lane) = 0.0;
+            if (lane >= N) return;
+            stage_terms(0, SL, lane, red_a.at(lane), red_b.at(lane));
+        });
+        Jout = c.wave_sum(red_a);
+        barout = c.wave_sum(red_b);
+        return true;
+    }
+
+    // ---- line search on the barrier objective (Armijo, kTrials step lengths alpha_t = a_pr 4^-t, first passing wins).
+    // Trial controls u_k = ucur_k + alpha kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1}), clamped to the
+    // fraction-to-the-boundary box.  All step lengths are integrated at once - lane t runs the serial dynamics for
+    // alpha_t into its own trial area (t = 0: the spare trajectory buffer) - and their costs are evaluated two trials
+    // per pass (lanes 0..31 / 32..63 = stages of trial 2p / 2p + 1); the winner is copied into the spare buffer.
+    MPC_HD bool line_search(int cur, double a_pr, double frac, double phi0, double dV1, double mu_, double &Jn,
+                            double &barn) {
+        const int CB = cur * 6, TB = (cur ^ 1) * 6;
+        const double fracu = 2.0 * frac;
+        const int TSZ = 6 * (N + 1);
+        c.phase([&](int lane) {
+            ls_feas.at(lane) = 0;
+            if (lane >= kTrials) return;
+            double alpha = a_pr;
+            for (int q = 0; q < lane; ++q) alpha *= 0.25;
+            const int base = lane == 0 ? TB : TRL + (lane - 1) * TSZ, stride = lane == 0 ? SL : 6;
+            double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
+            double dup0 = 0.0, dup1 = 0.0;
+            bool feas = true;
+#pragma unroll 1
+            for (int k = 0; k < N; ++k) {
                 const double e0 = x_0 - S(k, CB + W_X + 0), e1 = x_1 - S(k, CB + W_X + 1);
                 const double e2 = x_2 - S(k, CB + W_X + 2), e3 = x_3 - S(k, CB + W_X + 3);
                 const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
@@ -307,75 +379,81 @@ struct Solver {
                     s0 += kp00 * dup0 + kp01 * dup1;
                     s1 += kp01 * dup0 + kp11 * dup1;
                 }
-                u0 = fmin2(fmax2(c0 + s0, ulo_r(0) + fracu * (c0 - ulo_r(0))), uhi_r(0) - fracu * (uhi_r(0) - c0));
-                u1 = fmin2(fmax2(c1 + s1, ulo_r(1) + fracu * (c1 - ulo_r(1))), uhi_r(1) - fracu * (uhi_r(1) - c1));
+                const double u0 = fmin2(fmax2(c0 + s0, ulo_r(0) + fracu * (c0 - ulo_r(0))), uhi_r(0) - fracu * (uhi_r(0) - c0));
+                const double u1 = fmin2(fmax2(c1 + s1, ulo_r(1) + fracu * (c1 - ulo_r(1))), uhi_r(1) - fracu * (uhi_r(1) - c1));
                 dup0 = u0 - c0;
                 dup1 = u1 - c1;
-                S(k, TB + W_U + 0, u0);
-                S(k, TB + W_U + 1, u1);
-            }
-            S(k, TB + W_X + 0, x_0);
-            S(k, TB + W_X + 1, x_1);
-            S(k, TB + W_X + 2, x_2);
-            S(k, TB + W_X + 3, x_3);
-            double Sn, Cn, sb, cb_;
-            dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
-            const double n0 = x_0 + dt * (x_3 * Cn);
-            const double n1 = x_1 + dt * (x_3 * Sn);
-            const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
-            const double n3 = x_3 + dt * u0;
-            if (!first) {
+                const int o = base + k * stride;
+                c.st(o + 0, x_0);
+                c.st(o + 1, x_1);
+                c.st(o + 2, x_2);
+                c.st(o + 3, x_3);
+                c.st(o + 4, u0);
+                c.st(o + 5, u1);
+                double Sn, Cn, sb, cb_;
+                dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+                const double n0 = x_0 + dt * (x_3 * Cn);
+                const double n1 = x_1 + dt * (x_3 * Sn);
+                const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+                const double n3 = x_3 + dt * u0;
                 const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
                 if (n2 - xlo_r(0) < frac * (o2 - xlo_r(0)) || xhi_r(0) - n2 < frac * (xhi_r(0) - o2) ||
                     n3 - xlo_r(1) < frac * (o3 - xlo_r(1)) || xhi_r(1) - n3 < frac * (xhi_r(1) - o3)) {
                     feas = false;
                     break;
                 }
-            } else if (!(n2 > xlo_r(0)) || !(n2 < xhi_r(0)) || !(n3 > xlo_r(1)) || !(n3 < xhi_r(1))) {
-                feas = false;
-                break;
+                x_0 = n0;
+                x_1 = n1;
+                x_2 = n2;
+                x_3 = n3;
             }
-            x_0 = n0;
-            x_1 = n1;
-            x_2 = n2;
-            x_3 = n3;
-        }
-        if (!feas) {
-            c.tick(T_ROLL_DYN);
-            return false;
-        }
-        S(N, TB + W_X + 0, x_0);
-        S(N, TB + W_X + 1, x_1);
-        S(N, TB + W_X + 2, x_2);
-        S(N, TB + W_X + 3, x_3);
-        c.tick(T_ROLL_DYN);
-        // stage-parallel: control cost of stage k, tracking / collision cost and barrier of node k+1
-        c.phase([&](int lane) {
-            red_a.at(lane) = 0.0;
-            red_b.at(lane) = 0.0;
-            if (lane >= N) return;
-            const int k = lane;
-            const double u0 = S(k, TB + W_U + 0), u1 = S(k, TB + W_U + 1);
-            double J = 0.01 * sf * wc_ * (u0 * u0 + u1 * u1);
-            if (k >= 1) {
-                const double d0 = u0 - S(k - 1, TB + W_U + 0), d1 = u1 - S(k - 1, TB + W_U + 1);
-                J += 0.01 * sf * wd_ * (d0 * d0 + d1 * d1);
+            if (feas) {
+                const int o = base + N * stride;
+                c.st(o + 0, x_0);
+                c.st(o + 1, x_1);
+                c.st(o + 2, x_2);
+                c.st(o + 3, x_3);
             }
-            const double y0 = S(k + 1, TB + W_X + 0), y1 = S(k + 1, TB + W_X + 1);
-            const double y2 = S(k + 1, TB + W_X + 2), y3 = S(k + 1, TB + W_X + 3);
-            const double slack = (((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1))) *
-                                 (((y2 - xlo_r(0)) * (xhi_r(0) - y2)) * ((y3 - xlo_r(1)) * (xhi_r(1) - y3)));
-            if (k + 1 < N) {
-                J += sf * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
-                if (CC) J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
-            }
-            red_a.at(lane) = J;
-            red_b.at(lane) = -log(slack);
+            ls_feas.at(lane) = feas ? 1 : 0;
         });
-        Jout = c.wave_sum(red_a);
-        barout = c.wave_sum(red_b);
+        c.tick(T_ROLL_DYN);
+        int acc = -1;
+        double alpha = a_pr;
+#pragma unroll 1
+        for (int p = 0; p < kTrials / 2 && acc < 0; ++p, alpha *= 0.0625) {
+            const int f0 = c.wave_bcast(ls_feas, 2 * p), f1 = c.wave_bcast(ls_feas, 2 * p + 1);
+            if (!f0 && !f1) continue;
+            c.phase([&](int lane) {
+                red_a.at(lane) = 0.0;
+                red_b.at(lane) = 0.0;
+                const int h = lane >> 5, k = lane & 31, t = 2 * p + h;
+                if (k >= N || !(h ? f1 : f0)) return;
+                const int base = t == 0 ? TB : TRL + (t - 1) * TSZ, stride = t == 0 ? SL : 6;
+                stage_terms(base, stride, k, red_a.at(lane), red_b.at(lane));
+            });
+            double J0, J1, b0, b1;
+            c.wave_sum2(red_a, J0, J1);
+            c.wave_sum2(red_b, b0, b1);
+            const double a1 = alpha * 0.25;
+            if (f0 && J0 + mu_ * b0 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                acc = 2 * p;
+                Jn = J0;
+                barn = b0;
+            } else if (f1 && J1 + mu_ * b1 <= phi0 + 1e-4 * a1 * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                acc = 2 * p + 1;
+                Jn = J1;
+                barn = b1;
+            }
+        }
+        if (acc >= 1) {
+            const int base = TRL + (acc - 1) * TSZ;
+            c.phase([&](int lane) {
+                if (lane > N) return;
+                for (int e = 0; e < (lane < N ? 6 : 4); ++e) S(lane, TB + e, c.ld(base + lane * 6 + e));
+            });
+        }
         c.tick(T_ROLL_COST);
-        return true;
+        return acc >= 0;
     }
 
     // ---- the solve --------------------------------------------------------------------------------------
@@ -400,7 +478,7 @@ struct Solver {
         });
         if (x0[3] < 0.01) S(0, W_U + 0, (0.01 - x0[3]) / dt);
         double Jcur = 0.0, barcur = 0.0;
-        if (!rollout(0, 0, true, 0.0, 0.0, Jcur, barcur)) {
+        if (!rollout_init(Jcur, barcur)) {
             status_out = 3;
             return;
         }
@@ -858,15 +936,8 @@ struct Solver {
             // ============ line search on the barrier objective (Armijo, <= 6 trials, factor 1/4)
             const double phi0 = Jcur + mu * barcur;
             const int tb = cur ^ 1;
-            double alpha = a_pr, Jn = 0.0, barn = 0.0;
-            bool accepted = false;
-            for (int nls = 0; nls < 6; ++nls, alpha *= 0.25) {
-                if (!rollout(cur, tb, false, alpha, 0.5 * (1.0 - tau), Jn, barn)) continue;
-                if (Jn + mu * barn <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
-                    accepted = true;
-                    break;
-                }
-            }
+            double Jn = 0.0, barn = 0.0;
+            const bool accepted = line_search(cur, a_pr, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn);
             // ============ dual update (stage-parallel)
             {
                 const int NB = (accepted ? tb : cur) * 6;

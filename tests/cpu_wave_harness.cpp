@@ -30,6 +30,16 @@ struct HostCtx {
     double wave_min(mpc::wave::PerLane<double> &p) const {
         return mpc::wave::host_butterfly(p, [](double a, double b) { return mpc::fmin2(a, b); });
     }
+    void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
+        for (int off = 16; off; off >>= 1) {
+            double nv[mpc::wave::kLanes];
+            for (int l = 0; l < mpc::wave::kLanes; ++l) nv[l] = p.v[l] + p.v[l ^ off];
+            for (int l = 0; l < mpc::wave::kLanes; ++l) p.v[l] = nv[l];
+        }
+        lo = p.v[0];
+        hi = p.v[32];
+    }
+    int wave_bcast(mpc::wave::PerLane<int> &p, int lane) const { return p.v[lane]; }
     void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd, double &rn, double &rd) const {
         for (int off = mpc::wave::kLanes / 2; off; off >>= 1) {
             double nn[mpc::wave::kLanes], nd[mpc::wave::kLanes];
