@@ -439,12 +439,13 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, si
     return MPC_OK;
 }
 
-// Which kernel: the wave-cooperative one (one wave per instance) whenever the horizon fits its reduction buffers;
+// Which kernel: the wave-cooperative one (one wave per instance) whenever the horizon fits half a wave (stage-parallel
+// phases and the two-trials-per-pass line search);
 // MPC_KERNEL=lane|wave overrides (experiments, A/B tests).
 bool use_wave_kernel(int N) {
     const char *env = getenv("MPC_KERNEL");
     if (env && !strcmp(env, "lane")) return false;
-    return N <= 20;
+    return N <= mpc::wave::kMaxHorizon;
 }
 
 // Kernel choice + launch for B instances whose data already sits in device memory (shared by mpc_solve_batch and

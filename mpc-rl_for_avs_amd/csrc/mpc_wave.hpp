@@ -53,13 +53,13 @@ enum : int {
 enum : int {
     SC_P = 0,     // 36  value-function Hessian over (x, p), row-major 6x6
     SC_PV = 36,   // 6   value-function gradient
-    SC_T = 42,    // 64  T = P F (6x8) during a Riccati stage; reduction buffer (3 x 21) elsewhere; gains K
+    SC_T = 42,    // 64  T = P F (6x8) during a Riccati stage
     SC_H = 106,   // 64  stage KKT block H (8x8)
     SC_HV = 170,  // 8   its gradient
-    SC_SIG = 178, // 8   barrier curvature / gradient of the 4 bounded variables of the stage
+    SC_SPARE = 178,  // 8 (unused)
     SC_SIZE = 186
 };
-constexpr int SC_RED = SC_T;      // reductions: 3 arrays of 21
+constexpr int kMaxHorizon = 32;   // lanes 0..31 / 32..63 carry the stages of two line-search trials
 // compact stage cost Hessian / gradient, assembled for all stages before a sweep into slots that are free during it:
 // the stage's gain slots (overwritten by the gains once the stage is done) and the trial trajectory buffer
 enum : int {
@@ -78,26 +78,10 @@ MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
     return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0) + (kTrials - 1) * trial_doubles(N);
 }
 
-// entry (m, j) of F = [A B; 0 I] (6 x 8: rows x+ (4), p+ (2); columns x (4), p (2), u (2)) from the stage scalars
+// stage linearisation F = [A B; 0 I] (6 x 8: rows x+ (4), p+ (2); columns x (4), p (2), u (2)) as its nine scalars
 struct StageLin {
     double a02, a03, a12, a13, a23, b01, b11, b21, dt;
 };
-MPC_HD double F_entry(const StageLin &s, int m, int j) {
-    // branch-free select chain; m, j are lane-dependent
-    double v = 0.0;
-    v = (m == j && j < 4) ? 1.0 : v;                    // identity of A
-    v = (m == 0 && j == 2) ? s.a02 : v;
-    v = (m == 0 && j == 3) ? s.a03 : v;
-    v = (m == 1 && j == 2) ? s.a12 : v;
-    v = (m == 1 && j == 3) ? s.a13 : v;
-    v = (m == 2 && j == 3) ? s.a23 : v;
-    v = (m == 3 && j == 6) ? s.dt : v;                  // B
-    v = (m == 0 && j == 7) ? s.b01 : v;
-    v = (m == 1 && j == 7) ? s.b11 : v;
-    v = (m == 2 && j == 7) ? s.b21 : v;
-    v = ((m == 4 && j == 6) || (m == 5 && j == 7)) ? 1.0 : v;  // p+ = u
-    return v;
-}
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {

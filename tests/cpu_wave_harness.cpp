@@ -77,7 +77,7 @@ extern "C" int wave_solve_batch(int B, int N, double dt, const double *ref_table
                                 const uint8_t *is_collide, const double *others, int V, uint32_t flags,
                                 double w_distance, double w_collision, double tol, int max_iter, double *u0,
                                 double *U, double *X, int32_t *status, int32_t *iters, double *kkt) {
-    if (N > 20) return -1;
+    if (N > mpc::wave::kMaxHorizon) return -1;
     const int cc = (flags & 1u) ? 1 : 0;
     const int Vuse = cc ? V : 0;
     std::vector<double> table((size_t)M * mpc::REF_COLS);

@@ -32,7 +32,7 @@ def test_core_edge_cases(cpu_core, oracle, ref_table):
     inp = dict(state=np.array([[2.0, 45.0, -np.pi / 2, 0.0], [2.0, 45.0, -np.pi / 2, 10.0]]),
                ego_index=np.array([4, 4], np.int32), weights=np.ones((2, 3)), is_collide=np.zeros(2, np.uint8),
                vref=None, others=None)
-    for N in (5, 16, 20):
+    for N in (5, 16, 20, 32):
         got = cpu_core(ref_table, inp, N=N)
         want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], N=N,
                                   max_iter=100, xy_bounds=False)

@@ -75,13 +75,15 @@ def test_lane_kernel_fallback(oracle, ref_table, monkeypatch):
     assert (wave["status"] == lane["status"]).mean() > 0.98
     assert (rel_u0_err(lane["u0"], wave["u0"])[both] <= TOL).mean() > 0.995
     e.close()
-    e = engine.MPCEngine(horizon=30, max_iter=100)                    # N > 20 -> lane kernel
-    sub = dict(inp, vref=np.concatenate([inp["vref"], np.repeat(inp["vref"][:, -1:], 10, axis=1)], axis=1), others=None)
-    got = e.solve_batch(sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=sub["vref"])
-    want = _oracle(oracle, ref_table, sub, False, N=30)
-    both = (got["status"] == 0) & (want["status"] == 0)
-    assert both.mean() > 0.85 and (rel_u0_err(got["u0"], want["u0"])[both] <= TOL).mean() > 0.99
-    e.close()
+    for N in (30, 40):                          # 30: wave kernel with a run-time horizon; 40 > 32: lane kernel
+        e = engine.MPCEngine(horizon=N, max_iter=100)
+        sub = dict(inp, vref=np.concatenate([inp["vref"], np.repeat(inp["vref"][:, -1:], N - 20, axis=1)], axis=1),
+                   others=None)
+        got = e.solve_batch(sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=sub["vref"])
+        want = _oracle(oracle, ref_table, sub, False, N=N)
+        both = (got["status"] == 0) & (want["status"] == 0)
+        assert both.mean() > 0.8 and (rel_u0_err(got["u0"], want["u0"])[both] <= TOL).mean() > 0.99, N
+        e.close()
 
 
 def test_golden_fixtures(eng):
