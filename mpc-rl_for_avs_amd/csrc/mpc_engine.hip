@@ -38,13 +38,11 @@ int fail(int code, const std::string &msg) {
     } while (0)
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
-// Waves per SIMD the wave-cooperative kernel is compiled for.  2: ~200 VGPRs, no scratch (HBM traffic = inputs and
-// outputs only); 3: 168 VGPRs with 104 B/lane of scratch (23 MB of extra HBM writes per 4096-instance launch).
-// Measured on config 3: B = 4096 is bound by its slowest instance either way (14.4 ms both; 128 VGPRs / 4 waves:
-// 16.9 ms), while at B = 65536 the third resident wave is worth 1.05 M vs 0.85 M solves/s.  Small batches therefore
-// run the spill-free build and large ones the denser one.
-constexpr int kWaveOccSmall = 2, kWaveOccLarge = 3;
-constexpr int kWaveLargeBatch = 8192;
+// Waves per SIMD the wave-cooperative kernel is compiled for: 2 (~240 VGPRs, no scratch; HBM traffic = inputs and
+// outputs only).  LDS (15.9 KB per wave at N = 20 with the collision cost) allows 10 waves per CU, i.e. 2.5 per SIMD;
+// a 3-waves/SIMD build (168 VGPRs) spills 250 B/lane and measured slower at every batch size (B = 65536: 1.15 M vs
+// 1.39 M solves/s), a 4-wave build slower still.
+constexpr int kWaveOcc = 2;
 
 // LDS-resident workspace of one lane: element (slot, stage k) of this instance
 // (NC > 0: horizon known at compile time, so slot offsets fold into the ds_read/ds_write immediates)
@@ -471,17 +469,14 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
 #define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                            \
     rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights,      \
                                      d_coll, d_others, d_nveh, d_u0, d_U, d_X, d_status, d_iters)
-        const bool dense = B > kWaveLargeBatch;
         if (cc) {
-            if (N == 20 && dense) MPC_LAUNCH_W(true, 20, kWaveOccLarge);
-            else if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOccSmall);
-            else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOccSmall);
-            else MPC_LAUNCH_W(true, 0, kWaveOccSmall);
+            if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOcc);       /* BASELINE horizon */
+            else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOcc);  /* reference cfg.yaml default */
+            else MPC_LAUNCH_W(true, 0, kWaveOcc);
         } else {
-            if (N == 20 && dense) MPC_LAUNCH_W(false, 20, kWaveOccLarge);
-            else if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOccSmall);
-            else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOccSmall);
-            else MPC_LAUNCH_W(false, 0, kWaveOccSmall);
+            if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOcc);
+            else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOcc);
+            else MPC_LAUNCH_W(false, 0, kWaveOcc);
         }
 #undef MPC_LAUNCH_W
         if (rc) return rc;

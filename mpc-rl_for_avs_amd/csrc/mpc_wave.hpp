@@ -33,21 +33,21 @@ constexpr int kTrials = 6;   // step lengths tried by the line search: a_pr * 4^
 enum : int {
     W_X = 0,     // 4 (buffer 0; buffer 1 at +6)
     W_U = 4,     // 2
-    W_DYN = 12,  // 4  sin/cos(theta+beta), sin/cos(beta) of the current trajectory
-    W_ZXL = 16,  // 2
-    W_ZXU = 18,  // 2
-    W_ZUL = 20,  // 2
-    W_ZUU = 22,  // 2
-    W_Y = 24,    // 4  adjoint; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
-    W_KX = 28,   // 8
-    W_KP = 36,   // 3
-    W_KF = 39,   // 2
-    W_RV = 41,   // 1
-    W_SLOTS = 42,
-    W_LX = 42,   // 2  (collision-cost variant)
-    W_Q = 44,    // 3
-    W_QG = 47,   // 3
-    W_SLOTS_CC = 50
+    W_LIN = 12,  // 8  stage linearisation of the current trajectory: a02 a03 a12 a13 a23 b01 b11 b21
+    W_ZXL = 20,  // 2
+    W_ZXU = 22,  // 2
+    W_ZUL = 24,  // 2
+    W_ZUU = 26,  // 2
+    W_Y = 28,    // 4  node gradient g_k, then adjoint y_k; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
+    W_KX = 32,   // 8
+    W_KP = 40,   // 3
+    W_KF = 43,   // 2
+    W_RV = 45,   // 1
+    W_SLOTS = 46,
+    W_LX = 46,   // 2  (collision-cost variant)
+    W_Q = 48,    // 3
+    W_QG = 51,   // 3
+    W_SLOTS_CC = 54
 };
 // scratch behind the stage arrays
 enum : int {
@@ -507,23 +507,51 @@ struct Solver {
                 }
                 const int k = lane;
                 const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
-                double Sn, Cn, sb, cb_;
-                dyn_eval(S(k, CB + W_X + 2), u1, Sn, Cn, sb, cb_);
-                S(k, W_DYN + 0, Sn);
-                S(k, W_DYN + 1, Cn);
-                S(k, W_DYN + 2, sb);
-                S(k, W_DYN + 3, cb_);
-                if (CC && k >= 1) {
-                    double d8[8];
-                    dist(k, S(k, CB + W_X + 0), S(k, CB + W_X + 1), d8);
-                    S(k, W_LX + 0, sf * d8[0]);
-                    S(k, W_LX + 1, sf * d8[1]);
-                    S(k, W_Q + 0, sf * d8[2]);
-                    S(k, W_Q + 1, sf * d8[3]);
-                    S(k, W_Q + 2, sf * d8[4]);
-                    S(k, W_QG + 0, sf * d8[5]);
-                    S(k, W_QG + 1, sf * d8[6]);
-                    S(k, W_QG + 2, sf * d8[7]);
+                const double xk0 = S(k, CB + W_X + 0), xk1 = S(k, CB + W_X + 1), xk2 = S(k, CB + W_X + 2),
+                             xk3 = S(k, CB + W_X + 3);
+                {
+                    double Sn, Cn, sb, cb_, bp, bpp;
+                    dyn_eval(xk2, u1, Sn, Cn, sb, cb_);
+                    beta_derivs(sb, cb_, bp, bpp);
+                    S(k, W_LIN + 0, -dt * xk3 * Sn);
+                    S(k, W_LIN + 1, dt * Cn);
+                    S(k, W_LIN + 2, dt * xk3 * Cn);
+                    S(k, W_LIN + 3, dt * Sn);
+                    S(k, W_LIN + 4, dt * sb * kInvWheelbase);
+                    S(k, W_LIN + 5, -dt * xk3 * Sn * bp);
+                    S(k, W_LIN + 6, dt * xk3 * Cn * bp);
+                    S(k, W_LIN + 7, dt * xk3 * kInvWheelbase * cb_ * bp);
+                }
+                // gradient of the Lagrangian's separable part at node k (cost + bound multipliers), the start of the
+                // adjoint recursion below; lane 0 supplies the terminal node
+                if (k >= 1) {
+                    double g[4];
+                    track(k, xk0, xk1, xk2, xk3, g);
+                    double lx0 = sf * g[0], lx1 = sf * g[1], lx2 = sf * g[2], lx3 = sf * g[3];
+                    if (CC) {
+                        double d8[8];
+                        dist(k, xk0, xk1, d8);
+                        S(k, W_LX + 0, sf * d8[0]);
+                        S(k, W_LX + 1, sf * d8[1]);
+                        S(k, W_Q + 0, sf * d8[2]);
+                        S(k, W_Q + 1, sf * d8[3]);
+                        S(k, W_Q + 2, sf * d8[4]);
+                        S(k, W_QG + 0, sf * d8[5]);
+                        S(k, W_QG + 1, sf * d8[6]);
+                        S(k, W_QG + 2, sf * d8[7]);
+                        lx0 += sf * d8[0];
+                        lx1 += sf * d8[1];
+                        lx3 += sf * 2.0 * wcoll * xk3;
+                    }
+                    S(k, W_Y + 0, lx0);
+                    S(k, W_Y + 1, lx1);
+                    S(k, W_Y + 2, lx2 - S(k, W_ZXL + 0) + S(k, W_ZXU + 0));
+                    S(k, W_Y + 3, lx3 - S(k, W_ZXL + 1) + S(k, W_ZXU + 1));
+                } else {
+                    S(N, W_Y + 0, 0.0);
+                    S(N, W_Y + 1, 0.0);
+                    S(N, W_Y + 2, -S(N, W_ZXL + 0) + S(N, W_ZXU + 0));
+                    S(N, W_Y + 3, -S(N, W_ZXL + 1) + S(N, W_ZXU + 1));
                 }
                 const double zul0 = S(k, W_ZUL + 0), zul1 = S(k, W_ZUL + 1), zuu0 = S(k, W_ZUU + 0), zuu1 = S(k, W_ZUU + 1);
                 double cmx, cmn, sz = zul0 + zul1 + zuu0 + zuu1;
@@ -547,35 +575,28 @@ struct Solver {
             });
             const double cmax = c.wave_max(red_a), cmin = c.wave_min(red_b), sum_z = c.wave_sum(red_c);
             c.tick(T_PREP);
-            // ============ adjoint recursion (serial): y_k = dL/dx_k
+            // ============ adjoint recursion (serial): y_k = g_k + A_k' y_{k+1}, in place over the node gradients
             double sum_lam = 0.0;
             {
-                double y0 = 0.0, y1 = 0.0;
-                double y2 = -S(N, W_ZXL + 0) + S(N, W_ZXU + 0);
-                double y3 = -S(N, W_ZXL + 1) + S(N, W_ZXU + 1);
+                double y0 = S(N, W_Y + 0), y1 = S(N, W_Y + 1), y2 = S(N, W_Y + 2), y3 = S(N, W_Y + 3);
+                sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
 #pragma unroll 1
-                for (int k = N - 1; k >= 0; --k) {
-                    S(k + 1, W_Y + 0, y0);
-                    S(k + 1, W_Y + 1, y1);
-                    S(k + 1, W_Y + 2, y2);
-                    S(k + 1, W_Y + 3, y3);
+                for (int k = N - 1; k >= 1; --k) {
+                    const double a02 = S(k, W_LIN + 0), a03 = S(k, W_LIN + 1), a12 = S(k, W_LIN + 2), a13 = S(k, W_LIN + 3),
+                                 a23 = S(k, W_LIN + 4);
+                    const double t0 = S(k, W_Y + 0) + y0;
+                    const double t1 = S(k, W_Y + 1) + y1;
+                    const double t2 = S(k, W_Y + 2) + a02 * y0 + a12 * y1 + y2;
+                    const double t3 = S(k, W_Y + 3) + a03 * y0 + a13 * y1 + a23 * y2 + y3;
+                    y0 = t0;
+                    y1 = t1;
+                    y2 = t2;
+                    y3 = t3;
+                    S(k, W_Y + 0, y0);
+                    S(k, W_Y + 1, y1);
+                    S(k, W_Y + 2, y2);
+                    S(k, W_Y + 3, y3);
                     sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
-                    if (k >= 1) {
-                        const double v = S(k, CB + W_X + 3);
-                        const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2);
-                        const double a02 = -dt * v * Sn, a03 = dt * Cn, a12 = dt * v * Cn, a13 = dt * Sn,
-                                     a23 = dt * sb * kInvWheelbase;
-                        double lx[4];
-                        cost_grad(cur, k, lx);
-                        const double t0 = lx[0] + y0;
-                        const double t1 = lx[1] + y1;
-                        const double t2 = lx[2] - S(k, W_ZXL + 0) + S(k, W_ZXU + 0) + a02 * y0 + a12 * y1 + y2;
-                        const double t3 = lx[3] - S(k, W_ZXL + 1) + S(k, W_ZXU + 1) + a03 * y0 + a13 * y1 + a23 * y2 + y3;
-                        y0 = t0;
-                        y1 = t1;
-                        y2 = t2;
-                        y3 = t3;
-                    }
                 }
             }
             c.tick(T_ADJOINT);
@@ -599,11 +620,7 @@ struct Solver {
                     r0 -= rd_full * (S(k + 1, CB + W_U + 0) - u0);
                     r1 -= rd_full * (S(k + 1, CB + W_U + 1) - u1);
                 }
-                const double v = S(k, CB + W_X + 3);
-                const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
-                double bp, bpp;
-                beta_derivs(sb, cb_, bp, bpp);
-                const double b01 = -dt * v * Sn * bp, b11 = dt * v * Cn * bp, b21 = dt * v * kInvWheelbase * cb_ * bp;
+                const double b01 = S(k, W_LIN + 5), b11 = S(k, W_LIN + 6), b21 = S(k, W_LIN + 7);
                 r0 += dt * S(k + 1, W_Y + 3);
                 r1 += b01 * S(k + 1, W_Y + 0) + b11 * S(k + 1, W_Y + 1) + b21 * S(k + 1, W_Y + 2);
                 red_a.at(lane) = fmax2(fabs(r0), fabs(r1));
@@ -649,9 +666,6 @@ struct Solver {
                     const int k = lane;
                     const double rdk = (k >= 1) ? rd_full : 0.0;
                     const double v = S(k, CB + W_X + 3);
-                    const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
-                    double bp, bpp;
-                    beta_derivs(sb, cb_, bp, bpp);
                     const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
                     double sig[4], sgr[4];
                     for (int q = 0; q < 4; ++q) {   // 0: theta_k, 1: v_k, 2: a_k, 3: delta_k
@@ -667,6 +681,9 @@ struct Solver {
                     }
                     double wdd = 0.0, wtt = 0.0, wtv = 0.0, wtd = 0.0, wvd = 0.0;
                     if (!gn) {
+                        double Sn, Cn, sb, cb_, bp, bpp;
+                        dyn_eval(S(k, CB + W_X + 2), u1, Sn, Cn, sb, cb_);
+                        beta_derivs(sb, cb_, bp, bpp);
                         const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
                         const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
                         wdd = dt * v * (g * bp * bp + h * bpp) + dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
@@ -735,14 +752,10 @@ struct Solver {
 #pragma unroll 1
                 for (int k = N - 1; k >= 0; --k) {
                     const double rdk = (k >= 1) ? rd_full : 0.0;
-                    const double v = S(k, CB + W_X + 3);
-                    const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
-                    double bp, bpp;
-                    beta_derivs(sb, cb_, bp, bpp);
                     StageLin sl;
-                    sl.a02 = -dt * v * Sn; sl.a03 = dt * Cn; sl.a12 = dt * v * Cn; sl.a13 = dt * Sn;
-                    sl.a23 = dt * sb * kInvWheelbase;
-                    sl.b01 = -dt * v * Sn * bp; sl.b11 = dt * v * Cn * bp; sl.b21 = dt * v * kInvWheelbase * cb_ * bp;
+                    sl.a02 = S(k, W_LIN + 0); sl.a03 = S(k, W_LIN + 1); sl.a12 = S(k, W_LIN + 2); sl.a13 = S(k, W_LIN + 3);
+                    sl.a23 = S(k, W_LIN + 4);
+                    sl.b01 = S(k, W_LIN + 5); sl.b11 = S(k, W_LIN + 6); sl.b21 = S(k, W_LIN + 7);
                     sl.dt = dt;
                     c.tick(T_RIC_SCALARS);
                     // ---- exchange 1: T = P F (6x8)
@@ -859,13 +872,9 @@ struct Solver {
                         du0 += kp00 * dp0 + kp01 * dp1;
                         du1 += kp01 * dp0 + kp11 * dp1;
                     }
-                    const double v = S(k, CB + W_X + 3);
-                    const double Sn = S(k, W_DYN + 0), Cn = S(k, W_DYN + 1), sb = S(k, W_DYN + 2), cb_ = S(k, W_DYN + 3);
-                    double bp, bpp;
-                    beta_derivs(sb, cb_, bp, bpp);
-                    const double a02 = -dt * v * Sn, a03 = dt * Cn, a12 = dt * v * Cn, a13 = dt * Sn,
-                                 a23 = dt * sb * kInvWheelbase;
-                    const double b01 = -dt * v * Sn * bp, b11 = dt * v * Cn * bp, b21 = dt * v * kInvWheelbase * cb_ * bp;
+                    const double a02 = S(k, W_LIN + 0), a03 = S(k, W_LIN + 1), a12 = S(k, W_LIN + 2), a13 = S(k, W_LIN + 3),
+                                 a23 = S(k, W_LIN + 4);
+                    const double b01 = S(k, W_LIN + 5), b11 = S(k, W_LIN + 6), b21 = S(k, W_LIN + 7);
                     const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
                     const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
                     const double n2 = d2 + a23 * d3 + b21 * du1;
