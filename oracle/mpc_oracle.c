@@ -194,7 +194,7 @@ static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
 /* solve one instance.
  * status: 0 converged, 1 max_iter reached, 2 factorisation failure, 3 start not strictly feasible,
  *         4 stalled (no acceptable step in three consecutive iterations) */
-static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, double *kkt_out) {
+static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit, int *iters_out, double *kkt_out) {
     const int N = p->N;
     const double dt = p->dt;
     double rd_full = 0.02 * p->wd, rc = 0.02 * p->wc;
@@ -204,8 +204,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
     const double KSIG = 1e10; /* IPOPT kappa_Sigma */
     const int MAXLS = 6;      /* line-search trials per iteration */
     const double BTF = 0.25;  /* backtracking factor */
-    const double kap_eps = getenv("ORACLE_KEPS") ? atof(getenv("ORACLE_KEPS")) : 10.0;
-    const double kap_mu = getenv("ORACLE_KMU") ? atof(getenv("ORACLE_KMU")) : 0.2;
+    const double kap_eps = 10.0, kap_mu = 0.2;
 
     static _Thread_local double A[NMAX][4][4], Bm[NMAX][4][2];
     static _Thread_local double lxs[NMAX + 1][4], Qs[NMAX + 1][4][4], Qgs[NMAX + 1][4][4], lus[NMAX][2], lps[NMAX][2];
@@ -213,31 +212,43 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
     static _Thread_local double Kx[NMAX][2][4], Kp[NMAX][2][2], kf[NMAX][2], yv[NMAX + 2][4];
     static _Thread_local iter_t trial;
 
-    /* ---- cold start of the reference (pure_mpc.py:240-246: controls 0) rolled out through the dynamics;
-     *      a standing vehicle gets a_0 > 0 so that v_1.. are strictly inside v >= 0 */
-    memset(it, 0, sizeof(*it));
-    for (int i = 0; i < 4; ++i) it->x[0][i] = p->x0[i];
-    if (p->x0[3] < 0.01) it->u[0][0] = (0.01 - p->x0[3]) / dt;
-    for (int k = 0; k < N; ++k) {
-        dyn_t d;
-        dyn_eval(it->x[k], it->u[k], &d);
-        for (int i = 0; i < 4; ++i) it->x[k + 1][i] = it->x[k][i] + dt * d.f[i];
-        for (int i = 0; i < 2; ++i) it->zul[k][i] = it->zuu[k][i] = 1.0;
-        for (int i = p->i0; i < 4; ++i) it->zxl[k + 1][i] = it->zxu[k + 1][i] = 1.0;
-    }
-    for (int k = 1; k <= N; ++k)
-        for (int i = p->i0; i < 4; ++i)
-            if (!(it->x[k][i] > xlo_r(i)) || !(it->x[k][i] < xhi_r(i))) {
-                *iters_out = 0;
-                if (kkt_out) *kkt_out = INFINITY;
-                return 3;
-            }
-    for (int i = 0; i < 2; ++i)
-        if (!(it->u[0][i] > ulo_r(i)) || !(it->u[0][i] < uhi_r(i))) {
+    /* ---- start: cold like the reference (pure_mpc.py:240-246: controls 0; a standing vehicle gets a_0 > 0 so that
+     *      v_1.. are strictly inside v >= 0), or - opt-in, not in the reference - from given controls clamped 0.1 % of
+     *      the range inside their bounds; a warm start whose rollout leaves the state bounds falls back to the cold one */
+    int warm = uinit != NULL;
+    for (;;) {
+        memset(it, 0, sizeof(*it));
+        for (int i = 0; i < 4; ++i) it->x[0][i] = p->x0[i];
+        if (warm) {
+            for (int k = 0; k < N; ++k)
+                for (int i = 0; i < 2; ++i) {
+                    const double m = 1e-3 * (UHI[i] - ULO[i]);
+                    it->u[k][i] = fmin(fmax(uinit[2 * k + i], ULO[i] + m), UHI[i] - m);
+                }
+        } else if (p->x0[3] < 0.01) {
+            it->u[0][0] = (0.01 - p->x0[3]) / dt;
+        }
+        for (int k = 0; k < N; ++k) {
+            dyn_t d;
+            dyn_eval(it->x[k], it->u[k], &d);
+            for (int i = 0; i < 4; ++i) it->x[k + 1][i] = it->x[k][i] + dt * d.f[i];
+            for (int i = 0; i < 2; ++i) it->zul[k][i] = it->zuu[k][i] = 1.0;
+            for (int i = p->i0; i < 4; ++i) it->zxl[k + 1][i] = it->zxu[k + 1][i] = 1.0;
+        }
+        int feasible = 1;
+        for (int k = 1; k <= N; ++k)
+            for (int i = p->i0; i < 4; ++i)
+                if (!(it->x[k][i] > xlo_r(i)) || !(it->x[k][i] < xhi_r(i))) feasible = 0;
+        for (int i = 0; i < 2; ++i)
+            if (!(it->u[0][i] > ulo_r(i)) || !(it->u[0][i] < uhi_r(i))) feasible = 0;
+        if (feasible) break;
+        if (!warm) {
             *iters_out = 0;
             if (kkt_out) *kkt_out = INFINITY;
             return 3;
         }
+        warm = 0;
+    }
 
     /* ---- objective scaling like IPOPT's gradient-based scaling (nlp_scaling_max_gradient = 100):
      *      sf = 100 / max(100, |grad f|_inf at the starting trajectory) */
@@ -611,15 +622,34 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, int *iters_out, dou
  * outputs: u0 [B,2]; U [B,N,2] / X [B,N+1,4] / lam [B,N+1,4] optional (NULL to skip);
  *   status [B]; iters [B]; kkt [B] optional.
  * ------------------------------------------------------------------------------------------ */
+int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
+                            const int32_t *ego_index, const double *vref, const double *weights,
+                            const uint8_t *is_collide, const double *others, int V, uint32_t flags,
+                            double w_distance, double w_collision, double tol, int max_iter, const double *u_init,
+                            double *u0, double *U, double *X, double *lam, int32_t *status, int32_t *iters,
+                            double *kkt, int nthreads);
+
 int oracle_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state,
                        const int32_t *ego_index, const double *vref, const double *weights,
                        const uint8_t *is_collide, const double *others, int V, uint32_t flags,
                        double w_distance, double w_collision, double tol, int max_iter, double *u0,
                        double *U, double *X, double *lam, int32_t *status, int32_t *iters, double *kkt,
                        int nthreads) {
+    return oracle_solve_batch_warm(B, N, dt, ref_table, M, state, ego_index, vref, weights, is_collide, others, V, flags,
+                                   w_distance, w_collision, tol, max_iter, NULL, u0, U, X, lam, status, iters, kkt,
+                                   nthreads);
+}
+
+/* same with initial controls u_init [B,N,2] (NULL = cold start of the reference) */
+int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
+                            const int32_t *ego_index, const double *vref, const double *weights,
+                            const uint8_t *is_collide, const double *others, int V, uint32_t flags,
+                            double w_distance, double w_collision, double tol, int max_iter, const double *u_init,
+                            double *u0, double *U, double *X, double *lam, int32_t *status, int32_t *iters,
+                            double *kkt, int nthreads) {
     if (N < 1 || N > NMAX || V < 0 || V > VMAX || M < 1) return -1;
     g_cnt_iter = g_cnt_sweep = g_cnt_roll = 0;
-    opts_t o = {tol, getenv("ORACLE_MU0") ? atof(getenv("ORACLE_MU0")) : 0.1, max_iter};
+    opts_t o = {tol, 0.1, max_iter};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -659,7 +689,7 @@ int oracle_solve_batch(int B, int N, double dt, const double *ref_table, int M, 
         iter_t *it = (iter_t *)malloc(sizeof(iter_t));
         int its = 0;
         double e = 0.0;
-        int st = solve_one(&p, &o, it, &its, &e);
+        int st = solve_one(&p, &o, it, u_init ? u_init + (size_t)b * N * 2 : NULL, &its, &e);
         u0[2 * b + 0] = it->u[0][0];
         u0[2 * b + 1] = it->u[0][1];
         if (U)

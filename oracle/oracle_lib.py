@@ -35,6 +35,11 @@ def _load():
             ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ip, dp, dp, bp, dp,
             ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
             dp, dp, dp, dp, ip, ip, dp, ctypes.c_int]
+        _lib.oracle_solve_batch_warm.restype = ctypes.c_int
+        _lib.oracle_solve_batch_warm.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ip, dp, dp, bp, dp,
+            ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+            dp, dp, dp, dp, dp, ip, ip, dp, ctypes.c_int]
     return _lib
 
 
@@ -44,7 +49,7 @@ def _p(a, ty):
 
 def solve_batch(ref_table, state, ego_index, weights, is_collide, vref=None, others=None, N=20, dt=0.1,
                 collision_cost=False, w_distance=10.0, w_collision=1.0, tol=1e-8, max_iter=200, nthreads=0,
-                xy_bounds=True):
+                xy_bounds=True, u_init=None):
     """Solve B instances on the CPU. Returns dict(u0, U, X, lam, status, iters, kkt).
 
     xy_bounds=False drops the |x|,|y| <= 500 bounds of the reference NLP (agents/pure_mpc.py:272-274), which
@@ -66,12 +71,15 @@ def solve_batch(ref_table, state, ego_index, weights, is_collide, vref=None, oth
         V = others.shape[1]
     u0 = np.zeros((B, 2)); U = np.zeros((B, N, 2)); X = np.zeros((B, N + 1, 4)); lam = np.zeros((B, N + 1, 4))
     status = np.zeros(B, dtype=np.int32); iters = np.zeros(B, dtype=np.int32); kkt = np.zeros(B)
-    rc = lib.oracle_solve_batch(
+    if u_init is not None:           # warm start (not in the reference): initial controls [B, N, 2]
+        u_init = np.ascontiguousarray(u_init, dtype=np.float64)
+        assert u_init.shape == (B, N, 2)
+    rc = lib.oracle_solve_batch_warm(
         B, N, dt, _p(ref_table, ctypes.c_double), ref_table.shape[0], _p(state, ctypes.c_double),
         _p(ego_index, ctypes.c_int32), _p(vref, ctypes.c_double), _p(weights, ctypes.c_double),
         _p(is_collide, ctypes.c_uint8), _p(others, ctypes.c_double), V,
         (1 if collision_cost else 0) | (0 if xy_bounds else 2),
-        w_distance, w_collision, tol, max_iter, _p(u0, ctypes.c_double), _p(U, ctypes.c_double),
+        w_distance, w_collision, tol, max_iter, _p(u_init, ctypes.c_double), _p(u0, ctypes.c_double), _p(U, ctypes.c_double),
         _p(X, ctypes.c_double), _p(lam, ctypes.c_double), _p(status, ctypes.c_int32),
         _p(iters, ctypes.c_int32), _p(kkt, ctypes.c_double), nthreads)
     if rc != 0:

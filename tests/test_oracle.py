@@ -116,3 +116,22 @@ def test_edge_cases(oracle, ref_table):
     out = _solve(oracle, ref_table, state=np.array([[2.0, 45.0, -np.pi / 2, 31.0]]), ego_index=np.array([4]),
                  weights=np.ones((1, 3)), is_collide=np.zeros(1, np.uint8))
     assert out["status"][0] == 3
+
+
+def test_oracle_warm_start_reaches_the_same_solution_in_fewer_iterations(oracle, ref_table):
+    """`u_init` (not in the reference, which always starts cold): restarting from the own solution converges to it
+    again with fewer iterations.  Used for the warm-start study recorded in DESIGN.md section 8."""
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(96, 4, seed=5)
+    kw = dict(vref=inp["vref"], max_iter=100, xy_bounds=False, nthreads=2)
+    cold = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], **kw)
+    warm = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
+                              u_init=cold["U"], **kw)
+    both = (cold["status"] == 0) & (warm["status"] == 0)
+    assert both.mean() > 0.9
+    assert (np.abs(warm["u0"] - cold["u0"]).max(axis=1)[both] < 1e-6).mean() > 0.95
+    assert warm["iters"][both].mean() < 0.85 * cold["iters"][both].mean()
+    # controls outside the bounds are clamped inside, an infeasible warm start falls back to the cold one
+    wild = np.full_like(cold["U"], 50.0)
+    out = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], u_init=wild, **kw)
+    assert (out["status"] == 0).mean() > 0.85
