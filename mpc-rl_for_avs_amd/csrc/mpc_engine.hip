@@ -189,6 +189,25 @@ struct WaveCtx {
         __syncthreads();  // single-wave workgroup: orders the LDS traffic of the phase before what follows
     }
     __device__ __forceinline__ void tick(int) const {}  // section timing hook, used by tools/ubench only
+    // register-only per-lane work, the FP64 matrix core, lane permutation, lane broadcast
+    template <class F>
+    __device__ __forceinline__ void lanes(F &&f) {
+        f((int)threadIdx.x);
+    }
+    __device__ __forceinline__ void mfma(mpc::wave::PerLane<double> &a, mpc::wave::PerLane<double> &b,
+                                         mpc::wave::PerLane<double> &cd) const {
+        cd.v = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v, b.v, cd.v, 0, 0, 0);
+    }
+    __device__ __forceinline__ void take(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src,
+                                         mpc::wave::PerLane<int> &from) const {
+        dst.v = __shfl(src.v, from.v);
+    }
+    __device__ __forceinline__ double lane_get(mpc::wave::PerLane<double> &p, int lane) const {
+        const long long bits = __double_as_longlong(p.v);
+        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane);
+        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
     // wave reductions: xor-butterfly of lane shuffles, every lane ends with the result
     __device__ __forceinline__ double wave_sum(mpc::wave::PerLane<double> &p) const {
         double v = p.v;

@@ -59,6 +59,7 @@ enum : int {
     SC_SPARE = 178,  // 8 (unused)
     SC_SIZE = 186
 };
+constexpr bool kMfmaSweep = true;  // Riccati stage on the FP64 matrix cores (false: the LDS-staged version)
 constexpr int kMaxHorizon = 32;   // lanes 0..31 / 32..63 carry the stages of two line-search trials
 // compact stage cost Hessian / gradient, assembled for all stages before a sweep into slots that are free during it:
 // the stage's gain slots (overwritten by the gains once the stage is done) and the trial trajectory buffer
@@ -144,6 +145,11 @@ MPC_HD void F_column(const StageLin &s, int j, double *f) {
 //   void wave_max_ratio(PerLane<double>& n, PerLane<double>& d, double &rn, double &rd)   pair with the largest n/d
 //   void wave_sum2(PerLane<double>&, double &lo, double &hi)   sums over lanes 0..31 and 32..63
 //   int wave_bcast(PerLane<int>&, int lane)                    value of one lane
+//   void lanes(F f)                              f(lane) for the 64 lanes, no barrier (register-only work)
+//   void mfma(PerLane<double>& a, PerLane<double>& b, PerLane<double>& cd)   cd += a x b, v_mfma_f64_4x4x4f64:
+//        lane l = 16 hi + 4 blk + lo holds A_blk[row lo][k hi], B_blk[k hi][col lo], C/D_blk[row hi][col lo]
+//   void take(PerLane<double>& dst, PerLane<double>& src, PerLane<int>& from)   dst[l] = src[from[l]]
+//   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
 // ---------------------------------------------------------------------------------------------------
 template <bool CC, class CTX>
@@ -174,6 +180,13 @@ struct Solver {
     PerLane<int> r_slot, r_hv, r_hvab, r_i, r_j;
     PerLane<double> r_cst;
     PerLane<double> red_a, red_b, red_c;   // per-lane operands of the wave reductions
+    // MFMA sweep (kMfmaSweep): the 8x8 stage block lives in the C/D layout of v_mfma_f64_4x4x4f64 as 2x2 blocks of
+    // 4x4: lane l = 16 hi + 4 (2 I + J) + lo holds element (row 4 I + hi, col 4 J + lo)
+    PerLane<int> m_row, m_col;                     // element of this lane
+    PerLane<int> m_s1a, m_s1b, m_s2a, m_s2b;       // source lanes: block (I,J) <- block (K,I) [K = 0, 1], <- block (K,J)
+    PerLane<int> m_fa0, m_fa1, m_fb0, m_fb1;       // where F[4K+hi][4I+lo] / F[4K+hi][4J+lo] sit in LDS (>= 0: stage slot)
+    PerLane<int> m_lslot, m_hvslot, m_hvab, m_kx;  // stage-Hessian slot, gradient slot (column-0 lanes), gain slot to store
+    PerLane<double> m_lcst;
     PerLane<int> ls_feas;                  // line search: lane t = trial t stayed inside the fraction-to-the-boundary box
     MPC_HD void set_lane_roles() {
         c.phase([&](int lane) {
@@ -206,6 +219,77 @@ struct Solver {
             const int e = lane < 36 ? lane : (lane < 42 ? (lane - 36) * 6 : (lane < 54 ? (lane - 42) % 6 : 0));
             r_i.at(lane) = e / 6;
             r_j.at(lane) = e % 6;
+        });
+    }
+
+
+    // F = [A B; 0 I; 0 0] (8 x 8 with two zero rows) is made of 0, 1, dt and the eight stored linearisation values:
+    // LDS word of element (r, c), stage-relative (>= 0) or absolute (< 0: -(word + 1)) for the three constants
+    MPC_HD int f_word(int r, int c) const {
+        const int zero = -(SCR + SC_SPARE + 0 + 1), one = -(SCR + SC_SPARE + 1 + 1), dtw = -(SCR + SC_SPARE + 2 + 1);
+        if (r >= 6) return zero;
+        if (r == 4) return c == 6 ? one : zero;
+        if (r == 5) return c == 7 ? one : zero;
+        if (c < 4) {
+            if (r == c) return one;
+            if (r == 0 && c == 2) return W_LIN + 0;
+            if (r == 0 && c == 3) return W_LIN + 1;
+            if (r == 1 && c == 2) return W_LIN + 2;
+            if (r == 1 && c == 3) return W_LIN + 3;
+            if (r == 2 && c == 3) return W_LIN + 4;
+            return zero;
+        }
+        if (c == 6) return r == 3 ? dtw : zero;
+        if (c == 7) return r == 0 ? W_LIN + 5 : (r == 1 ? W_LIN + 6 : (r == 2 ? W_LIN + 7 : zero));
+        return zero;
+    }
+    MPC_HD void set_mfma_roles() {
+        sc(SC_SPARE + 0, 0.0);
+        sc(SC_SPARE + 1, 1.0);
+        sc(SC_SPARE + 2, dt);
+        c.phase([&](int lane) {
+            const int hi = lane >> 4, blk = (lane >> 2) & 3, I = blk >> 1, J = blk & 1, lo = lane & 3;
+            const int row = 4 * I + hi, col = 4 * J + lo;
+            m_row.at(lane) = row;
+            m_col.at(lane) = col;
+            const int rest = lane & ~12;
+            m_s1a.at(lane) = rest | ((0 + I) << 2);
+            m_s1b.at(lane) = rest | ((2 + I) << 2);
+            m_s2a.at(lane) = rest | ((0 + J) << 2);
+            m_s2b.at(lane) = rest | ((2 + J) << 2);
+            m_fa0.at(lane) = f_word(0 + hi, 4 * I + lo);
+            m_fa1.at(lane) = f_word(4 + hi, 4 * I + lo);
+            m_fb0.at(lane) = f_word(0 + hi, 4 * J + lo);
+            m_fb1.at(lane) = f_word(4 + hi, 4 * J + lo);
+            const int a = row < col ? row : col, b = row < col ? col : row;
+            int slot = -1;
+            double cst = 0.0;
+            switch (a * 8 + b) {
+                case 0 * 8 + 0: slot = A_L00; break;
+                case 0 * 8 + 1: slot = A_L01; break;
+                case 1 * 8 + 1: slot = A_L11; break;
+                case 2 * 8 + 2: slot = A_H22; break;
+                case 2 * 8 + 3: slot = A_H23; break;
+                case 3 * 8 + 3: slot = A_H33; break;
+                case 2 * 8 + 7: slot = A_WTD; break;
+                case 3 * 8 + 7: slot = A_WVD; break;
+                case 6 * 8 + 6: slot = A_H66; break;
+                case 7 * 8 + 7: slot = A_H77; break;
+                case 4 * 8 + 4: cst = 1.0; break;
+                case 5 * 8 + 5: cst = 1.0; break;
+                case 4 * 8 + 6: cst = -1.0; break;
+                case 5 * 8 + 7: cst = -1.0; break;
+                default: break;
+            }
+            m_lslot.at(lane) = slot;
+            m_lcst.at(lane) = cst;
+            // gradient: column-0 lanes carry element `row`
+            const int q = row;
+            m_hvslot.at(lane) = col != 0 ? -1
+                                         : (q < 4 ? A_HV0 + q : (q == 4 ? A_HV4 : (q == 5 ? A_HV5 : (q == 6 ? A_HV6 : A_HV7))));
+            m_hvab.at(lane) = (q < 4 || q == 5) ? 1 : 0;
+            // gains Kx(a, j) = -W(6 + a, j), j < 4: taken from the I = 0 copy of W
+            m_kx.at(lane) = (I == 0 && J == 0 && hi >= 2) ? W_KX + (hi - 2) * 4 + lo : -1;
         });
     }
 
@@ -448,6 +532,7 @@ struct Solver {
         cur_out = 0;
         kkt_out = INFINITY;
         set_lane_roles();
+        if (kMfmaSweep) set_mfma_roles();
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;
@@ -659,8 +744,10 @@ struct Solver {
                 dV1 = 0.0;
                 c.phase([&](int lane) {
                     // terminal value function: barrier terms of (theta, v)_N
-                    if (lane < 36) sc(SC_P + lane, ((lane % 7) == 0 && lane < 28) ? delta_w : 0.0);
-                    if (lane >= 36 && lane < 42) sc(SC_PV + lane - 36, 0.0);
+                    if (!kMfmaSweep) {
+                        if (lane < 36) sc(SC_P + lane, ((lane % 7) == 0 && lane < 28) ? delta_w : 0.0);
+                        if (lane >= 36 && lane < 42) sc(SC_PV + lane - 36, 0.0);
+                    }
                     if (lane >= N) return;
                     // ---- stage cost Hessian / gradient of stage k = lane (compact: the 10 distinct entries + 8 gradients)
                     const int k = lane;
@@ -742,105 +829,210 @@ struct Solver {
                     S(k, A_HV6, rc * u0 + rdk * (u0 - um0) + sgr[2]);
                     S(k, A_HV7, rc * u1 + rdk * (u1 - um1) + sgr[3]);
                 });
-                for (int i = 0; i < 2; ++i) {
-                    const double xi = S(N, CB + W_X + 2 + i);
-                    const double rl = frcp(xi - xlo_r(i)), ru = frcp(xhi_r(i) - xi);
-                    sc(SC_P + (2 + i) * 7, S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w);
-                    sc(SC_PV + 2 + i, mu * (ru - rl));
-                }
-                c.tick(T_RIC_INIT);
+                if (kMfmaSweep) {
+                    // ---- terminal value function (barrier terms of (theta, v)_N) in the matrix-core layout
+                    double tsig[2], tgr[2];
+                    for (int i = 0; i < 2; ++i) {
+                        const double xi = S(N, CB + W_X + 2 + i);
+                        const double rl = frcp(xi - xlo_r(i)), ru = frcp(xhi_r(i) - xi);
+                        tsig[i] = S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w;
+                        tgr[i] = mu * (ru - rl);
+                    }
+                    PerLane<double> Pd, pvd;
+                    c.lanes([&](int lane) {
+                        const int r = m_row.at(lane), cl = m_col.at(lane);
+                        double pe = 0.0;
+                        if (r == cl && r < 4) pe = r == 2 ? tsig[0] : (r == 3 ? tsig[1] : delta_w);
+                        Pd.at(lane) = pe;
+                        pvd.at(lane) = cl == 0 ? (r == 2 ? tgr[0] : (r == 3 ? tgr[1] : 0.0)) : 0.0;
+                    });
+                    c.tick(T_RIC_INIT);
 #pragma unroll 1
-                for (int k = N - 1; k >= 0; --k) {
-                    const double rdk = (k >= 1) ? rd_full : 0.0;
-                    StageLin sl;
-                    sl.a02 = S(k, W_LIN + 0); sl.a03 = S(k, W_LIN + 1); sl.a12 = S(k, W_LIN + 2); sl.a13 = S(k, W_LIN + 3);
-                    sl.a23 = S(k, W_LIN + 4);
-                    sl.b01 = S(k, W_LIN + 5); sl.b11 = S(k, W_LIN + 6); sl.b21 = S(k, W_LIN + 7);
-                    sl.dt = dt;
-                    c.tick(T_RIC_SCALARS);
-                    // ---- exchange 1: T = P F (6x8)
-                    c.phase([&](int lane) {
-                        if (lane >= 48) return;
-                        const int i = lane >> 3;
-                        double f[6];
-                        F_column(sl, lane & 7, f);
-                        double t = 0.0;
-                        for (int m = 0; m < 6; ++m) t = fma(sc(SC_P + i * 6 + m), f[m], t);
-                        sc(SC_T + lane, t);
-                    });
-                    c.tick(T_RIC_L1);
-                    // ---- exchange 2: H = L + F' T, HV = l + F' PV
-                    c.phase([&](int lane) {
-                        const int i = lane >> 3, j = lane & 7;
-                        double f[6];
-                        F_column(sl, i, f);
-                        const int ls = r_slot.at(lane);
-                        const double lv = S(k, ls >= 0 ? ls : 0);
-                        double h = (ls >= 0 ? lv : 0.0) + r_cst.at(lane) * rdk;
-                        for (int m = 0; m < 6; ++m) h = fma(f[m], sc(SC_T + m * 8 + j), h);
-                        sc(SC_H + lane, h);
-                        if (lane < 8) {
-                            F_column(sl, lane, f);
-                            double g = S(k, r_hv.at(lane) + (r_hvab.at(lane) ? AB : 0));
-                            for (int m = 0; m < 6; ++m) g = fma(f[m], sc(SC_PV + m), g);
-                            sc(SC_HV + lane, g);
-                        }
-                    });
-                    c.tick(T_RIC_L2);
-                    // ---- exchange 3: 2x2 control block, gains K = -Huu^-1 Hu., value function of node k
-                    //      P = sym(Hxx + Hxu K), pv = hx + Hxu kf   (every lane inverts the 2x2 block itself)
-                    bool okk = true;
-                    double kf0 = 0.0, kf1 = 0.0, hu0 = 0.0, hu1 = 0.0;
-                    c.phase([&](int lane) {
-                        const double ha = sc(SC_H + 6 * 8 + 6), hb = 0.5 * (sc(SC_H + 6 * 8 + 7) + sc(SC_H + 7 * 8 + 6)),
-                                     hc = sc(SC_H + 7 * 8 + 7);
-                        hu0 = sc(SC_HV + 6);
-                        hu1 = sc(SC_HV + 7);
-                        // operands of this lane, fetched before the block is tested so that all reads are in flight together
-                        const int i = r_i.at(lane), j = r_j.at(lane);
-                        const double hij = sc(SC_H + i * 8 + j), hji = sc(SC_H + j * 8 + i);
-                        const double hi6 = sc(SC_H + i * 8 + 6), hi7 = sc(SC_H + i * 8 + 7);
-                        const double hj6 = sc(SC_H + j * 8 + 6), hj7 = sc(SC_H + j * 8 + 7);
-                        const double h6j = sc(SC_H + 6 * 8 + j), h7j = sc(SC_H + 7 * 8 + j);
-                        const double h6i = sc(SC_H + 6 * 8 + i), h7i = sc(SC_H + 7 * 8 + i);
-                        const double hvi = sc(SC_HV + i);
+                    for (int k = N - 1; k >= 0; --k) {
+                        const double rdk = (k >= 1) ? rd_full : 0.0;
+                        // operands that do not depend on the recursion: F in its four block arrangements, the stage
+                        // Hessian / gradient (accumulator inputs)
+                        PerLane<double> FA0, FA1, FB0, FB1, Hm, hv;
+                        c.lanes([&](int lane) {
+                            const int base = k * SL;
+                            const int w0 = m_fa0.at(lane), w1 = m_fa1.at(lane), w2 = m_fb0.at(lane), w3 = m_fb1.at(lane);
+                            FA0.at(lane) = c.ld(w0 >= 0 ? base + w0 : -w0 - 1);
+                            FA1.at(lane) = c.ld(w1 >= 0 ? base + w1 : -w1 - 1);
+                            FB0.at(lane) = c.ld(w2 >= 0 ? base + w2 : -w2 - 1);
+                            FB1.at(lane) = c.ld(w3 >= 0 ? base + w3 : -w3 - 1);
+                            const int ls = m_lslot.at(lane);
+                            const double lv = c.ld(base + (ls >= 0 ? ls : 0));
+                            Hm.at(lane) = (ls >= 0 ? lv : 0.0) + m_lcst.at(lane) * rdk;
+                            const int hs = m_hvslot.at(lane);
+                            const double gv = c.ld(base + (hs >= 0 ? hs + (m_hvab.at(lane) ? AB : 0) : 0));
+                            hv.at(lane) = hs >= 0 ? gv : 0.0;
+                        });
+                        c.tick(T_RIC_SCALARS);
+                        // ---- T = P F  (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
+                        PerLane<double> PA0, PA1, T;
+                        c.take(PA0, Pd, m_s1a);
+                        c.take(PA1, Pd, m_s1b);
+                        c.lanes([&](int lane) { T.at(lane) = 0.0; });
+                        c.mfma(PA0, FB0, T);
+                        c.mfma(PA1, FB1, T);
+                        c.tick(T_RIC_L1);
+                        // ---- H = L + F' T,  h = l + F' p   (F in the C/D layout is F' as A operand)
+                        PerLane<double> TB0, TB1, pB0, pB1;
+                        c.take(TB0, T, m_s2a);
+                        c.take(TB1, T, m_s2b);
+                        c.take(pB0, pvd, m_s2a);
+                        c.take(pB1, pvd, m_s2b);
+                        c.mfma(FA0, TB0, Hm);
+                        c.mfma(FA1, TB1, Hm);
+                        c.mfma(FA0, pB0, hv);
+                        c.mfma(FA1, pB1, hv);
+                        c.tick(T_RIC_L2);
+                        // ---- 2x2 control block (uniform): elements (6,6) (6,7) (7,6) (7,7) sit in lanes 46 47 62 63,
+                        //      gradient elements 6, 7 in lanes 40, 56
+                        const double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
+                                     hc = c.lane_get(Hm, 63);
+                        const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
                         const double det = ha * hc - hb * hb;
                         if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
-                            okk = false;
-                            return;
+                            ok = false;
+                            break;
                         }
                         const double idet = frcp(det);
                         const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
-                        kf0 = -(i00 * hu0 + i01 * hu1);
-                        kf1 = -(i01 * hu0 + i11 * hu1);
-                        if (lane < 36) {
-                            const double k0j = -(i00 * h6j + i01 * h7j), k1j = -(i01 * h6j + i11 * h7j);
-                            const double k0i = -(i00 * h6i + i01 * h7i), k1i = -(i01 * h6i + i11 * h7i);
-                            const double nij = hij + hi6 * k0j + hi7 * k1j;
-                            const double nji = hji + hj6 * k0i + hj7 * k1i;
-                            sc(SC_P + lane, 0.5 * (nij + nji));
-                        } else if (lane < 42) {
-                            sc(SC_PV + i, hvi + hi6 * kf0 + hi7 * kf1);
-                        } else if (lane < 54) {
-                            const int a = (lane - 42) / 6;
-                            if (j < 4) {
-                                const double ia0 = a == 0 ? i00 : i01, ia1 = a == 0 ? i01 : i11;
-                                S(k, W_KX + a * 4 + j, -(ia0 * h6j + ia1 * h7j));
+                        const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
+                        dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
+                        c.tick(T_RIC_2X2);
+                        // ---- W = G H(u, .) with G = Huu^-1 embedded in a 4x4 block;  P = H - H(., u) W;  p = h + H(., u) kf
+                        PerLane<double> G, HB, HA, nHA, W, kfB;
+                        c.take(HB, Hm, m_s2b);
+                        c.take(HA, Hm, m_s1b);
+                        c.lanes([&](int lane) {
+                            const int hi = lane >> 4, lo = lane & 3;
+                            G.at(lane) = (hi == 2 && lo == 2) ? i00 : ((hi == 3 && lo == 3) ? i11 : ((hi >= 2 && lo >= 2) ? i01 : 0.0));
+                            W.at(lane) = 0.0;
+                            nHA.at(lane) = -HA.at(lane);
+                            kfB.at(lane) = (m_col.at(lane) == 0) ? (hi == 2 ? kf0 : (hi == 3 ? kf1 : 0.0)) : 0.0;
+                        });
+                        c.mfma(G, HB, W);
+                        c.mfma(nHA, W, Hm);      // Hm <- H - H(., u) G H(u, .)
+                        c.mfma(HA, kfB, hv);     // hv <- h + H(., u) kf
+                        c.lanes([&](int lane) {
+                            const int r = m_row.at(lane), cl = m_col.at(lane);
+                            Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) : 0.0;
+                            pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) : 0.0;
+                            const int ks = m_kx.at(lane);
+                            if (ks >= 0) S(k, ks, -W.at(lane));
+                            if (lane == 0) {
+                                S(k, W_KF + 0, kf0);
+                                S(k, W_KF + 1, kf1);
+                                S(k, W_KP + 0, rdk * i00);
+                                S(k, W_KP + 1, rdk * i01);
+                                S(k, W_KP + 2, rdk * i11);
                             }
-                        } else if (lane == 54) {
-                            S(k, W_KF + 0, kf0);
-                            S(k, W_KF + 1, kf1);
-                            S(k, W_KP + 0, rdk * i00);
-                            S(k, W_KP + 1, rdk * i01);
-                            S(k, W_KP + 2, rdk * i11);
-                        }
-                    });
-                    c.tick(T_RIC_L4);
-                    if (!okk) {
-                        ok = false;
-                        break;
+                        });
+                        c.tick(T_RIC_L4);
                     }
-                    dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
+                } else {
+                    for (int i = 0; i < 2; ++i) {
+                        const double xi = S(N, CB + W_X + 2 + i);
+                        const double rl = frcp(xi - xlo_r(i)), ru = frcp(xhi_r(i) - xi);
+                        sc(SC_P + (2 + i) * 7, S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w);
+                        sc(SC_PV + 2 + i, mu * (ru - rl));
+                    }
+                    c.tick(T_RIC_INIT);
+    #pragma unroll 1
+                    for (int k = N - 1; k >= 0; --k) {
+                        const double rdk = (k >= 1) ? rd_full : 0.0;
+                        StageLin sl;
+                        sl.a02 = S(k, W_LIN + 0); sl.a03 = S(k, W_LIN + 1); sl.a12 = S(k, W_LIN + 2); sl.a13 = S(k, W_LIN + 3);
+                        sl.a23 = S(k, W_LIN + 4);
+                        sl.b01 = S(k, W_LIN + 5); sl.b11 = S(k, W_LIN + 6); sl.b21 = S(k, W_LIN + 7);
+                        sl.dt = dt;
+                        c.tick(T_RIC_SCALARS);
+                        // ---- exchange 1: T = P F (6x8)
+                        c.phase([&](int lane) {
+                            if (lane >= 48) return;
+                            const int i = lane >> 3;
+                            double f[6];
+                            F_column(sl, lane & 7, f);
+                            double t = 0.0;
+                            for (int m = 0; m < 6; ++m) t = fma(sc(SC_P + i * 6 + m), f[m], t);
+                            sc(SC_T + lane, t);
+                        });
+                        c.tick(T_RIC_L1);
+                        // ---- exchange 2: H = L + F' T, HV = l + F' PV
+                        c.phase([&](int lane) {
+                            const int i = lane >> 3, j = lane & 7;
+                            double f[6];
+                            F_column(sl, i, f);
+                            const int ls = r_slot.at(lane);
+                            const double lv = S(k, ls >= 0 ? ls : 0);
+                            double h = (ls >= 0 ? lv : 0.0) + r_cst.at(lane) * rdk;
+                            for (int m = 0; m < 6; ++m) h = fma(f[m], sc(SC_T + m * 8 + j), h);
+                            sc(SC_H + lane, h);
+                            if (lane < 8) {
+                                F_column(sl, lane, f);
+                                double g = S(k, r_hv.at(lane) + (r_hvab.at(lane) ? AB : 0));
+                                for (int m = 0; m < 6; ++m) g = fma(f[m], sc(SC_PV + m), g);
+                                sc(SC_HV + lane, g);
+                            }
+                        });
+                        c.tick(T_RIC_L2);
+                        // ---- exchange 3: 2x2 control block, gains K = -Huu^-1 Hu., value function of node k
+                        //      P = sym(Hxx + Hxu K), pv = hx + Hxu kf   (every lane inverts the 2x2 block itself)
+                        bool okk = true;
+                        double kf0 = 0.0, kf1 = 0.0, hu0 = 0.0, hu1 = 0.0;
+                        c.phase([&](int lane) {
+                            const double ha = sc(SC_H + 6 * 8 + 6), hb = 0.5 * (sc(SC_H + 6 * 8 + 7) + sc(SC_H + 7 * 8 + 6)),
+                                         hc = sc(SC_H + 7 * 8 + 7);
+                            hu0 = sc(SC_HV + 6);
+                            hu1 = sc(SC_HV + 7);
+                            // operands of this lane, fetched before the block is tested so that all reads are in flight together
+                            const int i = r_i.at(lane), j = r_j.at(lane);
+                            const double hij = sc(SC_H + i * 8 + j), hji = sc(SC_H + j * 8 + i);
+                            const double hi6 = sc(SC_H + i * 8 + 6), hi7 = sc(SC_H + i * 8 + 7);
+                            const double hj6 = sc(SC_H + j * 8 + 6), hj7 = sc(SC_H + j * 8 + 7);
+                            const double h6j = sc(SC_H + 6 * 8 + j), h7j = sc(SC_H + 7 * 8 + j);
+                            const double h6i = sc(SC_H + 6 * 8 + i), h7i = sc(SC_H + 7 * 8 + i);
+                            const double hvi = sc(SC_HV + i);
+                            const double det = ha * hc - hb * hb;
+                            if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
+                                okk = false;
+                                return;
+                            }
+                            const double idet = frcp(det);
+                            const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
+                            kf0 = -(i00 * hu0 + i01 * hu1);
+                            kf1 = -(i01 * hu0 + i11 * hu1);
+                            if (lane < 36) {
+                                const double k0j = -(i00 * h6j + i01 * h7j), k1j = -(i01 * h6j + i11 * h7j);
+                                const double k0i = -(i00 * h6i + i01 * h7i), k1i = -(i01 * h6i + i11 * h7i);
+                                const double nij = hij + hi6 * k0j + hi7 * k1j;
+                                const double nji = hji + hj6 * k0i + hj7 * k1i;
+                                sc(SC_P + lane, 0.5 * (nij + nji));
+                            } else if (lane < 42) {
+                                sc(SC_PV + i, hvi + hi6 * kf0 + hi7 * kf1);
+                            } else if (lane < 54) {
+                                const int a = (lane - 42) / 6;
+                                if (j < 4) {
+                                    const double ia0 = a == 0 ? i00 : i01, ia1 = a == 0 ? i01 : i11;
+                                    S(k, W_KX + a * 4 + j, -(ia0 * h6j + ia1 * h7j));
+                                }
+                            } else if (lane == 54) {
+                                S(k, W_KF + 0, kf0);
+                                S(k, W_KF + 1, kf1);
+                                S(k, W_KP + 0, rdk * i00);
+                                S(k, W_KP + 1, rdk * i01);
+                                S(k, W_KP + 2, rdk * i11);
+                            }
+                        });
+                        c.tick(T_RIC_L4);
+                        if (!okk) {
+                            ok = false;
+                            break;
+                        }
+                        dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
+                    }
                 }
                 if (!ok) {
                     if (!gn) {

@@ -21,6 +21,29 @@ struct HostCtx {
         for (int lane = 0; lane < mpc::wave::kLanes; ++lane) f(lane);
     }
     void tick(int) const {}
+    template <class F>
+    void lanes(F &&f) {
+        for (int lane = 0; lane < mpc::wave::kLanes; ++lane) f(lane);
+    }
+    // v_mfma_f64_4x4x4f64: lane l = 16 hi + 4 blk + lo; D_blk[hi][lo] = C + sum_k A_blk[hi][k] B_blk[k][lo] with
+    // A_blk[row][k] in lane 16 k + 4 blk + row and B_blk[k][col] in lane 16 k + 4 blk + col (probed on MI355X,
+    // tools/ubench/mfma_f64_probe.hip)
+    void mfma(mpc::wave::PerLane<double> &a, mpc::wave::PerLane<double> &b, mpc::wave::PerLane<double> &cd) const {
+        double out[mpc::wave::kLanes];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) {
+            const int hi = l >> 4, blk = (l >> 2) & 3, lo = l & 3;
+            double acc = cd.v[l];
+            for (int k = 0; k < 4; ++k) acc = std::fma(a.v[16 * k + 4 * blk + hi], b.v[16 * k + 4 * blk + lo], acc);
+            out[l] = acc;
+        }
+        for (int l = 0; l < mpc::wave::kLanes; ++l) cd.v[l] = out[l];
+    }
+    void take(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src, mpc::wave::PerLane<int> &from) const {
+        double out[mpc::wave::kLanes];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) out[l] = src.v[from.v[l]];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
+    }
+    double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
     double wave_sum(mpc::wave::PerLane<double> &p) const {
         return mpc::wave::host_butterfly(p, [](double a, double b) { return a + b; });
     }
