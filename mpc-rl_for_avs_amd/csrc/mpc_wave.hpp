@@ -2,19 +2,19 @@
 //
 // Same NLP and same algorithm as mpc_core.hpp (which assigns one lane per instance), reorganised so that the
 // 64 lanes of a wave work on a single instance:
-//   * everything that is independent per stage (trig of the dynamics, cost and collision-potential values and
-//     derivatives, barrier terms, complementarity, dual residual, step-length ratios, dual update) runs
-//     stage-parallel, lane k = stage k, with reductions through LDS;
-//   * the Riccati / DDP factorisation stage is a lane-per-matrix-entry computation on the 8x8 stage KKT block
-//     [Hxx Hxp Hxu; . Hpp Hpu; . . Huu] (state 4 + previous control 2 + control 2) staged in LDS:
-//     T = P F (6x8), H = L + F'T (8x8), 2x2 solve, gains (2x6), P' = Hxx' + Hx'u K (6x6), four LDS exchanges;
-//   * only the true recursions (dynamics rollout, adjoint, linearised step) stay serial; they are executed
-//     redundantly by all lanes on wave-uniform values.
+//   * everything that is independent per stage (trig and linearisation of the dynamics, cost and collision-potential
+//     values and derivatives, barrier terms, complementarity, stage Hessians, dual residual, step-length ratios, dual
+//     update) runs stage-parallel, lane k = stage k, with shuffle-butterfly reductions;
+//   * the Riccati / DDP factorisation stage works on the 8x8 stage KKT block [Hxx Hxp Hxu; . Hpp Hpu; . . Huu]
+//     (state 4 + previous control 2 + control 2) held in registers in the C/D layout of v_mfma_f64_4x4x4f64 (2x2 blocks
+//     of 4x4): T = P F, H = L + F'T, W = Huu^-1 H(u,.), P' = H - H(.,u) W and the gradient recursion are nine FP64
+//     matrix-core instructions per stage; blocks move between operand positions by lane permutation, nothing is
+//     exchanged through LDS;
+//   * the line search integrates all six trial step lengths at once, lane t = trial t;
+//   * only the true recursions (adjoint, linearised step, one lane's rollout) are serial.
 // Why: measured on MI355X the one-lane-per-instance kernel is bound by the serial FP64 instruction stream of
-// its slowest instance (~47 k instructions per iteration at ~6-10 cycles each, Riccati stage = 770 of them),
-// with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state (8-9 KB) has to sit in
-// LDS.  One wave per instance keeps the same LDS footprint (16 waves per CU, 4 per SIMD, which hide each
-// other's LDS latencies) and cuts the serial stream to ~14 k instructions per iteration.
+// its slowest instance (~47 k instructions per iteration, dependent FP64 operations cost 16-32 cycles for a lone
+// wave), with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state has to sit in LDS.
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
 // (f(lane) per lane, followed by a wave barrier); tests/cpu_wave_harness.cpp runs the phases as loops over the
@@ -49,17 +49,11 @@ enum : int {
     W_QG = 51,   // 3
     W_SLOTS_CC = 54
 };
-// scratch behind the stage arrays
+// scratch behind the stage arrays: the three constants the F operands are made of besides the linearisation values
 enum : int {
-    SC_P = 0,     // 36  value-function Hessian over (x, p), row-major 6x6
-    SC_PV = 36,   // 6   value-function gradient
-    SC_T = 42,    // 64  T = P F (6x8) during a Riccati stage
-    SC_H = 106,   // 64  stage KKT block H (8x8)
-    SC_HV = 170,  // 8   its gradient
-    SC_SPARE = 178,  // 8 (unused)
-    SC_SIZE = 186
+    SC_SPARE = 0,  // 0.0, 1.0, dt
+    SC_SIZE = 4
 };
-constexpr bool kMfmaSweep = true;  // Riccati stage on the FP64 matrix cores (false: the LDS-staged version)
 constexpr int kMaxHorizon = 32;   // lanes 0..31 / 32..63 carry the stages of two line-search trials
 // compact stage cost Hessian / gradient, assembled for all stages before a sweep into slots that are free during it:
 // the stage's gain slots (overwritten by the gains once the stage is done) and the trial trajectory buffer
@@ -78,11 +72,6 @@ MPC_HD constexpr int trial_doubles(int N) { return 6 * (N + 1); }
 MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
     return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0) + (kTrials - 1) * trial_doubles(N);
 }
-
-// stage linearisation F = [A B; 0 I] (6 x 8: rows x+ (4), p+ (2); columns x (4), p (2), u (2)) as its nine scalars
-struct StageLin {
-    double a02, a03, a12, a13, a23, b01, b11, b21, dt;
-};
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
@@ -120,19 +109,6 @@ inline T host_butterfly(PerLane<T> &p, OP op) {
     return p.v[0];
 }
 #endif
-
-// column j of F as six values; j is lane-dependent, so the entries are blended with 0/1 indicator factors
-// (exact: the other products are +-0) instead of 64-bit select chains
-MPC_HD void F_column(const StageLin &s, int j, double *f) {
-    const double d0 = j == 0 ? 1.0 : 0.0, d1 = j == 1 ? 1.0 : 0.0, d2 = j == 2 ? 1.0 : 0.0, d3 = j == 3 ? 1.0 : 0.0;
-    const double d6 = j == 6 ? 1.0 : 0.0, d7 = j == 7 ? 1.0 : 0.0;
-    f[0] = fma(s.b01, d7, fma(s.a03, d3, fma(s.a02, d2, d0)));
-    f[1] = fma(s.b11, d7, fma(s.a13, d3, fma(s.a12, d2, d1)));
-    f[2] = fma(s.b21, d7, fma(s.a23, d3, d2));
-    f[3] = fma(s.dt, d6, d3);
-    f[4] = d6;
-    f[5] = d7;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // CTX (one per wave / instance) provides
@@ -173,12 +149,6 @@ struct Solver {
     MPC_HD void sc(int i, double v) { c.st(SCR + i, v); }
     MPC_HD double oth(int j, int q) const { return c.ld(OTH + j * 4 + q); }
 
-    // Lane roles of the Riccati exchanges, fixed for the whole solve (set_lane_roles):
-    //   exchange 2: lane (i, j) of the 8x8 block adds L(i, j) = [slot of the compact stage Hessian or none] + cst * rdk
-    //               lanes 0..7 add the stage gradient from slot hv (+ trial-buffer offset if hvab)
-    //   exchange 3: lanes 0..35 own P(i, j), 36..41 pv(i), 42..53 gain K(a, j), 54 the feed-forward / Kp
-    PerLane<int> r_slot, r_hv, r_hvab, r_i, r_j;
-    PerLane<double> r_cst;
     PerLane<double> red_a, red_b, red_c;   // per-lane operands of the wave reductions
     // MFMA sweep (kMfmaSweep): the 8x8 stage block lives in the C/D layout of v_mfma_f64_4x4x4f64 as 2x2 blocks of
     // 4x4: lane l = 16 hi + 4 (2 I + J) + lo holds element (row 4 I + hi, col 4 J + lo)
@@ -188,40 +158,25 @@ struct Solver {
     PerLane<int> m_lslot, m_hvslot, m_hvab, m_kx;  // stage-Hessian slot, gradient slot (column-0 lanes), gain slot to store
     PerLane<double> m_lcst;
     PerLane<int> ls_feas;                  // line search: lane t = trial t stayed inside the fraction-to-the-boundary box
-    MPC_HD void set_lane_roles() {
-        c.phase([&](int lane) {
-            const int i = lane >> 3, j = lane & 7;
-            const int lo = i < j ? i : j, hi = i < j ? j : i;
-            int slot = -1;
-            double cst = 0.0;
-            switch (lo * 8 + hi) {
-                case 0 * 8 + 0: slot = A_L00; break;
-                case 0 * 8 + 1: slot = A_L01; break;
-                case 1 * 8 + 1: slot = A_L11; break;
-                case 2 * 8 + 2: slot = A_H22; break;
-                case 2 * 8 + 3: slot = A_H23; break;
-                case 3 * 8 + 3: slot = A_H33; break;
-                case 2 * 8 + 7: slot = A_WTD; break;
-                case 3 * 8 + 7: slot = A_WVD; break;
-                case 6 * 8 + 6: slot = A_H66; break;
-                case 7 * 8 + 7: slot = A_H77; break;
-                case 4 * 8 + 4: cst = 1.0; break;
-                case 5 * 8 + 5: cst = 1.0; break;
-                case 4 * 8 + 6: cst = -1.0; break;
-                case 5 * 8 + 7: cst = -1.0; break;
-                default: break;
-            }
-            r_slot.at(lane) = slot;
-            r_cst.at(lane) = cst;
-            const int q = lane & 7;
-            r_hv.at(lane) = q < 4 ? A_HV0 + q : (q == 4 ? A_HV4 : (q == 5 ? A_HV5 : (q == 6 ? A_HV6 : A_HV7)));
-            r_hvab.at(lane) = (q < 4 || q == 5) ? 1 : 0;
-            const int e = lane < 36 ? lane : (lane < 42 ? (lane - 36) * 6 : (lane < 54 ? (lane - 42) % 6 : 0));
-            r_i.at(lane) = e / 6;
-            r_j.at(lane) = e % 6;
+    // Riccati operands of stage k that come from LDS: F(k) in the four block arrangements and the accumulator inputs
+    // L(k) (stage Hessian, C/D layout) and l(k) (stage gradient, column-0 lanes)
+    MPC_HD void load_stage_operands(int k, int AB, double rdk, PerLane<double> &FA0, PerLane<double> &FA1,
+                                    PerLane<double> &FB0, PerLane<double> &FB1, PerLane<double> &Hm, PerLane<double> &hv) {
+        c.lanes([&](int lane) {
+            const int base = k * SL;
+            const int w0 = m_fa0.at(lane), w1 = m_fa1.at(lane), w2 = m_fb0.at(lane), w3 = m_fb1.at(lane);
+            FA0.at(lane) = c.ld(w0 >= 0 ? base + w0 : -w0 - 1);
+            FA1.at(lane) = c.ld(w1 >= 0 ? base + w1 : -w1 - 1);
+            FB0.at(lane) = c.ld(w2 >= 0 ? base + w2 : -w2 - 1);
+            FB1.at(lane) = c.ld(w3 >= 0 ? base + w3 : -w3 - 1);
+            const int ls = m_lslot.at(lane);
+            const double lv = c.ld(base + (ls >= 0 ? ls : 0));
+            Hm.at(lane) = (ls >= 0 ? lv : 0.0) + m_lcst.at(lane) * rdk;
+            const int hs = m_hvslot.at(lane);
+            const double gv = c.ld(base + (hs >= 0 ? hs + (m_hvab.at(lane) ? AB : 0) : 0));
+            hv.at(lane) = hs >= 0 ? gv : 0.0;
         });
     }
-
 
     // F = [A B; 0 I; 0 0] (8 x 8 with two zero rows) is made of 0, 1, dt and the eight stored linearisation values:
     // LDS word of element (r, c), stage-relative (>= 0) or absolute (< 0: -(word + 1)) for the three constants
@@ -531,8 +486,7 @@ struct Solver {
         iters_out = 0;
         cur_out = 0;
         kkt_out = INFINITY;
-        set_lane_roles();
-        if (kMfmaSweep) set_mfma_roles();
+        set_mfma_roles();
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;
@@ -744,10 +698,6 @@ struct Solver {
                 dV1 = 0.0;
                 c.phase([&](int lane) {
                     // terminal value function: barrier terms of (theta, v)_N
-                    if (!kMfmaSweep) {
-                        if (lane < 36) sc(SC_P + lane, ((lane % 7) == 0 && lane < 28) ? delta_w : 0.0);
-                        if (lane >= 36 && lane < 42) sc(SC_PV + lane - 36, 0.0);
-                    }
                     if (lane >= N) return;
                     // ---- stage cost Hessian / gradient of stage k = lane (compact: the 10 distinct entries + 8 gradients)
                     const int k = lane;
@@ -829,7 +779,7 @@ struct Solver {
                     S(k, A_HV6, rc * u0 + rdk * (u0 - um0) + sgr[2]);
                     S(k, A_HV7, rc * u1 + rdk * (u1 - um1) + sgr[3]);
                 });
-                if (kMfmaSweep) {
+                {
                     // ---- terminal value function (barrier terms of (theta, v)_N) in the matrix-core layout
                     double tsig[2], tgr[2];
                     for (int i = 0; i < 2; ++i) {
@@ -851,22 +801,9 @@ struct Solver {
                     for (int k = N - 1; k >= 0; --k) {
                         const double rdk = (k >= 1) ? rd_full : 0.0;
                         // operands that do not depend on the recursion: F in its four block arrangements, the stage
-                        // Hessian / gradient (accumulator inputs)
+                        // Hessian / gradient as accumulator inputs (prefetching them one stage ahead measured neutral)
                         PerLane<double> FA0, FA1, FB0, FB1, Hm, hv;
-                        c.lanes([&](int lane) {
-                            const int base = k * SL;
-                            const int w0 = m_fa0.at(lane), w1 = m_fa1.at(lane), w2 = m_fb0.at(lane), w3 = m_fb1.at(lane);
-                            FA0.at(lane) = c.ld(w0 >= 0 ? base + w0 : -w0 - 1);
-                            FA1.at(lane) = c.ld(w1 >= 0 ? base + w1 : -w1 - 1);
-                            FB0.at(lane) = c.ld(w2 >= 0 ? base + w2 : -w2 - 1);
-                            FB1.at(lane) = c.ld(w3 >= 0 ? base + w3 : -w3 - 1);
-                            const int ls = m_lslot.at(lane);
-                            const double lv = c.ld(base + (ls >= 0 ? ls : 0));
-                            Hm.at(lane) = (ls >= 0 ? lv : 0.0) + m_lcst.at(lane) * rdk;
-                            const int hs = m_hvslot.at(lane);
-                            const double gv = c.ld(base + (hs >= 0 ? hs + (m_hvab.at(lane) ? AB : 0) : 0));
-                            hv.at(lane) = hs >= 0 ? gv : 0.0;
-                        });
+                        load_stage_operands(k, AB, rdk, FA0, FA1, FB0, FB1, Hm, hv);
                         c.tick(T_RIC_SCALARS);
                         // ---- T = P F  (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
                         PerLane<double> PA0, PA1, T;
@@ -931,107 +868,6 @@ struct Solver {
                             }
                         });
                         c.tick(T_RIC_L4);
-                    }
-                } else {
-                    for (int i = 0; i < 2; ++i) {
-                        const double xi = S(N, CB + W_X + 2 + i);
-                        const double rl = frcp(xi - xlo_r(i)), ru = frcp(xhi_r(i) - xi);
-                        sc(SC_P + (2 + i) * 7, S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w);
-                        sc(SC_PV + 2 + i, mu * (ru - rl));
-                    }
-                    c.tick(T_RIC_INIT);
-    #pragma unroll 1
-                    for (int k = N - 1; k >= 0; --k) {
-                        const double rdk = (k >= 1) ? rd_full : 0.0;
-                        StageLin sl;
-                        sl.a02 = S(k, W_LIN + 0); sl.a03 = S(k, W_LIN + 1); sl.a12 = S(k, W_LIN + 2); sl.a13 = S(k, W_LIN + 3);
-                        sl.a23 = S(k, W_LIN + 4);
-                        sl.b01 = S(k, W_LIN + 5); sl.b11 = S(k, W_LIN + 6); sl.b21 = S(k, W_LIN + 7);
-                        sl.dt = dt;
-                        c.tick(T_RIC_SCALARS);
-                        // ---- exchange 1: T = P F (6x8)
-                        c.phase([&](int lane) {
-                            if (lane >= 48) return;
-                            const int i = lane >> 3;
-                            double f[6];
-                            F_column(sl, lane & 7, f);
-                            double t = 0.0;
-                            for (int m = 0; m < 6; ++m) t = fma(sc(SC_P + i * 6 + m), f[m], t);
-                            sc(SC_T + lane, t);
-                        });
-                        c.tick(T_RIC_L1);
-                        // ---- exchange 2: H = L + F' T, HV = l + F' PV
-                        c.phase([&](int lane) {
-                            const int i = lane >> 3, j = lane & 7;
-                            double f[6];
-                            F_column(sl, i, f);
-                            const int ls = r_slot.at(lane);
-                            const double lv = S(k, ls >= 0 ? ls : 0);
-                            double h = (ls >= 0 ? lv : 0.0) + r_cst.at(lane) * rdk;
-                            for (int m = 0; m < 6; ++m) h = fma(f[m], sc(SC_T + m * 8 + j), h);
-                            sc(SC_H + lane, h);
-                            if (lane < 8) {
-                                F_column(sl, lane, f);
-                                double g = S(k, r_hv.at(lane) + (r_hvab.at(lane) ? AB : 0));
-                                for (int m = 0; m < 6; ++m) g = fma(f[m], sc(SC_PV + m), g);
-                                sc(SC_HV + lane, g);
-                            }
-                        });
-                        c.tick(T_RIC_L2);
-                        // ---- exchange 3: 2x2 control block, gains K = -Huu^-1 Hu., value function of node k
-                        //      P = sym(Hxx + Hxu K), pv = hx + Hxu kf   (every lane inverts the 2x2 block itself)
-                        bool okk = true;
-                        double kf0 = 0.0, kf1 = 0.0, hu0 = 0.0, hu1 = 0.0;
-                        c.phase([&](int lane) {
-                            const double ha = sc(SC_H + 6 * 8 + 6), hb = 0.5 * (sc(SC_H + 6 * 8 + 7) + sc(SC_H + 7 * 8 + 6)),
-                                         hc = sc(SC_H + 7 * 8 + 7);
-                            hu0 = sc(SC_HV + 6);
-                            hu1 = sc(SC_HV + 7);
-                            // operands of this lane, fetched before the block is tested so that all reads are in flight together
-                            const int i = r_i.at(lane), j = r_j.at(lane);
-                            const double hij = sc(SC_H + i * 8 + j), hji = sc(SC_H + j * 8 + i);
-                            const double hi6 = sc(SC_H + i * 8 + 6), hi7 = sc(SC_H + i * 8 + 7);
-                            const double hj6 = sc(SC_H + j * 8 + 6), hj7 = sc(SC_H + j * 8 + 7);
-                            const double h6j = sc(SC_H + 6 * 8 + j), h7j = sc(SC_H + 7 * 8 + j);
-                            const double h6i = sc(SC_H + 6 * 8 + i), h7i = sc(SC_H + 7 * 8 + i);
-                            const double hvi = sc(SC_HV + i);
-                            const double det = ha * hc - hb * hb;
-                            if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
-                                okk = false;
-                                return;
-                            }
-                            const double idet = frcp(det);
-                            const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
-                            kf0 = -(i00 * hu0 + i01 * hu1);
-                            kf1 = -(i01 * hu0 + i11 * hu1);
-                            if (lane < 36) {
-                                const double k0j = -(i00 * h6j + i01 * h7j), k1j = -(i01 * h6j + i11 * h7j);
-                                const double k0i = -(i00 * h6i + i01 * h7i), k1i = -(i01 * h6i + i11 * h7i);
-                                const double nij = hij + hi6 * k0j + hi7 * k1j;
-                                const double nji = hji + hj6 * k0i + hj7 * k1i;
-                                sc(SC_P + lane, 0.5 * (nij + nji));
-                            } else if (lane < 42) {
-                                sc(SC_PV + i, hvi + hi6 * kf0 + hi7 * kf1);
-                            } else if (lane < 54) {
-                                const int a = (lane - 42) / 6;
-                                if (j < 4) {
-                                    const double ia0 = a == 0 ? i00 : i01, ia1 = a == 0 ? i01 : i11;
-                                    S(k, W_KX + a * 4 + j, -(ia0 * h6j + ia1 * h7j));
-                                }
-                            } else if (lane == 54) {
-                                S(k, W_KF + 0, kf0);
-                                S(k, W_KF + 1, kf1);
-                                S(k, W_KP + 0, rdk * i00);
-                                S(k, W_KP + 1, rdk * i01);
-                                S(k, W_KP + 2, rdk * i11);
-                            }
-                        });
-                        c.tick(T_RIC_L4);
-                        if (!okk) {
-                            ok = false;
-                            break;
-                        }
-                        dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
                     }
                 }
                 if (!ok) {
