@@ -92,22 +92,20 @@ constexpr double kInvWheelbase = 1.0 / 2.5;  // Vehicle.LENGTH, agents/utils.py:
 // |delta| <= pi/3(1+1e-8), slacks and determinants are positive normal numbers.
 MPC_HD double frcp(double x) {  // 1/x for positive normal x
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-    return fma(y, e, y);
+    // v_rcp_f64 is good to 2^-24 (measured, tools/ubench/fp64_latency.hip): one third-order step gives 2^-72
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);
+    return fma(y, fma(e, e, e), y);
 #else
     return 1.0 / x;
 #endif
 }
 MPC_HD double frsqrt(double x) {  // 1/sqrt(x) for positive normal x
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * y, y, 1.0);           // 1 - x y^2
-    y = fma(y * e, fma(0.375, e, 0.5), y);    // third-order step
-    e = fma(-x * y, y, 1.0);
-    return fma(y * e, 0.5, y);
+    // v_rsq_f64 is good to 2^-24 (measured): one third-order step gives 2^-72
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);     // 1 - x y^2
+    return fma(y * e, fma(0.375, e, 0.5), y);
 #else
     return 1.0 / sqrt(x);
 #endif
