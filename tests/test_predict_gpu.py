@@ -137,3 +137,26 @@ def test_collector_on_device_equals_single_instance_path():
     assert n_all == T * B // 4 and n_ok / n_all > 0.97, (n_ok, n_all, worst)
     assert torch.isfinite(buf.advantages).all() and torch.isfinite(buf.returns).all()
     eng.close()
+
+
+def test_closed_loop_single_ego_follows_the_route():
+    """BASELINE config 1 (run_pure_mpc.py: single ego, horizon 20, one other vehicle), closed loop over 150 steps:
+    the ego tracks the reference path at the reference speed, yields when the detector fires, and arrives."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("run_pure_mpc", os.path.join(ROOT, "tools", "run_pure_mpc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    outcome, log, lat = mod.run(steps=150, n_others=0, seed=3, verbose=False)     # free road
+    log = np.array([r[:5] for r in log])
+    assert outcome == "arrived"
+    from mpc_rl_for_avs_amd.reference_path import reference_states
+    ref = reference_states()
+    d = np.min(np.linalg.norm(ref[None, :, :2] - log[:, None, :2], axis=2), axis=1)
+    assert d.max() < 0.8                                     # stays on the lane (half width 2 m)
+    assert abs(np.median(log[5:, 2]) - 10.0) < 1.0           # cruises at the reference speed
+    assert np.abs(log[:, 3]).max() <= 5.0 + 1e-6 and np.abs(log[:, 4]).max() <= np.pi / 3 + 1e-6
+    outcome2, log2, _ = mod.run(steps=150, n_others=1, seed=1, verbose=False)     # with cross traffic
+    assert outcome2 in ("arrived", "crashed", "timeout", "running")
+    assert np.mean([r[6] == 0 for r in log2]) > 0.8
