@@ -824,6 +824,11 @@ struct Solver {
                         c.mfma(FA0, pB0, hv);
                         c.mfma(FA1, pB1, hv);
                         c.tick(T_RIC_L2);
+                        // the control rows / columns of H in the block positions the Schur complement needs them; issued
+                        // before the scalar work on the 2x2 block so that the permutations overlap with it
+                        PerLane<double> HB, HA;
+                        c.take(HB, Hm, m_s2b);
+                        c.take(HA, Hm, m_s1b);
                         // ---- 2x2 control block (uniform): elements (6,6) (6,7) (7,6) (7,7) sit in lanes 46 47 62 63,
                         //      gradient elements 6, 7 in lanes 40, 56
                         const double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
@@ -834,31 +839,34 @@ struct Solver {
                             ok = false;
                             break;
                         }
+                        c.tick(T_RIC_2X2);
+                        // ---- W = adj(Huu) H(u, .) (adjugate embedded in a 4x4 block: the reciprocal of the determinant is
+                        //      computed while the matrix core works and scales the other operand afterwards);
+                        //      P = H - H(., u) W / det;  p = h + H(., u) kf
+                        PerLane<double> G, nHA, W, kfB;
+                        c.lanes([&](int lane) {
+                            const int hi = lane >> 4, lo = lane & 3;
+                            G.at(lane) = (hi == 2 && lo == 2) ? hc : ((hi == 3 && lo == 3) ? ha : ((hi >= 2 && lo >= 2) ? -hb : 0.0));
+                            W.at(lane) = 0.0;
+                        });
+                        c.mfma(G, HB, W);
                         const double idet = frcp(det);
                         const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
                         const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
                         dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
-                        c.tick(T_RIC_2X2);
-                        // ---- W = G H(u, .) with G = Huu^-1 embedded in a 4x4 block;  P = H - H(., u) W;  p = h + H(., u) kf
-                        PerLane<double> G, HB, HA, nHA, W, kfB;
-                        c.take(HB, Hm, m_s2b);
-                        c.take(HA, Hm, m_s1b);
                         c.lanes([&](int lane) {
-                            const int hi = lane >> 4, lo = lane & 3;
-                            G.at(lane) = (hi == 2 && lo == 2) ? i00 : ((hi == 3 && lo == 3) ? i11 : ((hi >= 2 && lo >= 2) ? i01 : 0.0));
-                            W.at(lane) = 0.0;
-                            nHA.at(lane) = -HA.at(lane);
+                            const int hi = lane >> 4;
+                            nHA.at(lane) = -idet * HA.at(lane);
                             kfB.at(lane) = (m_col.at(lane) == 0) ? (hi == 2 ? kf0 : (hi == 3 ? kf1 : 0.0)) : 0.0;
                         });
-                        c.mfma(G, HB, W);
-                        c.mfma(nHA, W, Hm);      // Hm <- H - H(., u) G H(u, .)
+                        c.mfma(nHA, W, Hm);      // Hm <- H - H(., u) Huu^-1 H(u, .)
                         c.mfma(HA, kfB, hv);     // hv <- h + H(., u) kf
                         c.lanes([&](int lane) {
                             const int r = m_row.at(lane), cl = m_col.at(lane);
                             Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) : 0.0;
                             pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) : 0.0;
                             const int ks = m_kx.at(lane);
-                            if (ks >= 0) S(k, ks, -W.at(lane));
+                            if (ks >= 0) S(k, ks, -idet * W.at(lane));
                             if (lane == 0) {
                                 S(k, W_KF + 0, kf0);
                                 S(k, W_KF + 1, kf1);
