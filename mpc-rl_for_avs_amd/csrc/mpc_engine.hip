@@ -19,6 +19,7 @@
 #include "../../include/mpc_mi355x.h"
 #include "mpc_core.hpp"
 #include "mpc_wave.hpp"
+#include "mpc_wave_dev.hpp"
 #include "mpc_preamble.hpp"
 
 namespace {
@@ -176,78 +177,13 @@ __global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
 // ---------------------------------------------------------------------------------------------------
 template <int NC>
-struct WaveCtx {
+struct WaveCtx : mpc::wave::WaveOps {
     static constexpr int kN = NC;
-    lds_double *L;        // this instance's LDS words
     const double *table;  // [M][REF_COLS] in global memory (wave-uniform index in the serial parts -> scalar loads)
     int e0, M;
-    __device__ __forceinline__ double ld(int i) const { return L[i]; }
-    __device__ __forceinline__ void st(int i, double v) { L[i] = v; }
-    template <class F>
-    __device__ __forceinline__ void phase(F &&f) {
-        f((int)threadIdx.x);
-        __syncthreads();  // single-wave workgroup: orders the LDS traffic of the phase before what follows
-    }
+    __device__ __forceinline__ WaveCtx(mpc::wave::lds_double_t *l, const double *t, int e, int m)
+        : mpc::wave::WaveOps{l}, table(t), e0(e), M(m) {}
     __device__ __forceinline__ void tick(int) const {}  // section timing hook, used by tools/ubench only
-    // register-only per-lane work, the FP64 matrix core, lane permutation, lane broadcast
-    template <class F>
-    __device__ __forceinline__ void lanes(F &&f) {
-        f((int)threadIdx.x);
-    }
-    __device__ __forceinline__ void mfma(mpc::wave::PerLane<double> &a, mpc::wave::PerLane<double> &b,
-                                         mpc::wave::PerLane<double> &cd) const {
-        cd.v = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v, b.v, cd.v, 0, 0, 0);
-    }
-    __device__ __forceinline__ void take(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src,
-                                         mpc::wave::PerLane<int> &from) const {
-        dst.v = __shfl(src.v, from.v);
-    }
-    __device__ __forceinline__ double lane_get(mpc::wave::PerLane<double> &p, int lane) const {
-        const long long bits = __double_as_longlong(p.v);
-        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane);
-        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
-        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    }
-    // wave reductions: xor-butterfly of lane shuffles, every lane ends with the result
-    __device__ __forceinline__ double wave_sum(mpc::wave::PerLane<double> &p) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-        return v;
-    }
-    __device__ __forceinline__ double wave_max(mpc::wave::PerLane<double> &p) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) v = mpc::fmax2(v, __shfl_xor(v, off));
-        return v;
-    }
-    __device__ __forceinline__ double wave_min(mpc::wave::PerLane<double> &p) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) v = mpc::fmin2(v, __shfl_xor(v, off));
-        return v;
-    }
-    __device__ __forceinline__ void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 16; off; off >>= 1) v += __shfl_xor(v, off);
-        lo = __shfl(v, 0);
-        hi = __shfl(v, 32);
-    }
-    __device__ __forceinline__ int wave_bcast(mpc::wave::PerLane<int> &p, int lane) const { return __shfl(p.v, lane); }
-    __device__ __forceinline__ void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd,
-                                                   double &rn, double &rd) const {
-        double n = pn.v, d = pd.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) {
-            const double n2 = __shfl_xor(n, off), d2 = __shfl_xor(d, off);
-            const bool take = mpc::wave::ratio_greater(n2, d2, n, d);
-            n = take ? n2 : n;
-            d = take ? d2 : d;
-        }
-        rn = n;
-        rd = d;
-    }
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
         idx = idx > M - 1 ? M - 1 : idx;
@@ -269,7 +205,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     const int lane = threadIdx.x;
     constexpr int SL = mpc::wave::stage_slots(CC);
-    WaveCtx<NC> ctx{(lds_double *)smem, ref5, ego_index[b], M};
+    WaveCtx<NC> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
     // inputs -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j)
     if (lane <= N) {

@@ -92,21 +92,31 @@ struct PerLane {
 #endif
 };
 
-// (n2/d2 > n1/d1) for positive denominators, division-free; ties keep the first pair.  When both cross products are
-// equal because both numerators are zero the first pair is kept as well.
-MPC_HD bool ratio_greater(double n2, double d2, double n1, double d1) { return n2 * d1 > n1 * d2; }
+// (n2/d2 > n1/d1) for positive denominators, division-free.  Equal ratios prefer the larger denominator, so that the
+// two partners of a symmetric exchange always agree on the winner.
+MPC_HD bool ratio_greater(double n2, double d2, double n1, double d1) {
+    const double a = n2 * d1, b = n1 * d2;
+    return a > b || (a == b && d2 > d1);
+}
 
-// Host-side model of the wave reductions the device does with xor-butterflies of lane shuffles (same pairing, so the
-// same rounding): combine(v[l], v[l ^ off]) for off = 32, 16, ..., 1; every lane ends with the full result.
+// Host-side model of the wave reductions (mpc_wave_dev.hpp): symmetric partner exchanges inside each 16-lane row
+// (xor 1, xor 2, mirror within 8, mirror within 16), then the four row results as (r0 op r1) op (r2 op r3).
 #if !defined(__HIPCC__)
+inline int row_partner(int l, int step) {
+    return step == 0 ? (l ^ 1) : (step == 1 ? (l ^ 2) : (step == 2 ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15)))));
+}
 template <class T, class OP>
-inline T host_butterfly(PerLane<T> &p, OP op) {
-    for (int off = kLanes / 2; off; off >>= 1) {
+inline void host_row_reduce(PerLane<T> &p, OP op) {
+    for (int step = 0; step < 4; ++step) {
         T nv[kLanes];
-        for (int l = 0; l < kLanes; ++l) nv[l] = op(p.v[l], p.v[l ^ off]);
+        for (int l = 0; l < kLanes; ++l) nv[l] = op(p.v[l], p.v[row_partner(l, step)]);
         for (int l = 0; l < kLanes; ++l) p.v[l] = nv[l];
     }
-    return p.v[0];
+}
+template <class T, class OP>
+inline T host_butterfly(PerLane<T> &p, OP op) {
+    host_row_reduce(p, op);
+    return op(op(p.v[0], p.v[16]), op(p.v[32], p.v[48]));
 }
 #endif
 

@@ -1,0 +1,119 @@
+// mpc_wave_dev.hpp - the device side of the CTX interface of mpc_wave.hpp (one wave64 = one workgroup = one MPC
+// instance): LDS access, per-lane sections, the FP64 matrix core, lane permutations and wave reductions.
+// WaveOps is the base of the product kernel's context (mpc_engine.hip) and of the profiling build
+// (tools/ubench/wave_sections.hip); tests/cpu_wave_harness.cpp is the host model of the same interface.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "mpc_wave.hpp"
+
+namespace mpc {
+namespace wave {
+
+typedef __attribute__((address_space(3))) double lds_double_t;
+
+// DPP row controls (GFX9): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// Reduction inside each 16-lane row with symmetric partner exchanges (xor 1, xor 2, mirror within 8, mirror within
+// 16): both partners combine the same two values, so all lanes of a row end bit-identical.
+template <class OP>
+__device__ __forceinline__ double row_reduce(double v, OP op) {
+    v = op(v, dpp_f64<kDppXor1>(v));
+    v = op(v, dpp_f64<kDppXor2>(v));
+    v = op(v, dpp_f64<kDppHalfMirror>(v));
+    v = op(v, dpp_f64<kDppMirror>(v));
+    return v;
+}
+
+struct WaveOps {
+    lds_double_t *L;  // this instance's LDS words
+    __device__ __forceinline__ double ld(int i) const { return L[i]; }
+    __device__ __forceinline__ void st(int i, double v) { L[i] = v; }
+    // A phase ends where other lanes may read what this one wrote to LDS.  The workgroup is one wave, whose LDS
+    // instructions execute in issue order, so no hardware barrier or wait is needed - only the compiler must keep the
+    // program order of the LDS accesses.
+    template <class F>
+    __device__ __forceinline__ void phase(F &&f) {
+        f((int)threadIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    template <class F>
+    __device__ __forceinline__ void lanes(F &&f) {
+        f((int)threadIdx.x);
+    }
+    __device__ __forceinline__ void mfma(PerLane<double> &a, PerLane<double> &b, PerLane<double> &cd) const {
+        cd.v = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v, b.v, cd.v, 0, 0, 0);
+    }
+    __device__ __forceinline__ void take(PerLane<double> &dst, PerLane<double> &src, PerLane<int> &from) const {
+        dst.v = __shfl(src.v, from.v);
+    }
+    __device__ __forceinline__ double lane_get(PerLane<double> &p, int lane) const { return readlane_f64(p.v, lane); }
+    __device__ __forceinline__ int wave_bcast(PerLane<int> &p, int lane) const {
+        return __builtin_amdgcn_readlane(p.v, lane);
+    }
+    // wave reductions: DPP inside the 16-lane rows, then the four row results (read with v_readlane) are combined
+    // as (r0 op r1) op (r2 op r3) identically in every lane
+    template <class OP>
+    __device__ __forceinline__ double reduce(double v, OP op) const {
+        v = row_reduce(v, op);
+        return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
+    }
+    __device__ __forceinline__ double wave_sum(PerLane<double> &p) const {
+        return reduce(p.v, [](double a, double b) { return a + b; });
+    }
+    __device__ __forceinline__ double wave_max(PerLane<double> &p) const {
+        return reduce(p.v, [](double a, double b) { return fmax2(a, b); });
+    }
+    __device__ __forceinline__ double wave_min(PerLane<double> &p) const {
+        return reduce(p.v, [](double a, double b) { return fmin2(a, b); });
+    }
+    __device__ __forceinline__ void wave_sum2(PerLane<double> &p, double &lo, double &hi) const {
+        const double v = row_reduce(p.v, [](double a, double b) { return a + b; });
+        lo = readlane_f64(v, 0) + readlane_f64(v, 16);
+        hi = readlane_f64(v, 32) + readlane_f64(v, 48);
+    }
+    __device__ __forceinline__ void wave_max_ratio(PerLane<double> &pn, PerLane<double> &pd, double &rn, double &rd) const {
+        double n = pn.v, d = pd.v;
+#define MPC_RATIO_STEP(CTRL)                                                      \
+    {                                                                             \
+        const double n2 = dpp_f64<CTRL>(n), d2 = dpp_f64<CTRL>(d);                \
+        const bool t = ratio_greater(n2, d2, n, d);                               \
+        n = t ? n2 : n;                                                           \
+        d = t ? d2 : d;                                                           \
+    }
+        MPC_RATIO_STEP(kDppXor1)
+        MPC_RATIO_STEP(kDppXor2)
+        MPC_RATIO_STEP(kDppHalfMirror)
+        MPC_RATIO_STEP(kDppMirror)
+#undef MPC_RATIO_STEP
+        double bn = readlane_f64(n, 0), bd = readlane_f64(d, 0);
+#pragma unroll
+        for (int r = 16; r < 64; r += 16) {
+            const double n2 = readlane_f64(n, r), d2 = readlane_f64(d, r);
+            const bool t = ratio_greater(n2, d2, bn, bd);
+            bn = t ? n2 : bn;
+            bd = t ? d2 : bd;
+        }
+        rn = bn;
+        rd = bd;
+    }
+};
+
+}  // namespace wave
+}  // namespace mpc

@@ -54,22 +54,19 @@ struct HostCtx {
         return mpc::wave::host_butterfly(p, [](double a, double b) { return mpc::fmin2(a, b); });
     }
     void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
-        for (int off = 16; off; off >>= 1) {
-            double nv[mpc::wave::kLanes];
-            for (int l = 0; l < mpc::wave::kLanes; ++l) nv[l] = p.v[l] + p.v[l ^ off];
-            for (int l = 0; l < mpc::wave::kLanes; ++l) p.v[l] = nv[l];
-        }
-        lo = p.v[0];
-        hi = p.v[32];
+        mpc::wave::host_row_reduce(p, [](double a, double b) { return a + b; });
+        lo = p.v[0] + p.v[16];
+        hi = p.v[32] + p.v[48];
     }
     int wave_bcast(mpc::wave::PerLane<int> &p, int lane) const { return p.v[lane]; }
     void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd, double &rn, double &rd) const {
-        for (int off = mpc::wave::kLanes / 2; off; off >>= 1) {
+        for (int step = 0; step < 4; ++step) {
             double nn[mpc::wave::kLanes], nd[mpc::wave::kLanes];
             for (int l = 0; l < mpc::wave::kLanes; ++l) {
-                const bool take = mpc::wave::ratio_greater(pn.v[l ^ off], pd.v[l ^ off], pn.v[l], pd.v[l]);
-                nn[l] = take ? pn.v[l ^ off] : pn.v[l];
-                nd[l] = take ? pd.v[l ^ off] : pd.v[l];
+                const int q = mpc::wave::row_partner(l, step);
+                const bool take = mpc::wave::ratio_greater(pn.v[q], pd.v[q], pn.v[l], pd.v[l]);
+                nn[l] = take ? pn.v[q] : pn.v[l];
+                nd[l] = take ? pd.v[q] : pd.v[l];
             }
             for (int l = 0; l < mpc::wave::kLanes; ++l) {
                 pn.v[l] = nn[l];
@@ -78,6 +75,11 @@ struct HostCtx {
         }
         rn = pn.v[0];
         rd = pd.v[0];
+        for (int r = 16; r < mpc::wave::kLanes; r += 16)
+            if (mpc::wave::ratio_greater(pn.v[r], pd.v[r], rn, rd)) {
+                rn = pn.v[r];
+                rd = pd.v[r];
+            }
     }
     double ref(int k, int c) const {
         int idx = e0 + k;

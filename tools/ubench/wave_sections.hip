@@ -7,88 +7,22 @@
 
 #include <cstdint>
 
-#include "../../mpc-rl_for_avs_amd/csrc/mpc_wave.hpp"
+#include "../../mpc-rl_for_avs_amd/csrc/mpc_wave_dev.hpp"
 
 namespace {
-typedef __attribute__((address_space(3))) double lds_double;
 
-struct ProfCtx {
+struct ProfCtx : mpc::wave::WaveOps {
     static constexpr int kN = 20;
-    lds_double *L;
     const double *table;
     int e0, M;
     unsigned long long *acc;   // [T_COUNT] of this instance (lane 0 writes)
     unsigned long long last;
-    __device__ __forceinline__ double ld(int i) const { return L[i]; }
-    __device__ __forceinline__ void st(int i, double v) { L[i] = v; }
-    template <class F>
-    __device__ __forceinline__ void phase(F &&f) {
-        f((int)threadIdx.x);
-        __syncthreads();
-    }
+    __device__ __forceinline__ ProfCtx(mpc::wave::lds_double_t *l, const double *t, int e, int m, unsigned long long *a)
+        : mpc::wave::WaveOps{l}, table(t), e0(e), M(m), acc(a), last(0ull) {}
     __device__ __forceinline__ void tick(int s) {
         const unsigned long long now = __builtin_readcyclecounter();
         if (threadIdx.x == 0) acc[s] += now - last;
         last = now;
-    }
-    // register-only per-lane work, the FP64 matrix core, lane permutation, lane broadcast
-    template <class F>
-    __device__ __forceinline__ void lanes(F &&f) {
-        f((int)threadIdx.x);
-    }
-    __device__ __forceinline__ void mfma(mpc::wave::PerLane<double> &a, mpc::wave::PerLane<double> &b,
-                                         mpc::wave::PerLane<double> &cd) const {
-        cd.v = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v, b.v, cd.v, 0, 0, 0);
-    }
-    __device__ __forceinline__ void take(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src,
-                                         mpc::wave::PerLane<int> &from) const {
-        dst.v = __shfl(src.v, from.v);
-    }
-    __device__ __forceinline__ double lane_get(mpc::wave::PerLane<double> &p, int lane) const {
-        const long long bits = __double_as_longlong(p.v);
-        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), lane);
-        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), lane);
-        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    }
-    // wave reductions: xor-butterfly of lane shuffles, every lane ends with the result
-    __device__ __forceinline__ double wave_sum(mpc::wave::PerLane<double> &p) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
-        return v;
-    }
-    __device__ __forceinline__ double wave_max(mpc::wave::PerLane<double> &p) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) v = mpc::fmax2(v, __shfl_xor(v, off));
-        return v;
-    }
-    __device__ __forceinline__ double wave_min(mpc::wave::PerLane<double> &p) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) v = mpc::fmin2(v, __shfl_xor(v, off));
-        return v;
-    }
-    __device__ __forceinline__ void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
-        double v = p.v;
-#pragma unroll
-        for (int off = 16; off; off >>= 1) v += __shfl_xor(v, off);
-        lo = __shfl(v, 0);
-        hi = __shfl(v, 32);
-    }
-    __device__ __forceinline__ int wave_bcast(mpc::wave::PerLane<int> &p, int lane) const { return __shfl(p.v, lane); }
-    __device__ __forceinline__ void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd,
-                                                   double &rn, double &rd) const {
-        double n = pn.v, d = pd.v;
-#pragma unroll
-        for (int off = 32; off; off >>= 1) {
-            const double n2 = __shfl_xor(n, off), d2 = __shfl_xor(d, off);
-            const bool take = mpc::wave::ratio_greater(n2, d2, n, d);
-            n = take ? n2 : n;
-            d = take ? d2 : d;
-        }
-        rn = n;
-        rd = d;
     }
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
@@ -109,7 +43,7 @@ __global__ __launch_bounds__(64, 2) void prof_kernel(mpc::SolveParams P, int B, 
     constexpr int N = 20;
     const int b = blockIdx.x, lane = threadIdx.x;
     constexpr int SL = mpc::wave::stage_slots(CC);
-    ProfCtx ctx{(lds_double *)smem, ref5, ego_index[b], M, cycles + (size_t)b * mpc::wave::T_COUNT, 0ull};
+    ProfCtx ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M, cycles + (size_t)b * mpc::wave::T_COUNT);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
     if (lane <= N) ctx.st(lane * SL + mpc::wave::W_RV, vref[(size_t)b * (N + 1) + lane]);
     if (CC && lane < P.V) {
