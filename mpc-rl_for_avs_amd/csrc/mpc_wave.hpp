@@ -4,7 +4,7 @@
 // 64 lanes of a wave work on a single instance:
 //   * everything that is independent per stage (trig and linearisation of the dynamics, cost and collision-potential
 //     values and derivatives, barrier terms, complementarity, stage Hessians, dual residual, step-length ratios, dual
-//     update) runs stage-parallel, lane k = stage k, with shuffle-butterfly reductions;
+//     update) runs stage-parallel, lane k = stage k, with register-level wave reductions;
 //   * the Riccati / DDP factorisation stage works on the 8x8 stage KKT block [Hxx Hxp Hxu; . Hpp Hpu; . . Huu]
 //     (state 4 + previous control 2 + control 2) held in registers in the C/D layout of v_mfma_f64_4x4x4f64 (2x2 blocks
 //     of 4x4): T = P F, H = L + F'T, W = Huu^-1 H(u,.), P' = H - H(.,u) W and the gradient recursion are nine FP64
@@ -17,8 +17,9 @@
 // wave), with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state has to sit in LDS.
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
-// (f(lane) per lane, followed by a wave barrier); tests/cpu_wave_harness.cpp runs the phases as loops over the
-// 64 lanes, so the same source is validated on the CPU against the oracle.
+// (f(lane) per lane; other lanes may read afterwards what a lane wrote to LDS); tests/cpu_wave_harness.cpp runs the
+// phases as loops over the 64 lanes and models the matrix core, the lane permutations and the reductions, so the same
+// source is validated on the CPU against the oracle.  The device side of CTX is mpc_wave_dev.hpp.
 #pragma once
 
 #include "mpc_core.hpp"
