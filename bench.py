@@ -88,6 +88,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
     if use_dist:
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"        # keep RCCL's version banner off stdout: rank 0 prints ONE line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
