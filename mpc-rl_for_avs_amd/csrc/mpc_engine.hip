@@ -1,13 +1,15 @@
-// mpc_engine.hip - gfx950 kernel and the C ABI (include/mpc_mi355x.h) of the batched MPC solve engine.
+// mpc_engine.hip - gfx950 kernels and the C ABI (include/mpc_mi355x.h) of the batched MPC solve engine.
 //
-// Execution model.  One wave64 lane solves one MPC instance start to finish (mpc_core.hpp); lanes never
-// exchange data.  The solver's per-stage state (iterates, multipliers, adjoint, Riccati gains: 46-54 doubles
-// per stage) lives in LDS, laid out [slot][stage][instance] so the active lanes of a wave read consecutive
-// doubles (bank-conflict free ds_read_b64); the 85-point reference path is staged into LDS once per
-// workgroup and gathered by ego_index + k.  HBM is touched only for the inputs (~0.9 KB per instance, read
-// once) and the outputs.  With ~9 KB of LDS per instance a CU (160 KB) holds 16 instances; a workgroup is
-// one wave carrying IPW of them (IPW = 1, 4 or 16 chosen from the batch size so that the workgroups cover
-// all 256 CUs / 8 XCDs before any CU gets a second one).
+// Kernels (all: workgroup = one wave64, no inter-workgroup communication, HBM touched only for inputs / outputs):
+//   mpc_solve_wave_kernel   one wave per MPC instance (mpc_wave.hpp + mpc_wave_dev.hpp), horizons <= 32: stage-parallel
+//                           phases, Riccati stage on the FP64 matrix cores, all line-search step lengths at once;
+//                           per-instance state (46-54 doubles per stage + trial areas, 14 KB at N = 20) in LDS
+//   mpc_solve_kernel        one lane per instance (mpc_core.hpp), IPW = 1, 4 or 16 instances per wave, LDS layout
+//                           [stage][slot][instance]; used for horizons 33..64 (and MPC_KERNEL=lane)
+//   mpc_preamble_kernel     observation -> problem data (mpc_preamble.hpp), 16 lanes per environment
+//   mpc_env_reset_kernel    episode boundaries of the per-environment detector state
+// Host side: argument checks, staging of host-pointer calls through one device buffer on the caller's stream,
+// per-handle device state (reference table, environment records, preamble outputs).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -39,10 +41,9 @@ int fail(int code, const std::string &msg) {
     } while (0)
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
-// Waves per SIMD the wave-cooperative kernel is compiled for: 2 (~240 VGPRs, no scratch; HBM traffic = inputs and
-// outputs only).  LDS (15.9 KB per wave at N = 20 with the collision cost) allows 10 waves per CU, i.e. 2.5 per SIMD;
-// a 3-waves/SIMD build (168 VGPRs) spills 250 B/lane and measured slower at every batch size (B = 65536: 1.15 M vs
-// 1.39 M solves/s), a 4-wave build slower still.
+// Waves per SIMD the wave-cooperative kernel is compiled for: 2 (~210 VGPRs, no scratch; HBM traffic = inputs and
+// outputs only).  LDS (14.4 KB per wave at N = 20 with the collision cost) allows 11 waves per CU; a 3-waves/SIMD
+// build (168 VGPRs, 32 B/lane scratch) measured the same at B = 4096 and B = 65536, a 4-wave build slower.
 constexpr int kWaveOcc = 2;
 
 // LDS-resident workspace of one lane: element (slot, stage k) of this instance

@@ -76,8 +76,7 @@ MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
-    T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_ASM, T_RIC_L2, T_RIC_2X2, T_RIC_L3,
-    T_RIC_L4, T_LINEAR, T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD, T_COUNT
+    T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_L2, T_RIC_2X2, T_RIC_L4, T_LINEAR, T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD, T_COUNT
 };
 
 // A value that differs per lane and lives across phases: one register per lane on the device; the host emulation,

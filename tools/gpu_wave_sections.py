@@ -12,8 +12,8 @@ import torch
 from mpc_rl_for_avs_amd import synth
 from mpc_rl_for_avs_amd.reference_path import reference_states
 
-NAMES = ["prep", "adjoint", "dualres", "ric_init", "ric_scalars", "ric_L1", "ric_asm", "ric_L2", "ric_2x2", "ric_L3",
-         "ric_L4", "linear", "ratios", "roll_dyn", "roll_cost", "dualupd"]
+NAMES = ["prep", "adjoint", "dualres", "ric_assembly", "ric_operands", "ric_T", "ric_H", "ric_2x2", "ric_schur",
+         "linear", "ratios", "roll_dyn", "roll_cost", "dualupd"]
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libwave_sections.so"))
 assert lib.wave_sections_count() == len(NAMES)
 dev = torch.device("cuda", 0)
@@ -43,13 +43,13 @@ def run(inp, idx, cc, V, label):
     iters = it.cpu().numpy()
     tot = c.sum(axis=1)
     print(f"--- {label}: B={B}, iterations mean {iters.mean():.1f} max {iters.max()}, cycles/iteration "
-          f"{(tot / np.maximum(iters, 1)).mean():.0f} (s_memtime counts at 100 MHz: x24 for 2.4 GHz core cycles)")
+          f"{(tot / np.maximum(iters, 1)).mean():.0f} (shader clock cycles)")
     share = c.sum(axis=0) / tot.sum()
     per_it = c.sum(axis=0) / iters.sum()
     for n, s, q in zip(NAMES, share, per_it):
         print(f"   {n:12s} {100 * s:5.1f} %   {q:8.1f} ticks/iteration")
-    ric = share[3:11].sum()
-    print(f"   riccati total {100 * ric:.1f} %, rollout total {100 * share[13:15].sum():.1f} %")
+    ric = share[3:9].sum()
+    print(f"   riccati total {100 * ric:.1f} %, rollout total {100 * share[11:13].sum():.1f} %")
 
 
 inp = synth.solver_inputs(4096, 8, seed=0, N=20)
