@@ -22,7 +22,9 @@ highway-env, gymnasium and stable-baselines3 are not available offline, so
     create_a2c_policy` (trainers/trainer_utils.py:6-45): flattened 80-d observation, separate 64-64 tanh towers
     for policy and value, diagonal Gaussian over a Box(-1, 1)^dim action (dim 1 = reference speed "v0",
     dim 3 = cost weights "v1", trainers/trainer.py:422-428).
-  * `RolloutBuffer.compute_returns_and_advantage` is generalised advantage estimation as SB3 defines it.
+  * `RolloutBuffer.compute_returns_and_advantage` is generalised advantage estimation as SB3 defines it, and
+    `OnPolicyTrainer` the PPO / A2C parameter update of the reference's `train()` methods, so that a whole
+    collect -> update loop runs without stable-baselines3.
 """
 from __future__ import annotations
 
@@ -322,3 +324,94 @@ class BatchedCollector:
         last_values = self.policy.predict_values(self._last_obs)
         self.buffer.compute_returns_and_advantage(last_values, dones)
         return dict(steps=n * self.env.num_envs, episodes=int(ep_done), crashed=int(crashed), arrived=int(arrived))
+
+
+class OnPolicyTrainer:
+    """collect -> update loop of the reference's MPC-RL agents for B environments (`PPO_MPC.learn/train`
+    agents/ppo_mpc.py:218-330, `A2C_MPC.train` agents/a2c_mpc.py:182-226; both are stable-baselines3's on-policy
+    algorithms with the MPC call inside `collect_rollouts`).  The update is what those `train()` methods compute:
+
+      ppo  n_epochs passes over the buffer in shuffled minibatches; clipped surrogate
+           -mean(min(A r, A clip(r, 1-eps, 1+eps))) with r = exp(logp - logp_old), advantages normalised per minibatch,
+           + vf_coef * mse(returns, V) + ent_coef * (-mean entropy); Adam, gradient-norm clip
+           (defaults of config/cfg.yaml:66-86: lr 3e-4, 10 epochs, clip 0.2, gamma 0.99, lambda 0.95)
+      a2c  one step on the whole buffer: -mean(A logp) + vf_coef * mse + ent_coef * (-mean entropy); RMSprop
+           (alpha 0.99, eps 1e-5), no advantage normalisation, lambda 1 (config/cfg.yaml:31-61)
+    """
+
+    def __init__(self, collector: BatchedCollector, learning_rate: float | None = None, n_epochs: int = 10,
+                 batch_size: int = 256, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
+                 max_grad_norm: float = 0.5, normalize_advantage: bool | None = None, seed: int = 0):
+        self.col = collector
+        self.algorithm = collector.algorithm
+        pol = collector.policy
+        if self.algorithm == "ppo":
+            self.opt = torch.optim.Adam(pol.parameters(), lr=3e-4 if learning_rate is None else learning_rate, eps=1e-5)
+            self.normalize_advantage = True if normalize_advantage is None else normalize_advantage
+        else:
+            self.opt = torch.optim.RMSprop(pol.parameters(), lr=7e-4 if learning_rate is None else learning_rate,
+                                           alpha=0.99, eps=1e-5)
+            self.normalize_advantage = False if normalize_advantage is None else normalize_advantage
+        self.n_epochs, self.batch_size, self.clip_range = int(n_epochs), int(batch_size), float(clip_range)
+        self.ent_coef, self.vf_coef, self.max_grad_norm = float(ent_coef), float(vf_coef), float(max_grad_norm)
+        self.gen = torch.Generator(device=collector.env.device)
+        self.gen.manual_seed(int(seed))
+        self.n_updates = 0
+
+    def _flat(self):
+        b = self.col.buffer
+        f = lambda t: t.reshape((-1,) + t.shape[2:])
+        return f(b.obs), f(b.actions), f(b.log_probs), f(b.advantages), f(b.returns)
+
+    def _loss(self, obs, actions, old_logp, adv, ret):
+        values, logp, entropy = self.col.policy.evaluate_actions(obs, actions)
+        if self.normalize_advantage and adv.numel() > 1:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        if self.algorithm == "ppo":
+            ratio = torch.exp(logp - old_logp)
+            pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1.0 - self.clip_range, 1.0 + self.clip_range)).mean()
+        else:
+            pg = -(adv * logp).mean()
+        vl = torch.nn.functional.mse_loss(ret, values)
+        el = -entropy.mean()
+        return pg + self.ent_coef * el + self.vf_coef * vl, pg, vl, el
+
+    def train(self):
+        """One update from the collector's (full) buffer; returns the mean losses."""
+        pol = self.col.policy
+        pol.train()
+        obs, actions, old_logp, adv, ret = self._flat()
+        n = obs.shape[0]
+        stats = []
+        if self.algorithm == "ppo":
+            for _ in range(self.n_epochs):
+                perm = torch.randperm(n, generator=self.gen, device=obs.device)
+                for lo in range(0, n, self.batch_size):
+                    idx = perm[lo:lo + self.batch_size]
+                    loss, pg, vl, el = self._loss(obs[idx], actions[idx], old_logp[idx], adv[idx], ret[idx])
+                    self.opt.zero_grad()
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(pol.parameters(), self.max_grad_norm)
+                    self.opt.step()
+                    stats.append(torch.stack([loss.detach(), pg.detach(), vl.detach(), el.detach()]))
+                self.n_updates += 1
+        else:
+            loss, pg, vl, el = self._loss(obs, actions, old_logp, adv, ret)
+            self.opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(pol.parameters(), self.max_grad_norm)
+            self.opt.step()
+            stats.append(torch.stack([loss.detach(), pg.detach(), vl.detach(), el.detach()]))
+            self.n_updates += 1
+        m = torch.stack(stats).mean(dim=0).tolist()
+        return dict(loss=m[0], policy_loss=m[1], value_loss=m[2], entropy_loss=m[3])
+
+    def learn(self, total_timesteps: int):
+        """collect_rollouts / train until `total_timesteps` environment steps were taken (BaseAlgorithm.learn)."""
+        log = []
+        while self.col.num_timesteps < total_timesteps:
+            roll = self.col.collect_rollouts()
+            upd = self.train()
+            log.append(dict(roll, **upd, timesteps=self.col.num_timesteps,
+                            mean_reward=float(self.col.buffer.rewards.mean())))
+        return log

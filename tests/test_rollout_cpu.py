@@ -117,3 +117,40 @@ def test_ppo_bootstraps_truncated_episodes_and_optional_mpc_reset():
     assert torch.equal(col.buffer.episode_starts[2], torch.ones(4))
     with pytest.raises(ValueError):
         rollout.BatchedCollector(env, rollout.ActorCritic(1), eng, version="v1")
+
+
+@pytest.mark.parametrize("algo", ["ppo", "a2c"])
+def test_policy_update_matches_the_published_losses_and_learns(algo):
+    """PPO / A2C update on the collector's buffer: first minibatch loss against the formulas written out here, and a
+    repeated updates on one buffer lower the value loss; `learn` alternates collection and updates."""
+    torch.manual_seed(1)
+    env = rollout.SyntheticIntersectionEnv(16, seed=2, n_others=2)
+    pol = rollout.ActorCritic(1)
+    col = rollout.BatchedCollector(env, pol, StubEngine(), version="v0", algorithm=algo, n_steps=8,
+                                   gae_lambda=0.95 if algo == "ppo" else 1.0)
+    tr = rollout.OnPolicyTrainer(col, n_epochs=2, batch_size=64, ent_coef=0.01)
+    col.collect_rollouts()
+    obs, act, oldlp, adv, ret = tr._flat()
+    assert obs.shape == (128, 10, 8) and adv.shape == (128,)
+    loss, pg, vl, el = tr._loss(obs, act, oldlp, adv, ret)
+    with torch.no_grad():
+        v, lp, ent = pol.evaluate_actions(obs, act)
+        a = (adv - adv.mean()) / (adv.std() + 1e-8) if algo == "ppo" else adv
+        if algo == "ppo":
+            r = torch.exp(lp - oldlp)
+            want_pg = -torch.minimum(a * r, a * r.clamp(0.8, 1.2)).mean()
+            assert torch.allclose(r, torch.ones_like(r), atol=1e-5)           # same policy: ratio 1
+        else:
+            want_pg = -(a * lp).mean()
+        want = want_pg + 0.01 * (-ent.mean()) + 0.5 * ((ret - v) ** 2).mean()
+    assert torch.allclose(loss, want, rtol=1e-5, atol=1e-6)
+    before = [p.detach().clone() for p in pol.parameters()]
+    first = tr.train()
+    assert any(not torch.equal(b, p.detach()) for b, p in zip(before, pol.parameters()))
+    assert tr.n_updates == (2 if algo == "ppo" else 1)
+    for _ in range(30):                                # same buffer again and again: the critic must fit its returns
+        last = tr.train()
+    assert last["value_loss"] < first["value_loss"]
+    log = tr.learn(total_timesteps=col.num_timesteps + 3 * 128)
+    assert len(log) == 3 and all(np.isfinite(list(r.values())).all() for r in log)
+    assert log[-1]["timesteps"] == col.num_timesteps
