@@ -160,3 +160,20 @@ def test_closed_loop_single_ego_follows_the_route():
     outcome2, log2, _ = mod.run(steps=150, n_others=1, seed=1, verbose=False)     # with cross traffic
     assert outcome2 in ("arrived", "crashed", "timeout", "running")
     assert np.mean([r[6] == 0 for r in log2]) > 0.8
+
+
+def test_learn_loop_with_mpc_in_the_loop_on_device():
+    """collect -> PPO update -> collect with the real engine and everything on the GPU (config 4 in miniature)."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, rollout
+    dev = torch.device("cuda", 0)
+    eng = engine.MPCEngine(horizon=20, max_iter=100)
+    env = rollout.SyntheticIntersectionEnv(64, device=dev, seed=4, n_others=3)
+    pol = rollout.ActorCritic(1).to(dev)
+    col = rollout.BatchedCollector(env, pol, eng, version="v0", algorithm="ppo", n_steps=8)
+    tr = rollout.OnPolicyTrainer(col, n_epochs=2, batch_size=128)
+    log = tr.learn(total_timesteps=3 * 64 * 8)
+    assert len(log) == 3 and col.num_timesteps == 3 * 64 * 8
+    assert all(np.isfinite([r["loss"], r["value_loss"], r["mean_reward"]]).all() for r in log)
+    assert (col.last_mpc["status"] == 0).float().mean() > 0.9
+    eng.close()
