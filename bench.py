@@ -51,6 +51,17 @@ def cpu_baseline(inp, sample: int):
                        f"mean {float(out['iters'].mean()):.1f} iterations"), out
 
 
+def pmc_counter(name):
+    """Mean per launch of one counter from the committed PMC passes (profiles/r*_pmc_summary.csv), or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return None
+    vals = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(open(files[-1]))}
+    return vals.get(name)
+
+
 def pmc_traffic_bytes():
     """HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
     same command, profiles/r*_pmc_summary.csv, KB units). The loads are 8-byte strided, outside the access widths
@@ -160,6 +171,17 @@ def main():
             "solver": {"converged_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
                        "iters_max": int(iters.max())},
         }
+        # the resource this kernel actually consumes: vector-instruction issue slots (a wave64 FP64 instruction
+        # occupies its SIMD for 4 cycles).  SIMD-cycles needed = wave-instructions (PMC) x 4; available = SIMDs x clock
+        # x kernel time.  Small because the batch ends with a few lone waves.
+        valu = pmc_counter("SQ_INSTS_VALU")
+        if valu is not None:
+            prop = torch.cuda.get_device_properties(dev)
+            simds = 4 * prop.multi_processor_count
+            clock_hz = 1e3 * float(getattr(prop, "clock_rate", 2.4e6))
+            res["valu_issue"] = {"wave_instructions_per_launch": valu, "simds": simds, "clock_ghz": clock_hz / 1e9,
+                                 "frac": valu * 4.0 / (simds * clock_hz * kern_ms * 1e-3),
+                                 "note": "fraction of the GPU's vector-instruction issue slots used during the kernel"}
         if world == 1 and not a.no_cpu_baseline:
             cb, oref = cpu_baseline(inp, sample=BATCH)
             res["cpu_baseline"] = cb
