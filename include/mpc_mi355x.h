@@ -40,6 +40,14 @@ extern "C" {
 #define MPC_FLAG_COLLISION_COST 1u /* add the distance/collision terms of agents/archive/pure_mpc.py:189-206 */
 #define MPC_FLAG_DEVICE_PTRS 2u    /* all data pointers are device memory (else host memory, copied internally) */
 #define MPC_FLAG_NO_SYNC 4u        /* with DEVICE_PTRS: enqueue only, do not synchronise the stream */
+#define MPC_FLAG_WARM_START 8u     /* NOT in the reference (which cold-starts every solve, agents/pure_mpc.py:240-246):
+                                      start from given controls instead of zeros.  They are clamped 0.1 % inside their
+                                      bounds; if their rollout leaves the state bounds the cold start is used.  Changes
+                                      the iterates (fewer of them), not the KKT point aimed at; horizons <= 32 only.
+                                      mpc_solve_batch: U (required) holds the initial controls on entry;
+                                      mpc_predict_batch: each environment starts from its previous solution advanced by
+                                      one stage (kept in the handle, forgotten by the reset calls);
+                                      mpc_reset_env_mask: forget only that memory, keep the detector state */
 
 /* per-instance solver status written to status[] */
 #define MPC_STATUS_CONVERGED 0

@@ -85,6 +85,12 @@ MPC_HD double uhi_r(int i) { return i == 0 ? 5.0 + 5e-8 : (MPC_PI / 3.0) + 1e-8 
 
 constexpr double kInvWheelbase = 1.0 / 2.5;  // Vehicle.LENGTH, agents/utils.py:18
 
+// warm start (opt-in, not in the reference): given initial controls are moved 0.1 % of the range inside their bounds
+MPC_HD double warm_clamp(double u, int i) {
+    const double lo = i == 0 ? -5.0 : -(MPC_PI / 3.0), hi = -lo, m = 1e-3 * (hi - lo);
+    return fmin2(fmax2(u, lo + m), hi - m);
+}
+
 // ---- lean FP64 math -------------------------------------------------------------------------------
 // The solver is bound by instruction issue / instruction-cache footprint, not by memory, so the generic
 // libm expansions (large-argument trig reduction, IEEE division with denormal fix-ups) are replaced by

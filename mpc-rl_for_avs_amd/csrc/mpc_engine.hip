@@ -198,8 +198,9 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
     const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
-    const int32_t *__restrict__ nveh, double w_collision, double *__restrict__ u0_out, double *__restrict__ U_out,
-    double *__restrict__ X_out, int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
+    const int32_t *__restrict__ nveh, double w_collision, const double *u_init, int u_shift, uint8_t *u_valid,
+    double *__restrict__ u0_out, double *U_out, double *__restrict__ X_out, int32_t *__restrict__ status_out,
+    int32_t *__restrict__ iters_out) {
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     const int b = blockIdx.x;
@@ -240,9 +241,20 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
                                              wcoll);
     int status, iters, cur;
     double kkt;
-    solver.solve(status, iters, cur, kkt);
+    // opt-in warm start: initial controls u_init[b][min(k + u_shift, N-1)] (u_shift = 1: the previous solution of this
+    // environment advanced by one stage), where u_valid (if given) says that there is one.  u_init may alias U_out: it
+    // is read here, before the solve, and written after it by the same wave.
+    const bool warm = u_init != nullptr && (u_valid == nullptr || u_valid[b] != 0);
+    if (warm && lane < N) {
+        const int src = min(lane + u_shift, N - 1);
+        ctx.st(lane * SL + mpc::wave::W_U + 0, mpc::warm_clamp(u_init[((size_t)b * N + src) * 2 + 0], 0));
+        ctx.st(lane * SL + mpc::wave::W_U + 1, mpc::warm_clamp(u_init[((size_t)b * N + src) * 2 + 1], 1));
+    }
+    __syncthreads();
+    solver.solve(status, iters, cur, kkt, warm);
     __syncthreads();
     const int CB = cur * 6;
+    if (lane == 0 && u_valid && U_out) u_valid[b] = 1;
     if (lane < 2) u0_out[(size_t)b * 2 + lane] = ctx.ld(CB + mpc::wave::W_U + lane);
     if (U_out && lane < N) {
         U_out[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 0);
@@ -304,13 +316,15 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
 }
 
 __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, const uint8_t *__restrict__ mask,
-                                     mpc::pre::EnvState *__restrict__ env, int cap) {
+                                     mpc::pre::EnvState *__restrict__ env, uint8_t *__restrict__ warm_valid, int cap,
+                                     int warm_only) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int b = ids ? ids[i] : i;
     if (b < 0 || b >= cap) return;
     if (mask && !mask[i]) return;
-    env[b] = mpc::pre::EnvState{};
+    if (!warm_only) env[b] = mpc::pre::EnvState{};
+    warm_valid[b] = 0;
 }
 
 }  // namespace
@@ -329,6 +343,8 @@ struct mpc_handle {
     // preamble kernel writes for the solve kernel
     mpc::pre::EnvState *d_env = nullptr;
     int env_cap = 0;
+    double *d_warm = nullptr;        // [env_cap][N][2] last control sequence per environment (MPC_FLAG_WARM_START)
+    uint8_t *d_warm_valid = nullptr; // [env_cap] 1 = d_warm holds a solution of the current episode
     void *d_pre = nullptr;
     size_t pre_bytes = 0;
     int pre_B = 0, pre_V = 0;   // shape of the last preamble output (for mpc_get_last_inputs)
@@ -381,14 +397,14 @@ int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t 
 template <bool CC, int NC, int OCC>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
-                const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, double *d_u0, double *d_U,
-                double *d_X, int32_t *d_status, int32_t *d_iters) {
+                const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
+                uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
-                       d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_u0, d_U, d_X, d_status,
-                       d_iters);
+                       d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_uinit, u_shift, d_uvalid,
+                       d_u0, d_U, d_X, d_status, d_iters);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
@@ -406,8 +422,8 @@ bool use_wave_kernel(int N) {
 // mpc_predict_batch).  d_nveh: vehicles present per instance or nullptr (= V for all).
 int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t stream, const double *d_state,
                    const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
-                   const double *d_others, const int32_t *d_nveh, double *d_u0, double *d_U, double *d_X,
-                   int32_t *d_status, int32_t *d_iters) {
+                   const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
+                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
     const int N = h->cfg.horizon;
     const int Vuse = cc ? V : 0;
     mpc::SolveParams P;
@@ -424,7 +440,8 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
         const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
 #define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                            \
     rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights,      \
-                                     d_coll, d_others, d_nveh, d_u0, d_U, d_X, d_status, d_iters)
+                                     d_coll, d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, \
+                                     d_iters)
         if (cc) {
             if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOcc);       /* BASELINE horizon */
             else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOcc);  /* reference cfg.yaml default */
@@ -437,6 +454,8 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
 #undef MPC_LAUNCH_W
         if (rc) return rc;
     } else {
+    if (d_uinit)
+        return fail(MPC_ERR_INVALID_ARG, "warm start is implemented by the wave kernel only (horizon <= 32)");
     const int ipw = choose_ipw(h, cc, B, N, Vuse);
     const size_t lds = lds_bytes(cc, ipw, N, h->M, Vuse);
     if (lds > h->lds_per_cu)
@@ -526,6 +545,8 @@ void mpc_destroy(mpc_handle *h) {
     if (h->d_ref) (void)hipFree(h->d_ref);
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_env) (void)hipFree(h->d_env);
+    if (h->d_warm) (void)hipFree(h->d_warm);
+    if (h->d_warm_valid) (void)hipFree(h->d_warm_valid);
     if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
 }
@@ -631,8 +652,12 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
         d_iters = reinterpret_cast<int32_t *>(sb + off_it);
     }
 
+    const bool warm = (flags & MPC_FLAG_WARM_START) != 0;
+    if (warm && !U) return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: MPC_FLAG_WARM_START needs U (initial controls in, solution out)");
+    if (warm && !dev)
+        HIP_TRY(hipMemcpyAsync(d_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
     if (int rc = dispatch_solve(h, B, cc, V, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, nullptr,
-                                d_u0, d_U, d_X, d_status, d_iters))
+                                warm ? d_U : nullptr, 0, nullptr, d_u0, d_U, d_X, d_status, d_iters))
         return rc;
 
     if (!dev) {
@@ -655,15 +680,28 @@ static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
     int cap = h->env_cap > 0 ? h->env_cap : 256;
     while (cap < B) cap *= 2;
     mpc::pre::EnvState *n = nullptr;
+    double *nw = nullptr;
+    uint8_t *nv = nullptr;
+    const size_t wrow = (size_t)h->cfg.horizon * 2 * sizeof(double);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&n), (size_t)cap * sizeof(mpc::pre::EnvState)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nw), (size_t)cap * wrow));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nv), (size_t)cap));
     HIP_TRY(hipMemsetAsync(n, 0, (size_t)cap * sizeof(mpc::pre::EnvState), stream));
+    HIP_TRY(hipMemsetAsync(nw, 0, (size_t)cap * wrow, stream));
+    HIP_TRY(hipMemsetAsync(nv, 0, (size_t)cap, stream));
     if (h->d_env) {
         HIP_TRY(hipMemcpyAsync(n, h->d_env, (size_t)h->env_cap * sizeof(mpc::pre::EnvState),
                                hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(nw, h->d_warm, (size_t)h->env_cap * wrow, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(nv, h->d_warm_valid, (size_t)h->env_cap, hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipFree(h->d_env));
+        HIP_TRY(hipFree(h->d_warm));
+        HIP_TRY(hipFree(h->d_warm_valid));
     }
     h->d_env = n;
+    h->d_warm = nw;
+    h->d_warm_valid = nv;
     h->env_cap = cap;
     return MPC_OK;
 }
@@ -758,8 +796,10 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
                        (int)B, d_obs, rows, h->d_ref, h->M, N, h->cfg.dt, d_rs, h->d_env, h->p_state, h->p_ego,
                        h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh);
     HIP_TRY(hipGetLastError());
+    const bool warm = (flags & MPC_FLAG_WARM_START) != 0;
     if (int rc = dispatch_solve(h, B, cc, V, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
-                                h->p_others, h->p_nveh, d_act, nullptr, nullptr, d_status, d_iters))
+                                h->p_others, h->p_nveh, warm ? h->d_warm : nullptr, 1, warm ? h->d_warm_valid : nullptr,
+                                d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters))
         return rc;
 
     if (!dev) {
@@ -781,6 +821,7 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (!env_ids || n < 0) {
         HIP_TRY(hipMemsetAsync(h->d_env, 0, (size_t)h->env_cap * sizeof(mpc::pre::EnvState), stream));
+        HIP_TRY(hipMemsetAsync(h->d_warm_valid, 0, (size_t)h->env_cap, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return MPC_OK;
     }
@@ -790,7 +831,7 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
     hipError_t e = hipMemcpyAsync(d_ids, env_ids, (size_t)n * 4, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int)n, d_ids,
-                           (const uint8_t *)nullptr, h->d_env, h->env_cap);
+                           (const uint8_t *)nullptr, h->d_env, h->d_warm_valid, h->env_cap, 0);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -817,7 +858,8 @@ int mpc_reset_env_mask(mpc_handle *h, int32_t B, const uint8_t *done, uint32_t f
     }
     const int n = B < h->env_cap ? B : h->env_cap;
     hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n,
-                       (const int32_t *)nullptr, d_done, h->d_env, h->env_cap);
+                       (const int32_t *)nullptr, d_done, h->d_env, h->d_warm_valid, h->env_cap,
+                       (flags & MPC_FLAG_WARM_START) ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && (tmp || !(flags & MPC_FLAG_NO_SYNC))) e = hipStreamSynchronize(stream);
     if (tmp) (void)hipFree(tmp);

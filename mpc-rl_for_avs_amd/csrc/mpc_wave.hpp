@@ -490,7 +490,9 @@ struct Solver {
     }
 
     // ---- the solve --------------------------------------------------------------------------------------
-    MPC_HD void solve(int &status_out, int &iters_out, int &cur_out, double &kkt_out) {
+    // warm: buffer 0 already holds initial controls (clamped inside their bounds by the caller) instead of the
+    // reference's cold start; if their rollout leaves the state bounds the cold start is used after all
+    MPC_HD void solve(int &status_out, int &iters_out, int &cur_out, double &kkt_out, bool warm = false) {
         int cur = 0;
         status_out = 1;
         iters_out = 0;
@@ -500,8 +502,6 @@ struct Solver {
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;
-            S(lane, W_U + 0, 0.0);
-            S(lane, W_U + 1, 0.0);
             for (int i = 0; i < 2; ++i) {
                 S(lane, W_ZUL + i, 1.0);
                 S(lane, W_ZUU + i, 1.0);
@@ -509,11 +509,18 @@ struct Solver {
                 S(lane + 1, W_ZXU + i, 1.0);
             }
         });
-        if (x0[3] < 0.01) S(0, W_U + 0, (0.01 - x0[3]) / dt);
         double Jcur = 0.0, barcur = 0.0;
-        if (!rollout_init(Jcur, barcur)) {
-            status_out = 3;
-            return;
+        if (!(warm && rollout_init(Jcur, barcur))) {
+            c.phase([&](int lane) {
+                if (lane >= N) return;
+                S(lane, W_U + 0, 0.0);
+                S(lane, W_U + 1, 0.0);
+            });
+            if (x0[3] < 0.01) S(0, W_U + 0, (0.01 - x0[3]) / dt);
+            if (!rollout_init(Jcur, barcur)) {
+                status_out = 3;
+                return;
+            }
         }
         // objective scaling: sf = 100 / clamp(|grad f|_inf at the start, 100, 1e4)
         {

@@ -17,6 +17,7 @@ from .reference_path import reference_states
 FLAG_COLLISION_COST = 1
 FLAG_DEVICE_PTRS = 2
 FLAG_NO_SYNC = 4
+FLAG_WARM_START = 8      # not in the reference: start from given / previous controls instead of zeros
 
 STATUS_CONVERGED = 0
 STATUS_MAX_ITER = 1
@@ -134,8 +135,9 @@ class MPCEngine:
 
     # ------------------------------------------------------------------ host (numpy) path
     def solve_batch(self, state, ego_index, weights, is_collide, vref=None, others=None, collision_cost=False,
-                    want_trajectories=True):
-        """Solve B instances given host arrays; returns dict(u0, U, X, status, iters)."""
+                    want_trajectories=True, u_init=None):
+        """Solve B instances given host arrays; returns dict(u0, U, X, status, iters).
+        u_init [B, N, 2] (optional, not in the reference): initial controls instead of the cold start."""
         N = self.horizon
         state = np.ascontiguousarray(state, dtype=np.float64)
         if state.ndim != 2 or state.shape[1] != 4:
@@ -160,6 +162,11 @@ class MPCEngine:
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
         flags = FLAG_COLLISION_COST if collision_cost else 0
+        if u_init is not None:
+            U = np.array(u_init, dtype=np.float64, order="C")       # in: initial controls, out: solution
+            if U.shape != (B, N, 2):
+                raise ValueError(f"u_init must be [B, N, 2] = {(B, N, 2)}, got {U.shape}")
+            flags |= FLAG_WARM_START
         rc = self._lib.mpc_solve_batch(self._h, B, _ptr(state), _ptr(ego_index), _ptr(vref), _ptr(weights),
                                        _ptr(is_collide), _ptr(others), V, flags, _ptr(u0), _ptr(U), _ptr(X),
                                        _ptr(status), _ptr(iters), None)
@@ -198,9 +205,10 @@ class MPCEngine:
         return out
 
     # ------------------------------------------------------------------ observation-level path
-    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False):
+    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False, warm_start=False):
         """obs[B, vehicles_count, 8] float32 -> dict(act[B, 2], status, iters): parsing, collision detector (with the
-        per-environment memory kept inside the engine), speed-profile rewrite and solve, all on the device."""
+        per-environment memory kept inside the engine), speed-profile rewrite and solve, all on the device.
+        warm_start (not in the reference): each environment starts from its previous solution advanced one stage."""
         obs = np.ascontiguousarray(obs, dtype=np.float32)
         if obs.ndim != 3 or obs.shape[2] != 8:
             raise ValueError(f"obs must be [B, vehicles_count, 8], got {obs.shape}")
@@ -210,13 +218,14 @@ class MPCEngine:
         act = np.empty((B, 2))
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
-        flags = FLAG_COLLISION_COST if collision_cost else 0
+        flags = (FLAG_COLLISION_COST if collision_cost else 0) | (FLAG_WARM_START if warm_start else 0)
         rc = self._lib.mpc_predict_batch(self._h, B, _ptr(obs), rows, _ptr(weights), _ptr(rs), flags, _ptr(act),
                                          _ptr(status), _ptr(iters), None)
         self._check(rc, "mpc_predict_batch")
         return dict(act=act, status=status, iters=iters)
 
-    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False):
+    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False,
+                            warm_start=False):
         """Zero-copy variant on torch device tensors (obs float32 [B, R, 8], weights float64 [B, 3], ref_speed float64
         [B] or None), enqueued on torch's current stream.  Returns dict(act, status, iters) of device tensors."""
         import torch
@@ -234,7 +243,8 @@ class MPCEngine:
             out = dict(act=torch.empty((B, 2), dtype=torch.float64, device=dev),
                        status=torch.empty(B, dtype=torch.int32, device=dev),
                        iters=torch.empty(B, dtype=torch.int32, device=dev))
-        flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC)
+        flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC) | \
+            (FLAG_WARM_START if warm_start else 0)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = self._lib.mpc_predict_batch(self._h, B, p(obs), rows, p(weights), p(ref_speed), flags, p(out["act"]),
@@ -251,14 +261,15 @@ class MPCEngine:
             rc = self._lib.mpc_reset_env_state(self._h, _ptr(ids), ids.size, None)
         self._check(rc, "mpc_reset_env_state")
 
-    def reset_env_mask_torch(self, done):
-        """Same from a uint8 device mask [B], enqueued on torch's current stream."""
+    def reset_env_mask_torch(self, done, warm_only=False):
+        """Same from a uint8 device mask [B], enqueued on torch's current stream; warm_only: forget just the warm-start
+        memory of those environments and keep their detector state."""
         import torch
         if done.dtype != torch.uint8 or not done.is_contiguous() or not done.is_cuda:
             raise ValueError("done: expected contiguous uint8 device tensor")
         stream = ctypes.c_void_p(torch.cuda.current_stream(done.device).cuda_stream)
         rc = self._lib.mpc_reset_env_mask(self._h, int(done.numel()), ctypes.c_void_p(done.data_ptr()),
-                                          FLAG_DEVICE_PTRS | FLAG_NO_SYNC, stream)
+                                          FLAG_DEVICE_PTRS | FLAG_NO_SYNC | (FLAG_WARM_START if warm_only else 0), stream)
         self._check(rc, "mpc_reset_env_mask")
 
     def env_state(self, B):

@@ -179,7 +179,7 @@ class PureMPC_Agent:
     weight_components = ["speed", "control", "input_diff"]   # agents/pure_mpc.py:15-22
 
     def __init__(self, env, cfg: dict, engine: MPCEngine | None = None, collision_cost: bool = False,
-                 device: int = 0, max_iter: int = 100, tol: float = 1e-8) -> None:
+                 device: int = 0, max_iter: int = 100, tol: float = 1e-8, warm_start: bool = False) -> None:
         # agents/base_agent.py:28-49
         self.env = env.unwrapped if hasattr(env, "unwrapped") else env
         self.env_config = self.env.config
@@ -201,6 +201,7 @@ class PureMPC_Agent:
         self.ttc_threshold = self.config.get("ttc_threshold", 3)
         self.default_weights = {f"weight_{k}": self.config[f"weight_{k}"] for k in PureMPC_Agent.weight_components}
         self.collision_cost = bool(collision_cost)
+        self.warm_start = bool(warm_start)       # predict_batch only; the reference always starts cold
         self._engine = engine if engine is not None else MPCEngine(
             horizon=self.horizon, dt=self.dt, max_iter=max_iter, tol=tol,
             w_distance=float(self.config.get("weight_distance", 10.0)),
@@ -294,7 +295,8 @@ class PureMPC_Agent:
         B = obs.shape[0]
         if w is None:
             w = np.tile([float(self.default_weights[f"weight_{k}"]) for k in PureMPC_Agent.weight_components], (B, 1))
-        out = self._engine.predict_batch(obs, w, None if rs is None else rs[:, 0], collision_cost=self.collision_cost)
+        out = self._engine.predict_batch(obs, w, None if rs is None else rs[:, 0], collision_cost=self.collision_cost,
+                                         warm_start=self.warm_start)
         self.last_solve = out
         bad = int(np.count_nonzero(out["status"]))
         if bad:                                             # agents/pure_mpc.py:303-305

@@ -259,12 +259,14 @@ class BatchedCollector:
     (agents/a2c_mpc.py:138-144).
     reset_mpc_on_done=False mirrors the reference, whose single MPC agent keeps its collision memory across
     episode boundaries; True forgets it (`mpc_reset_env_mask`) when an environment restarts.
+    warm_start=True (not in the reference) starts every solve from the environment's previous solution advanced by
+    one stage (`MPC_FLAG_WARM_START`).
     """
 
     def __init__(self, env, policy: ActorCritic, engine, version: str = "v0", algorithm: str = "ppo",
                  n_steps: int = 64, gamma: float = 0.99, gae_lambda: float = 0.95,
                  default_weights=(1.0, 1.0, 1.0), collision_cost: bool = False, reset_mpc_on_done: bool = False,
-                 gather_actions: bool = False, seed: int = 0):
+                 gather_actions: bool = False, seed: int = 0, warm_start: bool = False):
         if version not in ("v0", "v1") or algorithm not in ("ppo", "a2c"):
             raise ValueError("version must be v0|v1 and algorithm ppo|a2c")
         if version == "v1" and policy.action_dim < 3:
@@ -272,6 +274,7 @@ class BatchedCollector:
         self.env, self.policy, self.engine = env, policy, engine
         self.version, self.algorithm = version, algorithm
         self.collision_cost, self.reset_mpc_on_done, self.gather_actions = collision_cost, reset_mpc_on_done, gather_actions
+        self.warm_start = bool(warm_start)
         dev = env.device
         B = env.num_envs
         self.buffer = RolloutBuffer(n_steps, B, policy.action_dim, dev, gamma, gae_lambda)
@@ -303,7 +306,8 @@ class BatchedCollector:
             obs = self._last_obs
             actions, values, log_probs = self.policy(obs, generator=self.gen)
             weights, ref_speed = self.mpc_inputs(actions)
-            self.last_mpc = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost)
+            self.last_mpc = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
+                                                            warm_start=self.warm_start)
             mpc_action = self.last_mpc["act"]
             if self.gather_actions:
                 from . import sharding
@@ -315,6 +319,8 @@ class BatchedCollector:
                 rewards = rewards + self.buffer.gamma * tv * info["truncated"].to(tv.dtype)
             if self.reset_mpc_on_done:
                 self.engine.reset_env_mask_torch(dones.to(torch.uint8))
+            elif self.warm_start:            # a new episode must not start from the old one's plan
+                self.engine.reset_env_mask_torch(dones.to(torch.uint8), warm_only=True)
             self.buffer.add(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
             self._last_obs = new_obs
             self._last_episode_starts = dones.to(torch.float32)

@@ -47,7 +47,11 @@ def _host_solver(libname, srcname, symbol):
                                      dp, ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_int, dp, dp, dp, ip, ip, dp]
 
-    def solve(ref, inp, N=20, dt=0.1, collision_cost=False, tol=1e-8, max_iter=100):
+    warm = getattr(lib, symbol + "_warm", None)          # the wave harness also takes initial controls
+    if warm is not None:
+        warm.argtypes = lib.core_solve_batch.argtypes[:17] + [dp] + lib.core_solve_batch.argtypes[17:]
+
+    def solve(ref, inp, N=20, dt=0.1, collision_cost=False, tol=1e-8, max_iter=100, u_init=None):
         P = lambda a, t: None if a is None else a.ctypes.data_as(t)
         state = np.ascontiguousarray(inp["state"], dtype=np.float64)
         B = state.shape[0]
@@ -60,9 +64,16 @@ def _host_solver(libname, srcname, symbol):
         ref = np.ascontiguousarray(ref, dtype=np.float64)
         u0 = np.zeros((B, 2)); U = np.zeros((B, N, 2)); X = np.zeros((B, N + 1, 4))
         st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros(B)
-        rc = lib.core_solve_batch(B, N, dt, P(ref, dp), ref.shape[0], P(state, dp), P(ego, ip), P(vr, dp), P(w, dp),
-                                  P(c, bp), P(oth, dp), V, 1 if collision_cost else 0, 10.0, 1.0, tol, max_iter,
-                                  P(u0, dp), P(U, dp), P(X, dp), P(st, ip), P(it, ip), P(kkt, dp))
+        if u_init is not None:
+            ui = np.ascontiguousarray(u_init, dtype=np.float64)
+            assert warm is not None and ui.shape == (B, N, 2)
+            rc = warm(B, N, dt, P(ref, dp), ref.shape[0], P(state, dp), P(ego, ip), P(vr, dp), P(w, dp), P(c, bp),
+                      P(oth, dp), V, 1 if collision_cost else 0, 10.0, 1.0, tol, max_iter, P(ui, dp), P(u0, dp), P(U, dp),
+                      P(X, dp), P(st, ip), P(it, ip), P(kkt, dp))
+        else:
+            rc = lib.core_solve_batch(B, N, dt, P(ref, dp), ref.shape[0], P(state, dp), P(ego, ip), P(vr, dp), P(w, dp),
+                                      P(c, bp), P(oth, dp), V, 1 if collision_cost else 0, 10.0, 1.0, tol, max_iter,
+                                      P(u0, dp), P(U, dp), P(X, dp), P(st, ip), P(it, ip), P(kkt, dp))
         assert rc == 0
         return dict(u0=u0, U=U, X=X, status=st, iters=it, kkt=kkt)
 

@@ -91,17 +91,35 @@ struct HostCtx {
 
 template <bool CC>
 void run(const mpc::SolveParams &P, HostCtx &ctx, const double *x0, double ws, double wc, double wd, double wcoll,
-         int &st, int &it, int &cur, double &e) {
+         int &st, int &it, int &cur, double &e, bool warm) {
     mpc::wave::Solver<CC, HostCtx> s(P, ctx, x0, ws, wc, wd, wcoll);
-    s.solve(st, it, cur, e);
+    s.solve(st, it, cur, e, warm);
 }
 }  // namespace
+
+extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
+                                     const int32_t *ego_index, const double *vref, const double *weights,
+                                     const uint8_t *is_collide, const double *others, int V, uint32_t flags,
+                                     double w_distance, double w_collision, double tol, int max_iter,
+                                     const double *u_init, double *u0, double *U, double *X, int32_t *status,
+                                     int32_t *iters, double *kkt);
 
 extern "C" int wave_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state,
                                 const int32_t *ego_index, const double *vref, const double *weights,
                                 const uint8_t *is_collide, const double *others, int V, uint32_t flags,
                                 double w_distance, double w_collision, double tol, int max_iter, double *u0,
                                 double *U, double *X, int32_t *status, int32_t *iters, double *kkt) {
+    return wave_solve_batch_warm(B, N, dt, ref_table, M, state, ego_index, vref, weights, is_collide, others, V, flags,
+                                 w_distance, w_collision, tol, max_iter, nullptr, u0, U, X, status, iters, kkt);
+}
+
+// u_init: [B][N][2] initial controls (warm start) or nullptr (cold start of the reference)
+extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
+                                     const int32_t *ego_index, const double *vref, const double *weights,
+                                     const uint8_t *is_collide, const double *others, int V, uint32_t flags,
+                                     double w_distance, double w_collision, double tol, int max_iter,
+                                     const double *u_init, double *u0, double *U, double *X, int32_t *status,
+                                     int32_t *iters, double *kkt) {
     if (N > mpc::wave::kMaxHorizon) return -1;
     const int cc = (flags & 1u) ? 1 : 0;
     const int Vuse = cc ? V : 0;
@@ -138,12 +156,18 @@ extern "C" int wave_solve_batch(int B, int N, double dt, const double *ref_table
         const bool collide = is_collide[b] != 0;
         const double ws_ = collide ? 100.0 : weights[3 * b + 0];
         const double wcoll = (cc && collide) ? 3000.0 * w_collision : 0.0;
+        if (u_init)
+            for (int k = 0; k < N; ++k)
+                for (int i = 0; i < 2; ++i)
+                    L[k * SL + mpc::wave::W_U + i] = mpc::warm_clamp(u_init[((size_t)b * N + k) * 2 + i], i);
         int st, it, cur;
         double e;
         if (cc)
-            run<true>(P, ctx, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll, st, it, cur, e);
+            run<true>(P, ctx, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll, st, it, cur, e,
+                      u_init != nullptr);
         else
-            run<false>(P, ctx, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll, st, it, cur, e);
+            run<false>(P, ctx, state + 4 * (size_t)b, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll, st, it, cur, e,
+                       u_init != nullptr);
         const int CB = cur * 6;
         u0[2 * b + 0] = L[0 * SL + CB + mpc::wave::W_U + 0];
         u0[2 * b + 1] = L[0 * SL + CB + mpc::wave::W_U + 1];

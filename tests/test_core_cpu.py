@@ -47,3 +47,23 @@ def test_core_edge_cases(cpu_core, oracle, ref_table):
     inp2 = dict(inp, state=np.array([[2.0, 45.0, -np.pi / 2, 31.0]]), ego_index=np.array([4], np.int32),
                 weights=np.ones((1, 3)), is_collide=np.zeros(1, np.uint8), others=None)
     assert cpu_core(ref_table, inp2)["status"][0] == 3
+
+
+def test_wave_core_warm_start_matches_oracle(cpu_wave, oracle, ref_table):
+    """Opt-in warm start (initial controls instead of the reference's cold start): same iterates as the oracle given the
+    same initial controls, including the clamp into the bounds and the fall-back to the cold start."""
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(96, 8, seed=6)
+    kw = dict(vref=inp["vref"], others=inp["others"], collision_cost=True, max_iter=100, xy_bounds=False)
+    cold = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], **kw)
+    rng = np.random.default_rng(0)
+    shifted = np.concatenate([cold["U"][:, 1:], cold["U"][:, -1:]], axis=1)
+    shifted[::7] = rng.uniform(-8.0, 8.0, shifted[::7].shape)          # some wild ones: clamped, maybe infeasible
+    want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
+                              u_init=shifted, **kw)
+    got = cpu_wave(ref_table, inp, collision_cost=True, u_init=shifted)
+    both = (got["status"] == 0) & (want["status"] == 0)
+    assert both.mean() > 0.8 and (got["status"] == want["status"]).mean() > 0.97
+    assert (rel_u0_err(got["u0"], want["u0"])[both] <= 1e-4).mean() >= 0.99
+    assert (got["iters"] == want["iters"])[both].mean() > 0.95
+    assert want["iters"][both].mean() < cold["iters"][both].mean()

@@ -73,7 +73,8 @@ class _RankEngine:
     def __init__(self, offset):
         self.offset = offset
 
-    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False):
+    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False,
+                            warm_start=False):
         B = obs.shape[0]
         act = torch.zeros((B, 2), dtype=torch.float64)
         act[:, 0] = -1.0

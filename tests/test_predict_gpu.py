@@ -177,3 +177,58 @@ def test_learn_loop_with_mpc_in_the_loop_on_device():
     assert all(np.isfinite([r["loss"], r["value_loss"], r["mean_reward"]]).all() for r in log)
     assert (col.last_mpc["status"] == 0).float().mean() > 0.9
     eng.close()
+
+
+def test_warm_start_flag(oracle, ref_table):
+    """MPC_FLAG_WARM_START (opt-in, the reference always cold-starts): given the same initial controls the engine and
+    the oracle walk the same iterates; in closed loop (previous solution advanced one stage) the solves need fewer
+    iterations and mostly end in the same minimiser as cold-started ones."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, rollout, synth
+    inp = synth.solver_inputs(256, 4, seed=8)
+    e = engine.MPCEngine(horizon=20, max_iter=100)
+    cold = e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"])
+    init = np.concatenate([cold["U"][:, 1:], cold["U"][:, -1:]], axis=1)
+    init[::9] = 40.0                                                    # far outside the bounds: clamped
+    got = e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"], u_init=init)
+    want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
+                              vref=inp["vref"], u_init=init, max_iter=100, xy_bounds=False)
+    both = (got["status"] == 0) & (want["status"] == 0)
+    assert both.mean() > 0.9 and (got["status"] == want["status"]).mean() > 0.98
+    assert (rel_u0_err(got["u0"], want["u0"])[both] <= 1e-4).mean() > 0.995
+    assert (got["iters"] == want["iters"])[both].mean() > 0.95
+    with pytest.raises(engine.EngineError):                             # horizon 40 runs on the lane kernel: no warm start
+        e40 = engine.MPCEngine(horizon=40)
+        try:
+            e40.solve_batch(inp["state"][:4], inp["ego_index"][:4], inp["weights"][:4], inp["is_collide"][:4],
+                            u_init=np.zeros((4, 40, 2)))
+        finally:
+            e40.close()
+    e.close()
+    # closed loop: two identical environments and policies, one engine warm-started
+    dev = torch.device("cuda", 0)
+    runs = {}
+    for warm in (False, True):
+        eng = engine.MPCEngine(horizon=20, max_iter=100)
+        env = rollout.SyntheticIntersectionEnv(128, device=dev, seed=21, n_others=3)
+        torch.manual_seed(0)
+        pol = rollout.ActorCritic(1).to(dev)
+        col = rollout.BatchedCollector(env, pol, eng, version="v0", algorithm="ppo", n_steps=12, seed=5, warm_start=warm)
+        iters, conv = [], []
+        inner = eng.predict_batch_torch
+
+        def spy(*a, **k):
+            out = inner(*a, **k)
+            iters.append(out["iters"].float().mean().item())
+            conv.append((out["status"] == 0).float().mean().item())
+            return out
+
+        eng.predict_batch_torch = spy
+        col.collect_rollouts()
+        runs[warm] = (np.array(iters), np.array(conv), col.buffer.mpc_actions[0].cpu().numpy())
+        eng.close()
+    (ic, cc_, a0c), (iw, cw, a0w) = runs[False], runs[True]
+    assert np.array_equal(a0c, a0w)                                     # first step: nothing to start from yet
+    assert iw[1:].mean() < ic[1:].mean()                                # fewer iterations afterwards (a few %: the
+    #                                                                     barrier path is walked again)
+    assert cw.mean() > cc_.mean() - 0.03

@@ -14,7 +14,8 @@ class StubEngine:
     def __init__(self):
         self.calls = []
 
-    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False):
+    def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False,
+                            warm_start=False):
         self.calls.append(dict(obs=obs.clone(), weights=weights.clone(),
                                ref_speed=None if ref_speed is None else ref_speed.clone()))
         B = obs.shape[0]
@@ -22,7 +23,7 @@ class StubEngine:
         act[:, 0] = -0.5
         return dict(act=act, status=torch.zeros(B, dtype=torch.int32), iters=torch.zeros(B, dtype=torch.int32))
 
-    def reset_env_mask_torch(self, done):
+    def reset_env_mask_torch(self, done, warm_only=False):
         self.calls.append(dict(reset=done.clone()))
 
 
