@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     const int b = blockIdx.x;
+    if (b >= B) return;                          // grid = B workgroups of one wave
     if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     const int lane = threadIdx.x;
     constexpr int SL = mpc::wave::stage_slots(CC);
@@ -595,7 +596,6 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     const int N = h->cfg.horizon;
     const size_t N1 = (size_t)N + 1;
-    const int Vuse = cc ? V : 0;
 
     // ---- device views of the arguments
     const double *d_state = state, *d_vref = vref, *d_weights = weights, *d_others = others;

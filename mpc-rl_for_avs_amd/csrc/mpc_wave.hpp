@@ -13,8 +13,7 @@
 //   * the line search integrates all six trial step lengths at once, lane t = trial t;
 //   * only the true recursions (adjoint, linearised step, one lane's rollout) are serial.
 // Why: measured on MI355X the one-lane-per-instance kernel is bound by the serial FP64 instruction stream of
-// its slowest instance (~47 k instructions per iteration, dependent FP64 operations cost 16-32 cycles for a lone
-// wave), with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state has to sit in LDS.
+// its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state has to sit in LDS.
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
 // (f(lane) per lane; other lanes may read afterwards what a lane wrote to LDS); tests/cpu_wave_harness.cpp runs the
@@ -67,16 +66,17 @@ enum : int {
 };
 
 MPC_HD constexpr int stage_slots(bool cc) { return cc ? W_SLOTS_CC : W_SLOTS; }
-// doubles of LDS one instance needs: stage arrays + scratch + other vehicles
 // doubles of one line-search trial area: (x 4, u 2) per node
 MPC_HD constexpr int trial_doubles(int N) { return 6 * (N + 1); }
+// doubles of LDS one instance needs: stage arrays + constants + other vehicles + trial areas
 MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
     return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0) + (kTrials - 1) * trial_doubles(N);
 }
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
-    T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_L2, T_RIC_2X2, T_RIC_L4, T_LINEAR, T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD, T_COUNT
+    T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_L2, T_RIC_2X2, T_RIC_L4, T_LINEAR,
+    T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD, T_COUNT
 };
 
 // A value that differs per lane and lives across phases: one register per lane on the device; the host emulation,
@@ -114,7 +114,7 @@ inline void host_row_reduce(PerLane<T> &p, OP op) {
     }
 }
 template <class T, class OP>
-inline T host_butterfly(PerLane<T> &p, OP op) {
+inline T host_reduce(PerLane<T> &p, OP op) {
     host_row_reduce(p, op);
     return op(op(p.v[0], p.v[16]), op(p.v[32], p.v[48]));
 }
@@ -123,7 +123,7 @@ inline T host_butterfly(PerLane<T> &p, OP op) {
 // ---------------------------------------------------------------------------------------------------
 // CTX (one per wave / instance) provides
 //   double ld(int i), void st(int i, double v)   LDS words of this instance
-//   void phase(F f)                              f(lane) for the 64 lanes, then a barrier
+//   void phase(F f)                              f(lane) for the 64 lanes; LDS written in it is visible to all afterwards
 //   double ref(int k, int c)                     reference path column c at stage k
 //   static constexpr int kN                      compile-time horizon or 0
 //   void tick(int section)                       attributes the time since the previous tick to `section`

@@ -45,13 +45,13 @@ struct HostCtx {
     }
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
     double wave_sum(mpc::wave::PerLane<double> &p) const {
-        return mpc::wave::host_butterfly(p, [](double a, double b) { return a + b; });
+        return mpc::wave::host_reduce(p, [](double a, double b) { return a + b; });
     }
     double wave_max(mpc::wave::PerLane<double> &p) const {
-        return mpc::wave::host_butterfly(p, [](double a, double b) { return mpc::fmax2(a, b); });
+        return mpc::wave::host_reduce(p, [](double a, double b) { return mpc::fmax2(a, b); });
     }
     double wave_min(mpc::wave::PerLane<double> &p) const {
-        return mpc::wave::host_butterfly(p, [](double a, double b) { return mpc::fmin2(a, b); });
+        return mpc::wave::host_reduce(p, [](double a, double b) { return mpc::fmin2(a, b); });
     }
     void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
         mpc::wave::host_row_reduce(p, [](double a, double b) { return a + b; });
