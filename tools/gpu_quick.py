@@ -30,17 +30,18 @@ for (B, V, cc) in [(1024, 4, 0), (4096, 4, 0), (4096, 8, 1)]:
                 vref=t(inp['vref'], torch.float64), others=t(inp['others'], torch.float64), collision_cost=bool(cc))
     for max_iter in (0, 5, 10, 20, 40, 100):
         e = engine.MPCEngine(horizon=20, max_iter=max_iter)
-        for ipw in (1, 4, 16):
-            os.environ['MPC_IPW'] = str(ipw)
+        for kernel in ("wave", "lane") if max_iter == 100 else ("wave",):
+            os.environ['MPC_KERNEL'] = kernel
             out = e.solve_batch_torch(**args, sync=True)
             torch.cuda.synchronize()
             ts = []
-            for _ in range(3):
+            for _ in range(5):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(); e.solve_batch_torch(**args, out=out); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
             it = out['iters'].cpu().numpy(); st = out['status'].cpu().numpy()
             ms = np.median(ts)
-            print(f"B={B} V={V} cc={cc} max_iter={max_iter} ipw={ipw}: {ms:.3f} ms -> {B/ms*1e3:.0f} solves/s; iters mean {it.mean():.1f} "
-                  f"status {np.bincount(st)}", flush=True)
+            print(f"{kernel} kernel B={B} V={V} cc={cc} max_iter={max_iter}: {ms:.3f} ms -> {B/ms*1e3:.0f} solves/s; "
+                  f"iters mean {it.mean():.1f} status {np.bincount(st)}", flush=True)
+        os.environ['MPC_KERNEL'] = "wave"
         e.close()
