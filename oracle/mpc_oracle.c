@@ -23,12 +23,15 @@
  *               a in [-5,5], delta in [-pi/3,pi/3]                        agents/pure_mpc.py:272-280
  *   cold start  X[k]=state, U=0                                           agents/pure_mpc.py:240-246
  *
- * Algorithm (ours; the reference delegates to IPOPT): primal-dual interior point
- * with monotone barrier decrease, exact Lagrangian Hessian with IPOPT-style
- * inertia correction (delta_w), stage-wise Riccati factorisation of the KKT
- * system (state augmented with the previous control to carry the input-rate
- * cost), l1-merit backtracking line search, fraction-to-the-boundary rule.
- * X[0] is eliminated (it is pinned by the equality X[0]=state).
+ * Algorithm (ours; the reference delegates to IPOPT): primal-dual interior-point
+ * DDP in single shooting - monotone barrier decrease with IPOPT's error measures
+ * and gradient-based objective scaling, exact Lagrangian Hessian (Gauss-Newton
+ * model for an iteration whose control blocks are not positive definite, then a
+ * diagonal shift), stage-wise Riccati factorisation of the KKT system (state
+ * augmented with the previous control to carry the input-rate cost), nonlinear
+ * feedback rollouts with an Armijo line search on the barrier objective,
+ * fraction-to-the-boundary rule, split dual step.  The dynamics hold exactly at
+ * every iterate; X[0] is pinned by X[0] = state.
  */
 #include <math.h>
 #include <stdint.h>
@@ -368,9 +371,9 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         if (iter == o->max_iter) break;
 
         /* ---------------- backward (Riccati / DDP) sweep with the exact Lagrangian Hessian ------------------
-         * A control block Huu_k that is not positive definite (the reduced Hessian is then indefinite) is
-         * replaced stage-locally by V |Lambda| V' (eigenvalues reflected, floored): the step solves a
-         * convexified QP exactly, stays a descent direction, and no re-factorisation is needed. */
+         * If a control block Huu_k is not positive definite the sweep is repeated with the convex Gauss-Newton model
+         * (no constraint curvature, radial part of the collision potential); should that fail numerically too, a
+         * multiple of the identity is added. */
         double dV1 = 0.0, delta_w = 0.0;
         int nmod = 0, ok = 0, gn = 0;
         ++g_cnt_iter;
@@ -454,11 +457,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     for (int m = 0; m < 4; ++m) s += Bm[k][m][i] * px[m];
                     hu[i] = s;
                 }
-                /* 2x2 symmetric eigen-decomposition; reflect / floor the eigenvalues if needed */
+                /* 2x2 control block: positive definite? */
                 double ha = Huu[0][0], hb = 0.5 * (Huu[0][1] + Huu[1][0]), hc = Huu[1][1];
-                double hm = 0.5 * (ha + hc), hd = sqrt(0.25 * (ha - hc) * (ha - hc) + hb * hb);
-                double l1 = hm + hd, l2 = hm - hd;
-                (void)l1;
                 if (!(ha > 0.0) || !(hc > 0.0) || !(ha * hc - hb * hb > 1e-12 * ha * hc)) {
                     ok = 0;
                     break;
