@@ -163,8 +163,7 @@ def main():
                        "parallelism": f"instance-sharded x{world}, all-gather of actions"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                         "kernel": ("mpc_solve_kernel<CC=1,IPW=16,N=20>" if os.environ.get("MPC_KERNEL") == "lane"
-                                    else "mpc_solve_wave_kernel<CC=1,N=20>"), "kernel_ms": kern_ms,
+                         "kernel": "mpc_solve_wave_kernel<CC=1,N=20>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "path is bound by the serial FP64 + LDS-latency chain of its slowest instance; the working "
                                  "set is LDS-resident and HBM carries only inputs/outputs (DESIGN.md section 4)"},

@@ -43,7 +43,7 @@ extern "C" {
 #define MPC_FLAG_WARM_START 8u     /* NOT in the reference (which cold-starts every solve, agents/pure_mpc.py:240-246):
                                       start from given controls instead of zeros.  They are clamped 0.1 % inside their
                                       bounds; if their rollout leaves the state bounds the cold start is used.  Changes
-                                      the iterates (fewer of them), not the KKT point aimed at; horizons <= 32 only.
+                                      the iterates (fewer of them), not the KKT point aimed at.
                                       mpc_solve_batch: U (required) holds the initial controls on entry;
                                       mpc_predict_batch: each environment starts from its previous solution advanced by
                                       one stage (kept in the handle, forgotten by the reset calls);
@@ -149,9 +149,9 @@ int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *eg
 int mpc_get_last_inputs(mpc_handle *h, int32_t B, double *state, int32_t *ego_index, double *vref,
                         uint8_t *is_collide, double *others, int32_t *nveh);
 
-/* LDS bytes one workgroup of the solve kernel uses for a batch of B instances with V other vehicles in the
- * collision-cost term (V = 0: term off): path table + instances-per-wave x per-instance solver state.  The
- * engine keeps no per-instance state in HBM.  (diagnostics / capacity planning) */
+/* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
+ * collision-cost term (V = 0: term off); B is accepted for interface stability and does not matter.  The engine
+ * keeps no per-instance solver state in HBM.  (diagnostics / capacity planning) */
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);
 
 #ifdef __cplusplus

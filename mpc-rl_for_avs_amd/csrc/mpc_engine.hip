@@ -1,11 +1,9 @@
 // mpc_engine.hip - gfx950 kernels and the C ABI (include/mpc_mi355x.h) of the batched MPC solve engine.
 //
 // Kernels (all: workgroup = one wave64, no inter-workgroup communication, HBM touched only for inputs / outputs):
-//   mpc_solve_wave_kernel   one wave per MPC instance (mpc_wave.hpp + mpc_wave_dev.hpp), horizons <= 32: stage-parallel
-//                           phases, Riccati stage on the FP64 matrix cores, all line-search step lengths at once;
+//   mpc_solve_wave_kernel   one wave per MPC instance (mpc_wave.hpp + mpc_wave_dev.hpp): stage-parallel phases,
+//                           Riccati stage on the FP64 matrix cores, all line-search step lengths at once;
 //                           per-instance state (46-54 doubles per stage + trial areas, 14 KB at N = 20) in LDS
-//   mpc_solve_kernel        one lane per instance (mpc_core.hpp), IPW = 1, 4 or 16 instances per wave, LDS layout
-//                           [stage][slot][instance]; used for horizons 33..64 (and MPC_KERNEL=lane)
 //   mpc_preamble_kernel     observation -> problem data (mpc_preamble.hpp), 16 lanes per environment
 //   mpc_env_reset_kernel    episode boundaries of the per-environment detector state
 // Host side: argument checks, staging of host-pointer calls through one device buffer on the caller's stream,
@@ -46,134 +44,6 @@ constexpr int kBlock = 64;  // one wave64 per workgroup
 // build (168 VGPRs, 32 B/lane scratch) measured the same at B = 4096 and B = 65536, a 4-wave build slower.
 constexpr int kWaveOcc = 2;
 
-// LDS-resident workspace of one lane: element (slot, stage k) of this instance
-// (NC > 0: horizon known at compile time, so slot offsets fold into the ds_read/ds_write immediates)
-typedef __attribute__((address_space(3))) double lds_double;  // keeps ds_read/ds_write through the opaque asm
-
-template <int IPW, int NC, bool CCW>
-struct LdsWS {
-    static constexpr int kN = NC;
-    static constexpr int kReplicas = kBlock / IPW;  // lanes l, l+IPW, l+2*IPW, ... work on the same instance
-    lds_double *base;         // work + lane
-    const lds_double *obase;  // others + lane
-    const lds_double *table;  // [M][REF_COLS]
-    int N1r, e0, M;
-    // [stage][slot][instance]: one address register per stage, every slot (and the neighbouring stages) is
-    // then within the 16-bit immediate offset of ds_read_b64 / ds_write_b64
-    static constexpr int kSlots = CCW ? mpc::STAGE_SLOTS_CC : mpc::STAGE_SLOTS;
-    // The stage base is made opaque to the optimiser (an empty, CSE-able asm): otherwise loop strength reduction
-    // re-bases the addresses on constants > 64 KB and every access pays its own v_add_u32.
-    __device__ __forceinline__ lds_double *stage(int k) const {
-        lds_double *p = base + k * (kSlots * IPW);
-        asm("" : "+v"(p));
-        return p;
-    }
-    __device__ __forceinline__ double ld(int slot, int k) const { return stage(k)[slot * IPW]; }
-    __device__ __forceinline__ void st(int slot, int k, double v) { stage(k)[slot * IPW] = v; }
-    __device__ __forceinline__ double oth(int j, int c) const { return obase[(j * 4 + c) * IPW]; }
-    __device__ __forceinline__ int replica() const { return (int)threadIdx.x / IPW; }
-    // smallest replica index of this lane's instance whose `pass` is true, or -1 (one wave-wide ballot)
-    __device__ __forceinline__ int first_passing(bool pass) const {
-        const unsigned long long m = __ballot(pass);
-        const int inst = (int)threadIdx.x % IPW;
-        int r = -1;
-#pragma unroll
-        for (int q = kReplicas - 1; q >= 0; --q)
-            if ((m >> (inst + q * IPW)) & 1ull) r = q;
-        return r;
-    }
-    __device__ __forceinline__ double ref(int k, int c) const {
-        int idx = e0 + k;
-        idx = idx > M - 1 ? M - 1 : idx;
-        idx = idx < 0 ? 0 : idx;
-        return table[idx * mpc::REF_COLS + c];
-    }
-};
-
-__host__ __device__ constexpr int stage_slots(bool cc) { return cc ? mpc::STAGE_SLOTS_CC : mpc::STAGE_SLOTS; }
-
-// LDS bytes of one workgroup: path table + IPW workspaces + IPW other-vehicle blocks
-size_t lds_bytes(bool cc, int ipw, int N, int M, int V) {
-    return ((size_t)M * mpc::REF_COLS + (size_t)stage_slots(cc) * (N + 1) * ipw + (size_t)(cc ? V : 0) * 4 * ipw) *
-           sizeof(double);
-}
-
-template <bool CC, int IPW, int NC>
-__global__ __launch_bounds__(kBlock) void mpc_solve_kernel(
-    mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
-    const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
-    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
-    const int32_t *__restrict__ nveh, double w_collision, double *__restrict__ u0_out, double *__restrict__ U_out,
-    double *__restrict__ X_out, int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out) {
-    extern __shared__ double smem[];
-    const int N = NC > 0 ? NC : P.N;
-    double *s_table = smem;                                     // [M][REF_COLS]
-    double *s_work = s_table + M * mpc::REF_COLS;               // [N+1][slots][IPW]
-    double *s_oth = s_work + stage_slots(CC) * (N + 1) * IPW;   // [V][4][IPW]
-    for (int i = threadIdx.x; i < M * mpc::REF_COLS; i += kBlock) s_table[i] = ref5[i];
-    __syncthreads();
-    // All 64 lanes stay active: lane l works on instance l % IPW, i.e. every instance is computed by 64/IPW
-    // replica lanes that read and write the same LDS words with the same values.  Measured on MI355X
-    // (tools/ubench/ubench_waves.hip): FP64 VALU ops of a wave with < 16 active lanes are serialised across the
-    // whole CU (~5 cycles each, CU-wide), and 16-lane waves reach the full per-SIMD rate only when >= 64 lanes
-    // are active on the CU; a full wave always runs at 4 cycles per instruction on its own SIMD.
-    const int lane = threadIdx.x % IPW;
-    int b = blockIdx.x * IPW + lane;
-    b = b < B ? b : B - 1;  // ragged last workgroup: surplus lanes mirror the last instance
-
-    LdsWS<IPW, NC, CC> w{(lds_double *)(s_work + lane), (const lds_double *)(s_oth + lane),
-                         (const lds_double *)s_table, N + 1, ego_index[b], M};
-    double x0[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x0[i] = state[(size_t)b * 4 + i];
-    for (int k = 0; k <= N; ++k) {
-        double rv;
-        if (vref) {
-            rv = vref[(size_t)b * (N + 1) + k];
-        } else {
-            int idx = w.e0 + k;
-            idx = idx > M - 1 ? M - 1 : idx;
-            idx = idx < 0 ? 0 : idx;
-            rv = ref5[M * mpc::REF_COLS + idx];  // speed column is appended after the table
-        }
-        w.st(mpc::S_RV, k, rv);
-    }
-    const bool collide = is_collide[b] != 0;
-    if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
-    if (CC) {
-        for (int j = 0; j < P.V; ++j) {
-            const double *ov = others + ((size_t)b * Vin + j) * 4;
-            const double sp = ov[2] * P.dt, hh = ov[3];
-            s_oth[(j * 4 + 0) * IPW + lane] = ov[0];
-            s_oth[(j * 4 + 1) * IPW + lane] = ov[1];
-            s_oth[(j * 4 + 2) * IPW + lane] = sp * cos(hh);
-            s_oth[(j * 4 + 3) * IPW + lane] = sp * sin(hh);
-        }
-    }
-    const double ws_ = collide ? 100.0 : weights[(size_t)b * 3 + 0];  // agents/pure_mpc.py:143-147
-    const double wc_ = weights[(size_t)b * 3 + 1], wd_ = weights[(size_t)b * 3 + 2];
-    const double wcoll = (CC && collide) ? 3000.0 * w_collision : 0.0;
-
-    int status, iters, cur;
-    double kkt;
-    mpc::solve_instance<CC>(P, w, x0, ws_, wc_, wd_, wcoll, status, iters, cur, kkt);
-
-    const int CB = cur * mpc::BUF_SLOTS;
-    u0_out[(size_t)b * 2 + 0] = w.ld(CB + mpc::B_U + 0, 0);
-    u0_out[(size_t)b * 2 + 1] = w.ld(CB + mpc::B_U + 1, 0);
-    if (U_out)
-        for (int k = 0; k < N; ++k) {
-            U_out[((size_t)b * N + k) * 2 + 0] = w.ld(CB + mpc::B_U + 0, k);
-            U_out[((size_t)b * N + k) * 2 + 1] = w.ld(CB + mpc::B_U + 1, k);
-        }
-    if (X_out)
-        for (int k = 0; k <= N; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) X_out[((size_t)b * (N + 1) + k) * 4 + i] = w.ld(CB + mpc::B_X + i, k);
-    if (status_out) status_out[b] = status;
-    if (iters_out) iters_out[b] = iters;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
 // ---------------------------------------------------------------------------------------------------
@@ -211,17 +81,17 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     WaveCtx<NC> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
     // inputs -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j)
-    if (lane <= N) {
+    for (int node = lane; node <= N; node += kBlock) {
         double rv;
         if (vref) {
-            rv = vref[(size_t)b * (N + 1) + lane];
+            rv = vref[(size_t)b * (N + 1) + node];
         } else {
-            int idx = ctx.e0 + lane;
+            int idx = ctx.e0 + node;
             idx = idx > M - 1 ? M - 1 : idx;
             idx = idx < 0 ? 0 : idx;
             rv = ref5[M * mpc::REF_COLS + idx];
         }
-        ctx.st(lane * SL + mpc::wave::W_RV, rv);
+        ctx.st(node * SL + mpc::wave::W_RV, rv);
     }
     if (CC && lane < P.V) {
         const double *ov = others + ((size_t)b * Vin + lane) * 4;
@@ -261,10 +131,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
         U_out[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 0);
         U_out[((size_t)b * N + lane) * 2 + 1] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 1);
     }
-    if (X_out && lane <= N)
+    if (X_out)
+        for (int node = lane; node <= N; node += kBlock)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            X_out[((size_t)b * (N + 1) + lane) * 4 + i] = ctx.ld(lane * SL + CB + mpc::wave::W_X + i);
+            for (int i = 0; i < 4; ++i)
+                X_out[((size_t)b * (N + 1) + node) * 4 + i] = ctx.ld(node * SL + CB + mpc::wave::W_X + i);
     if (lane == 0) {
         if (status_out) status_out[b] = status;
         if (iters_out) iters_out[b] = iters;
@@ -358,43 +229,6 @@ namespace {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
-// Instances per wave.  Measured on MI355X (tools/gpu_quick.py): the solve is bound by the dependent-issue
-// latency of a wave, and waves that share a CU slow each other down, so one wave per CU is the sweet spot:
-// take the smallest slice that keeps the number of workgroups within the number of CUs, capped by what the
-// CU's LDS can hold (16 instances).  MPC_IPW=1|4|16 overrides (for experiments).
-int choose_ipw(const mpc_handle *h, bool cc, int B, int N, int V) {
-    const char *env = getenv("MPC_IPW");
-    const int cands[3] = {1, 4, 16};
-    if (env) {
-        const int f = atoi(env);
-        for (int c : cands)
-            if (c == f && lds_bytes(cc, c, N, h->M, V) <= h->lds_per_cu) return c;
-    }
-    int best = 1;
-    for (int c : cands) {
-        if (lds_bytes(cc, c, N, h->M, V) > h->lds_per_cu) break;
-        best = c;
-        if ((long long)B <= (long long)c * h->num_cu) break;
-    }
-    return best;
-}
-
-template <bool CC, int IPW, int NC>
-int launch(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
-           const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
-           const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, double *d_u0, double *d_U,
-           double *d_X, int32_t *d_status, int32_t *d_iters) {
-    auto kern = mpc_solve_kernel<CC, IPW, NC>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    const unsigned grid = (unsigned)((B + IPW - 1) / IPW);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego, d_vref,
-                       d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_u0, d_U, d_X, d_status,
-                       d_iters);
-    HIP_TRY(hipGetLastError());
-    return MPC_OK;
-}
-
 template <bool CC, int NC, int OCC>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
@@ -410,16 +244,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, si
     return MPC_OK;
 }
 
-// Which kernel: the wave-cooperative one (one wave per instance) whenever the horizon fits half a wave (stage-parallel
-// phases and the two-trials-per-pass line search);
-// MPC_KERNEL=lane|wave overrides (experiments, A/B tests).
-bool use_wave_kernel(int N) {
-    const char *env = getenv("MPC_KERNEL");
-    if (env && !strcmp(env, "lane")) return false;
-    return N <= mpc::wave::kMaxHorizon;
-}
-
-// Kernel choice + launch for B instances whose data already sits in device memory (shared by mpc_solve_batch and
+// Launch of the solve kernel for B instances whose data already sits in device memory (shared by mpc_solve_batch and
 // mpc_predict_batch).  d_nveh: vehicles present per instance or nullptr (= V for all).
 int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t stream, const double *d_state,
                    const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
@@ -436,55 +261,25 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
     P.mu_init = 0.1;
     P.w_distance = h->cfg.w_distance;
 
+    static_assert(MPC_MAX_HORIZON <= mpc::wave::kMaxHorizon, "lane k = stage k needs the horizon to fit a wave");
+    const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
+    if (wlds > h->lds_per_cu)
+        return fail(MPC_ERR_INVALID_ARG, "horizon / vehicle count too large for the LDS workspace of one instance");
     int rc;
-    if (use_wave_kernel(N)) {
-        const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
-#define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                            \
-    rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights,      \
-                                     d_coll, d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, \
-                                     d_iters)
-        if (cc) {
-            if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOcc);       /* BASELINE horizon */
-            else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOcc);  /* reference cfg.yaml default */
-            else MPC_LAUNCH_W(true, 0, kWaveOcc);
-        } else {
-            if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOcc);
-            else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOcc);
-            else MPC_LAUNCH_W(false, 0, kWaveOcc);
-        }
-#undef MPC_LAUNCH_W
-        if (rc) return rc;
-    } else {
-    if (d_uinit)
-        return fail(MPC_ERR_INVALID_ARG, "warm start is implemented by the wave kernel only (horizon <= 32)");
-    const int ipw = choose_ipw(h, cc, B, N, Vuse);
-    const size_t lds = lds_bytes(cc, ipw, N, h->M, Vuse);
-    if (lds > h->lds_per_cu)
-        return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: horizon/others/reference too large for the LDS workspace");
-#define MPC_LAUNCH_N(CCV, IPWV, NCV)                                                                           \
-    rc = launch<CCV, IPWV, NCV>(h, P, (int)B, (int)V, lds, stream, d_state, d_ego, d_vref, d_weights, d_coll,   \
-                                d_others, d_nveh, d_u0, d_U, d_X, d_status, d_iters)
-#define MPC_LAUNCH(CCV, IPWV)                                                                                   \
-    do {                                                                                                        \
-        if (N == 20) MPC_LAUNCH_N(CCV, IPWV, 20);       /* BASELINE horizon */                                  \
-        else if (N == 16) MPC_LAUNCH_N(CCV, IPWV, 16);  /* reference cfg.yaml default */                        \
-        else MPC_LAUNCH_N(CCV, IPWV, 0);                                                                        \
-    } while (0)
+#define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                              \
+    rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
+                                     d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters)
     if (cc) {
-        if (ipw == 16) MPC_LAUNCH(true, 16);
-        else if (ipw == 4) MPC_LAUNCH(true, 4);
-        else MPC_LAUNCH(true, 1);
+        if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOcc);       /* BASELINE horizon */
+        else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOcc);  /* reference cfg.yaml default */
+        else MPC_LAUNCH_W(true, 0, kWaveOcc);
     } else {
-        if (ipw == 16) MPC_LAUNCH(false, 16);
-        else if (ipw == 4) MPC_LAUNCH(false, 4);
-        else MPC_LAUNCH(false, 1);
+        if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOcc);
+        else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOcc);
+        else MPC_LAUNCH_W(false, 0, kWaveOcc);
     }
-#undef MPC_LAUNCH
-#undef MPC_LAUNCH_N
-    if (rc) return rc;
-    }
-
-    return MPC_OK;
+#undef MPC_LAUNCH_W
+    return rc;
 }
 
 }  // namespace
@@ -575,9 +370,7 @@ int mpc_set_reference(mpc_handle *h, const double *ref, int32_t M) {
 
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V) {
     if (!h || B < 0 || V < 0 || V > MPC_MAX_OTHERS) return -1;
-    const bool cc = V > 0;
-    const int ipw = choose_ipw(h, cc, B > 0 ? B : 1, h->cfg.horizon, V);
-    return (int64_t)lds_bytes(cc, ipw, h->cfg.horizon, h->M > 0 ? h->M : 85, V);
+    return (int64_t)mpc::wave::lds_doubles(V > 0, h->cfg.horizon, V) * (int64_t)sizeof(double);
 }
 
 int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t *ego_index, const double *vref,

@@ -1,7 +1,7 @@
 // mpc_wave.hpp - wave-cooperative interior-point DDP solver: ONE wave64 per MPC instance.
 //
-// Same NLP and same algorithm as mpc_core.hpp (which assigns one lane per instance), reorganised so that the
-// 64 lanes of a wave work on a single instance:
+// The NLP is the reference's (agents/pure_mpc.py:80-318), the algorithm the one DESIGN.md section 3 specifies,
+// organised so that the 64 lanes of a wave work on a single instance:
 //   * everything that is independent per stage (trig and linearisation of the dynamics, cost and collision-potential
 //     values and derivatives, barrier terms, complementarity, stage Hessians, dual residual, step-length ratios, dual
 //     update) runs stage-parallel, lane k = stage k, with register-level wave reductions;
@@ -12,8 +12,9 @@
 //     exchanged through LDS;
 //   * the line search integrates all six trial step lengths at once, lane t = trial t;
 //   * only the true recursions (adjoint, linearised step, one lane's rollout) are serial.
-// Why: measured on MI355X the one-lane-per-instance kernel is bound by the serial FP64 instruction stream of
-// its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4 SIMDs per CU usable because the per-instance state has to sit in LDS.
+// Why: measured on MI355X, a one-lane-per-instance kernel (the first design, since removed) is bound by the serial
+// FP64 instruction stream of its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4
+// SIMDs per CU usable because the per-instance state has to sit in LDS.
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
 // (f(lane) per lane; other lanes may read afterwards what a lane wrote to LDS); tests/cpu_wave_harness.cpp runs the
@@ -54,7 +55,7 @@ enum : int {
     SC_SPARE = 0,  // 0.0, 1.0, dt
     SC_SIZE = 4
 };
-constexpr int kMaxHorizon = 32;   // lanes 0..31 / 32..63 carry the stages of two line-search trials
+constexpr int kMaxHorizon = kLanes;   // lane k = stage k in the stage-parallel phases
 // compact stage cost Hessian / gradient, assembled for all stages before a sweep into slots that are free during it:
 // the stage's gain slots (overwritten by the gains once the stage is done) and the trial trajectory buffer
 enum : int {
@@ -258,7 +259,7 @@ struct Solver {
         });
     }
 
-    // ---- cost pieces (same formulas as mpc_core.hpp) ------------------------------------------------
+    // ---- cost pieces (agents/pure_mpc.py:119-214) --------------------------------------------------
     MPC_HD double track(int k, double x_0, double x_1, double x_2, double x_3, double *g) const {
         const double s = c.ref(k, R_SIN), cc = c.ref(k, R_COS);
         const double dx = x_0 - c.ref(k, R_X), dy = x_1 - c.ref(k, R_Y);
@@ -451,38 +452,61 @@ struct Solver {
         });
         c.tick(T_ROLL_DYN);
         int acc = -1;
-        double alpha = a_pr;
+        if (N <= kLanes / 2) {
+            // two trials per pass: lanes 0..31 / 32..63 = stages of trial 2p / 2p + 1
+            double alpha = a_pr;
 #pragma unroll 1
-        for (int p = 0; p < kTrials / 2 && acc < 0; ++p, alpha *= 0.0625) {
-            const int f0 = c.wave_bcast(ls_feas, 2 * p), f1 = c.wave_bcast(ls_feas, 2 * p + 1);
-            if (!f0 && !f1) continue;
-            c.phase([&](int lane) {
-                red_a.at(lane) = 0.0;
-                red_b.at(lane) = 0.0;
-                const int h = lane >> 5, k = lane & 31, t = 2 * p + h;
-                if (k >= N || !(h ? f1 : f0)) return;
-                const int base = t == 0 ? TB : TRL + (t - 1) * TSZ, stride = t == 0 ? SL : 6;
-                stage_terms(base, stride, k, red_a.at(lane), red_b.at(lane));
-            });
-            double J0, J1, b0, b1;
-            c.wave_sum2(red_a, J0, J1);
-            c.wave_sum2(red_b, b0, b1);
-            const double a1 = alpha * 0.25;
-            if (f0 && J0 + mu_ * b0 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
-                acc = 2 * p;
-                Jn = J0;
-                barn = b0;
-            } else if (f1 && J1 + mu_ * b1 <= phi0 + 1e-4 * a1 * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
-                acc = 2 * p + 1;
-                Jn = J1;
-                barn = b1;
+            for (int p = 0; p < kTrials / 2 && acc < 0; ++p, alpha *= 0.0625) {
+                const int f0 = c.wave_bcast(ls_feas, 2 * p), f1 = c.wave_bcast(ls_feas, 2 * p + 1);
+                if (!f0 && !f1) continue;
+                c.phase([&](int lane) {
+                    red_a.at(lane) = 0.0;
+                    red_b.at(lane) = 0.0;
+                    const int h = lane >> 5, k = lane & 31, t = 2 * p + h;
+                    if (k >= N || !(h ? f1 : f0)) return;
+                    const int base = t == 0 ? TB : TRL + (t - 1) * TSZ, stride = t == 0 ? SL : 6;
+                    stage_terms(base, stride, k, red_a.at(lane), red_b.at(lane));
+                });
+                double J0, J1, b0, b1;
+                c.wave_sum2(red_a, J0, J1);
+                c.wave_sum2(red_b, b0, b1);
+                const double a1 = alpha * 0.25;
+                if (f0 && J0 + mu_ * b0 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                    acc = 2 * p;
+                    Jn = J0;
+                    barn = b0;
+                } else if (f1 && J1 + mu_ * b1 <= phi0 + 1e-4 * a1 * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                    acc = 2 * p + 1;
+                    Jn = J1;
+                    barn = b1;
+                }
+            }
+        } else {
+            // long horizons (33..64 stages): one trial per pass, lane k = stage k
+            double alpha = a_pr;
+#pragma unroll 1
+            for (int t = 0; t < kTrials && acc < 0; ++t, alpha *= 0.25) {
+                if (!c.wave_bcast(ls_feas, t)) continue;
+                c.phase([&](int lane) {
+                    red_a.at(lane) = 0.0;
+                    red_b.at(lane) = 0.0;
+                    if (lane >= N) return;
+                    const int base = t == 0 ? TB : TRL + (t - 1) * TSZ, stride = t == 0 ? SL : 6;
+                    stage_terms(base, stride, lane, red_a.at(lane), red_b.at(lane));
+                });
+                const double J0 = c.wave_sum(red_a), b0 = c.wave_sum(red_b);
+                if (J0 + mu_ * b0 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                    acc = t;
+                    Jn = J0;
+                    barn = b0;
+                }
             }
         }
         if (acc >= 1) {
             const int base = TRL + (acc - 1) * TSZ;
             c.phase([&](int lane) {
-                if (lane > N) return;
-                for (int e = 0; e < (lane < N ? 6 : 4); ++e) S(lane, TB + e, c.ld(base + lane * 6 + e));
+                for (int node = lane; node <= N; node += kLanes)
+                    for (int e = 0; e < (node < N ? 6 : 4); ++e) S(node, TB + e, c.ld(base + node * 6 + e));
             });
         }
         c.tick(T_ROLL_COST);

@@ -81,12 +81,6 @@ def _host_solver(libname, srcname, symbol):
 
 
 @pytest.fixture(scope="session")
-def cpu_core():
-    """mpc_core.hpp: one lane per instance (fallback kernel)."""
-    return _host_solver("libcpu_core.so", "cpu_core_harness.cpp", "core_solve_batch")
-
-
-@pytest.fixture(scope="session")
 def cpu_wave():
     """mpc_wave.hpp: one wave per instance, the 64 lanes emulated by loops (default kernel)."""
     return _host_solver("libcpu_wave.so", "cpu_wave_harness.cpp", "wave_solve_batch")

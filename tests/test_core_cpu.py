@@ -1,15 +1,16 @@
-"""The kernels' solver cores, compiled for the host, against the oracle (CPU only): mpc_wave.hpp (one wave per
-instance, default kernel; its 64 lanes are emulated by loops over the phases) and mpc_core.hpp (one lane per
-instance, fallback).  Same arithmetic as the HIP kernels minus the lean device math (frcp/frsqrt use 1/x, 1/sqrt)."""
+"""The kernel's solver (mpc_wave.hpp: one wave per instance), compiled for the host, against the oracle (CPU only).  The
+64 lanes are emulated by loops over the phases, the matrix core, lane permutations and reductions by host models
+(tests/cpu_wave_harness.cpp).  Same arithmetic as the HIP kernel minus the lean device math (frcp/frsqrt use 1/x,
+1/sqrt)."""
 import numpy as np
 import pytest
 
 from conftest import rel_u0_err
 
 
-@pytest.fixture(params=["wave", "lane"])
-def cpu_core(request):
-    return request.getfixturevalue("cpu_wave" if request.param == "wave" else "cpu_core")
+@pytest.fixture()
+def cpu_core(cpu_wave):
+    return cpu_wave
 
 
 @pytest.mark.parametrize("V,cc", [(4, False), (8, True)])
@@ -32,13 +33,14 @@ def test_core_edge_cases(cpu_core, oracle, ref_table):
     inp = dict(state=np.array([[2.0, 45.0, -np.pi / 2, 0.0], [2.0, 45.0, -np.pi / 2, 10.0]]),
                ego_index=np.array([4, 4], np.int32), weights=np.ones((2, 3)), is_collide=np.zeros(2, np.uint8),
                vref=None, others=None)
-    for N in (5, 16, 20, 32):
+    for N in (5, 16, 20, 32, 33, 64):
         got = cpu_core(ref_table, inp, N=N)
         want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], N=N,
                                   max_iter=100, xy_bounds=False)
         assert np.array_equal(got["status"], want["status"])
         assert rel_u0_err(got["u0"], want["u0"]).max() < 1e-8
-    assert np.abs(got["U"][1]).max() < 1e-7          # on the reference at reference speed: zero controls
+        if N <= 32:                                      # still on the straight: on the reference at reference speed
+            assert np.abs(got["U"][1]).max() < 1e-7      # the optimal controls are zero
     # collision cost requested but no vehicles
     inp["others"] = np.zeros((2, 0, 4))
     got = cpu_core(ref_table, inp, collision_cost=True)

@@ -30,8 +30,7 @@ for (B, V, cc) in [(1024, 4, 0), (4096, 4, 0), (4096, 8, 1)]:
                 vref=t(inp['vref'], torch.float64), others=t(inp['others'], torch.float64), collision_cost=bool(cc))
     for max_iter in (0, 5, 10, 20, 40, 100):
         e = engine.MPCEngine(horizon=20, max_iter=max_iter)
-        for kernel in ("wave", "lane") if max_iter == 100 else ("wave",):
-            os.environ['MPC_KERNEL'] = kernel
+        for kernel in ("wave",):
             out = e.solve_batch_torch(**args, sync=True)
             torch.cuda.synchronize()
             ts = []
@@ -43,5 +42,4 @@ for (B, V, cc) in [(1024, 4, 0), (4096, 4, 0), (4096, 8, 1)]:
             ms = np.median(ts)
             print(f"{kernel} kernel B={B} V={V} cc={cc} max_iter={max_iter}: {ms:.3f} ms -> {B/ms*1e3:.0f} solves/s; "
                   f"iters mean {it.mean():.1f} status {np.bincount(st)}", flush=True)
-        os.environ['MPC_KERNEL'] = "wave"
         e.close()
