@@ -129,6 +129,32 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
                       const double *ref_speed, uint32_t flags, double *act, int32_t *status, int32_t *iters,
                       void *stream);
 
+/*
+ * Iterative-linear MPC: B calls of IterativeLinearMPC_Agent._solve (agents/pure_mpc_linear.py:153-203): nearest
+ * reference point (:38-60), forward simulation of the stored control profile (predict_motion, :84-110), linearisation
+ * about it (linear_model_matrix, :62-82) and the QP of _linear_mpc_control (:205-257), which the reference gives to
+ * cvxpy/ECOS and this engine solves with a Riccati-based primal-dual interior-point method.
+ *   state  [B][4]     x, y, v, yaw of the ego vehicle - the state order of that agent (:23, :198)
+ *   U      [B][N][2]  in: the stored profile (oa, od), zeros for a first call (:190-192); out: the new profile where
+ *                     status is 0, unchanged elsewhere (:193-196).  Required.
+ *   u0     [B][2]     acceleration, steer = U[b][0] where status is 0, else (0, 0) (:195)
+ *   X      [B][N+1][4] optional: states of the linear model under the new controls (x, y, v, yaw)
+ *   status [B]        MPC_STATUS_CONVERGED / MAX_ITER / FACTORIZATION, or MPC_STATUS_INFEASIBLE_START when the ego
+ *                     speed is outside [0, 40/3.6] (the QP then has no feasible point: x[2,0] == v0, :252-256)
+ *   target_index [B]  optional: index of the nearest reference point
+ *   flags: MPC_FLAG_DEVICE_PTRS, MPC_FLAG_NO_SYNC.  cfg.horizon, dt, max_iter apply; the weights and bounds are the
+ *   module constants of the reference (:27-37).
+ */
+int mpc_ltv_solve_batch(mpc_handle *h, int32_t B, const double *state, uint32_t flags, double *u0, double *U, double *X,
+                        int32_t *status, int32_t *iters, int32_t *target_index, void *stream);
+
+/* Observation-level entry of the same agent: Agent.predict (agents/base_agent.py:54-73) = _parse_obs + _solve for B
+ * parallel environments.  Environment b owns a stored profile inside the handle (zeros until its first solve, kept
+ * across calls, forgotten by mpc_reset_env_state / mpc_reset_env_mask).  obs, vehicles_count, act, status, iters as
+ * for mpc_predict_batch. */
+int mpc_ltv_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicles_count, uint32_t flags, double *act,
+                          int32_t *status, int32_t *iters, void *stream);
+
 /* Episode boundaries: forget collision memory / stop point of the listed environments (host array of n ids);
  * env_ids == NULL or n < 0 resets all.  Replaces constructing a new PureMPC_Agent (agents/pure_mpc.py:38-43,63). */
 int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *stream);

@@ -8,9 +8,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpc_mi355x.so")
 _SOURCES = [os.path.join(_HERE, "csrc", "mpc_engine.hip")]
-_DEPS = _SOURCES + [os.path.join(_HERE, "csrc", "mpc_core.hpp"), os.path.join(_HERE, "csrc", "mpc_wave.hpp"),
-         os.path.join(_HERE, "csrc", "mpc_preamble.hpp"), os.path.join(_HERE, "csrc", "mpc_wave_dev.hpp"),
-                    os.path.join(os.path.dirname(_HERE), "include", "mpc_mi355x.h")]
+_DEPS = _SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp", "mpc_ltv.hpp",
+                                                              "mpc_preamble.hpp", "mpc_wave_dev.hpp")] + \
+    [os.path.join(os.path.dirname(_HERE), "include", "mpc_mi355x.h")]
 
 
 def _hipcc() -> str:

@@ -18,6 +18,7 @@
 
 #include "../../include/mpc_mi355x.h"
 #include "mpc_core.hpp"
+#include "mpc_ltv.hpp"
 #include "mpc_wave.hpp"
 #include "mpc_wave_dev.hpp"
 #include "mpc_preamble.hpp"
@@ -60,6 +61,12 @@ struct WaveCtx : mpc::wave::WaveOps {
         idx = idx > M - 1 ? M - 1 : idx;
         idx = idx < 0 ? 0 : idx;
         return table[idx * mpc::REF_COLS + c];
+    }
+    __device__ __forceinline__ double refv(int k) const {   // speed column, stored behind the [M][REF_COLS] block
+        int idx = e0 + k;
+        idx = idx > M - 1 ? M - 1 : idx;
+        idx = idx < 0 ? 0 : idx;
+        return table[M * mpc::REF_COLS + idx];
     }
 };
 
@@ -143,6 +150,85 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// iterative-linear MPC (mpc_ltv.hpp; reference agents/pure_mpc_linear.py): ONE wave64 per instance, grid = B.
+// The ego state comes either from `state` ([B][4] x, y, v, yaw) or straight from the observation (`obs`, row 0 parsed
+// as agents/base_agent.py:96-102 does).  U holds the stored control profile (oa, od) on entry and, where the QP was
+// solved, the new one on exit; elsewhere it is left alone and the action is (0, 0) (pure_mpc_linear.py:193-196).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock, 2) void mpc_ltv_kernel(
+    mpc::ltv::LtvParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
+    const float *__restrict__ obs, int rows, double *U, double *__restrict__ u0_out, double *__restrict__ X_out,
+    int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out, int32_t *__restrict__ target_out) {
+    namespace ltv = mpc::ltv;
+    extern __shared__ double smem[];
+    const int N = P.N;
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    double x0[4];   // x, y, yaw, v
+    if (obs) {
+        const float *ob = obs + (size_t)b * rows * mpc::pre::kObsCols;
+        x0[0] = (double)ob[1];
+        x0[1] = (double)ob[2];
+        x0[2] = (double)mpc::pre::normalize_angle_f32(ob[5]);
+        x0[3] = (double)mpc::pre::speed_f32(ob[3], ob[4]);
+    } else {
+        x0[0] = state[(size_t)b * 4 + 0];
+        x0[1] = state[(size_t)b * 4 + 1];
+        x0[2] = state[(size_t)b * 4 + 3];
+        x0[3] = state[(size_t)b * 4 + 2];
+    }
+    WaveCtx<0> ctx((mpc::wave::lds_double_t *)smem, ref5, 0, M);
+    // nearest reference point, first minimum of the squared distance (calc_nearest_index_in_direction, :38-60);
+    // products and sum rounded separately like the Python expression
+    {
+        double best = INFINITY;
+        int bidx = 0;
+        for (int i = lane; i < M; i += kBlock) {
+            const double dx = ref5[i * mpc::REF_COLS + mpc::R_X] - x0[0], dy = ref5[i * mpc::REF_COLS + mpc::R_Y] - x0[1];
+            const double d = mpc::pre::f64add(mpc::pre::f64mul(dx, dx), mpc::pre::f64mul(dy, dy));
+            if (d < best) {
+                best = d;
+                bidx = i;
+            }
+        }
+        mpc::wave::PerLane<double> pv, pi;
+        pv.v = best;
+        const double m = ctx.wave_min(pv);
+        pi.v = best == m ? (double)bidx : 1e9;
+        ctx.e0 = (int)ctx.wave_min(pi);
+    }
+    if (lane < N) {
+        ctx.st(lane * ltv::L_SLOTS + ltv::L_U + 0, U[((size_t)b * N + lane) * 2 + 0]);
+        ctx.st(lane * ltv::L_SLOTS + ltv::L_U + 1, U[((size_t)b * N + lane) * 2 + 1]);
+    }
+    __syncthreads();
+    ltv::Solver<WaveCtx<0>> solver(P, ctx, x0);
+    int status, iters;
+    solver.solve(status, iters);
+    __syncthreads();
+    const bool ok = status == ltv::ST_CONVERGED;
+    if (lane < 2) u0_out[(size_t)b * 2 + lane] = ok ? ctx.ld(ltv::L_U + lane) : 0.0;
+    if (ok && lane < N) {
+        U[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 0);
+        U[((size_t)b * N + lane) * 2 + 1] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 1);
+    }
+    if (X_out && status != ltv::ST_INFEASIBLE)
+        for (int node = lane; node <= N; node += kBlock) {
+            double *o = X_out + ((size_t)b * (N + 1) + node) * 4;
+            o[0] = ctx.ld(node * ltv::L_SLOTS + ltv::L_X + 0);
+            o[1] = ctx.ld(node * ltv::L_SLOTS + ltv::L_X + 1);
+            o[2] = ctx.ld(node * ltv::L_SLOTS + ltv::L_X + 3);
+            o[3] = ctx.ld(node * ltv::L_SLOTS + ltv::L_X + 2);
+        }
+    if (lane == 0) {
+        if (status_out) status_out[b] = status;
+        if (iters_out) iters_out[b] = iters;
+        if (target_out) target_out[b] = ctx.e0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // observation -> problem data (mpc_preamble.hpp).  16 lanes per environment, 4 environments per wave: lane 0
 // parses, predicts the ego polyline into LDS and runs the detector state machine / speed profile; lane j tests other
 // vehicle j against that polyline (the part that scales with the number of vehicles).
@@ -189,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
 
 __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, const uint8_t *__restrict__ mask,
                                      mpc::pre::EnvState *__restrict__ env, uint8_t *__restrict__ warm_valid, int cap,
-                                     int warm_only) {
+                                     int warm_only, double *__restrict__ ltv_u, int ltv_row) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int b = ids ? ids[i] : i;
@@ -197,6 +283,8 @@ __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, con
     if (mask && !mask[i]) return;
     if (!warm_only) env[b] = mpc::pre::EnvState{};
     warm_valid[b] = 0;
+    if (ltv_u)                      // stored profile of the iterative-linear agent: oa = od = None -> zeros
+        for (int i = 0; i < ltv_row; ++i) ltv_u[(size_t)b * ltv_row + i] = 0.0;
 }
 
 }  // namespace
@@ -217,6 +305,7 @@ struct mpc_handle {
     int env_cap = 0;
     double *d_warm = nullptr;        // [env_cap][N][2] last control sequence per environment (MPC_FLAG_WARM_START)
     uint8_t *d_warm_valid = nullptr; // [env_cap] 1 = d_warm holds a solution of the current episode
+    double *d_ltv_u = nullptr;       // [env_cap][N][2] stored profile (oa, od) of the iterative-linear agent per environment
     void *d_pre = nullptr;
     size_t pre_bytes = 0;
     int pre_B = 0, pre_V = 0;   // shape of the last preamble output (for mpc_get_last_inputs)
@@ -343,6 +432,7 @@ void mpc_destroy(mpc_handle *h) {
     if (h->d_env) (void)hipFree(h->d_env);
     if (h->d_warm) (void)hipFree(h->d_warm);
     if (h->d_warm_valid) (void)hipFree(h->d_warm_valid);
+    if (h->d_ltv_u) (void)hipFree(h->d_ltv_u);
     if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
 }
@@ -473,12 +563,14 @@ static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
     int cap = h->env_cap > 0 ? h->env_cap : 256;
     while (cap < B) cap *= 2;
     mpc::pre::EnvState *n = nullptr;
-    double *nw = nullptr;
+    double *nw = nullptr, *nl = nullptr;
     uint8_t *nv = nullptr;
     const size_t wrow = (size_t)h->cfg.horizon * 2 * sizeof(double);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&n), (size_t)cap * sizeof(mpc::pre::EnvState)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nw), (size_t)cap * wrow));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nv), (size_t)cap));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nl), (size_t)cap * wrow));
+    HIP_TRY(hipMemsetAsync(nl, 0, (size_t)cap * wrow, stream));
     HIP_TRY(hipMemsetAsync(n, 0, (size_t)cap * sizeof(mpc::pre::EnvState), stream));
     HIP_TRY(hipMemsetAsync(nw, 0, (size_t)cap * wrow, stream));
     HIP_TRY(hipMemsetAsync(nv, 0, (size_t)cap, stream));
@@ -487,14 +579,17 @@ static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
                                hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemcpyAsync(nw, h->d_warm, (size_t)h->env_cap * wrow, hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipMemcpyAsync(nv, h->d_warm_valid, (size_t)h->env_cap, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(nl, h->d_ltv_u, (size_t)h->env_cap * wrow, hipMemcpyDeviceToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipFree(h->d_env));
         HIP_TRY(hipFree(h->d_warm));
         HIP_TRY(hipFree(h->d_warm_valid));
+        HIP_TRY(hipFree(h->d_ltv_u));
     }
     h->d_env = n;
     h->d_warm = nw;
     h->d_warm_valid = nv;
+    h->d_ltv_u = nl;
     h->env_cap = cap;
     return MPC_OK;
 }
@@ -607,6 +702,143 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
     return MPC_OK;
 }
 
+// ---- iterative-linear MPC (reference agents/pure_mpc_linear.py) ---------------------------------------------
+static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_state, const float *d_obs, int rows,
+                      double *d_U, double *d_u0, double *d_X, int32_t *d_status, int32_t *d_iters, int32_t *d_target) {
+    mpc::ltv::LtvParams P;
+    P.N = h->cfg.horizon;
+    P.max_iter = h->cfg.max_iter;
+    P.dt = h->cfg.dt;
+    const size_t lds = (size_t)mpc::ltv::lds_doubles(P.N) * sizeof(double);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(mpc_ltv_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_obs,
+                       rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_ltv_solve_batch(mpc_handle *h, int32_t B, const double *state, uint32_t flags, double *u0, double *U, double *X,
+                        int32_t *status, int32_t *iters, int32_t *target_index, void *stream_) {
+    if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_ltv_solve_batch: null handle");
+    if (B < 0 || !state || !u0 || !U)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_ltv_solve_batch: null required pointer or negative batch");
+    if (!h->d_ref) return fail(MPC_ERR_NO_REFERENCE, "mpc_ltv_solve_batch: call mpc_set_reference first");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int N = h->cfg.horizon;
+    const size_t N1 = (size_t)N + 1;
+    const bool dev = (flags & MPC_FLAG_DEVICE_PTRS) != 0;
+    const double *d_state = state;
+    double *d_u0 = u0, *d_U = U, *d_X = X;
+    int32_t *d_status = status, *d_iters = iters, *d_target = target_index;
+    size_t o_u0 = 0, o_U = 0, o_X = 0, o_st = 0, o_it = 0, o_tg = 0;
+    if (!dev) {
+        size_t off = 0;
+        auto seg = [&](size_t bytes) {
+            size_t o = off;
+            off += round_up(bytes, 16);
+            return o;
+        };
+        const size_t o_state = seg((size_t)B * 4 * 8);
+        o_u0 = seg((size_t)B * 2 * 8);
+        o_U = seg((size_t)B * N * 2 * 8);
+        o_X = X ? seg((size_t)B * N1 * 4 * 8) : 0;
+        o_st = seg((size_t)B * 4);
+        o_it = seg((size_t)B * 4);
+        o_tg = seg((size_t)B * 4);
+        if (h->stage_bytes < off) {
+            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
+            h->d_stage = nullptr;
+            h->stage_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_stage, off));
+            h->stage_bytes = off;
+        }
+        char *sb = static_cast<char *>(h->d_stage);
+        HIP_TRY(hipMemcpyAsync(sb + o_state, state, (size_t)B * 4 * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(sb + o_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
+        d_state = reinterpret_cast<double *>(sb + o_state);
+        d_u0 = reinterpret_cast<double *>(sb + o_u0);
+        d_U = reinterpret_cast<double *>(sb + o_U);
+        d_X = X ? reinterpret_cast<double *>(sb + o_X) : nullptr;
+        d_status = reinterpret_cast<int32_t *>(sb + o_st);
+        d_iters = reinterpret_cast<int32_t *>(sb + o_it);
+        d_target = reinterpret_cast<int32_t *>(sb + o_tg);
+    }
+    if (int rc = launch_ltv(h, B, stream, d_state, nullptr, 0, d_U, d_u0, d_X, d_status, d_iters, d_target)) return rc;
+    if (!dev) {
+        char *sb = static_cast<char *>(h->d_stage);
+        HIP_TRY(hipMemcpyAsync(u0, sb + o_u0, (size_t)B * 2 * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(U, sb + o_U, (size_t)B * N * 2 * 8, hipMemcpyDeviceToHost, stream));
+        if (X) HIP_TRY(hipMemcpyAsync(X, sb + o_X, (size_t)B * N1 * 4 * 8, hipMemcpyDeviceToHost, stream));
+        if (status) HIP_TRY(hipMemcpyAsync(status, sb + o_st, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        if (iters) HIP_TRY(hipMemcpyAsync(iters, sb + o_it, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        if (target_index) HIP_TRY(hipMemcpyAsync(target_index, sb + o_tg, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    } else if (!(flags & MPC_FLAG_NO_SYNC)) {
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return MPC_OK;
+}
+
+int mpc_ltv_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicles_count, uint32_t flags, double *act,
+                          int32_t *status, int32_t *iters, void *stream_) {
+    if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_ltv_predict_batch: null handle");
+    if (B < 0 || !obs || !act)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_ltv_predict_batch: null required pointer or negative batch");
+    if (vehicles_count < 1 || vehicles_count > MPC_MAX_OTHERS + 1)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_ltv_predict_batch: vehicles_count out of range");
+    if (!h->d_ref) return fail(MPC_ERR_NO_REFERENCE, "mpc_ltv_predict_batch: call mpc_set_reference first");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const int rows = vehicles_count;
+    const bool dev = (flags & MPC_FLAG_DEVICE_PTRS) != 0;
+    if (int rc = ensure_env(h, B, stream)) return rc;
+    const float *d_obs = obs;
+    double *d_act = act;
+    int32_t *d_status = status, *d_iters = iters;
+    size_t o_act = 0, o_st = 0, o_it = 0;
+    if (!dev) {
+        size_t off = 0;
+        auto seg = [&](size_t bytes) {
+            size_t o = off;
+            off += round_up(bytes, 16);
+            return o;
+        };
+        const size_t o_obs = seg((size_t)B * rows * mpc::pre::kObsCols * 4);
+        o_act = seg((size_t)B * 2 * 8);
+        o_st = seg((size_t)B * 4);
+        o_it = seg((size_t)B * 4);
+        if (h->stage_bytes < off) {
+            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
+            h->d_stage = nullptr;
+            h->stage_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_stage, off));
+            h->stage_bytes = off;
+        }
+        char *sb = static_cast<char *>(h->d_stage);
+        HIP_TRY(hipMemcpyAsync(sb + o_obs, obs, (size_t)B * rows * mpc::pre::kObsCols * 4, hipMemcpyHostToDevice, stream));
+        d_obs = reinterpret_cast<float *>(sb + o_obs);
+        d_act = reinterpret_cast<double *>(sb + o_act);
+        d_status = reinterpret_cast<int32_t *>(sb + o_st);
+        d_iters = reinterpret_cast<int32_t *>(sb + o_it);
+    }
+    if (int rc = launch_ltv(h, B, stream, nullptr, d_obs, rows, h->d_ltv_u, d_act, nullptr, d_status, d_iters, nullptr))
+        return rc;
+    if (!dev) {
+        char *sb = static_cast<char *>(h->d_stage);
+        HIP_TRY(hipMemcpyAsync(act, sb + o_act, (size_t)B * 2 * 8, hipMemcpyDeviceToHost, stream));
+        if (status) HIP_TRY(hipMemcpyAsync(status, sb + o_st, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        if (iters) HIP_TRY(hipMemcpyAsync(iters, sb + o_it, (size_t)B * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    } else if (!(flags & MPC_FLAG_NO_SYNC)) {
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return MPC_OK;
+}
+
 int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *stream_) {
     if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_reset_env_state: null handle");
     if (!h->d_env) return MPC_OK;   // nothing allocated yet: every environment is fresh
@@ -615,6 +847,7 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
     if (!env_ids || n < 0) {
         HIP_TRY(hipMemsetAsync(h->d_env, 0, (size_t)h->env_cap * sizeof(mpc::pre::EnvState), stream));
         HIP_TRY(hipMemsetAsync(h->d_warm_valid, 0, (size_t)h->env_cap, stream));
+        HIP_TRY(hipMemsetAsync(h->d_ltv_u, 0, (size_t)h->env_cap * h->cfg.horizon * 2 * sizeof(double), stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return MPC_OK;
     }
@@ -624,7 +857,7 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
     hipError_t e = hipMemcpyAsync(d_ids, env_ids, (size_t)n * 4, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int)n, d_ids,
-                           (const uint8_t *)nullptr, h->d_env, h->d_warm_valid, h->env_cap, 0);
+                           (const uint8_t *)nullptr, h->d_env, h->d_warm_valid, h->env_cap, 0, h->d_ltv_u, h->cfg.horizon * 2);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -652,7 +885,8 @@ int mpc_reset_env_mask(mpc_handle *h, int32_t B, const uint8_t *done, uint32_t f
     const int n = B < h->env_cap ? B : h->env_cap;
     hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n,
                        (const int32_t *)nullptr, d_done, h->d_env, h->d_warm_valid, h->env_cap,
-                       (flags & MPC_FLAG_WARM_START) ? 1 : 0);
+                       (flags & MPC_FLAG_WARM_START) ? 1 : 0, (flags & MPC_FLAG_WARM_START) ? nullptr : h->d_ltv_u,
+                       h->cfg.horizon * 2);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && (tmp || !(flags & MPC_FLAG_NO_SYNC))) e = hipStreamSynchronize(stream);
     if (tmp) (void)hipFree(tmp);

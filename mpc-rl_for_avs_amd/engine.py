@@ -38,7 +38,8 @@ class _Config(ctypes.Structure):
 
 _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_create", "mpc_destroy",
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
-            "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs"]
+            "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
+            "mpc_ltv_solve_batch", "mpc_ltv_predict_batch"]
 MAX_OTHERS = 16
 _lib = None
 
@@ -84,6 +85,10 @@ def load_library(path: str | None = None):
     lib.mpc_workspace_bytes.restype = ctypes.c_int64
     lib.mpc_predict_batch.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, dp, dp, ctypes.c_uint32, dp, ip, ip, vp]
     lib.mpc_predict_batch.restype = ctypes.c_int
+    lib.mpc_ltv_solve_batch.argtypes = [vp, ctypes.c_int32, dp, ctypes.c_uint32, dp, dp, dp, ip, ip, ip, vp]
+    lib.mpc_ltv_solve_batch.restype = ctypes.c_int
+    lib.mpc_ltv_predict_batch.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_uint32, dp, ip, ip, vp]
+    lib.mpc_ltv_predict_batch.restype = ctypes.c_int
     lib.mpc_reset_env_state.argtypes = [vp, ip, ctypes.c_int32, vp]
     lib.mpc_reset_env_state.restype = ctypes.c_int
     lib.mpc_reset_env_mask.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_uint32, vp]
@@ -250,6 +255,81 @@ class MPCEngine:
         rc = self._lib.mpc_predict_batch(self._h, B, p(obs), rows, p(weights), p(ref_speed), flags, p(out["act"]),
                                          p(out["status"]), p(out["iters"]), stream)
         self._check(rc, "mpc_predict_batch")
+        return out
+
+    # ------------------------------------------------------------------ iterative-linear MPC (pure_mpc_linear.py)
+    def ltv_solve_batch(self, state, U, want_traj=False):
+        """B calls of IterativeLinearMPC_Agent._solve.  state[B, 4] = x, y, v, yaw; U[B, N, 2] = stored profile (oa, od).
+        Returns dict(u0, U (new profile; the old one where status != 0), status, iters, target_index[, X])."""
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        B, N = state.shape[0], self.horizon
+        if state.shape != (B, 4):
+            raise ValueError(f"state must be [B, 4], got {state.shape}")
+        U = np.array(U, dtype=np.float64, order="C", copy=True)
+        if U.shape != (B, N, 2):
+            raise ValueError(f"U must be [B, {N}, 2], got {U.shape}")
+        u0 = np.empty((B, 2))
+        X = np.empty((B, N + 1, 4)) if want_traj else None
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        target = np.empty(B, dtype=np.int32)
+        rc = self._lib.mpc_ltv_solve_batch(self._h, B, _ptr(state), 0, _ptr(u0), _ptr(U), _ptr(X), _ptr(status),
+                                           _ptr(iters), _ptr(target), None)
+        self._check(rc, "mpc_ltv_solve_batch")
+        out = dict(u0=u0, U=U, status=status, iters=iters, target_index=target)
+        if want_traj:
+            out["X"] = X
+        return out
+
+    def ltv_solve_batch_torch(self, state, U, out=None, sync=False):
+        """Zero-copy variant: state float64 [B, 4] and U float64 [B, N, 2] device tensors; U is updated in place.
+        Returns dict(u0, status, iters) of device tensors."""
+        import torch
+        B, N, dev = int(state.shape[0]), self.horizon, state.device
+        for name, t, shape in (("state", state, (B, 4)), ("U", U, (B, N, 2))):
+            if t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda or t.device != dev or \
+                    tuple(t.shape) != shape:
+                raise ValueError(f"{name}: expected contiguous float64 tensor {shape} on {dev}")
+        if out is None:
+            out = dict(u0=torch.empty((B, 2), dtype=torch.float64, device=dev),
+                       status=torch.empty(B, dtype=torch.int32, device=dev),
+                       iters=torch.empty(B, dtype=torch.int32, device=dev))
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.mpc_ltv_solve_batch(self._h, B, p(state), FLAG_DEVICE_PTRS | (0 if sync else FLAG_NO_SYNC),
+                                           p(out["u0"]), p(U), None, p(out["status"]), p(out["iters"]), None, stream)
+        self._check(rc, "mpc_ltv_solve_batch")
+        return out
+
+    def ltv_predict_batch(self, obs):
+        """obs[B, vehicles_count, 8] float32 -> dict(act, status, iters): Agent.predict of the iterative-linear agent
+        with the per-environment stored profile kept inside the engine."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        if obs.ndim != 3 or obs.shape[2] != 8:
+            raise ValueError(f"obs must be [B, vehicles_count, 8], got {obs.shape}")
+        B, rows = obs.shape[:2]
+        act = np.empty((B, 2))
+        status = np.empty(B, dtype=np.int32)
+        iters = np.empty(B, dtype=np.int32)
+        rc = self._lib.mpc_ltv_predict_batch(self._h, B, _ptr(obs), rows, 0, _ptr(act), _ptr(status), _ptr(iters), None)
+        self._check(rc, "mpc_ltv_predict_batch")
+        return dict(act=act, status=status, iters=iters)
+
+    def ltv_predict_batch_torch(self, obs, out=None, sync=False):
+        """Zero-copy variant on a float32 device tensor [B, R, 8], enqueued on torch's current stream."""
+        import torch
+        if obs.dtype != torch.float32 or not obs.is_contiguous() or not obs.is_cuda or obs.dim() != 3 or obs.shape[2] != 8:
+            raise ValueError("obs: expected contiguous float32 device tensor [B, vehicles_count, 8]")
+        B, rows, dev = int(obs.shape[0]), int(obs.shape[1]), obs.device
+        if out is None:
+            out = dict(act=torch.empty((B, 2), dtype=torch.float64, device=dev),
+                       status=torch.empty(B, dtype=torch.int32, device=dev),
+                       iters=torch.empty(B, dtype=torch.int32, device=dev))
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self._lib.mpc_ltv_predict_batch(self._h, B, p(obs), rows, FLAG_DEVICE_PTRS | (0 if sync else FLAG_NO_SYNC),
+                                             p(out["act"]), p(out["status"]), p(out["iters"]), stream)
+        self._check(rc, "mpc_ltv_predict_batch")
         return out
 
     def reset_env_state(self, env_ids=None):

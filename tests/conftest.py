@@ -35,7 +35,8 @@ def _host_solver(libname, srcname, symbol):
     import ctypes
     out = os.path.join(ROOT, "tests", "_build", libname)
     src = os.path.join(ROOT, "tests", srcname)
-    deps = [src] + [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp")]
+    deps = [src, os.path.join(ROOT, "tests", "host_wave_ctx.hpp")] + \
+        [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off",
@@ -84,6 +85,55 @@ def _host_solver(libname, srcname, symbol):
 def cpu_wave():
     """mpc_wave.hpp: one wave per instance, the 64 lanes emulated by loops (default kernel)."""
     return _host_solver("libcpu_wave.so", "cpu_wave_harness.cpp", "wave_solve_batch")
+
+
+@pytest.fixture(scope="session")
+def cpu_ltv():
+    """mpc_ltv.hpp (iterative-linear MPC, one wave per instance) compiled for the host: solve(ref, state, U, N, max_iter)
+    with state [B, 4] = x, y, v, yaw and U [B, N, 2] the stored profile."""
+    import ctypes
+    out = os.path.join(ROOT, "tests", "_build", "libcpu_ltv.so")
+    src = os.path.join(ROOT, "tests", "cpu_ltv_harness.cpp")
+    deps = [src, os.path.join(ROOT, "tests", "host_wave_ctx.hpp")] + \
+        [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp", "mpc_ltv.hpp")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off",
+                        "-o", out, src], check=True)
+    lib = ctypes.CDLL(out)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
+    lib.ltv_solve_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp,
+                                    dp, ip, ip, ip]
+
+    def solve(ref, state, U, N=20, dt=0.1, max_iter=50):
+        P = lambda a, t: a.ctypes.data_as(t)
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        state = np.ascontiguousarray(state, dtype=np.float64)
+        B = state.shape[0]
+        U = np.array(U, dtype=np.float64, order="C", copy=True)
+        assert U.shape == (B, N, 2)
+        u0 = np.zeros((B, 2)); X = np.zeros((B, N + 1, 4))
+        st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); tg = np.zeros(B, np.int32)
+        rc = lib.ltv_solve_batch(B, N, dt, P(ref, dp), ref.shape[0], P(state, dp), max_iter, P(u0, dp), P(U, dp), P(X, dp),
+                                 P(st, ip), P(it, ip), P(tg, ip))
+        assert rc == 0
+        return dict(u0=u0, U=U, X=X, status=st, iters=it, target_index=tg)
+
+    return solve
+
+
+@pytest.fixture(scope="session")
+def ltv_oracle():
+    import ltv_oracle as L
+    return L
+
+
+def ltv_states(B, seed):
+    """Synthetic ego states for the iterative-linear agent: the generator of the NLP path, reordered to (x, y, v, yaw)
+    and rounded to float32 like a parsed observation."""
+    from mpc_rl_for_avs_amd import synth
+    inp = synth.solver_inputs(B, 2, seed=seed)
+    return np.ascontiguousarray(inp["state"][:, [0, 1, 3, 2]].astype(np.float32).astype(np.float64))
 
 
 def rel_u0_err(got, want):

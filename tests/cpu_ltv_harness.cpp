@@ -1,0 +1,66 @@
+// Host build of mpc-rl_for_avs_amd/csrc/mpc_ltv.hpp for tests only (-m "not gpu"): the wave-cooperative LTV-QP solver
+// with its lanes emulated (host_wave_ctx.hpp), compared with oracle/ltv_oracle.py on the CPU.  Never loaded by the
+// product.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../mpc-rl_for_avs_amd/csrc/mpc_ltv.hpp"
+#include "host_wave_ctx.hpp"
+
+// state [B][4] = x, y, v, yaw (interface order of the reference); U [B][N][2] in: stored profile, out: new profile
+// (unchanged unless status 0); u0 [B][2] ((0, 0) unless status 0); X [B][N+1][4] predicted states (x, y, v, yaw)
+extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state, int max_iter,
+                               double *u0, double *U, double *X, int32_t *status, int32_t *iters, int32_t *target) {
+    if (N > mpc::wave::kMaxHorizon || N < 1) return -1;
+    std::vector<double> table((size_t)M * mpc::REF_COLS), speeds((size_t)M);
+    for (int i = 0; i < M; ++i) {
+        table[i * mpc::REF_COLS + mpc::R_X] = ref_table[i * 4 + 0];
+        table[i * mpc::REF_COLS + mpc::R_Y] = ref_table[i * 4 + 1];
+        table[i * mpc::REF_COLS + mpc::R_H] = ref_table[i * 4 + 3];
+        table[i * mpc::REF_COLS + mpc::R_SIN] = std::sin(ref_table[i * 4 + 3]);
+        table[i * mpc::REF_COLS + mpc::R_COS] = std::cos(ref_table[i * 4 + 3]);
+        speeds[i] = ref_table[i * 4 + 2];
+    }
+    mpc::ltv::LtvParams P;
+    P.N = N;
+    P.max_iter = max_iter;
+    P.dt = dt;
+    const int nd = mpc::ltv::lds_doubles(N);
+    for (int b = 0; b < B; ++b) {
+        std::vector<double> L((size_t)nd, NAN);
+        // nearest reference point, first minimum (agents/pure_mpc_linear.py:38-60)
+        int best = 0;
+        double bd = INFINITY;
+        for (int i = 0; i < M; ++i) {
+            const double dx = ref_table[i * 4 + 0] - state[4 * b + 0], dy = ref_table[i * 4 + 1] - state[4 * b + 1];
+            const double d = dx * dx + dy * dy;
+            if (d < bd) {
+                bd = d;
+                best = i;
+            }
+        }
+        HostCtx ctx{L.data(), table.data(), best, M, speeds.data()};
+        for (int k = 0; k < N; ++k)
+            for (int i = 0; i < 2; ++i) L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_U + i] = U[((size_t)b * N + k) * 2 + i];
+        const double x0[4] = {state[4 * b + 0], state[4 * b + 1], state[4 * b + 3], state[4 * b + 2]};
+        mpc::ltv::Solver<HostCtx> solver(P, ctx, x0);
+        int st, it;
+        solver.solve(st, it);
+        const bool ok = st == mpc::ltv::ST_CONVERGED;
+        for (int i = 0; i < 2; ++i) u0[2 * b + i] = ok ? L[mpc::ltv::L_U + i] : 0.0;
+        if (ok)
+            for (int k = 0; k < N; ++k)
+                for (int i = 0; i < 2; ++i) U[((size_t)b * N + k) * 2 + i] = L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_U + i];
+        if (X)
+            for (int k = 0; k <= N; ++k) {
+                const double *x = &L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_X];
+                double *o = X + ((size_t)b * (N + 1) + k) * 4;
+                o[0] = x[0]; o[1] = x[1]; o[2] = x[3]; o[3] = x[2];
+            }
+        status[b] = st;
+        iters[b] = it;
+        if (target) target[b] = best;
+    }
+    return 0;
+}

@@ -1,0 +1,64 @@
+"""The LTV-QP kernel solver (mpc_ltv.hpp: one wave per instance), compiled for the host with its lanes emulated
+(tests/cpu_ltv_harness.cpp), against the CPU oracle (oracle/ltv_oracle.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import ltv_states, rel_u0_err
+
+TOL = 1e-4      # BASELINE north_star: controls within 1e-4 relative of the reference path
+
+
+@pytest.mark.parametrize("N", [5, 16, 20, 33, 64])
+def test_matches_oracle(cpu_ltv, ltv_oracle, ref_table, N):
+    st = ltv_states(48 if N <= 20 else 12, seed=100 + N)
+    nom = np.zeros((len(st), N, 2))
+    got = cpu_ltv(ref_table, st, nom, N=N)
+    want = ltv_oracle.solve_batch(ref_table, st, nom)
+    assert np.array_equal(got["status"], want["status"])
+    assert np.array_equal(got["target_index"], want["target_index"])
+    ok = want["status"] == 0
+    assert ok.mean() > 0.8
+    assert rel_u0_err(got["u0"], want["u0"])[ok].max() <= TOL
+    assert np.abs(got["U"] - want["U"])[ok].max() <= 1e-3
+    assert np.abs(got["X"] - want["X"])[ok].max() <= 1e-3
+    assert np.abs(got["iters"] - want["iters"])[ok].max() <= 3      # same iteration, rounding decides the last step
+    # where no QP was solved: action (0, 0), stored profile untouched
+    assert np.array_equal(got["u0"][~ok], np.zeros_like(got["u0"][~ok]))
+    assert np.array_equal(got["U"][~ok], nom[~ok])
+
+
+def test_second_call_linearises_about_the_first(cpu_ltv, ltv_oracle, ref_table):
+    st = ltv_states(64, seed=7)
+    first = cpu_ltv(ref_table, st, np.zeros((64, 20, 2)))
+    got = cpu_ltv(ref_table, st, first["U"])
+    want = ltv_oracle.solve_batch(ref_table, st, first["U"])
+    ok = (want["status"] == 0) & (got["status"] == 0)
+    assert np.array_equal(got["status"], want["status"]) and ok.mean() > 0.8
+    assert rel_u0_err(got["u0"], want["u0"])[ok].max() <= TOL
+    assert np.abs(got["u0"] - first["u0"])[ok].max() > 1e-3       # the model did change
+
+
+def test_edge_cases(cpu_ltv, ltv_oracle, ref_table):
+    L = ltv_oracle
+    st = ltv_states(6, seed=4)
+    st[0, 2] = 0.0                       # standing still: on the lower speed bound
+    st[1, 2] = np.float32(L.MAX_SPEED)   # float32 rounding of 40/3.6 is just below it: feasible
+    st[2, 2] = 11.5                      # above MAX_SPEED: infeasible
+    st[3, :2] = [200.0, 200.0]           # far from the path: huge terminal cost
+    st[4, 3] = 3.1                       # heading opposite to the path's -pi/2..-pi
+    nom = np.random.default_rng(5).uniform(-0.5, 0.5, (6, 20, 2))
+    nom[5, :, 0] = 9.0                   # a stored profile far outside the bounds only moves the operating point
+    got = cpu_ltv(ref_table, st, nom)
+    want = L.solve_batch(ref_table, st, nom)
+    assert np.array_equal(got["status"], want["status"])
+    assert got["status"][2] == L.STATUS_INFEASIBLE and got["iters"][2] == 0
+    ok = want["status"] == 0
+    assert ok.sum() == 5
+    assert rel_u0_err(got["u0"], want["u0"])[ok].max() <= TOL
+    assert got["u0"][0, 0] >= -1e-6      # cannot decelerate below zero speed
+    # bounds hold on what is returned
+    U = got["U"][ok]
+    assert U[:, :, 0].min() >= L.MAX_DECEL - 1e-7 and U[:, :, 0].max() <= L.MAX_ACCEL + 1e-7
+    assert np.abs(U[:, :, 1]).max() <= L.MAX_STEER + 1e-7
+    assert np.abs(np.diff(U[:, :, 1], axis=1)).max() <= L.MAX_DSTEER * 0.1 + 1e-7
+    assert got["X"][ok][:, :, 2].min() >= -1e-7 and got["X"][ok][:, :, 2].max() <= L.MAX_SPEED + 1e-7
