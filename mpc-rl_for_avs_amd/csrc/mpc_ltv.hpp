@@ -44,7 +44,8 @@ constexpr double kMaxSpeed = 40.0 / 3.6;
 
 // interior-point constants (the CPU oracle uses the same)
 constexpr double kSInitMin = 0.3, kZInit = 100.0;
-constexpr double kTolP = 1e-9, kTolD = 1e-4, kTolMu = 1e-10;   // |c - s|_inf, |grad L|_inf (reached once), s.z / m
+constexpr double kTolP = 1e-9, kTolMu = 1e-10;   // |c - s|_inf, s.z / m
+constexpr double kTolDRel = 1e-7;               // |grad L|_inf relative to max(1e3, its value at the start), reached once
 
 enum : int { ST_CONVERGED = 0, ST_MAX_ITER = 1, ST_FACTORIZATION = 2, ST_INFEASIBLE = 3 };
 
@@ -497,6 +498,7 @@ struct Solver {
         const double T = (double)N;
         int iter = 0;
         bool dual_ok = false;
+        double tol_d = 0.0;
         for (iter = 0; iter <= P.max_iter; ++iter) {
             // ============ residuals: primal (per inequality), complementarity, node terms of the adjoint
             const double y0 = 2.0 * T * kQfXY * (S(N, L_X + 0) - xr(N)), y1 = 2.0 * T * kQfXY * (S(N, L_X + 1) - yr(N));
@@ -561,9 +563,10 @@ struct Solver {
             });
             const double res_d = c.wave_max(red_a);
             // In exact arithmetic the dual residual shrinks by the same factor (1 - alpha) as the primal one; once mu is
-            // small its measured value is dominated by rounding in the multipliers of the active rows (~1e-12 / mu,
-            // harmless for the controls), so reaching kTolD once is what is required
-            dual_ok = dual_ok || res_d <= kTolD;
+            // small its measured value is dominated by rounding in the multipliers of the active rows (~ z^2 eps / mu,
+            // harmless for the controls), so reaching the tolerance once is what is required
+            if (iter == 0) tol_d = kTolDRel * fmax2(1e3, res_d);
+            dual_ok = dual_ok || res_d <= tol_d;
             if (res_p <= kTolP && dual_ok && mu <= kTolMu) {
                 status_out = ST_CONVERGED;
                 break;

@@ -42,7 +42,7 @@ WHEELBASE = 2.5                     # :131 default
 
 STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_FACTORIZATION, STATUS_INFEASIBLE = 0, 1, 2, 3
 S_INIT_MIN, Z_INIT = 1.0, 100.0    # initial slacks max(c, S_INIT_MIN), initial multipliers
-TOL_P, TOL_D, TOL_MU = 1e-9, 1e-4, 1e-10   # |c - s|_inf, |grad L|_inf (to be reached once, see solve_qp), s.z / m
+TOL_P, TOL_D_REL, TOL_MU = 1e-9, 1e-7, 1e-10   # |c - s|_inf, |grad L|_inf / max(1e3, start) (reached once), s.z / m
 
 
 def nearest_index(px, py, ref):
@@ -182,8 +182,10 @@ def solve_qp(H, g, C, c0, u_start, max_iter=50):
         r_d = grad - np.einsum("bmn,bm->bn", C, z)
         mu = (s * z).sum(axis=1) / m
         # exact arithmetic shrinks r_d by the same factor (1 - alpha) as r_p; once mu is small its measured value is
-        # rounding noise in the multipliers of the active rows (~1e-14 / mu here), so reaching TOL_D once is required
-        dual_ok |= np.abs(r_d).max(axis=1) <= TOL_D
+        # rounding noise in the multipliers of the active rows (~ z^2 eps / mu), so reaching the tolerance once is required
+        if it == 0:
+            tol_d = TOL_D_REL * np.maximum(1e3, np.abs(r_d).max(axis=1))
+        dual_ok |= np.abs(r_d).max(axis=1) <= tol_d
         done = (np.abs(r_p).max(axis=1) <= TOL_P) & dual_ok & (mu <= TOL_MU)
         newly = active & done
         status[newly] = STATUS_CONVERGED

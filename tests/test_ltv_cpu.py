@@ -1,9 +1,11 @@
 """The LTV-QP kernel solver (mpc_ltv.hpp: one wave per instance), compiled for the host with its lanes emulated
 (tests/cpu_ltv_harness.cpp), against the CPU oracle (oracle/ltv_oracle.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import ltv_states, rel_u0_err
+from conftest import GOLDEN, ltv_states, rel_u0_err
 
 TOL = 1e-4      # BASELINE north_star: controls within 1e-4 relative of the reference path
 
@@ -62,3 +64,15 @@ def test_edge_cases(cpu_ltv, ltv_oracle, ref_table):
     assert np.abs(U[:, :, 1]).max() <= L.MAX_STEER + 1e-7
     assert np.abs(np.diff(U[:, :, 1], axis=1)).max() <= L.MAX_DSTEER * 0.1 + 1e-7
     assert got["X"][ok][:, :, 2].min() >= -1e-7 and got["X"][ok][:, :, 2].max() <= L.MAX_SPEED + 1e-7
+
+
+def test_hard_closed_loop_instances(cpu_ltv, ltv_oracle, ref_table):
+    """Regression set: (state, stored profile) pairs met in closed loop far off the path (tools/gpu_ltv_closed_loop.py
+    with LTV_DUMP), whose multipliers are ~1e5: the measured dual residual is rounding noise long before mu reaches its
+    tolerance there, which an absolute dual tolerance never survived."""
+    d = np.load(os.path.join(GOLDEN, "ltv_closed_loop_hard.npz"))
+    got = cpu_ltv(ref_table, d["state"], d["U"])
+    want = ltv_oracle.solve_batch(ref_table, d["state"], d["U"])
+    assert (want["status"] == 0).all() and (got["status"] == 0).all()
+    assert rel_u0_err(got["u0"], want["u0"]).max() <= TOL
+    assert got["iters"].max() <= 30

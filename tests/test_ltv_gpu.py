@@ -1,9 +1,11 @@
 """The iterative-linear MPC path on the MI355X (mpc_ltv_solve_batch / mpc_ltv_predict_batch through the C ABI) against
 the CPU oracle (oracle/ltv_oracle.py) on the same seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import ltv_states, rel_u0_err
+from conftest import GOLDEN, ltv_states, rel_u0_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4      # BASELINE north_star: controls within 1e-4 relative of the reference path
@@ -149,3 +151,11 @@ def test_failure_semantics(eng, ltv_oracle):
     assert (out["status"][[0, 2, 3]] == 0).all()
     with pytest.raises(ValueError):
         eng.ltv_solve_batch(st, nom[:, :10])
+
+
+def test_hard_closed_loop_instances(eng, ltv_oracle, ref_table):
+    d = np.load(os.path.join(GOLDEN, "ltv_closed_loop_hard.npz"))
+    got = eng.ltv_solve_batch(d["state"], d["U"])
+    want = ltv_oracle.solve_batch(ref_table, d["state"], d["U"])
+    assert (want["status"] == 0).all() and (got["status"] == 0).all()
+    assert rel_u0_err(got["u0"], want["u0"]).max() <= TOL
