@@ -190,6 +190,28 @@ def main():
             res["parity"] = {"both_converged": int(both.sum()), "u0_rel_linf_max": float(err[both].max()),
                              "u0_rel_linf_p99": float(np.percentile(err[both], 99)),
                              "frac_within_1e-4": float((err[both] <= 1e-4).mean())}
+        if world == 1:
+            # side measurement (not the metric): the iterative-linear agent's QP (agents/pure_mpc_linear.py) on the same
+            # ego states, first call of an episode (zero stored profile), device-resident inputs
+            st_l = args["state"][:, [0, 1, 3, 2]].contiguous()
+            U_l = torch.zeros((BATCH, HORIZON, 2), dtype=torch.float64, device=dev)
+            o_l = eng.ltv_solve_batch_torch(st_l, U_l, sync=True)
+            ts = []
+            for _ in range(5):
+                U_l.zero_()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                eng.ltv_solve_batch_torch(st_l, U_l, out=o_l)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            st_q = o_l["status"].cpu().numpy()
+            res["ltv_qp"] = {"value": BATCH / (float(np.median(ts)) * 1e-3), "unit": "solves/s", "batch": BATCH,
+                             "ms": float(np.median(ts)), "solved_frac": float((st_q == 0).mean()),
+                             "speed_out_of_bounds_frac": float((st_q == 3).mean()),
+                             "iters_mean": float(o_l["iters"].cpu().numpy()[st_q == 0].mean()),
+                             "note": "mpc_ltv_solve_batch, reference agents/pure_mpc_linear.py; DESIGN.md section 4.5"}
         print(json.dumps(res), flush=True)
     eng.close()
     if use_dist:

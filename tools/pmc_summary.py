@@ -15,7 +15,8 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
     name = os.path.basename(d.rstrip("/"))
     acc = collections.defaultdict(lambda: collections.defaultdict(float))   # counter -> dispatch -> value
     kern = set()
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:            # gpurun_out/ keeps the files of earlier runs: only the newest pass counts
         for r in csv.DictReader(open(f)):
             if "mpc_solve" not in r["Kernel_Name"]:
                 continue
