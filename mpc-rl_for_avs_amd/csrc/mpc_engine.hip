@@ -318,6 +318,13 @@ namespace {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// next 16-byte aligned segment of a packed device allocation: returns its offset and advances `off`
+size_t carve(size_t &off, size_t bytes) {
+    const size_t o = off;
+    off += round_up(bytes, 16);
+    return o;
+}
+
 template <bool CC, int NC, int OCC>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
@@ -330,6 +337,17 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, si
                        d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_uinit, u_shift, d_uvalid,
                        d_u0, d_U, d_X, d_status, d_iters);
     HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+// staging buffer for host-pointer calls: grown on demand, reused across calls
+int ensure_stage(mpc_handle *h, size_t bytes) {
+    if (h->stage_bytes >= bytes) return MPC_OK;
+    if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
+    h->d_stage = nullptr;
+    h->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&h->d_stage, bytes));
+    h->stage_bytes = bytes;
     return MPC_OK;
 }
 
@@ -491,11 +509,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     if (!dev) {
         // pack everything into one staging allocation (8-byte aligned segments)
         size_t off = 0;
-        auto seg = [&](size_t bytes) {
-            size_t o = off;
-            off += round_up(bytes, 16);
-            return o;
-        };
+        auto seg = [&](size_t bytes) { return carve(off, bytes); };
         const size_t o_state = seg((size_t)B * 4 * 8), o_ego = seg((size_t)B * 4), o_w = seg((size_t)B * 3 * 8);
         const size_t o_c = seg((size_t)B), o_vref = vref ? seg((size_t)B * N1 * 8) : 0;
         const size_t o_oth = (cc && V > 0) ? seg((size_t)B * V * 4 * 8) : 0;
@@ -504,13 +518,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
         off_X = X ? seg((size_t)B * N1 * 4 * 8) : 0;
         off_st = seg((size_t)B * 4);
         off_it = seg((size_t)B * 4);
-        if (h->stage_bytes < off) {
-            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
-            h->d_stage = nullptr;
-            h->stage_bytes = 0;
-            HIP_TRY(hipMalloc(&h->d_stage, off));
-            h->stage_bytes = off;
-        }
+        if (int rc = ensure_stage(h, off)) return rc;
         char *sb = static_cast<char *>(h->d_stage);
         HIP_TRY(hipMemcpyAsync(sb + o_state, state, (size_t)B * 4 * 8, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(sb + o_ego, ego_index, (size_t)B * 4, hipMemcpyHostToDevice, stream));
@@ -615,11 +623,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
     // problem-data buffers written by the preamble kernel
     {
         size_t off = 0;
-        auto seg = [&](size_t bytes) {
-            size_t o = off;
-            off += round_up(bytes, 16);
-            return o;
-        };
+        auto seg = [&](size_t bytes) { return carve(off, bytes); };
         const size_t o_state = seg((size_t)B * 4 * 8), o_vref = seg((size_t)B * N1 * 8);
         const size_t o_oth = seg((size_t)B * (V > 0 ? V : 1) * 4 * 8), o_ego = seg((size_t)B * 4);
         const size_t o_nv = seg((size_t)B * 4), o_c = seg((size_t)B);
@@ -648,23 +652,13 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
     size_t off_act = 0, off_st = 0, off_it = 0;
     if (!dev) {
         size_t off = 0;
-        auto seg = [&](size_t bytes) {
-            size_t o = off;
-            off += round_up(bytes, 16);
-            return o;
-        };
+        auto seg = [&](size_t bytes) { return carve(off, bytes); };
         const size_t o_obs = seg((size_t)B * rows * mpc::pre::kObsCols * 4), o_w = seg((size_t)B * 3 * 8);
         const size_t o_rs = ref_speed ? seg((size_t)B * 8) : 0;
         off_act = seg((size_t)B * 2 * 8);
         off_st = seg((size_t)B * 4);
         off_it = seg((size_t)B * 4);
-        if (h->stage_bytes < off) {
-            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
-            h->d_stage = nullptr;
-            h->stage_bytes = 0;
-            HIP_TRY(hipMalloc(&h->d_stage, off));
-            h->stage_bytes = off;
-        }
+        if (int rc = ensure_stage(h, off)) return rc;
         char *sb = static_cast<char *>(h->d_stage);
         HIP_TRY(hipMemcpyAsync(sb + o_obs, obs, (size_t)B * rows * mpc::pre::kObsCols * 4, hipMemcpyHostToDevice,
                                stream));
@@ -736,11 +730,7 @@ int mpc_ltv_solve_batch(mpc_handle *h, int32_t B, const double *state, uint32_t 
     size_t o_u0 = 0, o_U = 0, o_X = 0, o_st = 0, o_it = 0, o_tg = 0;
     if (!dev) {
         size_t off = 0;
-        auto seg = [&](size_t bytes) {
-            size_t o = off;
-            off += round_up(bytes, 16);
-            return o;
-        };
+        auto seg = [&](size_t bytes) { return carve(off, bytes); };
         const size_t o_state = seg((size_t)B * 4 * 8);
         o_u0 = seg((size_t)B * 2 * 8);
         o_U = seg((size_t)B * N * 2 * 8);
@@ -748,13 +738,7 @@ int mpc_ltv_solve_batch(mpc_handle *h, int32_t B, const double *state, uint32_t 
         o_st = seg((size_t)B * 4);
         o_it = seg((size_t)B * 4);
         o_tg = seg((size_t)B * 4);
-        if (h->stage_bytes < off) {
-            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
-            h->d_stage = nullptr;
-            h->stage_bytes = 0;
-            HIP_TRY(hipMalloc(&h->d_stage, off));
-            h->stage_bytes = off;
-        }
+        if (int rc = ensure_stage(h, off)) return rc;
         char *sb = static_cast<char *>(h->d_stage);
         HIP_TRY(hipMemcpyAsync(sb + o_state, state, (size_t)B * 4 * 8, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(sb + o_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
@@ -802,22 +786,12 @@ int mpc_ltv_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t ve
     size_t o_act = 0, o_st = 0, o_it = 0;
     if (!dev) {
         size_t off = 0;
-        auto seg = [&](size_t bytes) {
-            size_t o = off;
-            off += round_up(bytes, 16);
-            return o;
-        };
+        auto seg = [&](size_t bytes) { return carve(off, bytes); };
         const size_t o_obs = seg((size_t)B * rows * mpc::pre::kObsCols * 4);
         o_act = seg((size_t)B * 2 * 8);
         o_st = seg((size_t)B * 4);
         o_it = seg((size_t)B * 4);
-        if (h->stage_bytes < off) {
-            if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
-            h->d_stage = nullptr;
-            h->stage_bytes = 0;
-            HIP_TRY(hipMalloc(&h->d_stage, off));
-            h->stage_bytes = off;
-        }
+        if (int rc = ensure_stage(h, off)) return rc;
         char *sb = static_cast<char *>(h->d_stage);
         HIP_TRY(hipMemcpyAsync(sb + o_obs, obs, (size_t)B * rows * mpc::pre::kObsCols * 4, hipMemcpyHostToDevice, stream));
         d_obs = reinterpret_cast<float *>(sb + o_obs);

@@ -45,7 +45,7 @@ constexpr double kMaxSpeed = 40.0 / 3.6;
 // interior-point constants (the CPU oracle uses the same)
 constexpr double kSInitMin = 0.3, kZInit = 100.0;
 constexpr double kTolP = 1e-9, kTolMu = 1e-10;   // |c - s|_inf, s.z / m
-constexpr double kTolDRel = 1e-7;               // |grad L|_inf relative to max(1e3, its value at the start), reached once
+constexpr double kTolDRel = 1e-9;               // |grad L|_inf relative to max(1e3, its value at the start)
 
 enum : int { ST_CONVERGED = 0, ST_MAX_ITER = 1, ST_FACTORIZATION = 2, ST_INFEASIBLE = 3 };
 
@@ -68,7 +68,10 @@ enum : int {
     L_DX = 50,   // 4  step of node k
     L_Y = 54,    // 2  node k: adjoint of (yaw, v)
     L_DR = 56,   // 1  stage k: z/s summed over its two rate-limit rows
-    L_SLOTS = 57
+    L_M = 57,    // 12 kap [g1 g2]' (2 x 6): the stiff rows' steps in constraint space are w / lambda, w = t + M [dx; du_prev]
+    L_Z = 69,    // 4  Z = Y kap, gives t = kap Fu' kf0 = -Z' hu for a new right-hand side
+    L_T = 73,    // 2  t of the current right-hand side
+    L_SLOTS = 75
 };
 enum : int { SC_ZERO = 0, SC_ONE = 1, SC_DT = 2, SC_SIZE = 4 };
 
@@ -177,12 +180,31 @@ struct Solver {
             default: return kMaxSpeed - S(k + 1, L_X + 3);
         }
     }
-    // step of the argument of inequality i of stage k for the direction parked in L_DU / L_DX
-    MPC_HD double darg(int k, int i) const {
+    // The rows the sweep treats by the Woodbury identity get their step in constraint space, f' [dx; dp; du] = w / lambda
+    // with w = t + M [dx_k; du_{k-1}]: differencing the controls (d_k - d_{k-1}) or summing accelerations into v would
+    // leave an absolute rounding error eps |du|, which the weights z / s ~ 1e16 of active rows turn into O(1) errors of dz.
+    // dr: step of d_k - d_{k-1} (rate rows), dv: step of v_{k+1} (speed rows), for the direction parked in L_DU / L_DX
+    MPC_HD void stiff_steps(int k, double &dr, double &dv) const {
+        double w0 = S(k, L_T + 0), w1 = S(k, L_T + 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double dj = S(k, L_DX + j);
+            w0 += S(k, L_M + j) * dj;
+            w1 += S(k, L_M + 6 + j) * dj;
+        }
+        if (k >= 1) {
+            const double p0 = S(k - 1, L_DU + 0), p1 = S(k - 1, L_DU + 1);
+            w0 += S(k, L_M + 4) * p0 + S(k, L_M + 5) * p1;
+            w1 += S(k, L_M + 10) * p0 + S(k, L_M + 11) * p1;
+        }
+        dv = w0 * frcp(S(k + 1, L_DV));
+        dr = k >= 1 ? w1 * frcp(S(k, L_DR)) : 0.0;
+    }
+    // step of the argument of inequality i of stage k
+    MPC_HD double darg(int k, int i, double dr, double dv) const {
         if (i < 2) return S(k, L_DU + 0);
         if (i < 4) return S(k, L_DU + 1);
-        if (i < 6) return S(k, L_DU + 1) - S(k - 1, L_DU + 1);
-        return S(k + 1, L_DX + 3);
+        return i < 6 ? dr : dv;
     }
     MPC_HD static bool valid(int k, int i) { return k >= 1 || (i != 4 && i != 5); }
 
@@ -362,6 +384,16 @@ struct Solver {
                     S(k, L_IH + 0, i00 - (z00 * y00 + z01 * y01));
                     S(k, L_IH + 1, i01 - (z00 * y10 + z01 * y11));
                     S(k, L_IH + 2, i11 - (z10 * y10 + z11 * y11));
+                    S(k, L_Z + 0, z00);
+                    S(k, L_Z + 1, z01);
+                    S(k, L_Z + 2, z10);
+                    S(k, L_Z + 3, z11);
+                    S(k, L_T + 0, t0);
+                    S(k, L_T + 1, t1);
+                }
+                if (lane < 6) {
+                    S(k, L_M + lane, k00 * g1[lane] + k01 * g2[lane]);
+                    S(k, L_M + 6 + lane, k01 * g1[lane] + k11 * g2[lane]);
                 }
             });
         }
@@ -386,6 +418,8 @@ struct Solver {
             const double i00 = S(k, L_IH + 0), i01 = S(k, L_IH + 1), i11 = S(k, L_IH + 2);
             S(k, L_KF + 0, -(i00 * hu0 + i01 * hu1));
             S(k, L_KF + 1, -(i01 * hu0 + i11 * hu1));
+            S(k, L_T + 0, -(S(k, L_Z + 0) * hu0 + S(k, L_Z + 2) * hu1));
+            S(k, L_T + 1, -(S(k, L_Z + 1) * hu0 + S(k, L_Z + 3) * hu1));
             p0 = h0 + S(k, L_KX + 0) * hu0 + S(k, L_KX + 4) * hu1;
             p1 = h1 + S(k, L_KX + 1) * hu0 + S(k, L_KX + 5) * hu1;
             p2 = h2 + S(k, L_KX + 2) * hu0 + S(k, L_KX + 6) * hu1;
@@ -497,7 +531,6 @@ struct Solver {
         const double m_ineq = (double)(8 * N - 2);
         const double T = (double)N;
         int iter = 0;
-        bool dual_ok = false;
         double tol_d = 0.0;
         for (iter = 0; iter <= P.max_iter; ++iter) {
             // ============ residuals: primal (per inequality), complementarity, node terms of the adjoint
@@ -511,7 +544,10 @@ struct Solver {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (!valid(k, i)) continue;
-                    const double r = cval(k, i) - s_[i].at(lane);
+                    // a residual below the rounding resolution of its constraint value is zero (kept, it would be
+                    // multiplied by z / s)
+                    const double cv = cval(k, i), rr = cv - s_[i].at(lane);
+                    const double r = fabs(rr) <= 8.0 * 2.220446049250313e-16 * kMaxSpeed ? 0.0 : rr;
                     rp_[i].at(lane) = r;
                     rpm = fmax2(rpm, fabs(r));
                     sz += s_[i].at(lane) * z_[i].at(lane);
@@ -562,11 +598,10 @@ struct Solver {
                 red_a.at(lane) = fmax2(fabs(r0), fabs(r1));
             });
             const double res_d = c.wave_max(red_a);
-            // In exact arithmetic the dual residual shrinks by the same factor (1 - alpha) as the primal one; once mu is
-            // small its measured value is dominated by rounding in the multipliers of the active rows (~ z^2 eps / mu,
-            // harmless for the controls), so reaching the tolerance once is what is required
+            // all three at the same iterate (the steps of the stiff rows are computed in constraint space, see darg: the
+            // measured dual residual keeps falling to ~1e-12 instead of drowning in rounding noise z^2 eps / mu)
             if (iter == 0) tol_d = kTolDRel * fmax2(1e3, res_d);
-            dual_ok = dual_ok || res_d <= tol_d;
+            const bool dual_ok = res_d <= tol_d;
             if (res_p <= kTolP && dual_ok && mu <= kTolMu) {
                 status_out = ST_CONVERGED;
                 break;
@@ -613,11 +648,13 @@ struct Solver {
                     double bn = 0.0, bd = 1.0, a1 = 0.0, a2 = 0.0, a0 = 0.0;
                     if (lane < N) {
                         const int k = lane;
+                        double dr, dv;
+                        stiff_steps(k, dr, dv);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (!valid(k, i)) continue;
                             const double s = s_[i].at(lane), z = z_[i].at(lane);
-                            const double ds = csign(i) * darg(k, i) + rp_[i].at(lane);
+                            const double ds = csign(i) * darg(k, i, dr, dv) + rp_[i].at(lane);
                             const double dz = -z - z * ds * frcp(s);
                             pr_[i].at(lane) = ds * dz;
                             if (wave::ratio_greater(-ds, s, bn, bd)) { bn = -ds; bd = s; }
@@ -667,6 +704,8 @@ struct Solver {
                     double bn = 0.0, bd = 1.0;
                     if (lane < N) {
                         const int k = lane;
+                        double dr, dv;
+                        stiff_steps(k, dr, dv);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (!valid(k, i)) {
@@ -675,7 +714,7 @@ struct Solver {
                                 continue;
                             }
                             const double s = s_[i].at(lane), z = z_[i].at(lane);
-                            const double ds = csign(i) * darg(k, i) + rp_[i].at(lane);
+                            const double ds = csign(i) * darg(k, i, dr, dv) + rp_[i].at(lane);
                             const double dz = (sigma_mu - pr_[i].at(lane) - s * z - z * ds) * frcp(s);
                             rp_[i].at(lane) = ds;     // the residual is not needed any more this iteration
                             pr_[i].at(lane) = dz;
