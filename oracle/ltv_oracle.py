@@ -20,7 +20,9 @@ KKT certificates of the returned solutions (tests/test_ltv_oracle.py).  The QP i
 
 Solver: the states are eliminated through the (linear) dynamics and the dense QP in the 2T controls is solved by an
 infeasible-start primal-dual interior-point method with Mehrotra's predictor-corrector (one common step length) -
-the same iteration the HIP kernel runs with a Riccati factorisation instead of the dense one.
+the same iteration the HIP kernel runs, with dense LU solves of the augmented system in (du, dz) where the kernel
+runs a Riccati sweep.  Stopping rule (same in the kernel): |c - s|_inf <= 1e-9, |grad L|_inf <= 1e-9 max(1e3, start),
+s.z / m <= 1e-10, all at one iterate.
 """
 from __future__ import annotations
 
@@ -42,7 +44,7 @@ WHEELBASE = 2.5                     # :131 default
 
 STATUS_CONVERGED, STATUS_MAX_ITER, STATUS_FACTORIZATION, STATUS_INFEASIBLE = 0, 1, 2, 3
 S_INIT_MIN, Z_INIT = 1.0, 100.0    # initial slacks max(c, S_INIT_MIN), initial multipliers
-TOL_P, TOL_D_REL, TOL_MU = 1e-9, 1e-7, 1e-10   # |c - s|_inf, |grad L|_inf / max(1e3, start) (reached once), s.z / m
+TOL_P, TOL_D_REL, TOL_MU = 1e-9, 1e-9, 1e-10   # |c - s|_inf, |grad L|_inf / max(1e3, its value at the start), s.z / m
 
 
 def nearest_index(px, py, ref):
@@ -174,18 +176,15 @@ def solve_qp(H, g, C, c0, u_start, max_iter=50):
     status = np.full(Bn, STATUS_MAX_ITER, dtype=np.int32)
     iters = np.zeros(Bn, dtype=np.int32)
     active = np.ones(Bn, dtype=bool)
-    dual_ok = np.zeros(Bn, dtype=bool)
     for it in range(max_iter + 1):
         c = c0 + np.einsum("bmn,bn->bm", C, u)
         r_p = c - s
         grad = np.einsum("bkl,bl->bk", H, u) + g
         r_d = grad - np.einsum("bmn,bm->bn", C, z)
         mu = (s * z).sum(axis=1) / m
-        # exact arithmetic shrinks r_d by the same factor (1 - alpha) as r_p; once mu is small its measured value is
-        # rounding noise in the multipliers of the active rows (~ z^2 eps / mu), so reaching the tolerance once is required
         if it == 0:
             tol_d = TOL_D_REL * np.maximum(1e3, np.abs(r_d).max(axis=1))
-        dual_ok |= np.abs(r_d).max(axis=1) <= tol_d
+        dual_ok = np.abs(r_d).max(axis=1) <= tol_d
         done = (np.abs(r_p).max(axis=1) <= TOL_P) & dual_ok & (mu <= TOL_MU)
         newly = active & done
         status[newly] = STATUS_CONVERGED
@@ -193,24 +192,35 @@ def solve_qp(H, g, C, c0, u_start, max_iter=50):
         active &= ~done
         if it == max_iter or not active.any():
             break
-        D = z / s
-        K = H + np.einsum("bmk,bm,bml->bkl", C, D, C)
+        # Newton step from the augmented system in (du, dz),
+        #   H du - C' dz = -r_d,   C du + (s/z) dz = -r_p + r_c / z     (ds eliminated through z ds + s dz = r_c),
+        # rows scaled so that no entry exceeds 1.  Unlike the normal equations H + C' (z/s) C its conditioning does
+        # not degrade as s -> 0 on the active rows (s/z -> 0 there), so dz does not pick up z/s times a rounding error.
+        rho = 1.0 / np.maximum(1.0, s / z)
+        K = np.zeros((Bn, n + m, n + m))
+        K[:, :n, :n] = H
+        K[:, :n, n:] = -np.swapaxes(C, 1, 2)
+        K[:, n:, :n] = C * rho[:, :, None]
+        K[:, n:, n:] = np.einsum("bm,mk->bmk", rho * s / z, np.eye(m))
         bad = active & ~np.isfinite(K).all(axis=(1, 2))
         status[bad] = STATUS_FACTORIZATION
         iters[bad] = it
         active &= ~bad
-        K[~active] = np.eye(n)             # finished instances ride along with a zero step
-        q_aff = -z * r_p / s
-        du = np.linalg.solve(K, -(grad - np.einsum("bmn,bm->bn", C, q_aff))[..., None])[..., 0]
-        ds = np.einsum("bmn,bn->bm", C, du) + r_p
-        dz = -z - z * ds / s
+        K[~active] = np.eye(n + m)             # finished instances ride along with a zero step
+
+        def newton(r_c):
+            rhs = np.concatenate([-r_d, rho * (-r_p + r_c / z)], axis=1)
+            sol = np.linalg.solve(K, rhs[..., None])[..., 0]
+            du_, dz_ = sol[:, :n], sol[:, n:]
+            ds_lin = np.einsum("bmn,bn->bm", C, du_) + r_p          # accurate where the slack is large
+            ds_cmp = (r_c - s * dz_) / z                              # accurate where the multiplier is large
+            return du_, np.where(s > z, ds_lin, ds_cmp), dz_
+
+        du, ds, dz = newton(-s * z)
         a_aff = np.minimum(_max_step(s, ds), _max_step(z, dz))
         mu_aff = ((s + a_aff[:, None] * ds) * (z + a_aff[:, None] * dz)).sum(axis=1) / m
         sigma = np.maximum((mu_aff / mu) ** 3, 0.1 * TOL_MU / mu)     # never aim below the stopping threshold
-        q = (sigma[:, None] * mu[:, None] - ds * dz - z * r_p) / s
-        du = np.linalg.solve(K, -(grad - np.einsum("bmn,bm->bn", C, q))[..., None])[..., 0]
-        ds2 = np.einsum("bmn,bn->bm", C, du) + r_p
-        dz2 = (sigma[:, None] * mu[:, None] - ds * dz - s * z - z * ds2) / s
+        du, ds2, dz2 = newton(sigma[:, None] * mu[:, None] - ds * dz - s * z)
         alpha = np.minimum(1.0, 0.99 * np.minimum(_max_step_unbounded(s, ds2), _max_step_unbounded(z, dz2)))
         alpha = np.where(active, alpha, 0.0)[:, None]
         u = u + alpha * du
