@@ -31,3 +31,24 @@ for seed in range(1, 7):
               f"iterations equal {(got['iters'] == want['iters'])[both].mean():.4f}, beyond 1e-4: {bad}, p99 err {np.percentile(err[both], 99):.2e}, "
               f"gpu status {np.bincount(got['status'], minlength=5)}, finite {np.isfinite(got['u0']).all()}", flush=True)
 print("worst p99", worst)
+
+# ---- the iterative-linear agent's QP: first call and two re-linearised rounds per seed
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ltv_oracle
+from conftest import ltv_states
+
+worst_l = 0.0
+for seed in range(1, 5):
+    st = ltv_states(768, seed=seed)
+    nom = np.zeros((768, 20, 2))
+    for rnd in range(3):
+        got = eng.ltv_solve_batch(st, nom)
+        want = ltv_oracle.solve_batch(ref, st, nom)
+        ok = (got["status"] == 0) & (want["status"] == 0)
+        err = np.abs(got["u0"] - want["u0"]).max(axis=1) / np.maximum(1.0, np.abs(want["u0"]).max(axis=1))
+        worst_l = max(worst_l, float(err[ok].max()))
+        print(f"LTV-QP seed {seed} round {rnd}: status equal {np.array_equal(got['status'], want['status'])}, solved {ok.mean():.4f}, "
+              f"iterations equal {(got['iters'] == want['iters'])[ok].mean():.4f}, beyond 1e-4: {int((err[ok] > 1e-4).sum())}, "
+              f"max err {err[ok].max():.2e}, p99 {np.percentile(err[ok], 99):.2e}", flush=True)
+        nom = got["U"]
+print("LTV-QP worst max err", worst_l)
