@@ -40,6 +40,7 @@ int fail(int code, const std::string &msg) {
     } while (0)
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
+constexpr int kMaxDevices = 64;
 // Waves per SIMD the wave-cooperative kernel is compiled for: 2 (~210 VGPRs, no scratch; HBM traffic = inputs and
 // outputs only).  LDS (14.4 KB per wave at N = 20 with the collision cost) allows 11 waves per CU; a 3-waves/SIMD
 // build (168 VGPRs, 32 B/lane scratch) measured the same at B = 4096 and B = 65536, a 4-wave build slower.
@@ -331,8 +332,14 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, si
                 const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
                 uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
+    // capture (hipGraph) of the launch
+    static size_t lds_set[kMaxDevices] = {};
+    if (h->device >= kMaxDevices || lds_set[h->device] < lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        if (h->device < kMaxDevices) lds_set[h->device] = lds;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
                        d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_uinit, u_shift, d_uvalid,
                        d_u0, d_U, d_X, d_status, d_iters);
@@ -704,8 +711,12 @@ static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_
     P.max_iter = h->cfg.max_iter;
     P.dt = h->cfg.dt;
     const size_t lds = (size_t)mpc::ltv::lds_doubles(P.N) * sizeof(double);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    static size_t lds_set[kMaxDevices] = {};
+    if (h->device >= kMaxDevices || lds_set[h->device] < lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (h->device < kMaxDevices) lds_set[h->device] = lds;
+    }
     hipLaunchKernelGGL(mpc_ltv_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_obs,
                        rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
     HIP_TRY(hipGetLastError());

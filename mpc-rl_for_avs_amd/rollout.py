@@ -89,14 +89,16 @@ class SyntheticIntersectionEnv:
         ego[:, 3] = 10.0
         pos, sp, h = self._spawn_others((B, K), 5.0, 60.0)
         m1, m2 = mask[:, None], mask[:, None, None]
-        self.ego = torch.where(m1, ego, self.ego)
-        self.opos = torch.where(m2, pos, self.opos)
-        self.ospeed = torch.where(m1, sp, self.ospeed)
-        self.ohead = torch.where(m1, h, self.ohead)
+        # state tensors are updated in place: a captured hipGraph (BatchedCollector(use_graph=True)) replays against
+        # fixed addresses
+        self.ego.copy_(torch.where(m1, ego, self.ego))
+        self.opos.copy_(torch.where(m2, pos, self.opos))
+        self.ospeed.copy_(torch.where(m1, sp, self.ospeed))
+        self.ohead.copy_(torch.where(m1, h, self.ohead))
         active = torch.ones((B, K), dtype=torch.bool, device=self.device) if self.K > 0 else \
             torch.zeros((B, K), dtype=torch.bool, device=self.device)
-        self.oactive = torch.where(m1, active, self.oactive)
-        self.t = torch.where(mask, torch.zeros_like(self.t), self.t)
+        self.oactive.copy_(torch.where(m1, active, self.oactive))
+        self.t.copy_(torch.where(mask, torch.zeros_like(self.t), self.t))
 
     # ---- observation (config/config.py:10-26) ------------------------------------------------------------------
     def observe(self) -> torch.Tensor:
@@ -140,18 +142,17 @@ class SyntheticIntersectionEnv:
         ny = y + v * torch.sin(th + beta) * dt
         nth = th + v / WHEELBASE * torch.sin(beta) * dt
         nv = torch.clamp(v + a * dt, 0.0, 30.0)
-        self.ego = torch.stack([nx, ny, nth, nv], dim=1)
+        self.ego.copy_(torch.stack([nx, ny, nth, nv], dim=1))
         if self.K > 0:
             step = (self.ospeed * dt)[..., None] * torch.stack([torch.cos(self.ohead), torch.sin(self.ohead)], dim=-1)
-            self.opos = self.opos + step
+            self.opos.add_(step)
             gone = (self.opos.abs().amax(dim=-1) > 65.0) | ~self.oactive
-            self.oactive = self.oactive & ~gone
             respawn = gone & (torch.rand(gone.shape, generator=self.gen, device=self.device) < self.spawn_probability)
             pos, sp, h = self._spawn_others(gone.shape, 40.0, 60.0)
-            self.opos = torch.where(respawn[..., None], pos, self.opos)
-            self.ospeed = torch.where(respawn, sp, self.ospeed)
-            self.ohead = torch.where(respawn, h, self.ohead)
-            self.oactive = self.oactive | respawn
+            self.opos.copy_(torch.where(respawn[..., None], pos, self.opos))
+            self.ospeed.copy_(torch.where(respawn, sp, self.ospeed))
+            self.ohead.copy_(torch.where(respawn, h, self.ohead))
+            self.oactive.copy_((self.oactive & ~gone) | respawn)
             dist = torch.linalg.norm(self.opos - self.ego[:, None, :2], dim=-1)
             crashed = ((dist < CRASH_DISTANCE) & self.oactive).any(dim=1)
         else:
@@ -164,7 +165,7 @@ class SyntheticIntersectionEnv:
         reward = (REWARD["collision"] * crashed + REWARD["high_speed"] * (self.ego[:, 3] / 10.0) +
                   REWARD["arrived"] * arrived + torch.where(on_road, REWARD["center_bonus"] * centering,
                                                             torch.full_like(centering, REWARD["off_road"])))
-        self.t = self.t + 1
+        self.t.add_(1)
         terminated = crashed | arrived
         truncated = (self.t >= EPISODE_STEPS) & ~terminated
         done = terminated | truncated
@@ -223,9 +224,11 @@ class RolloutBuffer:
         self.advantages, self.returns = z(T, B), z(T, B)
         self.mpc_actions = z(T, B, 2, dt=torch.float64)
         self.gamma, self.gae_lambda, self.n_steps, self.pos = float(gamma), float(gae_lambda), T, 0
+        self.pos_dev = torch.zeros(1, dtype=torch.int64, device=device)     # the same counter for captured graphs
 
     def reset(self):
         self.pos = 0
+        self.pos_dev.zero_()
 
     def add(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions=None):
         i = self.pos
@@ -234,6 +237,16 @@ class RolloutBuffer:
         if mpc_actions is not None:
             self.mpc_actions[i] = mpc_actions
         self.pos += 1
+        self.pos_dev.add_(1)
+
+    def add_at_device_pos(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions):
+        """`add` with the row taken from the device-side counter: no host value is baked into a captured graph."""
+        i = self.pos_dev
+        for dst, src in ((self.obs, obs), (self.actions, actions), (self.rewards, rewards),
+                         (self.episode_starts, episode_starts), (self.values, values), (self.log_probs, log_probs),
+                         (self.mpc_actions, mpc_actions)):
+            dst.index_copy_(0, i, src.to(dst.dtype).unsqueeze(0))
+        self.pos_dev.add_(1)
 
     def compute_returns_and_advantage(self, last_values, dones):
         last_gae = torch.zeros_like(last_values)
@@ -266,7 +279,7 @@ class BatchedCollector:
     def __init__(self, env, policy: ActorCritic, engine, version: str = "v0", algorithm: str = "ppo",
                  n_steps: int = 64, gamma: float = 0.99, gae_lambda: float = 0.95,
                  default_weights=(1.0, 1.0, 1.0), collision_cost: bool = False, reset_mpc_on_done: bool = False,
-                 gather_actions: bool = False, seed: int = 0, warm_start: bool = False):
+                 gather_actions: bool = False, seed: int = 0, warm_start: bool = False, use_graph: bool = False):
         if version not in ("v0", "v1") or algorithm not in ("ppo", "a2c"):
             raise ValueError("version must be v0|v1 and algorithm ppo|a2c")
         if version == "v1" and policy.action_dim < 3:
@@ -281,11 +294,20 @@ class BatchedCollector:
         self.default_weights = torch.tensor(default_weights, dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
-        self._last_obs = env.reset()
+        self._last_obs = env.reset().clone()                 # persistent tensors, updated in place (graph replays)
         self._last_episode_starts = torch.ones(B, dtype=torch.float32, device=dev)
+        zi = lambda: torch.zeros((), dtype=torch.int64, device=dev)
+        self._roll = dict(ep_done=zi(), crashed=zi(), arrived=zi(), dones=torch.zeros(B, dtype=torch.bool, device=dev))
         self.num_timesteps = 0
         self.last_mpc = None
+        self._mpc_out = None
         self.gathered_actions = None
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        if self.use_graph:
+            if gather_actions:
+                raise ValueError("use_graph and gather_actions are not combined (the collective stays outside the graph)")
+            self._capture()
 
     def mpc_inputs(self, actions):
         """RL action -> (weights[B,3] float64, ref_speed[B] float64 or None) as the reference maps them."""
@@ -294,42 +316,157 @@ class BatchedCollector:
             return self.default_weights, clipped[:, 0].to(torch.float64).contiguous()
         return clipped[:, :3].to(torch.float64).contiguous(), None
 
+    # ---- one rollout = begin, n steps, finish; split so that the step can be captured in a hipGraph and several
+    #      collectors can be interleaved (PipelinedCollector)
     @torch.no_grad()
+    def _begin_rollout(self):
+        self.policy.eval()
+        self.buffer.reset()
+        for k in ("ep_done", "crashed", "arrived"):
+            self._roll[k].zero_()
+
+    @torch.no_grad()
+    def _rollout_step(self, device_pos: bool = False):
+        obs = self._last_obs
+        actions, values, log_probs = self.policy(obs, generator=self.gen)
+        weights, ref_speed = self.mpc_inputs(actions)
+        self._mpc_out = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
+                                                        warm_start=self.warm_start, out=self._mpc_out)
+        self.last_mpc = self._mpc_out
+        mpc_action = self.last_mpc["act"]
+        if self.gather_actions:
+            from . import sharding
+            self.gathered_actions = sharding.all_gather_actions(mpc_action)
+        new_obs, rewards, dones, info = self.env.step(mpc_action)
+        if self.algorithm == "ppo":                      # agents/ppo_mpc.py:451-461
+            tv = self.policy.predict_values(info["terminal_obs"])
+            rewards = rewards + self.buffer.gamma * tv * info["truncated"].to(tv.dtype)
+        if self.reset_mpc_on_done:
+            self.engine.reset_env_mask_torch(dones.to(torch.uint8))
+        elif self.warm_start:            # a new episode must not start from the old one's plan
+            self.engine.reset_env_mask_torch(dones.to(torch.uint8), warm_only=True)
+        if device_pos:
+            self.buffer.add_at_device_pos(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
+        else:
+            self.buffer.add(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
+        self._last_obs.copy_(new_obs)
+        self._last_episode_starts.copy_(dones.to(torch.float32))
+        r = self._roll
+        r["dones"].copy_(dones)
+        r["ep_done"] += dones.sum()
+        r["crashed"] += info["crashed"].sum()
+        r["arrived"] += info["arrived"].sum()
+
+    def _capture(self):
+        """Capture one rollout step (policy -> mpc_predict_batch -> environment step -> buffer row) as a hipGraph: a step
+        is ~100 small launches, ~2 ms of host time, which a replay replaces by one launch.  Every tensor the step reads or
+        writes across steps lives at a fixed address (environment state, last observation, buffer, counters); the buffer
+        row comes from a device-side counter; both random generators are registered with the graph."""
+        dev = self.env.device
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # allocations and lazy initialisation happen outside the capture
+                self._rollout_step(device_pos=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        for gen in (self.gen, self.env.gen):
+            g.register_generator_state(gen)
+        with torch.cuda.graph(g, stream=side):
+            self._rollout_step(device_pos=True)
+        self._graph = g
+        self.buffer.reset()
+
+    def _step(self):
+        if self._graph is not None:
+            self._graph.replay()
+            self.buffer.pos += 1
+        else:
+            self._rollout_step()
+        self.num_timesteps += self.env.num_envs
+
+    @torch.no_grad()
+    def _finish_rollout(self):
+        last_values = self.policy.predict_values(self._last_obs)
+        self.buffer.compute_returns_and_advantage(last_values, self._roll["dones"])
+
+    def _rollout_stats(self, n):
+        r = self._roll
+        return dict(steps=n * self.env.num_envs, episodes=int(r["ep_done"]), crashed=int(r["crashed"]),
+                    arrived=int(r["arrived"]))
+
     def collect_rollouts(self, n_rollout_steps: int | None = None):
         n = self.buffer.n_steps if n_rollout_steps is None else int(n_rollout_steps)
         assert n == self.buffer.n_steps
-        self.policy.eval()
-        self.buffer.reset()
-        ep_done = crashed = arrived = 0
-        dones = torch.zeros(self.env.num_envs, dtype=torch.bool, device=self.env.device)
+        self._begin_rollout()
         for _ in range(n):
-            obs = self._last_obs
-            actions, values, log_probs = self.policy(obs, generator=self.gen)
-            weights, ref_speed = self.mpc_inputs(actions)
-            self.last_mpc = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
-                                                            warm_start=self.warm_start)
-            mpc_action = self.last_mpc["act"]
-            if self.gather_actions:
-                from . import sharding
-                self.gathered_actions = sharding.all_gather_actions(mpc_action)
-            new_obs, rewards, dones, info = self.env.step(mpc_action)
-            self.num_timesteps += self.env.num_envs
-            if self.algorithm == "ppo":                      # agents/ppo_mpc.py:451-461
-                tv = self.policy.predict_values(info["terminal_obs"])
-                rewards = rewards + self.buffer.gamma * tv * info["truncated"].to(tv.dtype)
-            if self.reset_mpc_on_done:
-                self.engine.reset_env_mask_torch(dones.to(torch.uint8))
-            elif self.warm_start:            # a new episode must not start from the old one's plan
-                self.engine.reset_env_mask_torch(dones.to(torch.uint8), warm_only=True)
-            self.buffer.add(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
-            self._last_obs = new_obs
-            self._last_episode_starts = dones.to(torch.float32)
-            ep_done = ep_done + dones.sum()
-            crashed = crashed + info["crashed"].sum()
-            arrived = arrived + info["arrived"].sum()
-        last_values = self.policy.predict_values(self._last_obs)
-        self.buffer.compute_returns_and_advantage(last_values, dones)
-        return dict(steps=n * self.env.num_envs, episodes=int(ep_done), crashed=int(crashed), arrived=int(arrived))
+            self._step()
+        self._finish_rollout()
+        return self._rollout_stats(n)
+
+    def flat_buffer(self):
+        """(obs, actions, log_probs, advantages, returns) with time and environment flattened, for the update"""
+        b = self.buffer
+        f = lambda t: t.reshape((-1,) + t.shape[2:])
+        return f(b.obs), f(b.actions), f(b.log_probs), f(b.advantages), f(b.returns)
+
+    def mean_reward(self):
+        return float(self.buffer.rewards.mean())
+
+
+class PipelinedCollector:
+    """Several BatchedCollectors (disjoint environment groups, one engine handle each, one shared policy) stepped
+    round-robin on their own HIP streams.  A batched MPC solve ends with a long tail - a few slow instances on an
+    otherwise idle GPU - and the groups are independent, so the tail of one group's solve overlaps
+    with the policy / preamble / bulk of the others'.  Pays only with `use_graph=True` collectors: in eager mode the host
+    needs ~2 ms to launch one group's step and the groups serialise on that.  Same data as running the collectors one
+    after the other (each group's chain of operations is unchanged and ordered on its stream); the update sees the
+    concatenated buffers."""
+
+    def __init__(self, collectors):
+        if not collectors:
+            raise ValueError("need at least one collector")
+        self.collectors = list(collectors)
+        c0 = self.collectors[0]
+        if any(c.policy is not c0.policy or c.algorithm != c0.algorithm or c.buffer.n_steps != c0.buffer.n_steps
+               for c in self.collectors):
+            raise ValueError("the collectors must share the policy, the algorithm and the rollout length")
+        if len({id(c.engine) for c in self.collectors}) != len(self.collectors):
+            raise ValueError("every collector needs its own engine handle (calls on one handle must not overlap)")
+        self.policy, self.algorithm, self.env = c0.policy, c0.algorithm, c0.env
+        self.streams = [torch.cuda.Stream(c.env.device) for c in self.collectors]
+
+    @property
+    def num_timesteps(self):
+        return sum(c.num_timesteps for c in self.collectors)
+
+    def collect_rollouts(self, n_rollout_steps: int | None = None):
+        n = self.collectors[0].buffer.n_steps if n_rollout_steps is None else int(n_rollout_steps)
+        cur = torch.cuda.current_stream(self.env.device)
+        for s in self.streams:
+            s.wait_stream(cur)                      # the groups see everything enqueued so far (policy update, resets)
+        for c, s in zip(self.collectors, self.streams):
+            with torch.cuda.stream(s):
+                c._begin_rollout()
+        for _ in range(n):
+            for c, s in zip(self.collectors, self.streams):
+                with torch.cuda.stream(s):
+                    c._step()
+        for c, s in zip(self.collectors, self.streams):
+            with torch.cuda.stream(s):
+                c._finish_rollout()
+        for s in self.streams:
+            cur.wait_stream(s)                      # ... and the update sees every group's buffer
+        stats = [c._rollout_stats(n) for c in self.collectors]
+        return {k: sum(d[k] for d in stats) for k in stats[0]}
+
+    def flat_buffer(self):
+        parts = [c.flat_buffer() for c in self.collectors]
+        return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(5))
+
+    def mean_reward(self):
+        return float(torch.cat([c.buffer.rewards.reshape(-1) for c in self.collectors]).mean())
 
 
 class OnPolicyTrainer:
@@ -345,7 +482,7 @@ class OnPolicyTrainer:
            (alpha 0.99, eps 1e-5), no advantage normalisation, lambda 1 (config/cfg.yaml:31-61)
     """
 
-    def __init__(self, collector: BatchedCollector, learning_rate: float | None = None, n_epochs: int = 10,
+    def __init__(self, collector, learning_rate: float | None = None, n_epochs: int = 10,
                  batch_size: int = 256, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
                  max_grad_norm: float = 0.5, normalize_advantage: bool | None = None, seed: int = 0):
         self.col = collector
@@ -365,9 +502,7 @@ class OnPolicyTrainer:
         self.n_updates = 0
 
     def _flat(self):
-        b = self.col.buffer
-        f = lambda t: t.reshape((-1,) + t.shape[2:])
-        return f(b.obs), f(b.actions), f(b.log_probs), f(b.advantages), f(b.returns)
+        return self.col.flat_buffer()
 
     def _loss(self, obs, actions, old_logp, adv, ret):
         values, logp, entropy = self.col.policy.evaluate_actions(obs, actions)
@@ -419,5 +554,5 @@ class OnPolicyTrainer:
             roll = self.col.collect_rollouts()
             upd = self.train()
             log.append(dict(roll, **upd, timesteps=self.col.num_timesteps,
-                            mean_reward=float(self.col.buffer.rewards.mean())))
+                            mean_reward=self.col.mean_reward()))
         return log

@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--others", type=int, default=4)
     ap.add_argument("--version", default="v0")
+    ap.add_argument("--graph", action="store_true", help="replay the rollout step as a captured hipGraph")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split this rank's environments into G groups stepped on G HIP streams (PipelinedCollector)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -38,24 +41,34 @@ def main():
     for total in a.envs:
         lo, hi = sharding.shard_range(total, rank, world)
         B = hi - lo
-        eng = engine.MPCEngine(horizon=20, max_iter=100, device=local)
-        env = rollout.SyntheticIntersectionEnv(B, device=dev, seed=rank, n_others=a.others)
+        G = max(1, min(a.groups, B))
         pol = rollout.ActorCritic(3 if a.version == "v1" else 1).to(dev)
-        col = rollout.BatchedCollector(env, pol, eng, version=a.version, algorithm="ppo", n_steps=a.steps,
-                                       collision_cost=False, gather_actions=use_dist)
+        engs, cols = [], []
+        for g in range(G):
+            glo, ghi = sharding.shard_range(B, g, G)
+            e_g = engine.MPCEngine(horizon=20, max_iter=100, device=local)
+            env = rollout.SyntheticIntersectionEnv(ghi - glo, device=dev, seed=rank * 97 + g, n_others=a.others)
+            engs.append(e_g)
+            cols.append(rollout.BatchedCollector(env, pol, e_g, version=a.version, algorithm="ppo", n_steps=a.steps,
+                                                 collision_cost=False, gather_actions=use_dist and G == 1 and not a.graph,
+                                                 seed=g, use_graph=a.graph))
+        col = cols[0] if G == 1 else rollout.PipelinedCollector(cols)
         col.collect_rollouts()                                   # warm-up (allocations, first launches)
         events = []
-        inner = eng.predict_batch_torch
 
-        def timed_predict(*args, **kw):                          # HIP events around the MPC call on torch's stream
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = inner(*args, **kw)
-            e1.record()
-            events.append((e0, e1))
-            return out
+        def timed(inner):                                        # HIP events around the MPC call on its stream
+            def call(*args, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = inner(*args, **kw)
+                e1.record()
+                events.append((e0, e1))
+                return out
+            return call
 
-        eng.predict_batch_torch = timed_predict
+        if not a.graph:                                          # a replayed graph does not pass through Python
+            for e_g in engs:
+                e_g.predict_batch_torch = timed(e_g.predict_batch_torch)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -69,16 +82,19 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-            assert col.gathered_actions.shape == (total, 2)
+            if G == 1 and not a.graph:
+                assert col.gathered_actions.shape == (total, 2)
         dm = sum(e0.elapsed_time(e1) for e0, e1 in events) * 1e-3
-        st = col.last_mpc["status"].cpu().numpy()
+        st = torch.cat([c.last_mpc["status"] for c in cols]).cpu().numpy()
         if rank == 0:
             print(json.dumps(dict(config=f"{total} envs on {world} GPU(s), {a.others} other vehicles, {a.version}/ppo, "
-                                         f"horizon 20", envs=total, n_gpus=world,
+                                         f"horizon 20" + (f", {G} groups on {G} streams" if G > 1 else "") + (", hipGraph step" if a.graph else ""),
+                              envs=total, n_gpus=world, groups=G, graph=bool(a.graph),
                               steps_per_env=a.steps, env_steps_per_s=total * a.steps / dt, ms_per_step=dt / a.steps * 1e3,
                               mpc_ms_per_step=dm / a.steps * 1e3, episodes=stats["episodes"], crashed=stats["crashed"],
                               arrived=stats["arrived"], converged_frac=float((st == 0).mean()))), flush=True)
-        eng.close()
+        for e_g in engs:
+            e_g.close()
     if use_dist:
         dist.destroy_process_group()
 
