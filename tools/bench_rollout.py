@@ -10,6 +10,7 @@ Prints one JSON line per configuration: env-steps/s (= MPC solves/s) and the tim
 import argparse
 import json
 import os
+
 import sys
 import time
 

@@ -2,6 +2,9 @@
 on S HIP streams, so that the straggler tail of one batch (a few lone waves, GPU mostly idle) overlaps with the bulk of
 the next.  Prints solves/s for S = 1, 2, 3, 4."""
 import os, sys, time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts: independent streams get their own hardware queues
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
