@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements (in_flight, ltv_qp): profiling runs, so that every launch of the solve "
+                         "kernel in the trace is one of the warm-up / timed steps")
     ap.add_argument("--streams", type=int, default=1,
                     help="batches in flight in the timed loop (default 1: one batch at a time, the headline definition)")
     a = ap.parse_args()
@@ -205,7 +208,7 @@ def main():
             res["parity"] = {"both_converged": int(both.sum()), "u0_rel_linf_max": float(err[both].max()),
                              "u0_rel_linf_p99": float(np.percentile(err[both], 99)),
                              "frac_within_1e-4": float((err[both] <= 1e-4).mean())}
-        if world == 1:
+        if world == 1 and not a.no_side:
             # side measurement (not the metric): the same batch solves with 6 of them in flight, round-robin on 6 HIP
             # streams - the straggler tail of one batch (a few lone waves, GPU mostly idle) overlaps with the bulk of the
             # next ones.  Same kernel, same inputs, identical outputs; what a serving loop with several independent

@@ -41,10 +41,10 @@ int fail(int code, const std::string &msg) {
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
 constexpr int kMaxDevices = 64;
-// Waves per SIMD the wave-cooperative kernel is compiled for: 2 (~210 VGPRs, no scratch; HBM traffic = inputs and
-// outputs only).  LDS (14.4 KB per wave at N = 20 with the collision cost) allows 11 waves per CU; a 3-waves/SIMD
-// build (168 VGPRs, 32 B/lane scratch) measured the same at B = 4096 and B = 65536, a 4-wave build slower.
-constexpr int kWaveOcc = 2;
+// Waves per SIMD the wave-cooperative kernel is compiled for: 3 (168 VGPRs, 32 B/lane of scratch).  LDS (14.4 KB per
+// wave at N = 20 with the collision cost) allows 11 waves per CU.  Same box: 2 waves (209 VGPRs, no scratch) 620 k
+// solves/s for one batch of 4096, 1.58 M at B = 65536; 3 waves 645 k and 1.75 M; a 4-wave build is slower.
+constexpr int kWaveOcc = 3;
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
