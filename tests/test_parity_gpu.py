@@ -221,6 +221,19 @@ def test_limits_of_the_interface(oracle):
         e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
                       others=np.concatenate([oth16, far[:, :1]], axis=1), collision_cost=True)      # 17 vehicles
     e.close()
+    # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (44 KB of LDS)
+    e = engine.MPCEngine(horizon=64, max_iter=100)
+    assert e.workspace_bytes(1, 16) == (54 * 65 + 4 + 64 + 5 * 6 * 65) * 8
+    sub = {k: (v[:24] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    vref64 = np.concatenate([sub["vref"], np.repeat(sub["vref"][:, -1:], 44, axis=1)], axis=1)
+    got = e.solve_batch(sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=vref64, others=oth16[:24],
+                        collision_cost=True)
+    want = oracle.solve_batch(ref, sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=vref64,
+                              others=oth16[:24], collision_cost=True, N=64, max_iter=100, xy_bounds=False)
+    both = (got["status"] == 0) & (want["status"] == 0)
+    assert both.sum() >= 8 and (rel_u0_err(got["u0"], want["u0"])[both] <= TOL).all()
+    assert (got["status"] == want["status"]).mean() > 0.8
+    e.close()
     for N in (1, 2, 3):
         e = engine.MPCEngine(horizon=N, max_iter=100)
         got = e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"][:, :N + 1])
