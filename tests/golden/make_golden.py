@@ -13,6 +13,10 @@
    (agents/pure_mpc_linear.py: calc_nearest_index_in_direction, linear_model_matrix, predict_motion), imported with an
    empty stand-in for cvxpy (used only inside `_linear_mpc_control`, which is not executed).
 
+4. ltv_oracle_solutions.npz - inputs and solutions of the CPU oracle of the iterative-linear agent's QP
+   (oracle/ltv_oracle.py) for 48 synthetic instances, first call and a call re-linearised about that solution, with
+   the objective value of an independent scipy SLSQP run for the first 6 (these pin OUR oracle, not ECOS).
+
 The fixtures are data (inputs / expected outputs) only.
 """
 import os
@@ -203,6 +207,34 @@ def ltv_reference_vectors():
     print("wrote ltv_reference_numpy.npz", {k: v.shape for k, v in out.items()})
 
 
+def ltv_oracle_vectors():
+    import ltv_oracle as L
+    from scipy.optimize import minimize
+    from mpc_rl_for_avs_amd import synth
+    from mpc_rl_for_avs_amd.reference_path import reference_states
+    ref = reference_states()
+    inp = synth.solver_inputs(48, 2, seed=303)
+    st = np.ascontiguousarray(inp["state"][:, [0, 1, 3, 2]].astype(np.float32).astype(np.float64))
+    nom = np.zeros((48, 20, 2))
+    a = L.solve_batch(ref, st, nom)
+    b = L.solve_batch(ref, st, a["U"])
+    out = dict(state=st, U0=nom, u0_first=a["u0"], U_first=a["U"], status_first=a["status"], iters_first=a["iters"],
+               target_index=a["target_index"], u0_second=b["u0"], U_second=b["U"], status_second=b["status"])
+    fs = np.full(6, np.nan)
+    fo = np.full(6, np.nan)
+    for i in range(6):
+        if a["status"][i] != 0:
+            continue
+        f = lambda u: L.objective_loops(u.reshape(20, 2), st[i], a["xref"][i], a["xbar"][i], 0.1)
+        cons = {"type": "ineq", "fun": lambda u: L.constraint_loops(u.reshape(20, 2), st[i], a["xbar"][i], 0.1)}
+        r = minimize(f, np.full(40, 0.05), constraints=[cons], method="SLSQP", options=dict(ftol=1e-15, maxiter=800))
+        fs[i], fo[i] = r.fun, f(a["U"][i].ravel())
+    out["slsqp_objective"], out["oracle_objective"] = fs, fo
+    print("ltv oracle: status", np.bincount(a["status"], minlength=4), np.bincount(b["status"], minlength=4),
+          "objective oracle - slsqp", np.nanmax(fo - fs))
+    np.savez_compressed(os.path.join(HERE, "ltv_oracle_solutions.npz"), **out)
+
+
 def oracle_vectors():
     import oracle_lib
     import nlp_spec as S
@@ -238,3 +270,4 @@ if __name__ == "__main__":
     ltv_reference_vectors()
     if "--reference-only" not in sys.argv:
         oracle_vectors()
+        ltv_oracle_vectors()

@@ -76,3 +76,23 @@ def test_hard_closed_loop_instances(cpu_ltv, ltv_oracle, ref_table):
     assert (want["status"] == 0).all() and (got["status"] == 0).all()
     assert rel_u0_err(got["u0"], want["u0"]).max() <= TOL
     assert got["iters"].max() <= 30
+
+
+def test_golden_solutions(cpu_ltv, ltv_oracle, ref_table):
+    """Committed oracle solutions (tests/golden/ltv_oracle_solutions.npz): the oracle still reproduces them, the kernel
+    solver matches them, and they are as good as an independent SLSQP run where that was recorded."""
+    g = np.load(os.path.join(GOLDEN, "ltv_oracle_solutions.npz"))
+    now = ltv_oracle.solve_batch(ref_table, g["state"], g["U0"])
+    assert np.array_equal(now["status"], g["status_first"]) and np.array_equal(now["target_index"], g["target_index"])
+    ok = g["status_first"] == 0
+    assert np.abs(now["u0"] - g["u0_first"])[ok].max() <= 1e-7
+    got = cpu_ltv(ref_table, g["state"], g["U0"])
+    assert np.array_equal(got["status"], g["status_first"])
+    assert rel_u0_err(got["u0"], g["u0_first"])[ok].max() <= TOL and np.abs(got["U"] - g["U_first"])[ok].max() <= 1e-3
+    got2 = cpu_ltv(ref_table, g["state"], g["U_first"])
+    ok2 = g["status_second"] == 0
+    assert np.array_equal(got2["status"], g["status_second"])
+    assert rel_u0_err(got2["u0"], g["u0_second"])[ok2].max() <= TOL
+    rec = np.isfinite(g["slsqp_objective"])
+    assert rec.sum() >= 4
+    assert (g["oracle_objective"][rec] <= g["slsqp_objective"][rec] + 1e-6 * np.abs(g["slsqp_objective"][rec])).all()

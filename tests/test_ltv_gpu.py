@@ -187,3 +187,15 @@ def test_gpu_solution_against_an_independent_solver(eng, ltv_oracle, ref_table):
         if r.success or abs(fg - r.fun) <= 1e-7 * abs(fg):
             assert np.abs(r.x[:2] - got["u0"][b]).max() <= 2e-4
     e.close()
+
+
+def test_golden_solutions(eng):
+    g = np.load(os.path.join(GOLDEN, "ltv_oracle_solutions.npz"))
+    got = eng.ltv_solve_batch(g["state"], g["U0"])
+    ok = g["status_first"] == 0
+    assert np.array_equal(got["status"], g["status_first"]) and np.array_equal(got["target_index"], g["target_index"])
+    assert rel_u0_err(got["u0"], g["u0_first"])[ok].max() <= TOL and np.abs(got["U"] - g["U_first"])[ok].max() <= 1e-3
+    got2 = eng.ltv_solve_batch(g["state"], g["U_first"])
+    ok2 = g["status_second"] == 0
+    assert np.array_equal(got2["status"], g["status_second"])
+    assert rel_u0_err(got2["u0"], g["u0_second"])[ok2].max() <= TOL
