@@ -386,7 +386,7 @@ struct Solver {
     // alpha_t into its own trial area (t = 0: the spare trajectory buffer) - and their costs are evaluated two trials
     // per pass (lanes 0..31 / 32..63 = stages of trial 2p / 2p + 1); the winner is copied into the spare buffer.
     MPC_HD bool line_search(int cur, double a_pr, double frac, double phi0, double dV1, double mu_, double &Jn,
-                            double &barn) {
+                            double &barn, int &acc_out) {
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
         const double fracu = 2.0 * frac;
         const int TSZ = 6 * (N + 1);
@@ -510,6 +510,7 @@ struct Solver {
             });
         }
         c.tick(T_ROLL_COST);
+        acc_out = acc;
         return acc >= 0;
     }
 
@@ -572,6 +573,7 @@ struct Solver {
         double mu = P.mu_init;
         const double mu_min = P.tol / 10.0;
         int iter = 0, nfail = 0;
+        double reg = 0.0;
 
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
@@ -732,7 +734,7 @@ struct Solver {
             // slots that are free during the sweep (the stage's gain slots and the trial trajectory buffer); the
             // sweep then needs three LDS exchanges per stage: T = P F, H = L + F'T, and (inverse, gains, P) together.
             const int AB = (cur ^ 1) * 6;   // trial buffer: hv0..3 at AB + W_X, hv5 at AB + W_U
-            double dV1 = 0.0, delta_w = 0.0;
+            double dV1 = 0.0, delta_w = reg;
             bool ok = false, gn = false;
             for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
                 ok = true;
@@ -872,10 +874,60 @@ struct Solver {
                         c.take(HA, Hm, m_s1b);
                         // ---- 2x2 control block (uniform): elements (6,6) (6,7) (7,6) (7,7) sit in lanes 46 47 62 63,
                         //      gradient elements 6, 7 in lanes 40, 56
-                        const double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
-                                     hc = c.lane_get(Hm, 63);
+                        double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
+                               hc = c.lane_get(Hm, 63);
                         const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
-                        const double det = ha * hc - hb * hb;
+                        double det = ha * hc - hb * hb;
+                        if ((!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) && !gn) {
+                            // not positive definite with the exact Hessian: this stage alone falls back to its
+                            // Gauss-Newton terms (constraint curvature off, radial part of the collision potential) -
+                            // they are taken out of H, the products with P stay
+                            double wdd, wtt = 0.0, wtv = 0.0, wtd = 0.0, wvd = 0.0, q00 = 0.0, q01 = 0.0, q11 = 0.0;
+                            {
+                                const double v = S(k, CB + W_X + 3);
+                                double Sn, Cn, sb, cb_, bp, bpp;
+                                dyn_eval(S(k, CB + W_X + 2), S(k, CB + W_U + 1), Sn, Cn, sb, cb_);
+                                beta_derivs(sb, cb_, bp, bpp);
+                                const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
+                                const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
+                                wdd = dt * v * (g * bp * bp + h * bpp) +
+                                      dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
+                                if (k >= 1) {
+                                    wtt = dt * v * g;
+                                    wtv = dt * h;
+                                    wtd = dt * v * g * bp;
+                                    wvd = dt * h * bp + dt * yy2 * cb_ * bp * kInvWheelbase;
+                                    if (CC) {
+                                        q00 = S(k, W_QG + 0) - S(k, W_Q + 0);
+                                        q01 = S(k, W_QG + 1) - S(k, W_Q + 1);
+                                        q11 = S(k, W_QG + 2) - S(k, W_Q + 2);
+                                    }
+                                }
+                            }
+                            c.lanes([&](int lane) {
+                                const int r = m_row.at(lane), cl = m_col.at(lane);
+                                const int a = r < cl ? r : cl, b = r < cl ? cl : r;
+                                double corr = 0.0;
+                                switch (a * 8 + b) {
+                                    case 0 * 8 + 0: corr = q00; break;
+                                    case 0 * 8 + 1: corr = q01; break;
+                                    case 1 * 8 + 1: corr = q11; break;
+                                    case 2 * 8 + 2: corr = -wtt; break;
+                                    case 2 * 8 + 3: corr = -wtv; break;
+                                    case 2 * 8 + 7: corr = -wtd; break;
+                                    case 3 * 8 + 7: corr = -wvd; break;
+                                    case 7 * 8 + 7: corr = -wdd; break;
+                                    default: break;
+                                }
+                                Hm.at(lane) += corr;
+                            });
+                            c.take(HB, Hm, m_s2b);
+                            c.take(HA, Hm, m_s1b);
+                            ha = c.lane_get(Hm, 46);
+                            hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62));
+                            hc = c.lane_get(Hm, 63);
+                            det = ha * hc - hb * hb;
+                        }
                         if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
                             ok = false;
                             break;
@@ -1007,7 +1059,16 @@ struct Solver {
             const double phi0 = Jcur + mu * barcur;
             const int tb = cur ^ 1;
             double Jn = 0.0, barn = 0.0;
-            const bool accepted = line_search(cur, a_pr, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn);
+            int acc_trial = -1;
+            const bool accepted = line_search(cur, a_pr, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn, acc_trial);
+            // Levenberg-Marquardt term kept across iterations: two or more backtracks (or no acceptable step) multiply it
+            // by 4 (from 1e-3), a full first trial divides it by 4 (to 0 below 1e-3)
+            if (accepted && acc_trial == 0) {
+                reg = 0.25 * reg;
+                if (reg < 1e-3) reg = 0.0;
+            } else if (!accepted || acc_trial >= 2) {
+                reg = (reg == 0.0) ? 1e-3 : fmin2(4.0 * reg, 1e6);
+            }
             // ============ dual update (stage-parallel)
             {
                 const int NB = (accepted ? tb : cur) * 6;

@@ -208,6 +208,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
     const int MAXLS = 6;      /* line-search trials per iteration */
     const double BTF = 0.25;  /* backtracking factor */
     const double kap_eps = 10.0, kap_mu = 0.2;
+    /* Levenberg-Marquardt term kept across iterations: added to the diagonal of the stage Hessians like delta_w.  Two or
+     * more backtracks (or no acceptable step) multiply it by 4 (from 1e-3), a full first trial divides it by 4 (to 0
+     * below 1e-3).  Without it instances on the nonconvex side of the heading wrap crawl with 1/64-steps for the whole
+     * iteration budget. */
+    const double REG_MIN = 1e-3, REG_FACTOR = 4.0, REG_MAX = 1e6;
+    double reg = 0.0;
 
     static _Thread_local double A[NMAX][4][4], Bm[NMAX][4][2];
     static _Thread_local double lxs[NMAX + 1][4], Qs[NMAX + 1][4][4], Qgs[NMAX + 1][4][4], lus[NMAX][2], lps[NMAX][2];
@@ -374,7 +380,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
          * If a control block Huu_k is not positive definite the sweep is repeated with the convex Gauss-Newton model
          * (no constraint curvature, radial part of the collision potential); should that fail numerically too, a
          * multiple of the identity is added. */
-        double dV1 = 0.0, delta_w = 0.0;
+        double dV1 = 0.0, delta_w = reg;
         int nmod = 0, ok = 0, gn = 0;
         ++g_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
@@ -390,6 +396,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 px[i] = (i >= p->i0) ? -mu / sl + mu / su : 0.0;
             }
             for (int k = N - 1; k >= 0; --k) {
+                /* a stage whose control block is not positive definite with the exact Hessian is redone with the
+                 * Gauss-Newton terms of that stage alone; only if that fails too the whole sweep is repeated */
+                int lgn = gn;
+            retry_stage:;
                 const double rdk = (k >= 1) ? rd_full : 0.0;
                 double Lxx[4][4], Lxu[4][2], Luu[2][2], lx[4], lu[2];
                 memset(Lxx, 0, sizeof(Lxx));
@@ -397,12 +407,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 memset(lx, 0, sizeof(lx));
                 if (k >= 1) {
                     for (int i = 0; i < 4; ++i) {
-                        for (int j = 0; j < 4; ++j) Lxx[i][j] = gn ? Qgs[k][i][j] : Qs[k][i][j];
+                        for (int j = 0; j < 4; ++j) Lxx[i][j] = lgn ? Qgs[k][i][j] : Qs[k][i][j];
                         double sl = it->x[k][i] - xlo_r(i), su = xhi_r(i) - it->x[k][i];
                         Lxx[i][i] += (i >= p->i0 ? it->zxl[k][i] / sl + it->zxu[k][i] / su : 0.0) + delta_w;
                         lx[i] = lxs[k][i] + (i >= p->i0 ? -mu / sl + mu / su : 0.0);
                     }
-                    if (!gn) {
+                    if (!lgn) {
                         Lxx[2][2] += Wtt[k];
                         Lxx[2][3] += Wtv[k];
                         Lxx[3][2] += Wtv[k];
@@ -416,7 +426,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     lu[i] = lus[k][i] - mu / sl + mu / su;
                 }
                 Luu[0][1] = Luu[1][0] = 0.0;
-                if (!gn) Luu[1][1] += Wdd[k];
+                if (!lgn) Luu[1][1] += Wdd[k];
                 double PA[4][4], PB[4][2];
                 for (int i = 0; i < 4; ++i) {
                     for (int j = 0; j < 4; ++j) {
@@ -460,6 +470,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 /* 2x2 control block: positive definite? */
                 double ha = Huu[0][0], hb = 0.5 * (Huu[0][1] + Huu[1][0]), hc = Huu[1][1];
                 if (!(ha > 0.0) || !(hc > 0.0) || !(ha * hc - hb * hb > 1e-12 * ha * hc)) {
+                    if (!lgn) {
+                        lgn = 1;
+                        goto retry_stage;
+                    }
                     ok = 0;
                     break;
                 }
@@ -582,6 +596,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
                     iter, nmod, gn, mu, delta_w, err_d, err_c0, E0, a_pr, alpha, a_du, nls, dV1, phi0, phi1, accepted);
         if (!accepted) trial = *it; /* keep the primal point; the dual step below still moves z */
+        if (accepted && nls == 0) {
+            reg = reg / REG_FACTOR;
+            if (reg < REG_MIN) reg = 0.0;
+        } else if (!accepted || nls >= 2) {
+            reg = (reg == 0.0) ? REG_MIN : fmin(REG_FACTOR * reg, REG_MAX);
+        }
         nfail = accepted ? 0 : nfail + 1;
         /* ---------------- dual step: multipliers that shrink share one fraction-to-the-boundary length, multipliers
          *                  that grow (no positivity issue) take the full Newton step ---------------- */
