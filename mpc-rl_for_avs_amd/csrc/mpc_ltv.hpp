@@ -111,22 +111,7 @@ struct Solver {
     MPC_HD double vr(int k) const { return c.refv(k); }
 
     MPC_HD int f_word(int r, int cl) const {
-        const int zero = -(SCR + SC_ZERO + 1), one = -(SCR + SC_ONE + 1), dtw = -(SCR + SC_DT + 1);
-        if (r >= 6) return zero;
-        if (r == 4) return cl == 6 ? one : zero;
-        if (r == 5) return cl == 7 ? one : zero;
-        if (cl < 4) {
-            if (r == cl) return one;
-            if (r == 0 && cl == 2) return L_LIN + 0;
-            if (r == 0 && cl == 3) return L_LIN + 1;
-            if (r == 1 && cl == 2) return L_LIN + 2;
-            if (r == 1 && cl == 3) return L_LIN + 3;
-            if (r == 2 && cl == 3) return L_LIN + 4;
-            return zero;
-        }
-        if (cl == 6) return r == 3 ? dtw : zero;
-        if (cl == 7) return r == 0 ? L_LIN + 5 : (r == 1 ? L_LIN + 6 : (r == 2 ? L_LIN + 7 : zero));
-        return zero;
+        return wave::stage_transition_word(r, cl, L_LIN, -(SCR + SC_ZERO + 1), -(SCR + SC_ONE + 1), -(SCR + SC_DT + 1));
     }
     MPC_HD void set_roles() {
         c.st(SCR + SC_ZERO, 0.0);

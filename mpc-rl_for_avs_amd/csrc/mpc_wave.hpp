@@ -121,6 +121,28 @@ inline T host_reduce(PerLane<T> &p, OP op) {
 }
 #endif
 
+// F = [A B; 0 I; 0 0] (8 x 8 with two zero rows; state 4, previous control 2, control 2) of the bicycle model - exact or
+// linearised about a nominal trajectory - is made of 0, 1, dt and eight stored values a02 a03 a12 a13 a23 b01 b11 b21
+// (slots lin .. lin + 7 of the stage): LDS word of element (r, c), stage-relative (>= 0) or, for the three constants,
+// the absolute word encoded as -(word + 1).  Shared by the NLP solver and the LTV-QP solver (mpc_ltv.hpp).
+MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int one, int dtw) {
+    if (r >= 6) return zero;
+    if (r == 4) return c == 6 ? one : zero;
+    if (r == 5) return c == 7 ? one : zero;
+    if (c < 4) {
+        if (r == c) return one;
+        if (r == 0 && c == 2) return lin + 0;
+        if (r == 0 && c == 3) return lin + 1;
+        if (r == 1 && c == 2) return lin + 2;
+        if (r == 1 && c == 3) return lin + 3;
+        if (r == 2 && c == 3) return lin + 4;
+        return zero;
+    }
+    if (c == 6) return r == 3 ? dtw : zero;
+    if (c == 7) return r == 0 ? lin + 5 : (r == 1 ? lin + 6 : (r == 2 ? lin + 7 : zero));
+    return zero;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // CTX (one per wave / instance) provides
 //   double ld(int i), void st(int i, double v)   LDS words of this instance
@@ -189,25 +211,9 @@ struct Solver {
         });
     }
 
-    // F = [A B; 0 I; 0 0] (8 x 8 with two zero rows) is made of 0, 1, dt and the eight stored linearisation values:
-    // LDS word of element (r, c), stage-relative (>= 0) or absolute (< 0: -(word + 1)) for the three constants
     MPC_HD int f_word(int r, int c) const {
-        const int zero = -(SCR + SC_SPARE + 0 + 1), one = -(SCR + SC_SPARE + 1 + 1), dtw = -(SCR + SC_SPARE + 2 + 1);
-        if (r >= 6) return zero;
-        if (r == 4) return c == 6 ? one : zero;
-        if (r == 5) return c == 7 ? one : zero;
-        if (c < 4) {
-            if (r == c) return one;
-            if (r == 0 && c == 2) return W_LIN + 0;
-            if (r == 0 && c == 3) return W_LIN + 1;
-            if (r == 1 && c == 2) return W_LIN + 2;
-            if (r == 1 && c == 3) return W_LIN + 3;
-            if (r == 2 && c == 3) return W_LIN + 4;
-            return zero;
-        }
-        if (c == 6) return r == 3 ? dtw : zero;
-        if (c == 7) return r == 0 ? W_LIN + 5 : (r == 1 ? W_LIN + 6 : (r == 2 ? W_LIN + 7 : zero));
-        return zero;
+        return stage_transition_word(r, c, W_LIN, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
+                                     -(SCR + SC_SPARE + 2 + 1));
     }
     MPC_HD void set_mfma_roles() {
         sc(SC_SPARE + 0, 0.0);
