@@ -70,3 +70,38 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not any(w in text for w in ("oracle_lib", "nlp_spec", "mpc_oracle", "ltv_oracle")), f
+
+
+def _c_client():
+    """tests/abi_client.c compiled with gcc: the ABI used from plain C (dlopen, no Python objects, no torch)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "_build", "abi_client")
+    src = os.path.join(ROOT, "tests", "abi_client.c")
+    hdr = os.path.join(ROOT, "include", "mpc_mi355x.h")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-o", exe, src, "-ldl", "-lm"], check=True)
+    return exe
+
+
+def test_c_client_without_gpu():
+    """The header compiles as C, every entry point the client binds resolves, argument errors come back as codes, and
+    without a device mpc_create says MPC_ERR_NO_DEVICE (with one it succeeds)."""
+    import subprocess
+    from mpc_rl_for_avs_amd import _build
+    _build.build()
+    r = subprocess.run([_c_client(), _build.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "create rc=" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_client_solves_on_gpu():
+    """Known answers through the ABI from plain C: NLP on the straight part of the path, state outside its bounds,
+    the iterative-linear QP."""
+    import subprocess
+    from mpc_rl_for_avs_amd import _build
+    _build.build()
+    r = subprocess.run([_c_client(), _build.LIB_PATH, "solve"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "create rc=0" in r.stdout and "solve ok" in r.stdout
