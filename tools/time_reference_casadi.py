@@ -18,8 +18,12 @@ def main():
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--vehicles", type=int, default=4)
     a = ap.parse_args()
-    from agents.pure_mpc import PureMPC_Agent            # the reference (needs casadi, gymnasium, shapely)
-    from mpc_rl_for_avs_amd import synth
+    try:
+        from agents.pure_mpc import PureMPC_Agent        # the reference (needs casadi, gymnasium, shapely)
+        from mpc_rl_for_avs_amd import synth
+    except ImportError as e:
+        raise SystemExit(f"not runnable here ({e}); see the module docstring: the reference checkout and this repository "
+                         f"must be on PYTHONPATH and the reference's requirements installed")
 
     class Env:
         unwrapped = None
