@@ -551,18 +551,30 @@ struct Solver {
                 }
             });
             const double res_p = c.wave_max(red_a), mu = c.wave_sum(red_b) / m_ineq;
-            // ============ adjoint of (yaw, v): suffix sums (x and y carry y0, y1 unchanged; a23 = 0 couples nothing else)
+            // ============ adjoint of (yaw, v): x and y carry y0, y1 unchanged, so the yaw adjoint is a suffix sum of the node
+            //              terms and the speed adjoint one of (term + a23 yaw-adjoint of the next node): two wave scans,
+            //              lane j = node j + 1
             {
-                double y2 = S(N, L_Y + 0), y3 = S(N, L_Y + 1);
-#pragma unroll 1
-                for (int k = N - 1; k >= 1; --k) {
-                    y3 = S(k, L_Y + 1) + S(k, L_LIN + 4) * y2 + y3;
-                    y2 = S(k, L_Y + 0) + y2;
-                    S(k, L_Y + 0, y2);
-                    S(k, L_Y + 1, y3);
-                }
+                PerLane<double> sc;
+                c.phase([&](int lane) { sc.at(lane) = lane < N ? S(lane + 1, L_Y + 0) : 0.0; });
+                c.wave_suffix_sum(sc);
+                c.phase([&](int lane) {
+                    if (lane < N) S(lane + 1, L_Y + 0, sc.at(lane));
+                });
+                c.phase([&](int lane) {
+                    const int k = lane + 1;
+                    double h = 0.0;
+                    if (lane < N) {
+                        h = S(k, L_Y + 1);
+                        if (k < N) h += S(k, L_LIN + 4) * S(k + 1, L_Y + 0);
+                    }
+                    sc.at(lane) = h;
+                });
+                c.wave_suffix_sum(sc);
+                c.phase([&](int lane) {
+                    if (lane < N) S(lane + 1, L_Y + 1, sc.at(lane));
+                });
             }
-            c.phase([&](int) {});
             // ============ dual residual of the controls
             c.phase([&](int lane) {
                 red_a.at(lane) = 0.0;

@@ -11,7 +11,8 @@
 //     matrix-core instructions per stage; blocks move between operand positions by lane permutation, nothing is
 //     exchanged through LDS;
 //   * the line search integrates all six trial step lengths at once, lane t = trial t;
-//   * only the true recursions (adjoint, linearised step, one lane's rollout) are serial.
+//   * the adjoint recursion is three suffix sums over the stages (A' = I + strictly triangular): wave scans;
+//   * only the true recursions (linearised step, one lane's rollout, the Riccati sweep itself) are serial.
 // Why: measured on MI355X, a one-lane-per-instance kernel (the first design, since removed) is bound by the serial
 // FP64 instruction stream of its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4
 // SIMDs per CU usable because the per-instance state has to sit in LDS.
@@ -159,6 +160,7 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //        lane l = 16 hi + 4 blk + lo holds A_blk[row lo][k hi], B_blk[k hi][col lo], C/D_blk[row hi][col lo]
 //   void take(PerLane<double>& dst, PerLane<double>& src, PerLane<int>& from)   dst[l] = src[from[l]]
 //   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
+//   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
 // ---------------------------------------------------------------------------------------------------
 template <bool CC, class CTX>
@@ -663,29 +665,57 @@ struct Solver {
             });
             const double cmax = c.wave_max(red_a), cmin = c.wave_min(red_b), sum_z = c.wave_sum(red_c);
             c.tick(T_PREP);
-            // ============ adjoint recursion (serial): y_k = g_k + A_k' y_{k+1}, in place over the node gradients
+            // ============ adjoint recursion y_k = g_k + A_k' y_{k+1}, in place over the node gradients.  A_k' = I + (strictly
+            //              triangular): y0 and y1 are plain suffix sums of the node gradients, y2 a suffix sum of
+            //              g2 + a02 y0+ + a12 y1+, y3 one of g3 + a03 y0+ + a13 y1+ + a23 y2+ (y+ = y_{k+1}) - three
+            //              wave scans, lane j = node j + 1, instead of N dependent steps
             double sum_lam = 0.0;
             {
-                double y0 = S(N, W_Y + 0), y1 = S(N, W_Y + 1), y2 = S(N, W_Y + 2), y3 = S(N, W_Y + 3);
-                sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
-#pragma unroll 1
-                for (int k = N - 1; k >= 1; --k) {
-                    const double a02 = S(k, W_LIN + 0), a03 = S(k, W_LIN + 1), a12 = S(k, W_LIN + 2), a13 = S(k, W_LIN + 3),
-                                 a23 = S(k, W_LIN + 4);
-                    const double t0 = S(k, W_Y + 0) + y0;
-                    const double t1 = S(k, W_Y + 1) + y1;
-                    const double t2 = S(k, W_Y + 2) + a02 * y0 + a12 * y1 + y2;
-                    const double t3 = S(k, W_Y + 3) + a03 * y0 + a13 * y1 + a23 * y2 + y3;
-                    y0 = t0;
-                    y1 = t1;
-                    y2 = t2;
-                    y3 = t3;
-                    S(k, W_Y + 0, y0);
-                    S(k, W_Y + 1, y1);
-                    S(k, W_Y + 2, y2);
-                    S(k, W_Y + 3, y3);
-                    sum_lam += fabs(y0) + fabs(y1) + fabs(y2) + fabs(y3);
-                }
+                PerLane<double> s0, s1;
+                c.phase([&](int lane) {
+                    const bool on = lane < N;
+                    s0.at(lane) = on ? S(lane + 1, W_Y + 0) : 0.0;
+                    s1.at(lane) = on ? S(lane + 1, W_Y + 1) : 0.0;
+                });
+                c.wave_suffix_sum(s0);
+                c.wave_suffix_sum(s1);
+                c.phase([&](int lane) {
+                    if (lane >= N) return;
+                    S(lane + 1, W_Y + 0, s0.at(lane));
+                    S(lane + 1, W_Y + 1, s1.at(lane));
+                });
+                PerLane<double> s2;
+                c.phase([&](int lane) {
+                    const int k = lane + 1;
+                    double h = 0.0;
+                    if (lane < N) {
+                        h = S(k, W_Y + 2);
+                        if (k < N) h += S(k, W_LIN + 0) * S(k + 1, W_Y + 0) + S(k, W_LIN + 2) * S(k + 1, W_Y + 1);
+                    }
+                    s2.at(lane) = h;
+                });
+                c.wave_suffix_sum(s2);
+                c.phase([&](int lane) {
+                    if (lane < N) S(lane + 1, W_Y + 2, s2.at(lane));
+                });
+                PerLane<double> s3;
+                c.phase([&](int lane) {
+                    const int k = lane + 1;
+                    double h = 0.0;
+                    if (lane < N) {
+                        h = S(k, W_Y + 3);
+                        if (k < N)
+                            h += S(k, W_LIN + 1) * S(k + 1, W_Y + 0) + S(k, W_LIN + 3) * S(k + 1, W_Y + 1) +
+                                 S(k, W_LIN + 4) * S(k + 1, W_Y + 2);
+                    }
+                    s3.at(lane) = h;
+                });
+                c.wave_suffix_sum(s3);
+                c.phase([&](int lane) {
+                    if (lane < N) S(lane + 1, W_Y + 3, s3.at(lane));
+                    red_a.at(lane) = lane < N ? fabs(s0.at(lane)) + fabs(s1.at(lane)) + fabs(s2.at(lane)) + fabs(s3.at(lane)) : 0.0;
+                });
+                sum_lam = c.wave_sum(red_a);
             }
             c.tick(T_ADJOINT);
             // ============ dual residual of the controls (stage-parallel)

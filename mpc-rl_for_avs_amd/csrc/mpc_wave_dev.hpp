@@ -15,6 +15,8 @@ typedef __attribute__((address_space(3))) double lds_double_t;
 
 // DPP row controls (GFX9): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+// row_shl:n - lane i of a 16-lane row reads lane i + n of the same row, 0 beyond the row (bound_ctrl)
+constexpr int kDppRowShl1 = 0x101, kDppRowShl2 = 0x102, kDppRowShl4 = 0x104, kDppRowShl8 = 0x108;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -82,6 +84,19 @@ struct WaveOps {
     }
     __device__ __forceinline__ double wave_min(PerLane<double> &p) const {
         return reduce(p.v, [](double a, double b) { return fmin2(a, b); });
+    }
+    // inclusive suffix sum over the lanes: log-step shifts inside each 16-lane row (DPP), then the totals of the rows
+    // above (row r's total sits in its lane 16 r after the row scan) are added
+    __device__ __forceinline__ void wave_suffix_sum(PerLane<double> &p) const {
+        double v = p.v;
+        v += dpp_f64<kDppRowShl1>(v);
+        v += dpp_f64<kDppRowShl2>(v);
+        v += dpp_f64<kDppRowShl4>(v);
+        v += dpp_f64<kDppRowShl8>(v);
+        const double t1 = readlane_f64(v, 16), t2 = readlane_f64(v, 32), t3 = readlane_f64(v, 48);
+        const int row = (int)threadIdx.x >> 4;
+        const double above = row == 0 ? (t1 + (t2 + t3)) : (row == 1 ? (t2 + t3) : (row == 2 ? t3 : 0.0));
+        p.v = v + above;
     }
     __device__ __forceinline__ void wave_sum2(PerLane<double> &p, double &lo, double &hi) const {
         const double v = row_reduce(p.v, [](double a, double b) { return a + b; });

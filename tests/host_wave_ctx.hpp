@@ -53,6 +53,19 @@ struct HostCtx {
     double wave_min(mpc::wave::PerLane<double> &p) const {
         return mpc::wave::host_reduce(p, [](double a, double b) { return mpc::fmin2(a, b); });
     }
+    // same order of additions as the device: shifts by 1, 2, 4, 8 inside each 16-lane row, then the rows above
+    void wave_suffix_sum(mpc::wave::PerLane<double> &p) const {
+        for (int sh = 1; sh <= 8; sh *= 2) {
+            double nv[mpc::wave::kLanes];
+            for (int l = 0; l < mpc::wave::kLanes; ++l) nv[l] = p.v[l] + (((l & 15) + sh < 16) ? p.v[l + sh] : 0.0);
+            for (int l = 0; l < mpc::wave::kLanes; ++l) p.v[l] = nv[l];
+        }
+        const double t1 = p.v[16], t2 = p.v[32], t3 = p.v[48];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) {
+            const int row = l >> 4;
+            p.v[l] += row == 0 ? (t1 + (t2 + t3)) : (row == 1 ? (t2 + t3) : (row == 2 ? t3 : 0.0));
+        }
+    }
     void wave_sum2(mpc::wave::PerLane<double> &p, double &lo, double &hi) const {
         mpc::wave::host_row_reduce(p, [](double a, double b) { return a + b; });
         lo = p.v[0] + p.v[16];
