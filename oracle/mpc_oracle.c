@@ -25,9 +25,11 @@
  *
  * Algorithm (ours; the reference delegates to IPOPT): primal-dual interior-point
  * DDP in single shooting - monotone barrier decrease with IPOPT's error measures
- * and gradient-based objective scaling, exact Lagrangian Hessian (Gauss-Newton
- * model for an iteration whose control blocks are not positive definite, then a
- * diagonal shift), stage-wise Riccati factorisation of the KKT system (state
+ * and gradient-based objective scaling, exact Lagrangian Hessian (a stage whose
+ * control block is not positive definite falls back to its Gauss-Newton terms;
+ * if that fails the whole sweep uses the Gauss-Newton model, then a growing
+ * diagonal shift; a Levenberg-Marquardt term adapted by the line search is kept
+ * across iterations), stage-wise Riccati factorisation of the KKT system (state
  * augmented with the previous control to carry the input-rate cost), nonlinear
  * feedback rollouts with an Armijo line search on the barrier objective,
  * fraction-to-the-boundary rule, split dual step.  The dynamics hold exactly at
