@@ -15,7 +15,8 @@ import os
 # read when the HIP runtime starts: with the default of 4 hardware queues, streams carrying independent batches can
 # end up sharing a queue and serialise ("batches in flight"); plain kernel launches only - replayed
 # hipGraphs (tools/bench_rollout.py --graph) measured slower with 8
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:      # multi-rank runs (RCCL) keep the runtime's default
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import sys
 import time
