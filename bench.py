@@ -186,7 +186,9 @@ def main():
                          "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                          "note": "path is bound by the serial FP64 + LDS-latency chain of its slowest instance; the working "
                                  "set is LDS-resident and HBM carries only inputs/outputs (DESIGN.md section 4)"},
-            "solver": {"converged_frac": float((status == 0).mean()), "iters_mean": float(iters.mean()),
+            "solver": {"converged_frac": float(((status == 0) | (status == 5)).mean()),
+                       "smooth_kkt_frac": float((status == 0).mean()), "on_kink_frac": float((status == 5).mean()),
+                       "iters_mean": float(iters.mean()), "iters_p99": float(np.percentile(iters, 99)),
                        "iters_max": int(iters.max())},
         }
         # the resource this kernel actually consumes: vector-instruction issue slots (a wave64 FP64 instruction
@@ -204,7 +206,7 @@ def main():
             cb, oref = cpu_baseline(inp, sample=BATCH)
             res["cpu_baseline"] = cb
             u0 = out["u0"].cpu().numpy()
-            both = (status == 0) & (oref["status"] == 0)
+            both = ((status == 0) | (status == 5)) & ((oref["status"] == 0) | (oref["status"] == 5))
             err = np.abs(u0 - oref["u0"]).max(axis=1) / np.maximum(1.0, np.abs(oref["u0"]).max(axis=1))
             res["parity"] = {"both_converged": int(both.sum()), "u0_rel_linf_max": float(err[both].max()),
                              "u0_rel_linf_p99": float(np.percentile(err[both], 99)),

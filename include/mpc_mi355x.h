@@ -54,8 +54,13 @@ extern "C" {
 #define MPC_STATUS_MAX_ITER 1       /* last iterate returned, like the reference (agents/pure_mpc.py:303-305) */
 #define MPC_STATUS_FACTORIZATION 2
 #define MPC_STATUS_INFEASIBLE_START 3 /* the initial state violates the state bounds of agents/pure_mpc.py:272-274 */
-#define MPC_STATUS_STALLED 4          /* no acceptable step in 3 consecutive iterations (non-smooth point of the
-                                         collision cost); last iterate returned */
+#define MPC_STATUS_STALLED 4          /* no acceptable step in 3 consecutive iterations; last iterate returned */
+#define MPC_STATUS_CONVERGED_ON_KINK 5 /* converged, with the collision cost on, to a point that holds a vehicle exactly at
+                                         the d = 1 m discontinuity of that cost (agents/archive/pure_mpc.py:189-196:
+                                         100/d^2 outside, 1000/d^2 inside): a KKT point of the outer branch with
+                                         |p - o|^2 >= 1 as a constraint, i.e. a local minimiser of the discontinuous
+                                         objective.  The reference's IPOPT has no such notion and ends there without
+                                         success (its last iterate is returned, agents/pure_mpc.py:303-305). */
 
 typedef struct mpc_handle mpc_handle;
 

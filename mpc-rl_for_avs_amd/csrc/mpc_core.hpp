@@ -100,6 +100,28 @@ MPC_HD void sincos_b(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -ca : ca;
 }
 
+// atan(t) for |t| <= ~4 (the steering angle whose tangent is t; used on the rare path that projects a rollout back
+// into the theta bounds): rational first guess, then Newton steps on sin(d) - t cos(d) = 0, whose update
+// (sin d - t cos d) / (cos d + t sin d) = tan(d - atan t) converges cubically
+MPC_HD double atan_b(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double at = fabs(t);
+    // |t| <= 1: t / (1 + 0.28125 t^2) (error < 5e-3); above: pi/2 - the same in 1/t
+    const double r = at <= 1.0 ? at : frcp(at);
+    const double g = r * frcp(fma(0.28125 * r, r, 1.0));
+    double d = at <= 1.0 ? g : 1.57079632679489655800e+00 - g;
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+        double sd, cd;
+        sincos_b(d, sd, cd);
+        d -= fma(-at, cd, sd) * frcp(fma(at, sd, cd));
+    }
+    return t < 0.0 ? -d : d;
+#else
+    return atan(t);
+#endif
+}
+
 // kinematic bicycle model (agents/pure_mpc.py:220-228): beta = atan(LENGTH_REAR/LENGTH * tan(delta)).
 // tan and atan are eliminated algebraically: with q = (4 cos^2 delta + sin^2 delta)^-1/2,
 //   cos(beta) = 2 cos(delta) q,  sin(beta) = sin(delta) q,  sin/cos(theta+beta) by the addition theorems.

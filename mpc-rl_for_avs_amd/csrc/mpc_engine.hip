@@ -133,7 +133,8 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     solver.solve(status, iters, cur, kkt, warm);
     __syncthreads();
     const int CB = cur * 6;
-    if (lane == 0 && u_valid && U_out) u_valid[b] = 1;
+    // only a converged solve may seed the next warm start
+    if (lane == 0 && u_valid && U_out) u_valid[b] = (status == MPC_STATUS_CONVERGED || status == MPC_STATUS_CONVERGED_ON_KINK) ? 1 : 0;
     if (lane < 2) u0_out[(size_t)b * 2 + lane] = ctx.ld(CB + mpc::wave::W_U + lane);
     if (U_out && lane < N) {
         U_out[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 0);

@@ -29,7 +29,11 @@ namespace mpc {
 namespace wave {
 
 constexpr int kLanes = 64;
-constexpr int kTrials = 6;   // step lengths tried by the line search: a_pr * 4^-t
+constexpr int kTrials = 4;   // step lengths tried by the line search: a_pr * 4^-t (six gained nothing: 4083 against 4084
+                             // of 4096 config-3 instances converged in the oracle, and cost 2 KB of LDS per instance)
+// A rollout that would take theta or v of the next node out of its bounds gets the one control that decides it (delta
+// resp. a) pulled back so that the node keeps this fraction of its slack
+constexpr double kProjKeep = 0.2;
 
 // per-stage slots in LDS (doubles); trajectory buffer b lives at b*6
 enum : int {
@@ -46,11 +50,15 @@ enum : int {
     W_KF = 43,   // 2
     W_RV = 45,   // 1
     W_SLOTS = 46,
-    W_LX = 46,   // 2  (collision-cost variant)
-    W_Q = 48,    // 3
-    W_QG = 51,   // 3
-    W_SLOTS_CC = 54
+    W_LX = 46,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
+    W_Q = 48,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
+    W_QG = 51,   // 3  its Gauss-Newton part; after the line search slot 0: vehicle a rejected trial took across d = 1
+    W_ZW = 54,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
+    W_WJ = 55,   // 1  its vehicle j (as a double), -1: none
+    W_SLOTS_CC = 56
 };
+// parked values (valid between the factorisation and the next preparation phase)
+enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1, W_CROSS = W_QG };
 // scratch behind the stage arrays: the three constants the F operands are made of besides the linearisation values
 enum : int {
     SC_SPARE = 0,  // 0.0, 1.0, dt
@@ -184,7 +192,7 @@ struct Solver {
     MPC_HD void sc(int i, double v) { c.st(SCR + i, v); }
     MPC_HD double oth(int j, int q) const { return c.ld(OTH + j * 4 + q); }
 
-    PerLane<double> red_a, red_b, red_c;   // per-lane operands of the wave reductions
+    PerLane<double> red_a, red_b, red_c, red_w;   // per-lane operands of the wave reductions
     // MFMA sweep (kMfmaSweep): the 8x8 stage block lives in the C/D layout of v_mfma_f64_4x4x4f64 as 2x2 blocks of
     // 4x4: lane l = 16 hi + 4 (2 I + J) + lo holds element (row 4 I + hi, col 4 J + lo)
     PerLane<int> m_row, m_col;                     // element of this lane
@@ -193,6 +201,12 @@ struct Solver {
     PerLane<int> m_lslot, m_hvslot, m_hvab, m_kx;  // stage-Hessian slot, gradient slot (column-0 lanes), gain slot to store
     PerLane<double> m_lcst;
     PerLane<int> ls_feas;                  // line search: lane t = trial t stayed inside the fraction-to-the-boundary box
+    // d = 1 discontinuity of the collision cost (archive/pure_mpc.py:189-196: 100/d^2 outside, 1000/d^2 inside).  A
+    // vehicle that a rejected trial took across d = 1 inwards is kept outside from then on by the constraint
+    // |p_k - o_jk|^2 - 1 >= 0 of that node (one per node, multiplier W_ZW): the cost jumps upwards there, so a minimiser
+    // pressed against d = 1 is a constrained stationary point of the outer branch (status 5), which no smooth method
+    // reaches otherwise (round 1: 3.7 % of the config-3 instances ended "stalled").  any_wall: some node has one.
+    int any_wall = 0;
     // Riccati operands of stage k that come from LDS: F(k) in the four block arrangements and the accumulator inputs
     // L(k) (stage Hessian, C/D layout) and l(k) (stage gradient, column-0 lanes)
     MPC_HD void load_stage_operands(int k, int AB, double rdk, PerLane<double> &FA0, PerLane<double> &FA1,
@@ -288,7 +302,7 @@ struct Solver {
             const double py = x_1 - (oth(j, 1) + k * oth(j, 3));
             const double d2 = fma(px, px, py * py);
             const double rd = frsqrt(d2), d = d2 * rd;
-            const double cst = (d < 1.0 ? 1000.0 : 100.0) * P.w_distance;
+            const double cst = (d2 < 1.0 ? 1000.0 : 100.0) * P.w_distance;   // same expression as wall_slack() + 1
             const double rde = frcp(d + 1e-6);
             const double inv2 = rde * rde;
             J += cst * inv2;
@@ -311,6 +325,14 @@ struct Solver {
             d8[0] = g0; d8[1] = g1; d8[2] = h00; d8[3] = h01; d8[4] = h11; d8[5] = c00; d8[6] = c01; d8[7] = c11;
         }
         return J;
+    }
+    // slack |p - o_jk|^2 - 1 of the wall constraint of node k and vehicle j at position (x_0, x_1), gradient (nx, ny)
+    MPC_HD double wall_slack(int k, double x_0, double x_1, int j, double &nx, double &ny) const {
+        const double px = x_0 - (oth(j, 0) + k * oth(j, 2));
+        const double py = x_1 - (oth(j, 1) + k * oth(j, 3));
+        nx = 2.0 * px;
+        ny = 2.0 * py;
+        return fma(px, px, py * py) - 1.0;
     }
     // scaled stage-cost gradient at node k of trajectory buffer cb
     MPC_HD void cost_grad(int cb, int k, double *lx) const {
@@ -341,11 +363,20 @@ struct Solver {
         }
         const int nb = base + (k + 1) * stride;
         const double y0 = c.ld(nb + 0), y1 = c.ld(nb + 1), y2 = c.ld(nb + 2), y3 = c.ld(nb + 3);
-        const double slack = (((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1))) *
-                             (((y2 - xlo_r(0)) * (xhi_r(0) - y2)) * ((y3 - xlo_r(1)) * (xhi_r(1) - y3)));
+        double slack = (((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1))) *
+                       (((y2 - xlo_r(0)) * (xhi_r(0) - y2)) * ((y3 - xlo_r(1)) * (xhi_r(1) - y3)));
         if (k + 1 < N) {
             J += sf * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
-            if (CC) J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
+            if (CC) {
+                J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
+                if (any_wall) {
+                    const double wjv = S(k + 1, W_WJ);
+                    if (wjv >= 0.0) {
+                        double nx, ny;
+                        slack *= wall_slack(k + 1, y0, y1, (int)wjv, nx, ny);
+                    }
+                }
+            }
         }
         Jk = J;
         bark = -log(slack);
@@ -396,7 +427,7 @@ struct Solver {
     MPC_HD bool line_search(int cur, double a_pr, double frac, double phi0, double dV1, double mu_, double &Jn,
                             double &barn, int &acc_out) {
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
-        const double fracu = 2.0 * frac;
+        const double fracu = 2.0 * frac, idt = 1.0 / dt;
         const int TSZ = 6 * (N + 1);
         c.phase([&](int lane) {
             ls_feas.at(lane) = 0;
@@ -421,8 +452,33 @@ struct Solver {
                     s0 += kp00 * dup0 + kp01 * dup1;
                     s1 += kp01 * dup0 + kp11 * dup1;
                 }
-                const double u0 = fmin2(fmax2(c0 + s0, ulo_r(0) + fracu * (c0 - ulo_r(0))), uhi_r(0) - fracu * (uhi_r(0) - c0));
-                const double u1 = fmin2(fmax2(c1 + s1, ulo_r(1) + fracu * (c1 - ulo_r(1))), uhi_r(1) - fracu * (uhi_r(1) - c1));
+                const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+                const double ulo0 = ulo_r(0) + fracu * (c0 - ulo_r(0)), uhi0 = uhi_r(0) - fracu * (uhi_r(0) - c0);
+                const double ulo1 = ulo_r(1) + fracu * (c1 - ulo_r(1)), uhi1 = uhi_r(1) - fracu * (uhi_r(1) - c1);
+                double u0 = fmin2(fmax2(c0 + s0, ulo0), uhi0);
+                double u1 = fmin2(fmax2(c1 + s1, ulo1), uhi1);
+                {
+                    // v of node k+1 is decided by a_k alone: keep it inside the node's box (kProjKeep of its slack)
+                    const double vlo = xlo_r(1) + kProjKeep * (o3 - xlo_r(1)), vhi = xhi_r(1) - kProjKeep * (xhi_r(1) - o3);
+                    const double a = fmin2(fmax2(u0, (vlo - x_3) * idt), (vhi - x_3) * idt);
+                    u0 = fmin2(fmax2(a, ulo0), uhi0);
+                }
+                double Sn, Cn, sb, cb_;
+                dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+                double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+                {
+                    // theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
+                    // node's box, take the delta that puts it on the edge of the box
+                    const double tlo = xlo_r(0) + kProjKeep * (o2 - xlo_r(0)), thi = xhi_r(0) - kProjKeep * (xhi_r(0) - o2);
+                    if ((n2 < tlo || n2 > thi) && x_3 > 1e-6) {
+                        const double sreq = ((n2 < tlo ? tlo : thi) - x_2) * (1.0 / kInvWheelbase) * frcp(dt * x_3);
+                        if (fabs(sreq) < 0.9) {
+                            u1 = fmin2(fmax2(atan_b(2.0 * sreq * frsqrt(1.0 - sreq * sreq)), ulo1), uhi1);
+                            dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+                            n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+                        }
+                    }
+                }
                 dup0 = u0 - c0;
                 dup1 = u1 - c1;
                 const int o = base + k * stride;
@@ -432,17 +488,23 @@ struct Solver {
                 c.st(o + 3, x_3);
                 c.st(o + 4, u0);
                 c.st(o + 5, u1);
-                double Sn, Cn, sb, cb_;
-                dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
                 const double n0 = x_0 + dt * (x_3 * Cn);
                 const double n1 = x_1 + dt * (x_3 * Sn);
-                const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
                 const double n3 = x_3 + dt * u0;
-                const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
                 if (n2 - xlo_r(0) < frac * (o2 - xlo_r(0)) || xhi_r(0) - n2 < frac * (xhi_r(0) - o2) ||
                     n3 - xlo_r(1) < frac * (o3 - xlo_r(1)) || xhi_r(1) - n3 < frac * (xhi_r(1) - o3)) {
                     feas = false;
                     break;
+                }
+                if (CC && any_wall && k + 1 < N) {
+                    const double wjv = S(k + 1, W_WJ);
+                    if (wjv >= 0.0) {
+                        double nx, ny;
+                        if (wall_slack(k + 1, n0, n1, (int)wjv, nx, ny) < frac * S(k + 1, W_GW)) {
+                            feas = false;
+                            break;
+                        }
+                    }
                 }
                 x_0 = n0;
                 x_1 = n1;
@@ -510,6 +572,36 @@ struct Solver {
                 }
             }
         }
+        if (CC && P.V > 0 && acc != 0) {
+            // vehicles that a rejected (fully integrated) trial took across d = 1 inwards, per node the one with the
+            // smallest slack at the current iterate; the dual update turns them into wall constraints
+            const int nrej = acc < 0 ? kTrials : acc;
+            int fe[kTrials];
+            for (int t = 0; t < kTrials; ++t) fe[t] = c.wave_bcast(ls_feas, t);
+            c.phase([&](int lane) {
+                const int k = lane;
+                if (k < 1 || k >= N) return;
+                const double x_0 = S(k, CB + W_X + 0), x_1 = S(k, CB + W_X + 1);
+                int cross = -1;
+                double gbest = INFINITY;
+                for (int j = 0; j < P.V; ++j) {
+                    double nx, ny;
+                    const double g0 = wall_slack(k, x_0, x_1, j, nx, ny);
+                    if (!(g0 > 0.0) || !(g0 < gbest)) continue;
+                    bool crossed = false;
+                    for (int t = 0; t < nrej; ++t) {
+                        if (!fe[t]) continue;
+                        const int o = (t == 0 ? TB + k * SL : TRL + (t - 1) * TSZ + k * 6);
+                        if (wall_slack(k, c.ld(o + 0), c.ld(o + 1), j, nx, ny) < 0.0) crossed = true;
+                    }
+                    if (crossed) {
+                        cross = j;
+                        gbest = g0;
+                    }
+                }
+                S(k, W_CROSS, (double)cross);
+            });
+        }
         if (acc >= 1) {
             const int base = TRL + (acc - 1) * TSZ;
             c.phase([&](int lane) {
@@ -541,7 +633,12 @@ struct Solver {
                 S(lane + 1, W_ZXL + i, 1.0);
                 S(lane + 1, W_ZXU + i, 1.0);
             }
+            if (CC) {
+                S(lane, W_ZW, 0.0);
+                S(lane, W_WJ, -1.0);
+            }
         });
+        any_wall = 0;
         double Jcur = 0.0, barcur = 0.0;
         if (!(warm && rollout_init(Jcur, barcur))) {
             c.phase([&](int lane) {
@@ -593,6 +690,7 @@ struct Solver {
                     red_a.at(lane) = 0.0;
                     red_b.at(lane) = INFINITY;
                     red_c.at(lane) = 0.0;
+                    if (CC) red_w.at(lane) = -1.0;
                     return;
                 }
                 const int k = lane;
@@ -614,6 +712,7 @@ struct Solver {
                 }
                 // gradient of the Lagrangian's separable part at node k (cost + bound multipliers), the start of the
                 // adjoint recursion below; lane 0 supplies the terminal node
+                double wall_z = -1.0, wall_c = 0.0;   // multiplier / complementarity product of the node's wall constraint
                 if (k >= 1) {
                     double g[4];
                     track(k, xk0, xk1, xk2, xk3, g);
@@ -632,6 +731,17 @@ struct Solver {
                         lx0 += sf * d8[0];
                         lx1 += sf * d8[1];
                         lx3 += sf * 2.0 * wcoll * xk3;
+                        if (any_wall) {
+                            const double wjv = S(k, W_WJ);
+                            if (wjv >= 0.0) {
+                                double nx, ny;
+                                const double g = wall_slack(k, xk0, xk1, (int)wjv, nx, ny);
+                                wall_z = S(k, W_ZW);
+                                wall_c = g * wall_z;
+                                lx0 -= wall_z * nx;
+                                lx1 -= wall_z * ny;
+                            }
+                        }
                     }
                     S(k, W_Y + 0, lx0);
                     S(k, W_Y + 1, lx1);
@@ -659,11 +769,18 @@ struct Solver {
                     cmn = fmin2(cmn, fmin2(c0, c1));
                     sz += zl + zu;
                 }
+                if (CC && wall_z >= 0.0) {
+                    cmx = fmax2(cmx, wall_c);
+                    cmn = fmin2(cmn, wall_c);
+                    sz += wall_z;
+                }
                 red_a.at(lane) = cmx;
                 red_b.at(lane) = cmn;
                 red_c.at(lane) = sz;
+                if (CC) red_w.at(lane) = wall_z;
             });
             const double cmax = c.wave_max(red_a), cmin = c.wave_min(red_b), sum_z = c.wave_sum(red_c);
+            const double zw_max = (CC && any_wall) ? c.wave_max(red_w) : 0.0;
             c.tick(T_PREP);
             // ============ adjoint recursion y_k = g_k + A_k' y_{k+1}, in place over the node gradients.  A_k' = I + (strictly
             //              triangular): y0 and y1 are plain suffix sums of the node gradients, y2 a suffix sum of
@@ -758,7 +875,7 @@ struct Solver {
             const double E0 = fmax2(err_d / s_d, cmax / s_c);
             kkt_out = E0;
             if (E0 <= P.tol) {
-                status_out = 0;
+                status_out = (CC && zw_max > 1e-6 * sf) ? 5 : 0;
                 break;
             }
             if (iter == P.max_iter) break;
@@ -828,6 +945,21 @@ struct Solver {
                         h33 = q33 + sig[1] + delta_w;
                         hv0 = lx[0];
                         hv1 = lx[1];
+                        if (CC && any_wall) {
+                            const double wjv = S(k, W_WJ);
+                            if (wjv >= 0.0) {
+                                // wall constraint g >= 0 of the node: (z/g) grad g grad g' - z d2g (d2g = 2 I, dropped by
+                                // the Gauss-Newton model), barrier gradient -mu/g grad g
+                                double nx, ny;
+                                const double rg = frcp(wall_slack(k, S(k, CB + W_X + 0), S(k, CB + W_X + 1), (int)wjv, nx, ny));
+                                const double zw = S(k, W_ZW), sg = zw * rg, cv = gn ? 0.0 : 2.0 * zw;
+                                l00 += sg * nx * nx - cv;
+                                l01 += sg * nx * ny;
+                                l11 += sg * ny * ny - cv;
+                                hv0 -= mu * rg * nx;
+                                hv1 -= mu * rg * ny;
+                            }
+                        }
                         hv2 = lx[2] + sgr[0];
                         hv3 = lx[3] + sgr[1];
                     } else {
@@ -937,6 +1069,10 @@ struct Solver {
                                         q00 = S(k, W_QG + 0) - S(k, W_Q + 0);
                                         q01 = S(k, W_QG + 1) - S(k, W_Q + 1);
                                         q11 = S(k, W_QG + 2) - S(k, W_Q + 2);
+                                        if (any_wall && S(k, W_WJ) >= 0.0) {
+                                            q00 += 2.0 * S(k, W_ZW);
+                                            q11 += 2.0 * S(k, W_ZW);
+                                        }
                                     }
                                 }
                             }
@@ -1050,6 +1186,10 @@ struct Solver {
                     S(k, W_Y + 1, du1);
                     S(k + 1, W_Y + 2, d2);
                     S(k + 1, W_Y + 3, d3);
+                    if (CC && any_wall) {
+                        S(k + 1, W_DXY + 0, d0);
+                        S(k + 1, W_DXY + 1, d1);
+                    }
                 }
             }
             c.tick(T_LINEAR);
@@ -1078,6 +1218,19 @@ struct Solver {
                     if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
                     if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
                 }
+                if (CC && any_wall && k + 1 < N) {
+                    const double wjv = S(k + 1, W_WJ);
+                    if (wjv >= 0.0) {
+                        double nx, ny;
+                        const double g = wall_slack(k + 1, S(k + 1, CB + W_X + 0), S(k + 1, CB + W_X + 1), (int)wjv, nx, ny);
+                        const double d = nx * S(k + 1, W_DXY + 0) + ny * S(k + 1, W_DXY + 1), rg = frcp(g);
+                        const double zw = S(k + 1, W_ZW), dzw = (mu - zw * d) * rg - zw;
+                        rp = fmax2(rp, -d * rg);
+                        if (-dzw * rdd > rdn * zw) { rdn = -dzw; rdd = zw; }
+                        S(k + 1, W_GW, g);
+                        S(k + 1, W_DZW, dzw);
+                    }
+                }
                 red_a.at(lane) = rp;
                 red_b.at(lane) = rdn;
                 red_c.at(lane) = rdd;
@@ -1097,6 +1250,9 @@ struct Solver {
             double Jn = 0.0, barn = 0.0;
             int acc_trial = -1;
             const bool accepted = line_search(cur, a_pr, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn, acc_trial);
+            const bool have_cross = CC && P.V > 0 && acc_trial != 0;
+            bool newwall = false;
+            double bar_shift = 0.0;
             // Levenberg-Marquardt term kept across iterations: two or more backtracks (or no acceptable step) multiply it
             // by 4 (from 1e-3), a full first trial divides it by 4 (to 0 below 1e-3)
             if (accepted && acc_trial == 0) {
@@ -1127,17 +1283,54 @@ struct Solver {
                         S(kk, szu, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : a_du) * dzu, 1e10 * mh), 1e-10 * mh));
                     }
                 });
+                // wall constraints: dual step of the active ones; a vehicle that a rejected trial took across d = 1
+                // becomes the node's wall (multiplier on the central path) if it is nearer than the present one
+                if (CC && (any_wall || have_cross)) {
+                    c.phase([&](int lane) {
+                        red_a.at(lane) = 0.0;
+                        red_b.at(lane) = 0.0;
+                        const int kn = lane + 1;
+                        if (kn >= N) return;
+                        const double wjv = S(kn, W_WJ), cr = have_cross ? S(kn, W_CROSS) : -1.0;
+                        const double xn0 = S(kn, NB + W_X + 0), xn1 = S(kn, NB + W_X + 1);
+                        double nx, ny, gcur = INFINITY, flag = 0.0;
+                        if (wjv >= 0.0) {
+                            gcur = wall_slack(kn, xn0, xn1, (int)wjv, nx, ny);
+                            const double zw = S(kn, W_ZW), dzw = S(kn, W_DZW), ml = mu * frcp(gcur);
+                            S(kn, W_ZW, fmax2(fmin2(zw + (dzw > 0.0 ? 1.0 : a_du) * dzw, 1e10 * ml), 1e-10 * ml));
+                            flag = 1.0;
+                        }
+                        if (cr >= 0.0 && cr != wjv) {
+                            const double gc = wall_slack(kn, xn0, xn1, (int)cr, nx, ny);
+                            if (gc > 0.0 && gc < gcur) {
+                                S(kn, W_WJ, cr);
+                                S(kn, W_ZW, mu * frcp(gc));
+                                // the barrier value carried for the current point changes with the constraint set
+                                red_b.at(lane) = (wjv >= 0.0 ? log(gcur) : 0.0) - log(gc);
+                                flag = 3.0;
+                            }
+                        }
+                        red_a.at(lane) = flag;
+                    });
+                    const double wf = c.wave_max(red_a);
+                    any_wall = wf > 0.0;
+                    newwall = wf > 2.0;
+                    if (newwall) bar_shift = c.wave_sum(red_b);
+                }
             }
             if (accepted) {
                 cur = tb;
                 Jcur = Jn;
                 barcur = barn;
                 nfail = 0;
+            } else if (newwall) {
+                nfail = 0;
             } else if (++nfail >= 3) {
                 status_out = 4;
                 ++iter;
                 break;
             }
+            barcur += bar_shift;
         }
         iters_out = iter;
         cur_out = cur;

@@ -24,6 +24,12 @@ STATUS_MAX_ITER = 1
 STATUS_FACTORIZATION = 2
 STATUS_INFEASIBLE_START = 3
 STATUS_STALLED = 4
+STATUS_CONVERGED_ON_KINK = 5     # include/mpc_mi355x.h
+
+
+def converged(status):
+    """Solved to tolerance (0, or 5: on the d = 1 discontinuity of the collision cost)."""
+    return (status == STATUS_CONVERGED) | (status == STATUS_CONVERGED_ON_KINK)
 
 
 class EngineError(RuntimeError):

@@ -297,7 +297,8 @@ class BatchedCollector:
         self._last_obs = env.reset().clone()                 # persistent tensors, updated in place (graph replays)
         self._last_episode_starts = torch.ones(B, dtype=torch.float32, device=dev)
         zi = lambda: torch.zeros((), dtype=torch.int64, device=dev)
-        self._roll = dict(ep_done=zi(), crashed=zi(), arrived=zi(), dones=torch.zeros(B, dtype=torch.bool, device=dev))
+        self._roll = dict(ep_done=zi(), crashed=zi(), arrived=zi(), unconverged=zi(),
+                          dones=torch.zeros(B, dtype=torch.bool, device=dev))
         self.num_timesteps = 0
         self.last_mpc = None
         self._mpc_out = None
@@ -322,7 +323,7 @@ class BatchedCollector:
     def _begin_rollout(self):
         self.policy.eval()
         self.buffer.reset()
-        for k in ("ep_done", "crashed", "arrived"):
+        for k in ("ep_done", "crashed", "arrived", "unconverged"):
             self._roll[k].zero_()
 
     @torch.no_grad()
@@ -356,6 +357,10 @@ class BatchedCollector:
         r["ep_done"] += dones.sum()
         r["crashed"] += info["crashed"].sum()
         r["arrived"] += info["arrived"].sum()
+        # like the reference (agents/pure_mpc.py:303-305) an unconverged solve still acts with its last iterate; the
+        # collector counts them so that a training run can see what fraction of its actions that was
+        st = self.last_mpc["status"]
+        r["unconverged"] += ((st != 0) & (st != 5)).sum()
 
     def _capture(self):
         """Capture one rollout step (policy -> mpc_predict_batch -> environment step -> buffer row) as a hipGraph: a step
@@ -394,7 +399,7 @@ class BatchedCollector:
     def _rollout_stats(self, n):
         r = self._roll
         return dict(steps=n * self.env.num_envs, episodes=int(r["ep_done"]), crashed=int(r["crashed"]),
-                    arrived=int(r["arrived"]))
+                    arrived=int(r["arrived"]), mpc_unconverged=int(r["unconverged"]))
 
     def collect_rollouts(self, n_rollout_steps: int | None = None):
         n = self.buffer.n_steps if n_rollout_steps is None else int(n_rollout_steps)

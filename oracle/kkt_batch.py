@@ -1,0 +1,137 @@
+"""TEST INFRASTRUCTURE - first-order optimality certificates for whole batches of candidate solutions.
+
+Only tests/, __graft_entry__.smoke() and bench.py's parity side object may import this; never the product path.
+
+Independent of every solver in this repository: given only the primal point (X, U) an engine returned, it decides
+whether multipliers EXIST that make it a KKT point of the reference NLP (agents/pure_mpc.py:128-280, restated in
+oracle/nlp_batch.py), to stated tolerances.  Nothing a solver computed besides (X, U) is used.
+
+How: the state rows of the stationarity system determine the equality multipliers by the adjoint recursion
+    lam_k = (I + dt A_k)' lam_{k+1} - grad_{x_k} f + zL_k - zU_k                      (L = f + lam'c - zL'(x-lo) - zU'(hi-x))
+so the control rows  r_k = grad_{u_k} f - dt B_k' lam_{k+1} - zL^u_k + zU^u_k  are affine in the bound multipliers,
+r = r0 + G z.  A certificate is a z with 0 <= z_i <= eps_c * scale / slack_i  (non-negative, complementary to
+relative eps_c) that makes |r|_inf small: a box-constrained least-squares problem with 2N = 40 rows per instance
+(scipy lsq_linear / BVLS), over the bounds whose slack is small enough for their multiplier to matter.
+
+With the collision cost on, the objective is discontinuous at d = 1 (archive/pure_mpc.py:189-196: it jumps UP by
+900 w_distance / d^2 when a vehicle comes nearer than 1 m).  A point with a vehicle exactly at d = 1 is a local minimiser
+of that function iff it is a KKT point of the outer branch with the constraint |p_k - o_jk|^2 >= 1 added (moving
+inwards only increases the cost): pairs with | |p-o|^2 - 1 | <= wall_tol enter the certificate as such constraints, and
+`n_wall` reports how many a point needed.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import lsq_linear
+
+import nlp_batch as nb
+
+
+def certify(p: nb.Batch, X, U, eps_c=1e-6, wall_tol=1e-6, relax=1e-8, slack_max=10.0, chunk=512):
+    """Certificates for all instances of `p` at (X[B,N+1,4], U[B,N,2]).
+
+    eps_c: complementarity allowed to the multipliers, z_i * slack_i <= eps_c * scale.  The default 1e-6 is what a
+    solver stopping on IPOPT's scaled error at tol 1e-8 guarantees here: the objective is scaled by up to 1e-2
+    (nlp_scaling_max_gradient: 100 / |grad f(start)|_inf), so z s <= 1e-8 in scaled units is 1e-6 in the units of
+    `scale` = |grad f(solution)|_inf when the gradient has fallen to the order of 1 (the reference's own tol 1e-6 would
+    be 1e-4 in these units).  slack_max: bounds with more slack get no multiplier candidate.
+
+    Returns dict of arrays [B]:
+      stationarity   |r|_inf / scale of the best multipliers, scale = max(1, |grad f|_inf)  (relative, like IPOPT's s_d)
+      feasibility    |c|_inf  (initial condition + dynamics defects)
+      bound_violation   beyond the bounds relaxed by `relax` (IPOPT's bound_relax_factor)
+      n_active       bounds / walls that received a multiplier candidate;  n_wall of them walls
+      scale
+    """
+    B, N = p.B, p.N
+    out = {k: np.zeros(B) for k in ("stationarity", "feasibility", "bound_violation", "scale")}
+    out["n_active"] = np.zeros(B, dtype=np.int64)
+    out["n_wall"] = np.zeros(B, dtype=np.int64)
+    for s in range(0, B, chunk):
+        sel = np.arange(s, min(B, s + chunk))
+        r = _certify_chunk(p.take(sel), X[sel], U[sel], eps_c, wall_tol, relax, slack_max)
+        for k in out:
+            out[k][sel] = r[k]
+    return out
+
+
+def _certify_chunk(p, X, U, eps_c, wall_tol, relax, slack_max):
+    B, N, dt = p.B, p.N, p.dt
+    gX, gU = nb.cost_grad(p, X, U)
+    _, d = nb.dyn(X, U)
+    A, Bm = nb.dyn_jac(d)
+    Phi = np.eye(4)[None, None] + dt * A                       # [B, N, 4, 4]   d x_{k+1} / d x_k
+    scale = np.maximum(1.0, np.maximum(np.abs(gX).max(axis=(1, 2)), np.abs(gU).max(axis=(1, 2))))
+    # ---- base multipliers (all bound multipliers zero) and control residual r0
+    lam = np.zeros((B, N + 2, 4))
+    lam[:, N] = -gX[:, N]
+    for k in range(N - 1, 0, -1):
+        lam[:, k] = np.einsum("bji,bj->bi", Phi[:, k], lam[:, k + 1]) - gX[:, k]
+    r0 = gU - dt * np.einsum("bkji,bkj->bki", Bm, lam[:, 1:N + 1])          # [B, N, 2]
+    # ---- sensitivity of r_k to a unit shift of lam_j along each state direction: Sens[b, j, k] (2 x 4), k + 1 <= j
+    Sens = np.zeros((B, N + 1, N, 2, 4))
+    for j in range(1, N + 1):
+        Mj = np.tile(np.eye(4), (B, 1, 1))                                    # d lam_{m} / d lam_j, m = j
+        for k in range(j - 1, -1, -1):                                        # row k uses lam_{k+1}
+            Sens[:, j, k] = -dt * np.einsum("bji,bjl->bil", Bm[:, k], Mj)
+            if k >= 1:
+                Mj = np.einsum("bji,bjl->bil", Phi[:, k], Mj)                # lam_k shift = Phi_k' (lam_{k+1} shift)
+    # ---- slacks
+    xlo, xhi = nb.X_LO - relax * np.maximum(1, np.abs(nb.X_LO)), nb.X_HI + relax * np.maximum(1, np.abs(nb.X_HI))
+    ulo, uhi = nb.U_LO - relax * np.maximum(1, np.abs(nb.U_LO)), nb.U_HI + relax * np.maximum(1, np.abs(nb.U_HI))
+    sxl, sxu = X - xlo, xhi - X
+    sul, suu = U - ulo, uhi - U
+    viol = np.maximum(0.0, -np.minimum(np.minimum(sxl.min(axis=(1, 2)), sxu.min(axis=(1, 2))),
+                                       np.minimum(sul.min(axis=(1, 2)), suu.min(axis=(1, 2)))))
+    feas = np.abs(nb.constraints(p, X, U)).max(axis=(1, 2))
+    walls = None
+    if p.cc and p.others is not None and p.others.shape[1]:
+        dp = X[:, :N, None, :2] - p.other_pos()                               # [B, N, V, 2]
+        g = np.sum(dp * dp, axis=-1) - 1.0
+        walls = (np.abs(g) <= wall_tol)
+        walls[:, 0] = False                                                   # X_0 is pinned
+    stat = np.zeros(B)
+    nact = np.zeros(B, dtype=np.int64)
+    nwall = np.zeros(B, dtype=np.int64)
+    for b in range(B):
+        cols, ub = [], []
+        zmax = eps_c * scale[b]
+        thr = slack_max      # a bound with more slack could hold a multiplier of at most eps_c / slack_max, relative
+
+        def add(col, slack):
+            cols.append(col.ravel())
+            ub.append(zmax / max(slack, 1e-300))
+        for k, i in zip(*np.nonzero(sul[b] < thr)):
+            c = np.zeros((N, 2)); c[k, i] = -1.0
+            add(c, sul[b, k, i])
+        for k, i in zip(*np.nonzero(suu[b] < thr)):
+            c = np.zeros((N, 2)); c[k, i] = 1.0
+            add(c, suu[b, k, i])
+        for j, i in zip(*np.nonzero(sxl[b, 1:] < thr)):
+            add(Sens[b, j + 1, :, :, i], sxl[b, j + 1, i])                    # zL shifts lam_j by +e_i
+        for j, i in zip(*np.nonzero(sxu[b, 1:] < thr)):
+            add(-Sens[b, j + 1, :, :, i], sxu[b, j + 1, i])
+        if walls is not None:
+            for j, v in zip(*np.nonzero(walls[b])):
+                col = Sens[b, j, :, :, 0] * (2.0 * dp[b, j, v, 0]) + Sens[b, j, :, :, 1] * (2.0 * dp[b, j, v, 1])
+                cols.append(col.ravel())
+                ub.append(np.inf)                                             # an active wall: multiplier free in sign +
+                nwall[b] += 1
+        rb = r0[b].ravel()
+        if cols:
+            # scaled unknowns: a boxed multiplier as a fraction t in [0, 1] of its box, a free one (box beyond anything
+            # the residual could ask for) in units of `scale` - BVLS is only reliable on well-scaled columns
+            G = np.stack(cols, axis=1)
+            ubv = np.array(ub)
+            cn = np.maximum(np.abs(G).max(axis=0), 1e-300)
+            free = ubv * cn > 1e3 * scale[b]
+            unit = np.where(free, scale[b] / cn, np.minimum(ubv, 1e300))
+            hi = np.where(free, np.inf, 1.0)
+            Gs = G * unit[None, :] / scale[b]
+            sol = lsq_linear(Gs, -rb / scale[b], bounds=(np.zeros(len(ub)), hi), method="bvls", tol=1e-15, max_iter=1000)
+            res = rb + G @ (sol.x * unit)
+        else:
+            res = rb
+        stat[b] = np.abs(res).max() / scale[b]
+        nact[b] = len(cols)
+    return dict(stationarity=stat, feasibility=feas, bound_violation=viol, scale=scale, n_active=nact, n_wall=nwall)

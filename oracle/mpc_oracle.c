@@ -169,6 +169,12 @@ typedef struct {
     double x[NMAX + 1][4], u[NMAX][2];
     double zxl[NMAX + 1][4], zxu[NMAX + 1][4], zul[NMAX][2], zuu[NMAX][2];
     double lam[NMAX + 1][4]; /* equality multipliers (IPOPT sign: L = f + lam'g), filled at exit */
+    /* d = 1 discontinuity of the collision cost (archive/pure_mpc.py:189-196: 100/d^2 outside, 1000/d^2 inside): per
+     * node the nearest vehicle on the outer branch (-1: none) is kept outside by the constraint |p - o|^2 - 1 >= 0 with
+     * multiplier zw - the cost jumps upwards when it is crossed inwards, so a minimiser pressed against d = 1 is a
+     * constrained stationary point of the outer branch (status 5), which no smooth method reaches otherwise */
+    double zw[NMAX + 1];
+    int wj[NMAX + 1];
 } iter_t;
 
 /* bounds relaxed like IPOPT's bound_relax_factor = 1e-8 so that a strict interior always exists */
@@ -177,6 +183,11 @@ static double xhi_r(int i) { return XHI[i] + 1e-8 * fmax(1.0, fabs(XHI[i])); }
 static double ulo_r(int i) { return ULO[i] - 1e-8 * fmax(1.0, fabs(ULO[i])); }
 static double uhi_r(int i) { return UHI[i] + 1e-8 * fmax(1.0, fabs(UHI[i])); }
 
+/* slack |p_k - o_jk|^2 - 1 of the wall constraint of node k and vehicle j */
+static double wall_slack(const prob_t *p, int k, const double *x, int j) {
+    double px = x[0] - (p->ox[j] + k * p->osx[j]), py = x[1] - (p->oy[j] + k * p->osy[j]);
+    return px * px + py * py - 1.0;
+}
 /* barrier objective of a dynamically feasible trajectory (node-0 state cost is a constant and dropped) */
 static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
     int N = p->N;
@@ -193,12 +204,15 @@ static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
     }
     for (int k = 1; k <= N; ++k)
         for (int i = p->i0; i < 4; ++i) bar -= log(it->x[k][i] - xlo_r(i)) + log(xhi_r(i) - it->x[k][i]);
+    for (int k = 1; k < N; ++k)
+        if (it->wj[k] >= 0) bar -= log(wall_slack(p, k, it->x[k], it->wj[k]));
     return J + mu * bar;
 }
 
 /* solve one instance.
  * status: 0 converged, 1 max_iter reached, 2 factorisation failure, 3 start not strictly feasible,
- *         4 stalled (no acceptable step in three consecutive iterations) */
+ *         4 stalled (no acceptable step in three consecutive iterations),
+ *         5 converged with a vehicle held at the d = 1 discontinuity of the collision cost */
 static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit, int *iters_out, double *kkt_out) {
     const int N = p->N;
     const double dt = p->dt;
@@ -207,7 +221,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
     const double mu_min = o->tol / 10.0;
     int status = 1, iter = 0, nfail = 0;
     const double KSIG = 1e10; /* IPOPT kappa_Sigma */
-    const int MAXLS = 6;      /* line-search trials per iteration */
+    const int MAXLS = 4;      /* line-search trials per iteration */
     const double BTF = 0.25;  /* backtracking factor */
     const double kap_eps = 10.0, kap_mu = 0.2;
     /* Levenberg-Marquardt term kept across iterations: added to the diagonal of the stage Hessians like delta_w.  Two or
@@ -215,6 +229,13 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * below 1e-3).  Without it instances on the nonconvex side of the heading wrap crawl with 1/64-steps for the whole
      * iteration budget. */
     const double REG_MIN = 1e-3, REG_FACTOR = 4.0, REG_MAX = 1e6;
+    /* a rollout that would take theta or v of the next node out of its bounds gets the one control that decides it
+     * (delta resp. a) pulled back so that the node keeps PROJ_KEEP of its slack: the Newton direction of a single
+     * shooting method knows the state bounds only to first order, and without this every trial of an instance that
+     * runs along theta = -pi (the reference heading of the exit straight IS the bound, base_agent.py:146-152 vs
+     * pure_mpc.py:273) is infeasible until the step is tiny (2048 instances of config 2: 66 -> 10 with 40 iterations
+     * or more, none left at the cap) */
+    const double PROJ_KEEP = 0.2;
     double reg = 0.0;
 
     static _Thread_local double A[NMAX][4][4], Bm[NMAX][4][2];
@@ -222,6 +243,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
     static _Thread_local double Wtt[NMAX], Wtv[NMAX], Wtd[NMAX], Wvd[NMAX], Wdd[NMAX];
     static _Thread_local double Kx[NMAX][2][4], Kp[NMAX][2][2], kf[NMAX][2], yv[NMAX + 2][4];
     static _Thread_local iter_t trial;
+    static _Thread_local double gw[NMAX + 1], wn[NMAX + 1][2]; /* wall slack and its gradient at the current iterate */
 
     /* ---- start: cold like the reference (pure_mpc.py:240-246: controls 0; a standing vehicle gets a_0 > 0 so that
      *      v_1.. are strictly inside v >= 0), or - opt-in, not in the reference - from given controls clamped 0.1 % of
@@ -252,6 +274,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 if (!(it->x[k][i] > xlo_r(i)) || !(it->x[k][i] < xhi_r(i))) feasible = 0;
         for (int i = 0; i < 2; ++i)
             if (!(it->u[0][i] > ulo_r(i)) || !(it->u[0][i] < uhi_r(i))) feasible = 0;
+        for (int k = 0; k <= N; ++k) {
+            it->wj[k] = -1;
+            it->zw[k] = 0.0;
+        }
         if (feasible) break;
         if (!warm) {
             *iters_out = 0;
@@ -295,6 +321,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             Bm[k][2][1] = dt * x[3] / WHEELBASE * d.cb * d.bp;
             Bm[k][3][0] = dt;
             if (k >= 1) stage_cost(p, k, x, lxs[k], Qs[k], Qgs[k]);
+            if (it->wj[k] >= 0) {
+                int j = it->wj[k];
+                gw[k] = wall_slack(p, k, x, j);
+                wn[k][0] = 2.0 * (x[0] - (p->ox[j] + k * p->osx[j]));
+                wn[k][1] = 2.0 * (x[1] - (p->oy[j] + k * p->osy[j]));
+            }
             double rdk = (k >= 1) ? rd_full : 0.0;
             for (int i = 0; i < 2; ++i) {
                 double dprev = (k >= 1) ? (u[i] - it->u[k - 1][i]) : 0.0;
@@ -325,9 +357,11 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 sum_lam += fabs(y[i]);
                 if (i >= p->i0) sum_z += it->zxl[k + 1][i] + it->zxu[k + 1][i];
             }
+            if (it->wj[k] >= 0) sum_z += it->zw[k];
             if (k >= 1)
                 for (int i = 0; i < 4; ++i) {
                     double s = lxs[k][i] - it->zxl[k][i] + it->zxu[k][i];
+                    if (i < 2 && it->wj[k] >= 0) s -= it->zw[k] * wn[k][i];
                     for (int j = 0; j < 4; ++j) s += A[k][j][i] * y[j];
                     yv[k][i] = s;
                 }
@@ -363,6 +397,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     ec = fmax(ec, fmax(fabs(cl - mu), fabs(cu - mu)));
                     err_c0 = fmax(err_c0, fmax(cl, cu));
                 }
+            for (int k = 1; k < N; ++k)
+                if (it->wj[k] >= 0) {
+                    double cw = gw[k] * it->zw[k];
+                    ec = fmax(ec, fabs(cw - mu));
+                    err_c0 = fmax(err_c0, cw);
+                }
             double E_mu = fmax(err_d / s_d, ec / s_c);
             if (E_mu <= kap_eps * mu && mu > mu_min) {
                 mu = fmax(mu_min, fmin(kap_mu * mu, pow(mu, 1.5)));
@@ -374,6 +414,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         if (kkt_out) *kkt_out = E0;
         if (E0 <= o->tol) {
             status = 0;
+            for (int k = 1; k < N; ++k)
+                if (it->wj[k] >= 0 && it->zw[k] > 1e-6 * p->sf) status = 5;
             break;
         }
         if (iter == o->max_iter) break;
@@ -413,6 +455,14 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                         double sl = it->x[k][i] - xlo_r(i), su = xhi_r(i) - it->x[k][i];
                         Lxx[i][i] += (i >= p->i0 ? it->zxl[k][i] / sl + it->zxu[k][i] / su : 0.0) + delta_w;
                         lx[i] = lxs[k][i] + (i >= p->i0 ? -mu / sl + mu / su : 0.0);
+                    }
+                    if (it->wj[k] >= 0) {
+                        const double sg = it->zw[k] / gw[k];
+                        for (int i = 0; i < 2; ++i) {
+                            for (int j = 0; j < 2; ++j) Lxx[i][j] += sg * wn[k][i] * wn[k][j];
+                            if (!lgn) Lxx[i][i] -= 2.0 * it->zw[k];
+                            lx[i] -= mu / gw[k] * wn[k][i];
+                        }
                     }
                     if (!lgn) {
                         Lxx[2][2] += Wtt[k];
@@ -522,7 +572,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         /* ---------------- linear forward sweep: full primal-dual Newton step, step-length limits -------- */
         const double tau = fmax(0.99, 1.0 - mu);
         static _Thread_local double dxl[NMAX + 1][4], dul[NMAX][2];
-        static _Thread_local double dzxl[NMAX + 1][4], dzxu[NMAX + 1][4], dzul[NMAX][2], dzuu[NMAX][2];
+        static _Thread_local double dzxl[NMAX + 1][4], dzxu[NMAX + 1][4], dzul[NMAX][2], dzuu[NMAX][2], dzw[NMAX + 1];
         double a_pr = 1.0, a_du = 1.0;
         memset(dxl[0], 0, sizeof(dxl[0]));
         for (int k = 0; k < N; ++k) {
@@ -555,11 +605,19 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 if (dzxl[k + 1][i] < 0) a_du = fmin(a_du, -tau * it->zxl[k + 1][i] / dzxl[k + 1][i]);
                 if (dzxu[k + 1][i] < 0) a_du = fmin(a_du, -tau * it->zxu[k + 1][i] / dzxu[k + 1][i]);
             }
+            if (k + 1 < N && it->wj[k + 1] >= 0) {
+                double d = wn[k + 1][0] * dxl[k + 1][0] + wn[k + 1][1] * dxl[k + 1][1];
+                if (d < 0) a_pr = fmin(a_pr, -tau * gw[k + 1] / d);
+                dzw[k + 1] = (mu - it->zw[k + 1] * d) / gw[k + 1] - it->zw[k + 1];
+                if (dzw[k + 1] < 0) a_du = fmin(a_du, -tau * it->zw[k + 1] / dzw[k + 1]);
+            }
         }
 
         /* ---------------- nonlinear rollout with feedback, Armijo on the barrier objective ------------- */
         double phi0 = barrier_objective(p, it, mu), alpha = a_pr, phi1 = phi0;
         int accepted = 0, nls = 0;
+        int cross[NMAX + 1]; /* vehicle that a rejected trial took across d = 1 inwards (smallest slack), per node */
+        for (int k = 0; k <= N; ++k) cross[k] = -1;
         for (nls = 0; nls < MAXLS; ++nls, alpha *= BTF) {
             int feas = 1;
             ++g_cnt_roll;
@@ -577,8 +635,32 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     double hi_c = uhi_r(i) - (1.0 - tau) * (uhi_r(i) - it->u[k][i]);
                     trial.u[k][i] = fmin(fmax(trial.u[k][i], lo_c), hi_c);
                 }
+                {
+                    /* v of node k+1 is decided by a_k alone: keep it inside the node's box */
+                    const double *xo = it->x[k + 1];
+                    double vlo = xlo_r(3) + PROJ_KEEP * (xo[3] - xlo_r(3)), vhi = xhi_r(3) - PROJ_KEEP * (xhi_r(3) - xo[3]);
+                    double a = fmin(fmax(trial.u[k][0], (vlo - trial.x[k][3]) / dt), (vhi - trial.x[k][3]) / dt);
+                    double lo_c = ulo_r(0) + (1.0 - tau) * (it->u[k][0] - ulo_r(0)), hi_c = uhi_r(0) - (1.0 - tau) * (uhi_r(0) - it->u[k][0]);
+                    trial.u[k][0] = fmin(fmax(a, lo_c), hi_c);
+                }
                 dyn_t d;
                 dyn_eval(trial.x[k], trial.u[k], &d);
+                {
+                    /* theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
+                     * node's box, take the delta that puts it on the edge of the box */
+                    const double *xo = it->x[k + 1];
+                    const double tlo = xlo_r(2) + PROJ_KEEP * (xo[2] - xlo_r(2)), thi = xhi_r(2) - PROJ_KEEP * (xhi_r(2) - xo[2]);
+                    const double th1 = trial.x[k][2] + dt * d.f[2], vk = trial.x[k][3];
+                    if ((th1 < tlo || th1 > thi) && vk > 1e-6) {
+                        double sreq = ((th1 < tlo ? tlo : thi) - trial.x[k][2]) * WHEELBASE / (dt * vk);
+                        if (fabs(sreq) < 0.9) {
+                            double del = atan(2.0 * sreq / sqrt(1.0 - sreq * sreq));
+                            double lo_d = ulo_r(1) + (1.0 - tau) * (it->u[k][1] - ulo_r(1)), hi_d = uhi_r(1) - (1.0 - tau) * (uhi_r(1) - it->u[k][1]);
+                            trial.u[k][1] = fmin(fmax(del, lo_d), hi_d);
+                            dyn_eval(trial.x[k], trial.u[k], &d);
+                        }
+                    }
+                }
                 for (int i = 0; i < 4; ++i) {
                     trial.x[k + 1][i] = trial.x[k][i] + dt * d.f[i];
                     if (i < p->i0) continue;
@@ -586,13 +668,26 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                         xhi_r(i) - trial.x[k + 1][i] < 0.5 * (1.0 - tau) * (xhi_r(i) - it->x[k + 1][i]))
                         feas = 0;
                 }
+                if (k + 1 < N && it->wj[k + 1] >= 0 &&
+                    wall_slack(p, k + 1, trial.x[k + 1], it->wj[k + 1]) < 0.5 * (1.0 - tau) * gw[k + 1])
+                    feas = 0;
             }
+            if (getenv("ORACLE_TRACE2")) fprintf(stderr, "   trial %d alpha %.3e feas %d\n", nls, alpha, feas);
             if (!feas) continue;
             phi1 = barrier_objective(p, &trial, mu);
+            if (getenv("ORACLE_TRACE2")) fprintf(stderr, "      phi1-phi0 %.6e need %.6e\n", phi1 - phi0, 1e-4 * alpha * 2.0 * dV1);
             if (phi1 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
                 accepted = 1;
                 break;
             }
+            if (p->cc)
+                for (int k = 1; k < N; ++k)
+                    for (int j = 0; j < p->V; ++j) {
+                        double g0 = wall_slack(p, k, it->x[k], j);
+                        if (g0 > 0.0 && wall_slack(p, k, trial.x[k], j) < 0.0 &&
+                            (cross[k] < 0 || g0 < wall_slack(p, k, it->x[k], cross[k])))
+                            cross[k] = j;
+                    }
         }
         if (getenv("ORACLE_TRACE"))
             fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
@@ -621,6 +716,23 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 trial.zul[k][i] = fmax(fmin(zl, KSIG * mu / sln), mu / (KSIG * sln));
                 trial.zuu[k][i] = fmax(fmin(zu, KSIG * mu / sun), mu / (KSIG * sun));
             }
+        int newwall = 0;
+        for (int k = 1; k < N; ++k) {
+            if (it->wj[k] >= 0) {
+                double gn = wall_slack(p, k, trial.x[k], it->wj[k]);
+                double z = it->zw[k] + (dzw[k] > 0 ? 1.0 : a_du) * dzw[k];
+                trial.zw[k] = fmax(fmin(z, KSIG * mu / gn), mu / (KSIG * gn));
+            }
+            if (cross[k] >= 0 && cross[k] != it->wj[k]) {
+                double gc = wall_slack(p, k, trial.x[k], cross[k]);
+                if (gc > 0.0 && (it->wj[k] < 0 || gc < wall_slack(p, k, trial.x[k], it->wj[k]))) {
+                    trial.wj[k] = cross[k];
+                    trial.zw[k] = mu / gc;
+                    newwall = 1;
+                }
+            }
+        }
+        if (newwall && !accepted) nfail = 0;
         *it = trial;
         /* three consecutive iterations without an acceptable step: the primal point cannot move any more (a kink of
          * the collision cost at d = 1, or numerical stationarity) - stop instead of burning the iteration budget */

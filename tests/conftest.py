@@ -136,6 +136,13 @@ def ltv_states(B, seed):
     return np.ascontiguousarray(inp["state"][:, [0, 1, 3, 2]].astype(np.float32).astype(np.float64))
 
 
+def converged(status):
+    """Solved to tolerance: 0 = KKT point of the smooth NLP, 5 = KKT point with a vehicle held at the d = 1 discontinuity
+    of the collision cost (include/mpc_mi355x.h)."""
+    status = np.asarray(status)
+    return (status == 0) | (status == 5)
+
+
 def rel_u0_err(got, want):
     """max-norm error of the returned action relative to max(1, |u0_ref|_inf)  (BASELINE.md accuracy metric)."""
     return np.abs(got - want).max(axis=1) / np.maximum(1.0, np.abs(want).max(axis=1))

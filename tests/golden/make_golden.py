@@ -237,7 +237,8 @@ def ltv_oracle_vectors():
 
 def oracle_vectors():
     import oracle_lib
-    import nlp_spec as S
+    import nlp_batch as nb
+    import kkt_batch as kb
     from mpc_rl_for_avs_amd import synth
     from mpc_rl_for_avs_amd.reference_path import reference_states
     ref = reference_states()
@@ -246,28 +247,24 @@ def oracle_vectors():
         inp = synth.solver_inputs(32, V, seed=seed)
         sol = oracle_lib.solve_batch(ref, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
                                      vref=inp["vref"], others=inp["others"], collision_cost=cc, max_iter=100)
-        stat = np.full(32, np.nan)
-        for b in range(32):
-            if sol["status"][b] != 0:
-                continue
-            p = S.Problem.build(20, 0.1, inp["state"][b], inp["ego_index"][b], ref.copy(), inp["weights"][b],
-                                inp["is_collide"][b], collision_cost=cc, others=inp["others"][b])
-            p.ref[:, 2] = inp["vref"][b]
-            c = S.kkt_certificate(p, sol["X"][b], sol["U"][b], act_tol=1e-5)
-            g = max(1.0, np.abs(S.pack(*S.cost_grad(p, sol["X"][b], sol["U"][b]))).max())
-            stat[b] = c["stationarity"] / g
+        p = nb.Batch.build(ref, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
+                           others=inp["others"], collision_cost=cc)
+        cert = kb.certify(p, sol["X"], sol["U"])
+        conv = (sol["status"] == 0) | (sol["status"] == 5)
+        stat = np.where(conv, cert["stationarity"], np.nan)
         for k in ("state", "ego_index", "vref", "weights", "is_collide", "others"):
             out[f"{name}_{k}"] = inp[k]
         for k in ("u0", "U", "X", "status", "iters"):
             out[f"{name}_{k}"] = sol[k]
         out[f"{name}_kkt_rel_stationarity"] = stat
-        print(name, "status", np.bincount(sol["status"]), "worst certified rel stationarity", np.nanmax(stat))
+        print(name, "status", np.bincount(sol["status"], minlength=6), "worst certified rel stationarity", np.nanmax(stat))
     np.savez_compressed(os.path.join(HERE, "oracle_solutions.npz"), **out)
 
 
 if __name__ == "__main__":
-    reference_vectors()
-    ltv_reference_vectors()
+    if "--oracle-only" not in sys.argv:      # the reference's own numpy code (needs /root/reference)
+        reference_vectors()
+        ltv_reference_vectors()
     if "--reference-only" not in sys.argv:
         oracle_vectors()
         ltv_oracle_vectors()

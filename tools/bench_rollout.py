@@ -93,7 +93,7 @@ def main():
                               envs=total, n_gpus=world, groups=G, graph=bool(a.graph),
                               steps_per_env=a.steps, env_steps_per_s=total * a.steps / dt, ms_per_step=dt / a.steps * 1e3,
                               mpc_ms_per_step=dm / a.steps * 1e3, episodes=stats["episodes"], crashed=stats["crashed"],
-                              arrived=stats["arrived"], converged_frac=float((st == 0).mean()))), flush=True)
+                              arrived=stats["arrived"], converged_frac=float(((st == 0) | (st == 5)).mean()))), flush=True)
         for e_g in engs:
             e_g.close()
     if use_dist:
