@@ -123,7 +123,7 @@ def _certify_chunk(p, X, U, eps_c, wall_tol, relax, slack_max):
             # the residual could ask for) in units of `scale` - BVLS is only reliable on well-scaled columns
             G = np.stack(cols, axis=1)
             ubv = np.array(ub)
-            cn = np.maximum(np.abs(G).max(axis=0), 1e-300)
+            cn = np.maximum(np.abs(G).max(axis=0), 1e-200)
             free = ubv * cn > 1e3 * scale[b]
             unit = np.where(free, scale[b] / cn, np.minimum(ubv, 1e300))
             hi = np.where(free, np.inf, 1.0)

@@ -1,0 +1,48 @@
+"""Development aid: the latency figures the kernel is tuned against (MI355X): a lone wave's time per iteration (typical
+instance / straggler), one batch of config 3 / of the live objective, the bulk regime."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from mpc_rl_for_avs_amd import synth, engine
+dev = torch.device('cuda:0')
+
+
+def run(B, V, cc, max_iter=100, idx=None, reps=7):
+    inp = synth.solver_inputs(max(B, 4096), V, seed=0)
+    sel = np.arange(B) if idx is None else np.asarray(idx)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a[sel]), dtype=dt, device=dev)
+    args = dict(state=t(inp['state'], torch.float64), ego_index=t(inp['ego_index'], torch.int32),
+                weights=t(inp['weights'], torch.float64), is_collide=t(inp['is_collide'], torch.uint8),
+                vref=t(inp['vref'], torch.float64), others=t(inp['others'], torch.float64), collision_cost=bool(cc))
+    e = engine.MPCEngine(horizon=20, max_iter=max_iter)
+    out = e.solve_batch_torch(**args, sync=True)
+    ts = []
+    for _ in range(reps):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); e.solve_batch_torch(**args, out=out); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    st = out['status'].cpu().numpy(); it = out['iters'].cpu().numpy()
+    e.close()
+    return float(np.median(ts)), st, it
+
+
+full_ms, st, it = run(4096, 8, 1)
+strag = int(np.argmax(it))
+typ = int(np.argmin(np.abs(it - np.median(it))))
+for name, i in (("typical", typ), ("straggler", strag)):
+    ms, s1, i1 = run(1, 8, 1, idx=[i])
+    print(f"lone wave, {name} instance {i}: {ms*1e3:.0f} us / {i1[0]} iterations = {ms*1e3/max(i1[0],1):.1f} us per iteration (status {s1[0]})")
+conv = ((st == 0) | (st == 5)).mean()
+print(f"config 3 B=4096: {full_ms:.3f} ms -> {4096/full_ms*1e3:.0f} solves/s, converged {conv:.4f}, iters mean {it.mean():.2f} p99 {np.percentile(it,99):.0f} max {it.max()}")
+for mi in (40, 60):
+    ms, s2, i2 = run(4096, 8, 1, max_iter=mi)
+    print(f"config 3 B=4096 max_iter={mi}: {ms:.3f} ms -> {4096/ms*1e3:.0f} solves/s, converged {(((s2==0)|(s2==5)).mean()):.4f}")
+ms, s2, i2 = run(4096, 4, 0)
+print(f"live objective B=4096 V=4: {ms:.3f} ms -> {4096/ms*1e3:.0f} solves/s, converged {(((s2==0)|(s2==5)).mean()):.4f}, iters mean {i2.mean():.2f} max {i2.max()}")
+ms, s2, i2 = run(1024, 4, 0)
+print(f"config 2 B=1024 V=4: {ms:.3f} ms -> {1024/ms*1e3:.0f} solves/s, iters max {i2.max()}")
+inp = None
+ms, s2, i2 = run(65536, 8, 1, reps=3) if "--bulk" in sys.argv else (None, None, None)
+if ms:
+    print(f"bulk B=65536 config 3: {ms:.2f} ms -> {65536/ms*1e3:.0f} solves/s")
