@@ -5,19 +5,17 @@ A "step" is one pass of the hot path (`mpc_solve_batch`) over one batch of synth
 resident in HBM: configs[2] of BASELINE.json = batch 4096, horizon 20, 8 other vehicles, collision cost on.
 With N GPUs every rank owns its own 4096 instances (weak scaling) and the step ends with the RCCL all-gather of
 the actions, the path's only exchange.  Prints ONE JSON line on rank 0.
+
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (torch.distributed.run as a child
+process, before this process has touched the GPU) and exits with the child's code; under torchrun WORLD_SIZE must
+equal --gpus.  `n_gpus` in the output is always the number of ranks that ran.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
-
-# read when the HIP runtime starts: with the default of 4 hardware queues, streams carrying independent batches can
-# end up sharing a queue and serialise (DESIGN.md section 5, "batches in flight"); plain kernel launches only - replayed
-# hipGraphs (tools/bench_rollout.py --graph) measured slower with 8
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:      # multi-rank runs (RCCL) keep the runtime's default
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
+import subprocess
 import sys
 import time
 
@@ -27,75 +25,100 @@ sys.path.insert(0, ROOT)
 BATCH = 4096
 HORIZON = 20
 V = 8
+MAX_ITER = 100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: FP64 vector
 ALG_BYTES_PER_SOLVE = 756 + 32 * V   # inputs + u0/status/iters, FP64
 
 
-def cpu_baseline(inp, sample: int):
-    """The CPU oracle (a from-scratch port of the same NLP + algorithm, oracle/mpc_oracle.c) on the host cores.
-    OpenMP over instances; the thread count with the best wall time is reported (more threads than physical
-    cores only adds scheduling noise on this short job)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle_lib
-    from mpc_rl_for_avs_amd.reference_path import reference_states
-    ncpu = os.cpu_count() or 1
-    sl = slice(0, sample)
-    ref = reference_states()
-    best = None
-    for cores in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32)}, reverse=True):
-        for _ in range(2):
-            t0 = time.perf_counter()
-            out = oracle_lib.solve_batch(ref, inp["state"][sl], inp["ego_index"][sl], inp["weights"][sl],
-                                         inp["is_collide"][sl], vref=inp["vref"][sl], others=inp["others"][sl],
-                                         collision_cost=True, max_iter=100, xy_bounds=False, nthreads=cores)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[0]:
-                best = (dt, cores, out)
-    dt, cores, out = best
-    return dict(value=sample / dt, unit="solves/s", cores=cores, kind="port",
-                sample=f"first {sample} instances of the same batch, oracle/mpc_oracle.c (OpenMP over instances, "
-                       f"{cores} of {ncpu} hardware threads, best wall time {dt:.2f} s), "
-                       f"mean {float(out['iters'].mean()):.1f} iterations"), out
-
-
-def pmc_counter(name):
-    """Mean per launch of one counter from the committed PMC passes (profiles/r*_pmc_summary.csv), or None."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
-    if not files:
-        return None
-    vals = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(open(files[-1]))}
-    return vals.get(name)
-
-
-def pmc_traffic_bytes():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
-    same command, profiles/r*_pmc_summary.csv, KB units). The loads are 8-byte strided, outside the access widths
-    MI355X_MICROARCH.md calibrates, so the raw counters are used (no x2 correction)."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
-    if not files:
-        return None
-    vals = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(open(files[-1]))}
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true",
-                    help="skip the side measurements (in_flight, ltv_qp): profiling runs, so that every launch of the solve "
-                         "kernel in the trace is one of the warm-up / timed steps")
+                    help="skip the side measurements: profiling runs, so that every launch of the solve kernel in the trace "
+                         "is one of the warm-up / timed steps")
     ap.add_argument("--streams", type=int, default=1,
                     help="batches in flight in the timed loop (default 1: one batch at a time, the headline definition)")
-    a = ap.parse_args()
+    return ap.parse_args()
+
+
+def spawn_ranks(a) -> int:
+    """--gpus N > 1 outside torchrun: one process per GPU via torch.distributed.run; this parent never touches a GPU."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def conv_mask(status):
+    return (status == 0) | (status == 5)
+
+
+def cpu_baseline(inp):
+    """The CPU oracle (a from-scratch port of the same NLP + algorithm, oracle/mpc_oracle.c) on the host cores: the
+    whole batch with OpenMP over instances at the thread count with the best wall time, and a bounded sample on ONE
+    thread.  Also returns the oracle's solutions (the parity check) and its work counters."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib
+    from mpc_rl_for_avs_amd.reference_path import reference_states
+    ncpu = os.cpu_count() or 1
+    ref = reference_states()
+
+    def run(n, threads):
+        sl = slice(0, n)
+        t0 = time.perf_counter()
+        out = oracle_lib.solve_batch(ref, inp["state"][sl], inp["ego_index"][sl], inp["weights"][sl],
+                                     inp["is_collide"][sl], vref=inp["vref"][sl], others=inp["others"][sl],
+                                     collision_cost=True, max_iter=MAX_ITER, xy_bounds=False, nthreads=threads)
+        return time.perf_counter() - t0, out
+    best = None
+    for cores in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32)}, reverse=True):
+        for _ in range(3):
+            dt, out = run(BATCH, cores)
+            if best is None or dt < best[0]:
+                best = (dt, cores, out)
+    dt, cores, out = best
+    work = oracle_lib.last_work()
+    n1 = 1024
+    dt1 = min(run(n1, 1)[0] for _ in range(2))
+    return dict(value=BATCH / dt, unit="solves/s", cores=cores, kind="port",
+                sample=f"all {BATCH} instances of the same batch, oracle/mpc_oracle.c, OpenMP over instances, {cores} of "
+                       f"{ncpu} hardware threads (best of the thread counts tried, best of 3 runs: {dt:.3f} s), "
+                       f"mean {float(out['iters'].mean()):.1f} iterations",
+                one_thread={"value": n1 / dt1, "unit": "solves/s", "cores": 1,
+                            "sample": f"first {n1} instances, best of 2 runs: {dt1:.2f} s"}), out, work
+
+
+def pmc_summary():
+    """The committed rocprofv3 PMC passes of this command (separate --pmc runs, tools/pmc_run.sh -> tools/pmc_summary.py
+    -> profiles/rNN_pmc_summary.csv): {counter: mean per launch}, and the file they come from."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    if not files:
+        return {}, None
+    vals = {r["counter"]: float(r["mean_per_launch"]) for r in csv.DictReader(open(files[-1]))}
+    return vals, os.path.relpath(files[-1], ROOT)
+
+
+def main():
+    a = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
+    world = int(world_env or "1")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {a.gpus} "
+                         f"or plainly as `python bench.py --gpus {a.gpus}`")
+    # read when the HIP runtime starts: with the default of 4 hardware queues, streams carrying independent batches can
+    # end up sharing a queue and serialise (the in_flight side measurement); multi-rank runs keep the runtime's default
+    if world == 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import numpy as np
     import torch
@@ -104,9 +127,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
@@ -122,7 +142,7 @@ def main():
     args = dict(state=t(inp["state"], torch.float64), ego_index=t(inp["ego_index"], torch.int32),
                 weights=t(inp["weights"], torch.float64), is_collide=t(inp["is_collide"], torch.uint8),
                 vref=t(inp["vref"], torch.float64), others=t(inp["others"], torch.float64), collision_cost=True)
-    eng = engine.MPCEngine(horizon=HORIZON, max_iter=100, device=local_rank)
+    eng = engine.MPCEngine(horizon=HORIZON, max_iter=MAX_ITER, device=local_rank)
     out = dict(u0=torch.empty((BATCH, 2), dtype=torch.float64, device=dev),
                status=torch.empty(BATCH, dtype=torch.int32, device=dev),
                iters=torch.empty(BATCH, dtype=torch.int32, device=dev))
@@ -132,133 +152,227 @@ def main():
     side = [torch.cuda.Stream(dev) for _ in range(n_str)] if n_str > 1 else [torch.cuda.current_stream(dev)]
     outs_s = [out] + [dict((k, torch.empty_like(v)) for k, v in out.items()) for _ in range(n_str - 1)]
 
-    def step(i=0):
+    def step(i, ev=None):
         nonlocal gathered
         with torch.cuda.stream(side[i % n_str]):
-            eng.solve_batch_torch(**args, out=outs_s[i % n_str])      # enqueued on that stream
+            if ev is not None:
+                ev[0].record()
+            eng.solve_batch_torch(**args, out=outs_s[i % n_str])      # enqueued on torch's current stream = side[i]
+            if ev is not None:
+                ev[1].record()
             if use_dist:
                 gathered = sharding.all_gather_actions(outs_s[i % n_str]["u0"])
 
     for i in range(max(a.warmup, n_str if n_str > 1 else 0)):
         step(i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    # kernel-only events (same stream the kernel is launched on = torch's current stream)
+    # kernel-only HIP events, recorded on the stream the kernel is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        with torch.cuda.stream(side[i % n_str]):
-            ev[i][0].record()
-            eng.solve_batch_torch(**args, out=outs_s[i % n_str])
-            ev[i][1].record()
-            if use_dist:
-                gathered = sharding.all_gather_actions(outs_s[i % n_str]["u0"])
+        step(i, ev[i])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
         assert gathered.shape == (world * BATCH, 2)
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    kern = np.array([s.elapsed_time(e) for s, e in ev])
+    # with several batches in flight the events of one stream bracket a kernel that shares the GPU: not a kernel time
+    kern_ms = float(kern.mean()) if n_str == 1 else None
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
 
     if rank == 0:
         value = world * BATCH * a.steps / elapsed
-        achieved = BATCH * ALG_BYTES_PER_SOLVE / (kern_ms * 1e-3) / 1e9
+        conv = conv_mask(status)
+        pmc, pmc_file = pmc_summary()
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "mpc_solve_wave_kernel<CC=1,N=20>", "kernel_ms": kern_ms,
+                "kernel_ms_median": float(np.median(kern)) if n_str == 1 else None,
+                "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
+                "note": "path is bound by the serial FP64 + LDS-latency chain of its slowest instance; the working set is "
+                        "LDS-resident and HBM carries only inputs/outputs (DESIGN.md section 4)"}
+        if kern_ms is not None:
+            roof["achieved"] = BATCH * ALG_BYTES_PER_SOLVE / (kern_ms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # KB units; the loads are 8-byte strided, outside the access widths MI355X_MICROARCH.md calibrates: raw counters
+            roof["traffic"] = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            roof["traffic_source"] = f"{pmc_file}: separate rocprofv3 --pmc passes of this command, not measured in this run"
         res = {
             "metric": "MPC solves/sec (horizon=20, batch=4096)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: batch=4096 pure_mpc horizon=20, 8 other vehicles, "
-                                   "collision cost on, cold start, tol 1e-8, max_iter 100; per-GPU batch fixed",
-                       "batch_per_gpu": BATCH, "horizon": HORIZON, "n_vehicles": V, "seed": "rank",
+            "config": {"workload": f"BASELINE configs[2]: batch=4096 pure_mpc horizon=20, 8 other vehicles, collision cost "
+                                   f"on, cold start, tol 1e-8, max_iter {MAX_ITER}; per-GPU batch fixed",
+                       "batch_per_gpu": BATCH, "horizon": HORIZON, "n_vehicles": V, "seed": "rank", "max_iter": MAX_ITER,
                        "parallelism": f"instance-sharded x{world}, all-gather of actions" +
                                       (f", {n_str} batches in flight on {n_str} streams" if n_str > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                         "kernel": "mpc_solve_wave_kernel<CC=1,N=20>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
-                         "note": "path is bound by the serial FP64 + LDS-latency chain of its slowest instance; the working "
-                                 "set is LDS-resident and HBM carries only inputs/outputs (DESIGN.md section 4)"},
-            "solver": {"converged_frac": float(((status == 0) | (status == 5)).mean()),
-                       "smooth_kkt_frac": float((status == 0).mean()), "on_kink_frac": float((status == 5).mean()),
-                       "iters_mean": float(iters.mean()), "iters_p99": float(np.percentile(iters, 99)),
-                       "iters_max": int(iters.max())},
+            "roofline": roof,
+            "solver": {"converged_frac": float(conv.mean()), "smooth_kkt_frac": float((status == 0).mean()),
+                       "on_kink_frac": float((status == 5).mean()), "iters_mean": float(iters.mean()),
+                       "iters_p99": float(np.percentile(iters, 99)), "iters_max": int(iters.max()),
+                       "value_converged_only": value * float(conv.mean())},
         }
-        # the resource this kernel actually consumes: vector-instruction issue slots (a wave64 FP64 instruction
-        # occupies its SIMD for 4 cycles).  SIMD-cycles needed = wave-instructions (PMC) x 4; available = SIMDs x clock
-        # x kernel time.  Small because the batch ends with a few lone waves.
-        valu = pmc_counter("SQ_INSTS_VALU")
-        if valu is not None:
+        # the resource this kernel actually consumes: vector-instruction issue slots (a wave64 FP64 instruction occupies
+        # its SIMD for 4 cycles).  SIMD-cycles needed = wave-instructions (PMC) x 4; available = SIMDs x clock x kernel time.
+        if "SQ_INSTS_VALU" in pmc and kern_ms is not None:
             prop = torch.cuda.get_device_properties(dev)
             simds = 4 * prop.multi_processor_count
             clock_hz = 1e3 * float(getattr(prop, "clock_rate", 2.4e6))
-            res["valu_issue"] = {"wave_instructions_per_launch": valu, "simds": simds, "clock_ghz": clock_hz / 1e9,
-                                 "frac": valu * 4.0 / (simds * clock_hz * kern_ms * 1e-3),
+            res["valu_issue"] = {"wave_instructions_per_launch": pmc["SQ_INSTS_VALU"], "simds": simds,
+                                 "clock_ghz": clock_hz / 1e9,
+                                 "frac": pmc["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * kern_ms * 1e-3),
+                                 "source": f"{pmc_file} (instruction count of a separate --pmc pass) over this run's kernel time",
                                  "note": "fraction of the GPU's vector-instruction issue slots used during the kernel"}
         if world == 1 and not a.no_cpu_baseline:
-            cb, oref = cpu_baseline(inp, sample=BATCH)
+            cb, oref, work = cpu_baseline(inp)
             res["cpu_baseline"] = cb
-            u0 = out["u0"].cpu().numpy()
-            both = ((status == 0) | (status == 5)) & ((oref["status"] == 0) | (oref["status"] == 5))
+            # algorithmic FP64 rate: operations the algorithm needs (counted by the oracle, which runs the same iteration)
+            # over the GPU's kernel time
+            if kern_ms is not None:
+                res["fp64"] = {"flops_per_solve": work["flops"] / BATCH, "transcendentals_per_solve": work["transcendentals"] / BATCH,
+                               "flops_per_iteration": work["flops"] / max(work["iterations"], 1.0),
+                               "achieved_tflops": work["flops"] / (kern_ms * 1e-3) / 1e12, "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                               "frac": work["flops"] / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                               "note": "operation counts of oracle/mpc_oracle.c (oracle_last_work) for this batch over the kernel "
+                                       "time: algorithmic flops, not issued instructions"}
+            # parity: against the oracle instance by instance, and - independently of any solver - KKT certificates of
+            # the reference NLP for every solution the engine calls converged (oracle/kkt_batch.py)
+            import kkt_batch as kb
+            import nlp_batch as nb
+            from mpc_rl_for_avs_amd.reference_path import reference_states
+            full = dict(u0=torch.empty((BATCH, 2), dtype=torch.float64, device=dev),
+                        U=torch.empty((BATCH, HORIZON, 2), dtype=torch.float64, device=dev),
+                        X=torch.empty((BATCH, HORIZON + 1, 4), dtype=torch.float64, device=dev),
+                        status=torch.empty(BATCH, dtype=torch.int32, device=dev),
+                        iters=torch.empty(BATCH, dtype=torch.int32, device=dev))
+            eng.solve_batch_torch(**args, out=full, sync=True)
+            u0 = full["u0"].cpu().numpy()
+            both = conv & conv_mask(oref["status"])
             err = np.abs(u0 - oref["u0"]).max(axis=1) / np.maximum(1.0, np.abs(oref["u0"]).max(axis=1))
+            sel = np.nonzero(conv)[0]
+            p = nb.Batch.build(reference_states(), inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
+                               vref=inp["vref"], others=inp["others"], collision_cost=True)
+            cert = kb.certify(p.take(sel), full["X"].cpu().numpy()[sel], full["U"].cpu().numpy()[sel])
             res["parity"] = {"both_converged": int(both.sum()), "u0_rel_linf_max": float(err[both].max()),
                              "u0_rel_linf_p99": float(np.percentile(err[both], 99)),
-                             "frac_within_1e-4": float((err[both] <= 1e-4).mean())}
+                             "frac_within_1e-4": float((err[both] <= 1e-4).mean()),
+                             "status_equal_frac": float((status == oref["status"]).mean()),
+                             "n_certified": int((cert["stationarity"] <= 1e-8).sum()), "n_converged": int(sel.size),
+                             "kkt_stationarity_max": float(cert["stationarity"].max()),
+                             "kkt_feasibility_max": float(cert["feasibility"].max()),
+                             "kkt_bound_violation_max": float(cert["bound_violation"].max()),
+                             "note": "certificates: relative stationarity with re-fitted multipliers (complementarity 1e-6), "
+                                     "oracle/kkt_batch.py; 'ref' = CPU oracle + certificates because CasADi/IPOPT cannot run here"}
         if world == 1 and not a.no_side:
-            # side measurement (not the metric): the same batch solves with 6 of them in flight, round-robin on 6 HIP
-            # streams - the straggler tail of one batch (a few lone waves, GPU mostly idle) overlaps with the bulk of the
-            # next ones.  Same kernel, same inputs, identical outputs; what a serving loop with several independent
-            # environment groups would run.
-            n_fl = 6        # HIP spreads streams over 4 hardware queues: 6 streams keep all of them busy whatever the mapping
-            streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
-            outs = []
-            for sq in streams:
-                with torch.cuda.stream(sq):
-                    outs.append(eng.solve_batch_torch(**args))
-            torch.cuda.synchronize()
-            k_fl = max(3 * a.steps, 12 * n_fl)      # long enough that the unoverlapped tail of the last batches is small
-            t1 = time.perf_counter()
-            for i in range(k_fl):
-                with torch.cuda.stream(streams[i % n_fl]):
-                    eng.solve_batch_torch(**args, out=outs[i % n_fl])
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t1
-            res["in_flight"] = {"streams": n_fl, "steps": k_fl, "value": BATCH * k_fl / el, "unit": "solves/s",
-                                "ms_per_batch": el / k_fl * 1e3,
-                                "identical_outputs": bool(all(torch.equal(o["u0"], out["u0"]) for o in outs)),
-                                "note": "throughput with 6 batches of 4096 in flight; `value` above is one batch at a time"}
-            # side measurement (not the metric): the iterative-linear agent's QP (agents/pure_mpc_linear.py) on the same
-            # ego states, first call of an episode (zero stored profile), device-resident inputs
-            st_l = args["state"][:, [0, 1, 3, 2]].contiguous()
-            U_l = torch.zeros((BATCH, HORIZON, 2), dtype=torch.float64, device=dev)
-            o_l = eng.ltv_solve_batch_torch(st_l, U_l, sync=True)
-            ts = []
-            for _ in range(5):
-                U_l.zero_()
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                eng.ltv_solve_batch_torch(st_l, U_l, out=o_l)
-                e1.record()
-                torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1))
-            st_q = o_l["status"].cpu().numpy()
-            res["ltv_qp"] = {"value": BATCH / (float(np.median(ts)) * 1e-3), "unit": "solves/s", "batch": BATCH,
-                             "ms": float(np.median(ts)), "solved_frac": float((st_q == 0).mean()),
-                             "speed_out_of_bounds_frac": float((st_q == 3).mean()),
-                             "iters_mean": float(o_l["iters"].cpu().numpy()[st_q == 0].mean()),
-                             "note": "mpc_ltv_solve_batch, reference agents/pure_mpc_linear.py; DESIGN.md section 4.5"}
+            res.update(side_measurements(a, eng, args, inp, out, dev))
         print(json.dumps(res), flush=True)
     eng.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def side_measurements(a, eng, args, inp, out, dev):
+    """Not the metric: other iteration caps, batches in flight, the PCIe-inclusive call, the observation-level call,
+    the iterative-linear QP.  Medians of event-timed repetitions."""
+    import numpy as np
+    import torch
+    from mpc_rl_for_avs_amd import engine
+    res = {}
+
+    def timed(fn, reps=7):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    # other iteration caps (the reference allows 1000, agents/pure_mpc.py:294; unconverged instances return their last iterate)
+    caps = {}
+    for mi in (40, 60):
+        e2 = engine.MPCEngine(horizon=HORIZON, max_iter=mi, device=dev.index)
+        o2 = e2.solve_batch_torch(**args, sync=True)
+        ms = timed(lambda: e2.solve_batch_torch(**args, out=o2))
+        st2 = o2["status"].cpu().numpy()
+        caps[str(mi)] = {"ms": ms, "value": BATCH / (ms * 1e-3), "converged_frac": float(conv_mask(st2).mean())}
+        e2.close()
+    res["max_iter_sweep"] = caps
+    # batches in flight: the straggler tail of one batch overlaps with the bulk of the next ones (same kernel, same inputs,
+    # identical outputs) - what a serving loop with several independent environment groups would run
+    n_fl = 6
+    streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
+    outs = []
+    for sq in streams:
+        with torch.cuda.stream(sq):
+            outs.append(eng.solve_batch_torch(**args))
+    torch.cuda.synchronize()
+    k_fl = max(3 * a.steps, 12 * n_fl)
+    t1 = time.perf_counter()
+    for i in range(k_fl):
+        with torch.cuda.stream(streams[i % n_fl]):
+            eng.solve_batch_torch(**args, out=outs[i % n_fl])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    res["in_flight"] = {"streams": n_fl, "steps": k_fl, "value": BATCH * k_fl / el, "unit": "solves/s",
+                        "ms_per_batch": el / k_fl * 1e3,
+                        "identical_outputs": bool(all(torch.equal(o["u0"], out["u0"]) for o in outs)),
+                        "note": "throughput with 6 batches of 4096 in flight; `value` above is one batch at a time"}
+    # the same call with HOST pointers (numpy in, numpy out): H2D of the inputs, solve, D2H of u0/status/iters
+    ts = []
+    for _ in range(6):
+        t1 = time.perf_counter()
+        eng.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
+                        others=inp["others"], collision_cost=True, want_trajectories=False)
+        ts.append(time.perf_counter() - t1)
+    ms = float(np.median(ts[1:])) * 1e3
+    res["pcie_inclusive"] = {"ms": ms, "value": BATCH / (ms * 1e-3), "unit": "solves/s",
+                             "note": "mpc_solve_batch with host pointers, wall time of the synchronous call"}
+    # observation-level call (device preamble + solve, per-environment detector state): fresh handle, first step of an episode
+    from mpc_rl_for_avs_amd import synth
+    obs = torch.as_tensor(synth.make_obs_batch(BATCH, V, seed=0), device=dev)
+    w = args["weights"]
+    e3 = engine.MPCEngine(horizon=HORIZON, max_iter=MAX_ITER, device=dev.index)
+    o3 = e3.predict_batch_torch(obs, w, collision_cost=True, sync=True)
+
+    def pred():
+        e3.reset_env_state()
+        e3.predict_batch_torch(obs, w, collision_cost=True, out=o3)
+    ms = timed(pred, reps=5)
+    st3 = o3["status"].cpu().numpy()
+    res["predict_batch"] = {"ms": ms, "value": BATCH / (ms * 1e-3), "unit": "env-steps/s",
+                            "converged_frac": float(conv_mask(st3).mean()),
+                            "note": "mpc_predict_batch (observation in, action out) incl. the reset of the detector state"}
+    e3.close()
+    # the iterative-linear agent's QP (agents/pure_mpc_linear.py) on the same ego states, first call of an episode
+    st_l = args["state"][:, [0, 1, 3, 2]].contiguous()
+    U_l = torch.zeros((BATCH, HORIZON, 2), dtype=torch.float64, device=dev)
+    o_l = eng.ltv_solve_batch_torch(st_l, U_l, sync=True)
+
+    def ltv():
+        U_l.zero_()
+        eng.ltv_solve_batch_torch(st_l, U_l, out=o_l)
+    ms = timed(ltv, reps=5)
+    st_q = o_l["status"].cpu().numpy()
+    res["ltv_qp"] = {"value": BATCH / (ms * 1e-3), "unit": "solves/s", "batch": BATCH, "ms": ms,
+                     "solved_frac": float((st_q == 0).mean()), "speed_out_of_bounds_frac": float((st_q == 3).mean()),
+                     "iters_mean": float(o_l["iters"].cpu().numpy()[st_q == 0].mean()),
+                     "note": "mpc_ltv_solve_batch, reference agents/pure_mpc_linear.py; DESIGN.md section 4.5"}
+    return res
 
 
 if __name__ == "__main__":

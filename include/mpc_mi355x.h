@@ -169,10 +169,25 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
 int mpc_reset_env_mask(mpc_handle *h, int32_t B, const uint8_t *done, uint32_t flags, void *stream);
 
 /* Detector state of environments 0..B-1 after the last mpc_predict_batch (host arrays, any may be NULL; synchronises):
- * is_collide, ego_index, collision_memory, stop_index (-1 = none) [B]; conflict_index [B][MPC_MAX_OTHERS] (-1 = none).
- * Serves the attributes callers read from the agent (agents/pure_mpc.py:38-43: is_collide, conflict_index, stop_point). */
+ * is_collide, ego_index, collision_memory, stop_index (-1 = none) [B]; conflict_index [B][MPC_MAX_OTHERS] (-1 = none);
+ * conflict_points [B][MPC_MAX_OTHERS][2] (NaN = none): where the predicted paths cross.
+ * Serves the attributes callers / plots read from the agent (agents/pure_mpc.py:38-43, 589-593: is_collide,
+ * conflict_points, conflict_index, agent_collide, stop_point). */
 int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *ego_index, int32_t *collision_memory,
-                      int32_t *stop_index, int32_t *conflict_index);
+                      int32_t *stop_index, int32_t *conflict_index, double *conflict_points);
+
+/* Checkpoint / resume of the per-environment detector records (the reference never saves them: its agent state is lost
+ * with the process, agents/pure_mpc.py:38-43).  mpc_env_state_bytes(): size of one opaque record;
+ * mpc_save_env_state copies records 0..B-1 to a host buffer of B * that size; mpc_set_env_state puts them back (into
+ * this or another handle of the same library version), growing the handle's capacity if needed.  Both synchronise. */
+int64_t mpc_env_state_bytes(void);
+int mpc_save_env_state(mpc_handle *h, int32_t B, void *records);
+int mpc_set_env_state(mpc_handle *h, int32_t B, const void *records);
+
+/* Size the per-environment buffers (detector records, warm-start controls) for B environments now.  They otherwise grow
+ * on demand, which frees the old buffers: not allowed inside a stream capture (a captured graph holds the addresses)
+ * and it waits for the device to go idle.  Call this once before capturing a step into a hipGraph. */
+int mpc_reserve_envs(mpc_handle *h, int32_t B);
 
 /* Problem data the last mpc_predict_batch derived from the observations (host arrays, any may be NULL; synchronises):
  * state [B][4], ego_index [B], vref [B][N+1], is_collide [B], others [B][max(vehicles_count-1,1)][4], nveh [B].

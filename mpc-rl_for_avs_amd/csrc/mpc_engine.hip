@@ -10,6 +10,8 @@
 // per-handle device state (reference table, environment records, preamble outputs).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     __shared__ pre::P2 s_ego[kPreEnvs][pre::kPredHorizon + 1];
     __shared__ int s_ne[kPreEnvs];
     __shared__ int32_t s_conf[kPreEnvs][pre::kMaxOthers];
+    __shared__ pre::P2 s_cpt[kPreEnvs][pre::kMaxOthers];
     const int g = threadIdx.x / kPreGroup, l = threadIdx.x % kPreGroup;
     const int bq = blockIdx.x * kPreEnvs + g;
     const bool live = bq < B;
@@ -259,7 +262,11 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     if (!replay && l == 0)
         s_ne[g] = pre::ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, s_ego[g]);
     __syncthreads();
-    if (!replay) s_conf[g][l] = l < p.observed ? pre::detect_vehicle(ob + (l + 1) * pre::kObsCols, s_ego[g], s_ne[g], R, dt) : -1;
+    if (!replay) {
+        pre::P2 cp{0.0, 0.0};
+        s_conf[g][l] = l < p.observed ? pre::detect_vehicle(ob + (l + 1) * pre::kObsCols, s_ego[g], s_ne[g], R, dt, cp) : -1;
+        s_cpt[g][l] = cp;
+    }
     __syncthreads();
     if (l != 0 || !live) return;
     pre::EnvState st = env[b];
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     for (int j = p.observed; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
     int32_t e = 0;
     uint8_t c = 0;
-    pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], st, e, vref + (size_t)b * (N + 1), c);
+    pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], s_cpt[g], st, e, vref + (size_t)b * (N + 1), c);
     ego_index[b] = e;
     is_collide[b] = c;
     nveh[b] = p.observed;
@@ -304,6 +311,8 @@ struct mpc_handle {
     // observation-level path (mpc_predict_batch): per-environment detector state and the problem data the
     // preamble kernel writes for the solve kernel
     mpc::pre::EnvState *d_env = nullptr;
+    int32_t *d_ids = nullptr;   // scratch of mpc_reset_env_state
+    int ids_cap = 0;
     int env_cap = 0;
     double *d_warm = nullptr;        // [env_cap][N][2] last control sequence per environment (MPC_FLAG_WARM_START)
     uint8_t *d_warm_valid = nullptr; // [env_cap] 1 = d_warm holds a solution of the current episode
@@ -335,11 +344,14 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, si
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC>;
     // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
     // capture (hipGraph) of the launch
-    static size_t lds_set[kMaxDevices] = {};
-    if (h->device >= kMaxDevices || lds_set[h->device] < lds) {
+    static std::atomic<size_t> lds_set[kMaxDevices];      // zero-initialised; concurrent callers at worst both set it
+    if (h->device >= kMaxDevices || lds_set[h->device].load(std::memory_order_acquire) < lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds));
-        if (h->device < kMaxDevices) lds_set[h->device] = lds;
+        if (h->device < kMaxDevices) {
+            size_t cur = lds_set[h->device].load(std::memory_order_relaxed);
+            while (cur < lds && !lds_set[h->device].compare_exchange_weak(cur, lds, std::memory_order_release)) {}
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
                        d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_uinit, u_shift, d_uvalid,
@@ -351,6 +363,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, si
 // staging buffer for host-pointer calls: grown on demand, reused across calls
 int ensure_stage(mpc_handle *h, size_t bytes) {
     if (h->stage_bytes >= bytes) return MPC_OK;
+    HIP_TRY(hipDeviceSynchronize());     // host-pointer calls are synchronous, but be safe against work of other streams
     if (h->d_stage) HIP_TRY(hipFree(h->d_stage));
     h->d_stage = nullptr;
     h->stage_bytes = 0;
@@ -459,6 +472,7 @@ void mpc_destroy(mpc_handle *h) {
     if (h->d_warm) (void)hipFree(h->d_warm);
     if (h->d_warm_valid) (void)hipFree(h->d_warm_valid);
     if (h->d_ltv_u) (void)hipFree(h->d_ltv_u);
+    if (h->d_ids) (void)hipFree(h->d_ids);
     if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
 }
@@ -573,41 +587,48 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     return MPC_OK;
 }
 
-// grow the per-environment state array to at least B records (new records start as fresh episodes)
+// grow the per-environment state array to at least B records (new records start as fresh episodes).  The old buffers
+// are released, so this must not happen while earlier work may still use them: not inside a stream capture (a captured
+// graph has the addresses baked in - size the handle first with mpc_reserve_envs), and only after the device is idle.
 static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
     if (B <= h->env_cap) return MPC_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(MPC_ERR_INVALID_ARG, "per-environment buffers must grow, which is not possible inside a stream capture: "
+                                         "call mpc_reserve_envs before capturing");
     int cap = h->env_cap > 0 ? h->env_cap : 256;
     while (cap < B) cap *= 2;
-    mpc::pre::EnvState *n = nullptr;
-    double *nw = nullptr, *nl = nullptr;
-    uint8_t *nv = nullptr;
     const size_t wrow = (size_t)h->cfg.horizon * 2 * sizeof(double);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&n), (size_t)cap * sizeof(mpc::pre::EnvState)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nw), (size_t)cap * wrow));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nv), (size_t)cap));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&nl), (size_t)cap * wrow));
-    HIP_TRY(hipMemsetAsync(nl, 0, (size_t)cap * wrow, stream));
-    HIP_TRY(hipMemsetAsync(n, 0, (size_t)cap * sizeof(mpc::pre::EnvState), stream));
-    HIP_TRY(hipMemsetAsync(nw, 0, (size_t)cap * wrow, stream));
-    HIP_TRY(hipMemsetAsync(nv, 0, (size_t)cap, stream));
-    if (h->d_env) {
-        HIP_TRY(hipMemcpyAsync(n, h->d_env, (size_t)h->env_cap * sizeof(mpc::pre::EnvState),
-                               hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(nw, h->d_warm, (size_t)h->env_cap * wrow, hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(nv, h->d_warm_valid, (size_t)h->env_cap, hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(nl, h->d_ltv_u, (size_t)h->env_cap * wrow, hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipFree(h->d_env));
-        HIP_TRY(hipFree(h->d_warm));
-        HIP_TRY(hipFree(h->d_warm_valid));
-        HIP_TRY(hipFree(h->d_ltv_u));
+    void *nb[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[4] = {(size_t)cap * sizeof(mpc::pre::EnvState), (size_t)cap * wrow, (size_t)cap, (size_t)cap * wrow};
+    void *old[4] = {h->d_env, h->d_warm, h->d_warm_valid, h->d_ltv_u};
+    const size_t old_bytes[4] = {(size_t)h->env_cap * sizeof(mpc::pre::EnvState), (size_t)h->env_cap * wrow,
+                                 (size_t)h->env_cap, (size_t)h->env_cap * wrow};
+    hipError_t e = hipDeviceSynchronize();       // in-flight MPC_FLAG_NO_SYNC work on any stream still uses the old buffers
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+        e = hipMalloc(&nb[i], bytes[i]);
+        if (e == hipSuccess) e = hipMemset(nb[i], 0, bytes[i]);
+        if (e == hipSuccess && old[i]) e = hipMemcpy(nb[i], old[i], old_bytes[i], hipMemcpyDeviceToDevice);
     }
-    h->d_env = n;
-    h->d_warm = nw;
-    h->d_warm_valid = nv;
-    h->d_ltv_u = nl;
+    if (e != hipSuccess) {
+        for (int i = 0; i < 4; ++i)
+            if (nb[i]) (void)hipFree(nb[i]);
+        return fail(MPC_ERR_HIP, std::string("ensure_env: ") + hipGetErrorString(e));
+    }
+    for (int i = 0; i < 4; ++i)
+        if (old[i]) (void)hipFree(old[i]);
+    h->d_env = static_cast<mpc::pre::EnvState *>(nb[0]);
+    h->d_warm = static_cast<double *>(nb[1]);
+    h->d_warm_valid = static_cast<uint8_t *>(nb[2]);
+    h->d_ltv_u = static_cast<double *>(nb[3]);
     h->env_cap = cap;
     return MPC_OK;
+}
+
+int mpc_reserve_envs(mpc_handle *h, int32_t B) {
+    if (!h || B < 0) return fail(MPC_ERR_INVALID_ARG, "mpc_reserve_envs: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return ensure_env(h, B, nullptr);
 }
 
 int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicles_count, const double *weights,
@@ -636,6 +657,13 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         const size_t o_oth = seg((size_t)B * (V > 0 ? V : 1) * 4 * 8), o_ego = seg((size_t)B * 4);
         const size_t o_nv = seg((size_t)B * 4), o_c = seg((size_t)B);
         if (h->pre_bytes < off) {
+            // the old buffer may still be in use by enqueued (MPC_FLAG_NO_SYNC) work, and a captured graph holds its
+            // address: never inside a capture, and only once the device is idle
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: the problem-data buffer must grow, which is not possible "
+                                                 "inside a stream capture: run one step of this size before capturing");
+            HIP_TRY(hipDeviceSynchronize());
             if (h->d_pre) HIP_TRY(hipFree(h->d_pre));
             h->d_pre = nullptr;
             h->pre_bytes = 0;
@@ -712,11 +740,14 @@ static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_
     P.max_iter = h->cfg.max_iter;
     P.dt = h->cfg.dt;
     const size_t lds = (size_t)mpc::ltv::lds_doubles(P.N) * sizeof(double);
-    static size_t lds_set[kMaxDevices] = {};
-    if (h->device >= kMaxDevices || lds_set[h->device] < lds) {
+    static std::atomic<size_t> lds_set[kMaxDevices];
+    if (h->device >= kMaxDevices || lds_set[h->device].load(std::memory_order_acquire) < lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (h->device < kMaxDevices) lds_set[h->device] = lds;
+        if (h->device < kMaxDevices) {
+            size_t cur = lds_set[h->device].load(std::memory_order_relaxed);
+            while (cur < lds && !lds_set[h->device].compare_exchange_weak(cur, lds, std::memory_order_release)) {}
+        }
     }
     hipLaunchKernelGGL(mpc_ltv_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_obs,
                        rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
@@ -838,8 +869,17 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
         return MPC_OK;
     }
     if (n == 0) return MPC_OK;
-    int32_t *d_ids = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_ids), (size_t)n * 4));
+    if (n > h->ids_cap) {                       // handle-owned, grow-only (no allocation per call)
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (h->d_ids) HIP_TRY(hipFree(h->d_ids));
+        h->d_ids = nullptr;
+        h->ids_cap = 0;
+        int cap = 256;
+        while (cap < n) cap *= 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_ids), (size_t)cap * 4));
+        h->ids_cap = cap;
+    }
+    int32_t *d_ids = h->d_ids;
     hipError_t e = hipMemcpyAsync(d_ids, env_ids, (size_t)n * 4, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(mpc_env_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (int)n, d_ids,
@@ -847,7 +887,6 @@ int mpc_reset_env_state(mpc_handle *h, const int32_t *env_ids, int32_t n, void *
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(d_ids);
     if (e != hipSuccess) return fail(MPC_ERR_HIP, std::string("mpc_reset_env_state: ") + hipGetErrorString(e));
     return MPC_OK;
 }
@@ -881,7 +920,7 @@ int mpc_reset_env_mask(mpc_handle *h, int32_t B, const uint8_t *done, uint32_t f
 }
 
 int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *ego_index, int32_t *collision_memory,
-                      int32_t *stop_index, int32_t *conflict_index) {
+                      int32_t *stop_index, int32_t *conflict_index, double *conflict_points) {
     if (!h || B < 0) return fail(MPC_ERR_INVALID_ARG, "mpc_get_env_state: bad argument");
     if (B == 0) return MPC_OK;
     if (!h->d_env || B > h->env_cap) return fail(MPC_ERR_INVALID_ARG, "mpc_get_env_state: no such environments");
@@ -898,7 +937,35 @@ int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *eg
         if (conflict_index)
             for (int j = 0; j < MPC_MAX_OTHERS; ++j)
                 conflict_index[(size_t)b * MPC_MAX_OTHERS + j] = j < s.n_conflict ? s.conflict[j] : -1;
+        if (conflict_points)
+            for (int j = 0; j < MPC_MAX_OTHERS; ++j) {
+                const bool hit = j < s.n_conflict && s.conflict[j] >= 0;
+                conflict_points[((size_t)b * MPC_MAX_OTHERS + j) * 2 + 0] = hit ? s.conflict_pt[j][0] : NAN;
+                conflict_points[((size_t)b * MPC_MAX_OTHERS + j) * 2 + 1] = hit ? s.conflict_pt[j][1] : NAN;
+            }
     }
+    return MPC_OK;
+}
+
+int64_t mpc_env_state_bytes(void) { return (int64_t)sizeof(mpc::pre::EnvState); }
+
+int mpc_save_env_state(mpc_handle *h, int32_t B, void *records) {
+    if (!h || B < 0 || (!records && B > 0)) return fail(MPC_ERR_INVALID_ARG, "mpc_save_env_state: bad argument");
+    if (B == 0) return MPC_OK;
+    if (!h->d_env || B > h->env_cap) return fail(MPC_ERR_INVALID_ARG, "mpc_save_env_state: no such environments");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(records, h->d_env, (size_t)B * sizeof(mpc::pre::EnvState), hipMemcpyDeviceToHost));
+    return MPC_OK;
+}
+
+int mpc_set_env_state(mpc_handle *h, int32_t B, const void *records) {
+    if (!h || B < 0 || (!records && B > 0)) return fail(MPC_ERR_INVALID_ARG, "mpc_set_env_state: bad argument");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (int rc = ensure_env(h, B, nullptr)) return rc;
+    HIP_TRY(hipMemcpy(h->d_env, records, (size_t)B * sizeof(mpc::pre::EnvState), hipMemcpyHostToDevice));
     return MPC_OK;
 }
 

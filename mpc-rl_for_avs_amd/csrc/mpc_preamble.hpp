@@ -46,6 +46,8 @@ struct EnvState {
     int32_t last_valid_stop1; // last_valid_stop_point, same encoding
     int32_t conflict[kMaxOthers];   // conflict_index per vehicle, -1 = None
     int32_t memorized[kMaxOthers];
+    double conflict_pt[kMaxOthers][2];    // conflict_points (agents/pure_mpc.py:590, 656): where the paths cross
+    double memorized_pt[kMaxOthers][2];   // memorized_conflict_points (:40, 666)
 };
 
 // ---- operations that must round one by one like numpy's (no FMA contraction, also after inlining) -----------
@@ -357,7 +359,7 @@ MPC_HD bool replays_memory(const EnvState &st) { return st.collision_memory > 0 
 // part 2 - a4 for ONE other vehicle (agents/pure_mpc.py:575-660): reference index of the conflict point or -1.
 // o = its observation row; the constant-velocity polyline is float32 arithmetic (agents/pure_mpc.py:529-550:
 // step = speed * dt * [cos h, sin h], positions accumulate).
-MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt) {
+MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt, P2 &pt_out) {
     const float sp = speed_f32(o[3], o[4]);
     const float sdt = f32mul(sp, (float)dt);
     const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
@@ -370,7 +372,9 @@ MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable 
         ag[m] = P2{(double)ax, (double)ay};
     }
     P2 pt;
+    pt_out = P2{0.0, 0.0};
     if (!first_crossing(ego, ne, ag, kPredHorizon + 1, pt)) return -1;
+    pt_out = pt;
     const int ego_time = argmin_dist(ego, ne, pt);
     const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
     int dtm = ego_time - agent_time;
@@ -381,10 +385,14 @@ MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable 
 // part 3 - detector state machine (agents/pure_mpc.py:558-563, 661-676), a6 ego index, a5 speed profile
 // (agents/pure_mpc.py:678-724).  conflict: the part-2 results of vehicles 0..observed-1 (unused when replaying).
 MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *ref_speed, const int32_t *conflict,
-                       EnvState &st, int32_t &ego_index_out, double *vref, uint8_t &collide_out) {
+                       const P2 *conflict_pt, EnvState &st, int32_t &ego_index_out, double *vref, uint8_t &collide_out) {
     if (replays_memory(st)) {
         st.n_conflict = st.n_memorized;
-        for (int j = 0; j < kMaxOthers; ++j) st.conflict[j] = st.memorized[j];
+        for (int j = 0; j < kMaxOthers; ++j) {
+            st.conflict[j] = st.memorized[j];
+            st.conflict_pt[j][0] = st.memorized_pt[j][0];
+            st.conflict_pt[j][1] = st.memorized_pt[j][1];
+        }
         st.is_collide = 1;
         st.collision_memory -= 1;
     } else {
@@ -392,14 +400,21 @@ MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *
         st.n_conflict = p.observed;
         for (int j = 0; j < kMaxOthers; ++j) {
             st.conflict[j] = j < p.observed ? conflict[j] : -1;
-            any = any || st.conflict[j] >= 0;
+            const bool hit = st.conflict[j] >= 0;
+            st.conflict_pt[j][0] = hit ? conflict_pt[j].x : 0.0;
+            st.conflict_pt[j][1] = hit ? conflict_pt[j].y : 0.0;
+            any = any || hit;
         }
         st.is_collide = any ? 1 : 0;
         if (any) {
             st.collision_memory = kMemorySteps;
             st.has_memorized = 1;
             st.n_memorized = st.n_conflict;
-            for (int j = 0; j < kMaxOthers; ++j) st.memorized[j] = st.conflict[j];
+            for (int j = 0; j < kMaxOthers; ++j) {
+                st.memorized[j] = st.conflict[j];
+                st.memorized_pt[j][0] = st.conflict_pt[j][0];
+                st.memorized_pt[j][1] = st.conflict_pt[j][1];
+            }
         } else if (st.collision_memory > 0) {
             st.collision_memory -= 1;
             st.is_collide = 1;
@@ -475,12 +490,13 @@ MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, d
     write_vehicles(obs, p, state, others);
     nveh_out = p.observed;
     int32_t conflict[kMaxOthers];
+    P2 cpt[kMaxOthers];
     if (!replays_memory(st)) {
         P2 ego[kPredHorizon + 1];
         const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, ego);
-        for (int j = 0; j < p.observed; ++j) conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt);
+        for (int j = 0; j < p.observed; ++j) conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt, cpt[j]);
     }
-    finish_env(p, R, N, ref_speed, conflict, st, ego_index_out, vref, collide_out);
+    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out);
 }
 
 }  // namespace pre

@@ -48,11 +48,12 @@ struct WaveOps {
     __device__ __forceinline__ void st(int i, double v) { L[i] = v; }
     // A phase ends where other lanes may read what this one wrote to LDS.  The workgroup is one wave, whose LDS
     // instructions execute in issue order, so no hardware barrier or wait is needed - only the compiler must keep the
-    // program order of the LDS accesses.
+    // program order of the LDS accesses: an acquire-release fence at wavefront scope (stores of the phase stay above
+    // it, loads of the next one below it; it emits no instruction) plus the wave barrier.
     template <class F>
     __device__ __forceinline__ void phase(F &&f) {
         f((int)threadIdx.x);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     template <class F>

@@ -45,7 +45,8 @@ class _Config(ctypes.Structure):
 _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_create", "mpc_destroy",
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
-            "mpc_ltv_solve_batch", "mpc_ltv_predict_batch"]
+            "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
+            "mpc_set_env_state", "mpc_reserve_envs"]
 MAX_OTHERS = 16
 _lib = None
 
@@ -99,8 +100,16 @@ def load_library(path: str | None = None):
     lib.mpc_reset_env_state.restype = ctypes.c_int
     lib.mpc_reset_env_mask.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_uint32, vp]
     lib.mpc_reset_env_mask.restype = ctypes.c_int
-    lib.mpc_get_env_state.argtypes = [vp, ctypes.c_int32, ip, ip, ip, ip, ip]
+    lib.mpc_get_env_state.argtypes = [vp, ctypes.c_int32, ip, ip, ip, ip, ip, dp]
     lib.mpc_get_env_state.restype = ctypes.c_int
+    lib.mpc_env_state_bytes.argtypes = []
+    lib.mpc_env_state_bytes.restype = ctypes.c_int64
+    lib.mpc_save_env_state.argtypes = [vp, ctypes.c_int32, vp]
+    lib.mpc_save_env_state.restype = ctypes.c_int
+    lib.mpc_set_env_state.argtypes = [vp, ctypes.c_int32, vp]
+    lib.mpc_set_env_state.restype = ctypes.c_int
+    lib.mpc_reserve_envs.argtypes = [vp, ctypes.c_int32]
+    lib.mpc_reserve_envs.restype = ctypes.c_int
     lib.mpc_get_last_inputs.argtypes = [vp, ctypes.c_int32, dp, ip, dp, vp, dp, ip]
     lib.mpc_get_last_inputs.restype = ctypes.c_int
     _lib = lib
@@ -360,14 +369,32 @@ class MPCEngine:
 
     def env_state(self, B):
         """Detector state of environments 0..B-1 (host copies): is_collide, ego_index, collision_memory, stop_index,
-        conflict_index[B, 16] (-1 = none)."""
+        conflict_index[B, 16] (-1 = none), conflict_points[B, 16, 2] (NaN = none)."""
         o = dict(is_collide=np.empty(B, np.int32), ego_index=np.empty(B, np.int32),
                  collision_memory=np.empty(B, np.int32), stop_index=np.empty(B, np.int32),
-                 conflict_index=np.empty((B, MAX_OTHERS), np.int32))
+                 conflict_index=np.empty((B, MAX_OTHERS), np.int32), conflict_points=np.empty((B, MAX_OTHERS, 2)))
         rc = self._lib.mpc_get_env_state(self._h, B, _ptr(o["is_collide"]), _ptr(o["ego_index"]),
-                                         _ptr(o["collision_memory"]), _ptr(o["stop_index"]), _ptr(o["conflict_index"]))
+                                         _ptr(o["collision_memory"]), _ptr(o["stop_index"]), _ptr(o["conflict_index"]),
+                                         _ptr(o["conflict_points"]))
         self._check(rc, "mpc_get_env_state")
         return o
+
+    def save_env_state(self, B) -> np.ndarray:
+        """Checkpoint of the detector records of environments 0..B-1: opaque bytes [B, record size]."""
+        buf = np.zeros((B, int(self._lib.mpc_env_state_bytes())), dtype=np.uint8)
+        self._check(self._lib.mpc_save_env_state(self._h, B, _ptr(buf)), "mpc_save_env_state")
+        return buf
+
+    def load_env_state(self, records: np.ndarray):
+        """Put back what `save_env_state` returned (this or another engine)."""
+        records = np.ascontiguousarray(records, dtype=np.uint8)
+        if records.ndim != 2 or records.shape[1] != int(self._lib.mpc_env_state_bytes()):
+            raise ValueError("records: expected [B, mpc_env_state_bytes()] uint8")
+        self._check(self._lib.mpc_set_env_state(self._h, records.shape[0], _ptr(records)), "mpc_set_env_state")
+
+    def reserve_envs(self, B):
+        """Size the per-environment buffers now (required before capturing a step for B environments in a hipGraph)."""
+        self._check(self._lib.mpc_reserve_envs(self._h, int(B)), "mpc_reserve_envs")
 
     def last_inputs(self, B, vehicles_count):
         """The problem data the last predict_batch derived from its observations (host copies)."""

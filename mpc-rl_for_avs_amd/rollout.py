@@ -368,6 +368,8 @@ class BatchedCollector:
         writes across steps lives at a fixed address (environment state, last observation, buffer, counters); the buffer
         row comes from a device-side counter; both random generators are registered with the graph."""
         dev = self.env.device
+        if hasattr(self.engine, "reserve_envs"):     # the handle's per-environment buffers must not grow inside the capture
+            self.engine.reserve_envs(self.env.num_envs)
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):

@@ -158,7 +158,8 @@ static double stage_cost_raw(const prob_t *p, int k, const double *x, double *lx
 }
 
 /* optional work counters (ORACLE_COUNT=1, single thread): iterations, backward sweeps, rollouts */
-static long g_cnt_iter, g_cnt_sweep, g_cnt_roll;
+static long g_cnt_iter, g_cnt_sweep, g_cnt_roll, g_cnt_solve;
+static int g_cnt_N, g_cnt_V, g_cnt_cc;
 
 typedef struct {
     double tol, mu_init;
@@ -426,8 +427,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
          * multiple of the identity is added. */
         double dV1 = 0.0, delta_w = reg;
         int nmod = 0, ok = 0, gn = 0;
+#pragma omp atomic
         ++g_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
+#pragma omp atomic
             ++g_cnt_sweep;
             ok = 1;
             dV1 = 0.0;
@@ -620,6 +623,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         for (int k = 0; k <= N; ++k) cross[k] = -1;
         for (nls = 0; nls < MAXLS; ++nls, alpha *= BTF) {
             int feas = 1;
+#pragma omp atomic
             ++g_cnt_roll;
             trial = *it;
             for (int k = 0; k < N && feas; ++k) {
@@ -783,6 +787,10 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
                             double *kkt, int nthreads) {
     if (N < 1 || N > NMAX || V < 0 || V > VMAX || M < 1) return -1;
     g_cnt_iter = g_cnt_sweep = g_cnt_roll = 0;
+    g_cnt_solve = B;
+    g_cnt_N = N;
+    g_cnt_V = (flags & 1u) ? V : 0;
+    g_cnt_cc = (flags & 1u) ? 1 : 0;
     opts_t o = {tol, 0.1, max_iter};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -845,4 +853,38 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
     if (getenv("ORACLE_COUNT"))
         fprintf(stderr, "oracle work: %ld iterations, %ld backward sweeps, %ld rollouts\n", g_cnt_iter, g_cnt_sweep, g_cnt_roll);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Work of the last oracle_solve_batch* call ("the CPU oracle must carry an exact flop counter so
+ * the figure is measured, not estimated").  Counted exactly: interior-point iterations, backward sweeps (an iteration
+ * repeats its sweep when a fallback is needed) and line-search rollouts, over all instances.  Converted to floating
+ * point operations with the per-stage operation counts of the statements of solve_one above (+ - * / sqrt fmin fmax
+ * fabs and comparisons count 1; sin cos tan atan log are counted apart as transcendentals):
+ *   derivatives of a stage   dyn_eval 18 + A, B entries 22 + tracking cost/gradient/Hessian 41 + control terms 8
+ *                            (+ per vehicle 53 + 6 with the collision cost), 6 transcendentals
+ *   adjoint + dual residual  22 + 8 + 40 + curvature terms 18 + 40, 6 transcendentals (dyn_eval again)
+ *   complementarity          50
+ *   backward sweep stage     820 (PA 128, PB 64, Hxx 128, Hxu 96, hx 32, Huu 84, hu 18, stage Hessian 52, 2x2 and gains
+ *                            58, value function 160)
+ *   linear forward stage     128
+ *   rollout stage            113 + barrier objective 29 (+ 13 per vehicle + 3), 6 + 8 transcendentals
+ *   dual update stage        64
+ * out[0] = iterations, out[1] = sweeps, out[2] = rollouts, out[3] = solves, out[4] = arithmetic flops,
+ * out[5] = transcendentals.
+ * ------------------------------------------------------------------------------------------ */
+void oracle_last_work(double out[6]) {
+    const double N = g_cnt_N, V = g_cnt_V, cc = g_cnt_cc;
+    const double per_iter = N * ((18 + 22 + 41 + 8 + cc * (V * 53 + 6)) + (22 + 8 + 40 + 18 + 40) + 50 + 128 + 64);
+    const double per_iter_t = N * (6 + 6);
+    const double per_sweep = N * 820;
+    const double per_roll = N * (113 + 29 + cc * (V * 13 + 3));
+    const double per_roll_t = N * (6 + 8);
+    const double start = N * (26 + 27 + cc * V * 23), start_t = N * 6;   /* first rollout + objective scaling */
+    out[0] = (double)g_cnt_iter;
+    out[1] = (double)g_cnt_sweep;
+    out[2] = (double)g_cnt_roll;
+    out[3] = (double)g_cnt_solve;
+    out[4] = g_cnt_solve * start + g_cnt_iter * per_iter + g_cnt_sweep * per_sweep + g_cnt_roll * per_roll;
+    out[5] = g_cnt_solve * start_t + g_cnt_iter * per_iter_t + g_cnt_roll * per_roll_t;
 }

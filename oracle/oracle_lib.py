@@ -40,7 +40,17 @@ def _load():
             ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ip, dp, dp, bp, dp,
             ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
             dp, dp, dp, dp, dp, ip, ip, dp, ctypes.c_int]
+        _lib.oracle_last_work.restype = None
+        _lib.oracle_last_work.argtypes = [dp]
     return _lib
+
+
+def last_work():
+    """Work of the last solve_batch call, counted by the oracle: dict(iterations, sweeps, rollouts, solves, flops,
+    transcendentals) - flops / transcendentals by the per-stage operation counts documented in mpc_oracle.c."""
+    out = np.zeros(6)
+    _load().oracle_last_work(out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return dict(zip(("iterations", "sweeps", "rollouts", "solves", "flops", "transcendentals"), out.tolist()))
 
 
 def _p(a, ty):

@@ -1,6 +1,6 @@
-"""Host-side mirror of the reference interface (pure_mpc.py) against golden vectors produced by the reference's
-own numpy code (tests/golden/make_golden.py), plus the hand-derived geometry KATs that replace shapely (CPU only).
-The solve itself is stubbed by a recording fake engine here - the real engine needs a GPU."""
+"""The numpy mirror of the reference's preamble (tests/host_preamble.py, the checker of the device preamble) against
+golden vectors produced by the reference's own numpy code (tests/golden/make_golden.py), plus the hand-derived geometry
+KATs that replace shapely (CPU only).  The solve itself is stubbed by a recording fake engine here."""
 import os
 
 import numpy as np
@@ -32,8 +32,8 @@ class FakeEngine:
 
 @pytest.fixture()
 def agent():
-    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
-    return PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
+    from host_preamble import HostPreambleAgent
+    return HostPreambleAgent(Env(), dict(CFG), engine=FakeEngine())
 
 
 @pytest.fixture(scope="module")
@@ -95,7 +95,7 @@ def test_future_position_predictors_match_reference(agent, gold):
 
 
 def test_stop_profile_with_float32_speed_matches_reference(agent, gold):
-    from mpc_rl_for_avs_amd.pure_mpc import _EnvState
+    from host_preamble import _EnvState
     for (ego_index, conflict, speed), want in zip(gold["stop_profile32_in"], gold["stop_profile32_out"]):
         st = _EnvState()
         st.ego_index, st.is_collide, st.conflict_index = int(ego_index), True, [int(conflict)]
@@ -105,7 +105,7 @@ def test_stop_profile_with_float32_speed_matches_reference(agent, gold):
 
 def test_path_crossing_kats():
     """Hand-derived replacements for shapely's LineString.intersection cases (agents/pure_mpc.py:615-633)."""
-    from mpc_rl_for_avs_amd.pure_mpc import first_path_crossing
+    from host_preamble import first_path_crossing
     ego = np.array([[0.0, 0.0], [0.0, 1.0], [0.0, 2.0], [1.0, 3.0]])
     # transversal crossing -> the Point
     np.testing.assert_allclose(first_path_crossing(ego, np.array([[-1.0, 0.5], [1.0, 0.5]])), [0.0, 0.5])
@@ -158,7 +158,7 @@ def test_collision_state_machine_and_solver_inputs(agent):
 
 def test_predict_batch_host_equals_looped_predict():
     from mpc_rl_for_avs_amd import synth
-    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    from host_preamble import HostPreambleAgent as PureMPC_Agent
     obs = synth.make_obs_batch(12, 4, seed=9)
     a = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
     a.predict_batch_host(obs)

@@ -183,7 +183,8 @@ def test_agent_api_end_to_end(oracle, ref_table):
     agent = PureMPC_Agent(Env(), cfg)
     act = agent.predict_batch(obs)
     assert act.shape == (48, 2)
-    ref_agent = PureMPC_Agent(Env(), cfg)
+    from host_preamble import HostPreambleAgent
+    ref_agent = HostPreambleAgent(Env(), cfg, engine=agent._engine)
     egos, others = zip(*[ref_agent._vehicles_from_obs(o) for o in obs])
     while len(ref_agent._states) < 48:
         ref_agent._states.append(type(ref_agent._states[0])())
@@ -196,7 +197,8 @@ def test_agent_api_end_to_end(oracle, ref_table):
     single = PureMPC_Agent(Env(), cfg)
     a0 = single.predict(obs[0])
     assert a0.shape == (2,) and np.array_equal(a0, act[0])
-    assert single.predict(obs[0], return_numpy=False).steer == single.last_solve["u0"][0, 1]
+    single.reset_env_state()
+    assert single.predict(obs[0], return_numpy=False).steer == single.last_solve["act"][0, 1]
 
 
 def test_limits_of_the_interface(oracle):

@@ -24,9 +24,10 @@ def _episode_obs(B, V, t, rng):
 @pytest.mark.parametrize("V,cc", [(4, False), (9, True)])
 def test_predict_batch_matches_host_preamble_plus_solve(V, cc):
     from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    from host_preamble import HostPreambleAgent
     B, T = 200, 13
     dev = PureMPC_Agent(Env(), dict(CFG), collision_cost=cc)
-    host = PureMPC_Agent(Env(), dict(CFG), collision_cost=cc, engine=dev._engine)
+    host = HostPreambleAgent(Env(), dict(CFG), collision_cost=cc, engine=dev._engine)
     rng = np.random.default_rng(V)
     fired = 0
     for t in range(T):
@@ -48,6 +49,9 @@ def test_predict_batch_matches_host_preamble_plus_solve(V, cc):
         for b in range(B):
             ci = [-1 if c is None else c for c in host._states[b].conflict_index]
             assert list(env["conflict_index"][b, :len(ci)]) == ci
+            for j, pt in enumerate(host._states[b].conflict_points):
+                if pt is not None:
+                    assert np.allclose(env["conflict_points"][b, j], pt, rtol=0, atol=1e-9)
         both = (st == 0) & (host.last_solve["status"] == 0)
         assert both.mean() > 0.8
         assert (rel_u0_err(act, want_act)[both] <= 1e-4).mean() > 0.995
@@ -55,7 +59,7 @@ def test_predict_batch_matches_host_preamble_plus_solve(V, cc):
         fired += int(want["is_collide"].sum())
         if t == 5:
             ids = np.where(rng.uniform(size=B) < 0.4)[0]
-            dev.reset_env_state(ids)              # also resets host._engine (shared) - harmless, host keeps its own
+            dev.reset_env_state(ids)              # the engine's records; the mirror keeps its own states
             for i in ids:
                 host._states[i] = type(host._states[i])()
     assert fired > B
@@ -109,7 +113,7 @@ def test_collector_on_device_equals_single_instance_path():
     reference's single-environment call sequence over the environments gives for the same observations."""
     import torch
     from mpc_rl_for_avs_amd import engine, rollout
-    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    from host_preamble import HostPreambleAgent as PureMPC_Agent
     dev = torch.device("cuda", 0)
     B, T = 48, 12
     eng = engine.MPCEngine(horizon=20, max_iter=100)
@@ -269,3 +273,51 @@ def test_warm_start_flag(oracle, ref_table):
     assert iw[1:].mean() < ic[1:].mean()                                # fewer iterations afterwards (a few %: the
     #                                                                     barrier path is walked again)
     assert cw.mean() > cc_.mean() - 0.03
+
+
+def test_single_agent_attributes_and_checkpoint():
+    """`predict()` of the product agent (one device call, B = 1) leaves the attributes the reference's callers and plots
+    read (agents/pure_mpc.py:38-43, 589-593), equal to the numpy mirror's; the detector record can be saved and put back
+    (`mpc_save_env_state` / `mpc_set_env_state`), after which the agent repeats itself exactly."""
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    from host_preamble import HostPreambleAgent
+    a = PureMPC_Agent(Env(), dict(CFG))
+    m = HostPreambleAgent(Env(), dict(CFG), engine=a._engine)
+    obs = np.zeros((10, 8), np.float32)
+    obs[0] = [1, 2.0, 30.0, 0.0, -10.0, -np.pi / 2, -1.0, 0.0]      # ego driving down the approach lane
+    obs[1] = [1, -15.0, 12.0, 8.0, 0.0, 0.0, 0.0, 1.0]              # crosses the ego path at (2, 12) ahead
+    obs[2] = [1, 40.0, -2.0, -8.0, 0.0, np.pi, 0.0, -1.0]           # far away on another lane: no crossing
+    act = a.predict(obs)
+    want = m.predict(obs)
+    assert act.shape == (2,) and np.allclose(act, want, rtol=0, atol=1e-7)
+    assert a.is_collide and m.is_collide and a.collision_memory == m.collision_memory == 10
+    assert a.ego_index == m.ego_index == 19
+    assert a.conflict_index == m.conflict_index == [37, None]
+    assert a.agent_collide == [True, False]
+    assert np.allclose(a.conflict_points[0], m.conflict_points[0], atol=1e-9) and a.conflict_points[1] is None
+    assert np.allclose(a.stop_point, m.stop_point)
+    assert len(a.agent_current_locations) == 2 and np.allclose(a.agent_current_locations[0], [-15.0, 12.0])
+    fut = a.agent_future_locations
+    assert len(fut) == 2 and len(fut[0]) == 31 and np.allclose(fut[0][-1], [-15.0 + 30 * 0.8, 12.0], atol=1e-4)
+    assert a.last_acc == act[0]
+    # the vehicle disappears: memory counts down on both sides
+    obs2 = obs.copy()
+    obs2[1:] = 0
+    for i in range(3):
+        assert np.allclose(a.predict(obs2), m.predict(obs2), rtol=0, atol=1e-7)
+        assert a.is_collide and a.collision_memory == m.collision_memory == 9 - i
+    # checkpoint, run on, restore, repeat
+    saved = a.save_env_state(1)
+    assert saved.shape == (1, a._engine._lib.mpc_env_state_bytes())
+    run1 = [a.predict(obs2).copy() for _ in range(9)]
+    mem1 = a.collision_memory
+    a.load_env_state(saved)
+    run2 = [a.predict(obs2).copy() for _ in range(9)]
+    assert all(np.array_equal(x, y) for x, y in zip(run1, run2)) and a.collision_memory == mem1
+    # into another engine
+    b = PureMPC_Agent(Env(), dict(CFG))
+    b.load_env_state(saved)
+    assert np.array_equal(b.predict(obs2), run1[0])
+    b.reset_env_state()
+    b.predict(obs2)
+    assert not b.is_collide and b.conflict_index == []
