@@ -169,6 +169,8 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //   void take(PerLane<double>& dst, PerLane<double>& src, PerLane<int>& from)   dst[l] = src[from[l]]
 //   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
 //   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
+//   int opaque(int v)                            v, but the compiler cannot see that (keeps recomputable per-lane tables
+//                                                from being hoisted out of the iteration loop and held in registers)
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
 // ---------------------------------------------------------------------------------------------------
 template <bool CC, class CTX>
@@ -231,11 +233,13 @@ struct Solver {
         return stage_transition_word(r, c, W_LIN, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
                                      -(SCR + SC_SPARE + 2 + 1));
     }
+    // The role tables are pure functions of the lane id.  They are recomputed at the start of every factorisation (a
+    // few dozen integer operations against ~150 k cycles of an iteration) from a lane id the compiler cannot see through,
+    // so that their 16 registers are live during the sweep only and not across the line search and the stage-parallel
+    // phases, where the kernel is short of registers.
     MPC_HD void set_mfma_roles() {
-        sc(SC_SPARE + 0, 0.0);
-        sc(SC_SPARE + 1, 1.0);
-        sc(SC_SPARE + 2, dt);
-        c.phase([&](int lane) {
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque(lane_);
             const int hi = lane >> 4, blk = (lane >> 2) & 3, I = blk >> 1, J = blk & 1, lo = lane & 3;
             const int row = 4 * I + hi, col = 4 * J + lo;
             m_row.at(lane) = row;
@@ -277,7 +281,7 @@ struct Solver {
                                          : (q < 4 ? A_HV0 + q : (q == 4 ? A_HV4 : (q == 5 ? A_HV5 : (q == 6 ? A_HV6 : A_HV7))));
             m_hvab.at(lane) = (q < 4 || q == 5) ? 1 : 0;
             // gains Kx(a, j) = -W(6 + a, j), j < 4: taken from the I = 0 copy of W
-            m_kx.at(lane) = (I == 0 && J == 0 && hi >= 2) ? W_KX + (hi - 2) * 4 + lo : -1;
+            m_kx.at(lane_) = (I == 0 && J == 0 && hi >= 2) ? W_KX + (hi - 2) * 4 + lo : -1;
         });
     }
 
@@ -623,7 +627,9 @@ struct Solver {
         iters_out = 0;
         cur_out = 0;
         kkt_out = INFINITY;
-        set_mfma_roles();
+        sc(SC_SPARE + 0, 0.0);   // the constants F is made of besides the linearisation values (fetched by address)
+        sc(SC_SPARE + 1, 1.0);
+        sc(SC_SPARE + 2, dt);
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;
@@ -670,13 +676,15 @@ struct Solver {
                 red_a.at(lane) = g;
             });
             const double gmax = fmax2(0.02 * (wc_ + wd_) * fabs(S(0, W_U + 0)), c.wave_max(red_a));
-            sf = 100.0 / fmin2(fmax2(100.0, gmax), 1e4);
-            Jcur *= sf;
+            sf = c.uni(100.0 / fmin2(fmax2(100.0, gmax), 1e4));
+            Jcur = c.uni(Jcur * sf);
+            barcur = c.uni(barcur);
         }
-        const double rd_full = 0.02 * sf * wd_, rc = 0.02 * sf * wc_, qtt = 10.0 * sf;
-        const double q33 = sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0));
+        // wave-uniform doubles that live across the whole solve: in scalar registers (CTX::uni), not in vector registers
+        const double rd_full = c.uni(0.02 * sf * wd_), rc = c.uni(0.02 * sf * wc_), qtt = c.uni(10.0 * sf);
+        const double q33 = c.uni(sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0)));
         double mu = P.mu_init;
-        const double mu_min = P.tol / 10.0;
+        const double mu_min = c.uni(P.tol / 10.0);
         int iter = 0, nfail = 0;
         double reg = 0.0;
 
@@ -867,7 +875,7 @@ struct Solver {
                 const double ec = fmax2(cmax - mu, mu - cmin);
                 const double E_mu = fmax2(err_d / s_d, ec / s_c);
                 if (E_mu <= 10.0 * mu && mu > mu_min) {
-                    mu = fmax2(mu_min, fmin2(0.2 * mu, mu * sqrt(mu)));
+                    mu = c.uni(fmax2(mu_min, fmin2(0.2 * mu, mu * sqrt(mu))));
                     continue;
                 }
                 break;
@@ -889,6 +897,7 @@ struct Solver {
             const int AB = (cur ^ 1) * 6;   // trial buffer: hv0..3 at AB + W_X, hv5 at AB + W_U
             double dV1 = 0.0, delta_w = reg;
             bool ok = false, gn = false;
+            set_mfma_roles();
             for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
                 ok = true;
                 dV1 = 0.0;
@@ -1159,7 +1168,7 @@ struct Solver {
 
             c.tick(T_RIC_INIT);
             // ============ linearised Newton step (serial recursion), parked in the adjoint slots
-            const double tau = fmax2(0.99, 1.0 - mu);
+            const double tau = c.uni(fmax2(0.99, 1.0 - mu));
             {
                 double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
 #pragma unroll 1
@@ -1240,12 +1249,12 @@ struct Solver {
                 const double rp = c.wave_max(red_a);
                 double rdn, rdd;
                 c.wave_max_ratio(red_b, red_c, rdn, rdd);
-                a_pr = (rp > tau) ? tau / rp : 1.0;
-                a_du = (rdn > tau * rdd) ? tau * rdd / rdn : 1.0;
+                a_pr = c.uni((rp > tau) ? tau / rp : 1.0);
+                a_du = c.uni((rdn > tau * rdd) ? tau * rdd / rdn : 1.0);
             }
             c.tick(T_RATIOS);
             // ============ line search on the barrier objective (Armijo, <= 6 trials, factor 1/4)
-            const double phi0 = Jcur + mu * barcur;
+            const double phi0 = c.uni(Jcur + mu * barcur);
             const int tb = cur ^ 1;
             double Jn = 0.0, barn = 0.0;
             int acc_trial = -1;
@@ -1261,6 +1270,7 @@ struct Solver {
             } else if (!accepted || acc_trial >= 2) {
                 reg = (reg == 0.0) ? 1e-3 : fmin2(4.0 * reg, 1e6);
             }
+            reg = c.uni(reg);
             // ============ dual update (stage-parallel)
             {
                 const int NB = (accepted ? tb : cur) * 6;
@@ -1320,8 +1330,8 @@ struct Solver {
             }
             if (accepted) {
                 cur = tb;
-                Jcur = Jn;
-                barcur = barn;
+                Jcur = c.uni(Jn);
+                barcur = c.uni(barn);
                 nfail = 0;
             } else if (newwall) {
                 nfail = 0;
@@ -1330,7 +1340,7 @@ struct Solver {
                 ++iter;
                 break;
             }
-            barcur += bar_shift;
+            if (newwall) barcur = c.uni(barcur + bar_shift);
         }
         iters_out = iter;
         cur_out = cur;

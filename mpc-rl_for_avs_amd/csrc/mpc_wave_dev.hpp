@@ -31,6 +31,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ double readlane_first_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // Reduction inside each 16-lane row with symmetric partner exchanges (xor 1, xor 2, mirror within 8, mirror within
 // 16): both partners combine the same two values, so all lanes of a row end bit-identical.
 template <class OP>
@@ -50,9 +56,12 @@ struct WaveOps {
     // instructions execute in issue order, so no hardware barrier or wait is needed - only the compiler must keep the
     // program order of the LDS accesses: an acquire-release fence at wavefront scope (stores of the phase stay above
     // it, loads of the next one below it; it emits no instruction) plus the wave barrier.
+    // (the lane id is handed out through opaque(): whatever a phase derives from it - LDS addresses of its stage, role
+    // flags - is then recomputed in that phase, a handful of integer operations, instead of being hoisted out of the
+    // iteration loop and kept in registers the kernel does not have)
     template <class F>
     __device__ __forceinline__ void phase(F &&f) {
-        f((int)threadIdx.x);
+        f(opaque((int)threadIdx.x));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -67,6 +76,14 @@ struct WaveOps {
         dst.v = __shfl(src.v, from.v);
     }
     __device__ __forceinline__ double lane_get(PerLane<double> &p, int lane) const { return readlane_f64(p.v, lane); }
+    // A wave-uniform double that the VALU computed sits in two vector registers like any per-lane value; moved to a scalar
+    // register pair it costs none (and when scalar registers run out the compiler parks them in lanes of a vector
+    // register, 32 doubles per register, instead of spilling vector registers to scratch memory).
+    __device__ __forceinline__ double uni(double v) const { return readlane_first_f64(v); }
+    __device__ __forceinline__ int opaque(int v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
     __device__ __forceinline__ int wave_bcast(PerLane<int> &p, int lane) const {
         return __builtin_amdgcn_readlane(p.v, lane);
     }

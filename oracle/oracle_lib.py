@@ -11,14 +11,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libmpc_oracle.so")
+_SAN = os.environ.get("MPC_TEST_SANITIZE") == "1"      # ASan + UBSan build (tests/test_sanitizers.py)
+_LIB_PATH = os.path.join(_HERE, "_build", "san" if _SAN else "", "libmpc_oracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "mpc_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["san"] if _SAN else []) + (["-B"] if force else []), check=True)
     return _LIB_PATH
 
 

@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# MPC_TEST_SANITIZE=1 (set by tests/test_sanitizers.py for a child process that preloads libasan): the host builds of the
+# kernel sources and the oracle are compiled with AddressSanitizer + UndefinedBehaviorSanitizer into their own directory
+SANITIZE = os.environ.get("MPC_TEST_SANITIZE") == "1"
+BUILD_DIR = os.path.join(ROOT, "tests", "_build", "san") if SANITIZE else os.path.join(ROOT, "tests", "_build")
+HOST_CXXFLAGS = (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if SANITIZE else ["-O2"]) + \
+    ["-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off"]
 
 
 def pytest_configure(config):
@@ -33,14 +39,13 @@ def oracle():
 def _host_solver(libname, srcname, symbol):
     """Host build of one of the kernel cores (tests/cpu_*_harness.cpp) wrapped as solve(ref, inp, ...)."""
     import ctypes
-    out = os.path.join(ROOT, "tests", "_build", libname)
+    out = os.path.join(BUILD_DIR, libname)
     src = os.path.join(ROOT, "tests", srcname)
     deps = [src, os.path.join(ROOT, "tests", "host_wave_ctx.hpp")] + \
         [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off",
-                        "-o", out, src], check=True)
+        subprocess.run(["g++"] + HOST_CXXFLAGS + ["-o", out, src], check=True)
     lib = ctypes.CDLL(out)
     lib.core_solve_batch = getattr(lib, symbol)
     dp, ip, bp = (ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8))
@@ -89,17 +94,20 @@ def cpu_wave():
 
 @pytest.fixture(scope="session")
 def cpu_ltv():
+    return _ltv_solver()
+
+
+def _ltv_solver():
     """mpc_ltv.hpp (iterative-linear MPC, one wave per instance) compiled for the host: solve(ref, state, U, N, max_iter)
     with state [B, 4] = x, y, v, yaw and U [B, N, 2] the stored profile."""
     import ctypes
-    out = os.path.join(ROOT, "tests", "_build", "libcpu_ltv.so")
+    out = os.path.join(BUILD_DIR, "libcpu_ltv.so")
     src = os.path.join(ROOT, "tests", "cpu_ltv_harness.cpp")
     deps = [src, os.path.join(ROOT, "tests", "host_wave_ctx.hpp")] + \
         [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp", "mpc_ltv.hpp")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off",
-                        "-o", out, src], check=True)
+        subprocess.run(["g++"] + HOST_CXXFLAGS + ["-o", out, src], check=True)
     lib = ctypes.CDLL(out)
     dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
     lib.ltv_solve_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ctypes.c_int, dp, dp,

@@ -41,6 +41,7 @@ extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table,
             }
         }
         HostCtx ctx{L.data(), table.data(), best, M, speeds.data()};
+        ctx.nwords = nd;
         for (int k = 0; k < N; ++k)
             for (int i = 0; i < 2; ++i) L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_U + i] = U[((size_t)b * N + k) * 2 + i];
         const double x0[4] = {state[4 * b + 0], state[4 * b + 1], state[4 * b + 3], state[4 * b + 2]};

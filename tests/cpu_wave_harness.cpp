@@ -59,6 +59,7 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     for (int b = 0; b < B; ++b) {
         std::vector<double> L((size_t)nd, NAN);
         HostCtx ctx{L.data(), table.data(), ego_index[b], M};
+        ctx.nwords = nd;   // the kernel source must stay inside lds_doubles() for every horizon / vehicle count
         for (int k = 0; k <= N; ++k) {
             int idx = ego_index[b] + k;
             idx = idx > M - 1 ? M - 1 : idx;

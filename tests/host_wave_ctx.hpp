@@ -5,6 +5,8 @@
 #pragma once
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "../mpc-rl_for_avs_amd/csrc/mpc_wave.hpp"
 
@@ -14,8 +16,21 @@ struct HostCtx {
     const double *table;  // [M][REF_COLS]
     int e0, M;
     const double *speeds = nullptr;  // [M] speed column of the reference table (refv)
-    double ld(int i) const { return L[i]; }
-    void st(int i, double v) { L[i] = v; }
+    int nwords = 0;                  // size of L in doubles (lds_doubles()): every access is checked against it when set
+    void check(int i) const {
+        if (nwords > 0 && (i < 0 || i >= nwords)) {
+            std::fprintf(stderr, "host_wave_ctx: LDS word %d outside the instance's %d words\n", i, nwords);
+            std::abort();
+        }
+    }
+    double ld(int i) const {
+        check(i);
+        return L[i];
+    }
+    void st(int i, double v) {
+        check(i);
+        L[i] = v;
+    }
     template <class F>
     void phase(F &&f) {
         for (int lane = 0; lane < mpc::wave::kLanes; ++lane) f(lane);
@@ -44,6 +59,8 @@ struct HostCtx {
         for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
     }
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
+    int opaque(int v) const { return v; }
+    double uni(double v) const { return v; }
     double wave_sum(mpc::wave::PerLane<double> &p) const {
         return mpc::wave::host_reduce(p, [](double a, double b) { return a + b; });
     }

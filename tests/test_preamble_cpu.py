@@ -14,13 +14,17 @@ from test_host import CFG, Env, FakeEngine
 
 @pytest.fixture(scope="module")
 def pre():
-    out = os.path.join(ROOT, "tests", "_build", "libcpu_preamble.so")
+    return load_pre()
+
+
+def load_pre():
+    import conftest
+    out = os.path.join(conftest.BUILD_DIR, "libcpu_preamble.so")
     src = os.path.join(ROOT, "tests", "cpu_preamble_harness.cpp")
     deps = [src] + [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_preamble.hpp")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.run(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-ffp-contract=off",
-                        "-o", out, src], check=True)
+        subprocess.run(["g++"] + conftest.HOST_CXXFLAGS + ["-o", out, src], check=True)
     lib = ctypes.CDLL(out)
     lib.preamble_ego_future.restype = ctypes.c_int
     lib.preamble_ego_future.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,

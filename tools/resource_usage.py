@@ -19,7 +19,8 @@ def main():
         m = re.search(r"remark: [^ ]+ +(?:Function )?Name: (\S+)", line) or re.search(r":\s+(?:Function )?Name: (\S+)", line)
         if m:
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-            cur = {"name": re.sub(r"\(.*", "", name).replace("(anonymous namespace)::", "")}
+            name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+            cur = {"name": re.sub(r"\(.*", "", name)}
             rows.append(cur)
             continue
         m = re.search(r":\s+([A-Za-z ]+(?:\[[^\]]*\])?): (\d+)", line)
