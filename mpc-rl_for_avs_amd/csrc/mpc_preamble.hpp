@@ -240,19 +240,25 @@ MPC_HD int seg_intersections(P2 p, P2 q, P2 a, P2 b, Hit *h) {
     return 2;
 }
 
-// First intersection of the ego polyline with the (straight) agent polyline ag[0..na-1], ordered along the ego path;
-// a collinear overlap yields the middle vertex of the overlapping stretch (agents/pure_mpc.py:615-633 on shapely's
-// result).  Returns false if they do not meet.
-MPC_HD bool first_crossing(const P2 *ego, int ne, const P2 *ag, int na, P2 &out) {
-    if (ne < 2 || na < 2) return false;
+// Intersections of the ego polyline with the (straight) agent polyline ag[0..na-1], as the candidate list the reference
+// builds from shapely's result (agents/pure_mpc.py:615-633): every transversal crossing is a candidate, a collinear overlap
+// contributes the middle vertex of the overlapping stretch.  ORDER: along the ego's direction of travel.  shapely / GEOS
+// returns the members of a Multi* result in the iteration order of a hash map of its overlay graph, which cannot be
+// reproduced (or relied on); with a single crossing - a straight agent path meets the straight-arc-straight ego path
+// more than once only when it cuts the arc twice - there is nothing to order.  Returns the number of candidates (<= maxc).
+constexpr int kMaxCross = 4;
+MPC_HD int path_crossings(const P2 *ego, int ne, const P2 *ag, int na, P2 *out, int maxc) {
+    if (ne < 2 || na < 2) return 0;
     const P2 a = ag[0], b = ag[na - 1];
-    for (int i = 0; i < ne - 1; ++i) {
+    int nc = 0;
+    for (int i = 0; i < ne - 1 && nc < maxc; ++i) {
         Hit h[2];
         const int nh = seg_intersections(ego[i], ego[i + 1], a, b, h);
         if (nh == 0) continue;
         if (nh == 1) {
-            out = h[0].p;
-            return true;
+            // a crossing exactly at an ego vertex is found by both segments that share it
+            if (nc == 0 || !close2(out[nc - 1], h[0].p)) out[nc++] = h[0].p;
+            continue;
         }
         // collinear overlap starting on ego segment i
         constexpr int kMaxPts = 2 + kPredHorizon + kPredHorizon + 1;
@@ -261,7 +267,8 @@ MPC_HD bool first_crossing(const P2 *ego, int ne, const P2 *ag, int na, P2 &out)
         int np = 0;
         pts[np++] = h[0].p;
         pts[np++] = h[1].p;
-        for (int j = i + 1; j < ne - 1; ++j) {
+        int j = i + 1;
+        for (; j < ne - 1; ++j) {
             Hit h2[2];
             if (seg_intersections(ego[j], ego[j + 1], a, b, h2) != 2) break;
             pts[np++] = h2[1].p;
@@ -294,10 +301,17 @@ MPC_HD bool first_crossing(const P2 *ego, int ne, const P2 *ag, int na, P2 &out)
         int nu = 0;
         for (int m = 0; m < np; ++m)
             if (nu == 0 || !close2(pts[nu - 1], pts[m])) pts[nu++] = pts[m];
-        out = pts[nu / 2];
-        return true;
+        out[nc++] = pts[nu / 2];
+        i = j - 1;      // go on behind the overlap
     }
-    return false;
+    return nc;
+}
+// the first candidate (the only one in all but double-crossing scenes)
+MPC_HD bool first_crossing(const P2 *ego, int ne, const P2 *ag, int na, P2 &out) {
+    P2 c[1];
+    if (path_crossings(ego, ne, ag, na, c, 1) == 0) return false;
+    out = c[0];
+    return true;
 }
 
 MPC_HD int argmin_dist(const P2 *pts, int n, P2 p) {
@@ -371,15 +385,23 @@ MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable 
         ay = f32add(ay, sty);
         ag[m] = P2{(double)ax, (double)ay};
     }
-    P2 pt;
+    // candidate loop of agents/pure_mpc.py:635-654: the first intersection point whose ego / agent sample indices differ
+    // by less than TIME_THRESHOLD decides (with 31 samples that is every point except the pairing 0 / 30)
+    P2 cand[kMaxCross];
     pt_out = P2{0.0, 0.0};
-    if (!first_crossing(ego, ne, ag, kPredHorizon + 1, pt)) return -1;
-    pt_out = pt;
-    const int ego_time = argmin_dist(ego, ne, pt);
-    const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
-    int dtm = ego_time - agent_time;
-    dtm = dtm < 0 ? -dtm : dtm;
-    return dtm < kTimeThreshold ? R.nearest(pt.x, pt.y) : -1;
+    const int nc = path_crossings(ego, ne, ag, kPredHorizon + 1, cand, kMaxCross);
+    for (int q = 0; q < nc; ++q) {
+        const P2 pt = cand[q];
+        const int ego_time = argmin_dist(ego, ne, pt);
+        const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
+        int dtm = ego_time - agent_time;
+        dtm = dtm < 0 ? -dtm : dtm;
+        if (dtm < kTimeThreshold) {
+            pt_out = pt;
+            return R.nearest(pt.x, pt.y);
+        }
+    }
+    return -1;
 }
 
 // part 3 - detector state machine (agents/pure_mpc.py:558-563, 661-676), a6 ego index, a5 speed profile

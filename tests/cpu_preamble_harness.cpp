@@ -65,3 +65,16 @@ extern "C" int preamble_first_crossing(const double *ego, int ne, const double *
     out[1] = p.y;
     return 1;
 }
+
+// all candidates, in the order the detector tries them: out [maxc][2]; returns their number
+extern "C" int preamble_path_crossings(const double *ego, int ne, const double *ag, int na, double *out, int maxc) {
+    std::vector<mpc::pre::P2> e((size_t)ne), a((size_t)na), c((size_t)(maxc > 0 ? maxc : 1));
+    for (int i = 0; i < ne; ++i) e[(size_t)i] = mpc::pre::P2{ego[i * 2], ego[i * 2 + 1]};
+    for (int i = 0; i < na; ++i) a[(size_t)i] = mpc::pre::P2{ag[i * 2], ag[i * 2 + 1]};
+    const int n = mpc::pre::path_crossings(e.data(), ne, a.data(), na, c.data(), maxc);
+    for (int i = 0; i < n; ++i) {
+        out[i * 2] = c[(size_t)i].x;
+        out[i * 2 + 1] = c[(size_t)i].y;
+    }
+    return n;
+}

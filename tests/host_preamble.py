@@ -54,30 +54,32 @@ def _seg_intersections(p, q, a, b, eps=1e-12):
     return [(lo, p + lo * r), (hi, p + hi * r)]
 
 
-def first_path_crossing(ego_path, agent_path):
-    """First intersection point of two polylines, ordered along the ego polyline; None if they do not meet.
-
-    The reference takes shapely's `ego_path.intersection(agent_path)` and uses a Point as is, the middle
-    coordinate of a LineString (collinear overlap) and the first member of a Multi* geometry
-    (agents/pure_mpc.py:615-633).  Here a transversal crossing returns the crossing point and an overlap
-    returns the middle vertex of the overlapping stretch; for multiple crossings the one met first when
-    travelling along the ego path is used (GEOS orders Multi* members by its own noding, which can differ -
-    see DESIGN.md, deviations)."""
+def path_crossings(ego_path, agent_path, max_candidates=4):
+    """Intersection points of two polylines as the candidate list the reference builds from shapely's result
+    (agents/pure_mpc.py:615-633): every transversal crossing, and for a collinear overlap the middle vertex of the
+    overlapping stretch.  ORDER: along the ego's direction of travel - GEOS returns the members of a Multi* geometry in
+    the iteration order of a hash map of its overlay graph, which cannot be reproduced; a straight agent path meets the
+    ego path more than once only when it cuts the arc twice."""
     ego = np.asarray(ego_path, dtype=np.float64)
     ag = np.asarray(agent_path, dtype=np.float64)
+    out = []
     if len(ego) < 2 or len(ag) < 2:
-        return None
+        return out
     a, b = ag[0], ag[-1]                   # constant-velocity prediction: the agent polyline is one straight segment
-    best = None
-    for i in range(len(ego) - 1):
+    i = 0
+    while i < len(ego) - 1 and len(out) < max_candidates:
         hits = _seg_intersections(ego[i], ego[i + 1], a, b)
         if not hits:
+            i += 1
             continue
         if len(hits) == 1:
-            cand = (i + hits[0][0], hits[0][1])
-            if best is None or cand[0] < best[0]:
-                best = cand
-            break
+            pt = np.asarray(hits[0][1], dtype=np.float64)
+            # a crossing exactly at an ego vertex is found by both segments that share it
+            if not out or not (abs(out[-1][0] - pt[0]) <= 1e-12 + 1e-5 * abs(pt[0]) and
+                               abs(out[-1][1] - pt[1]) <= 1e-12 + 1e-5 * abs(pt[1])):
+                out.append(pt)
+            i += 1
+            continue
         # collinear overlap starting on this ego segment: collect the overlapping stretch over following segments
         pts = [hits[0][1], hits[1][1]]
         j = i + 1
@@ -99,9 +101,15 @@ def first_path_crossing(ego_path, agent_path):
         for _, pt in keyed:
             if not uniq or not np.allclose(uniq[-1], pt, atol=1e-12):
                 uniq.append(pt)
-        best = (i + hits[0][0], np.array(uniq[len(uniq) // 2]))
-        break
-    return None if best is None else np.asarray(best[1], dtype=np.float64)
+        out.append(np.array(uniq[len(uniq) // 2], dtype=np.float64))
+        i = j                               # go on behind the overlap
+    return out
+
+
+def first_path_crossing(ego_path, agent_path):
+    """The first candidate of `path_crossings` (the only one in all but double-crossing scenes); None if none."""
+    c = path_crossings(ego_path, agent_path, 1)
+    return c[0] if c else None
 
 
 class _EnvState:
@@ -355,14 +363,14 @@ class HostPreambleAgent:
             agent_future = self.predict_future_positions(np.array(veh.position), veh.speed, veh.heading, self.dt,
                                                          PREDICTION_HORIZON)
             ag_arr = np.asarray(agent_future, dtype=np.float64)
-            point = first_path_crossing(ego_arr, ag_arr)
-            detected, conflict_idx = False, None
-            if point is not None:
+            detected, conflict_idx, point = False, None, None
+            for point in path_crossings(ego_arr, ag_arr):            # candidate loop of agents/pure_mpc.py:635-654
                 ego_time = int(np.argmin(np.linalg.norm(ego_arr - point, axis=1)))
                 agent_time = int(np.argmin(np.linalg.norm(ag_arr - point, axis=1)))
                 if abs(ego_time - agent_time) < TIME_THRESHOLD:
                     detected = True
                     conflict_idx = int(np.argmin(np.linalg.norm(self.reference_trajectory - point, axis=1)))
+                    break
             collide.append(detected)
             st.conflict_points.append(point if detected else None)
             st.conflict_index.append(conflict_idx if detected else None)

@@ -191,3 +191,44 @@ def test_preamble_collinear_and_degenerate_cases(pre, ref_table):
         np.testing.assert_allclose(got["vref"], want["vref"], rtol=0, atol=1e-12)
         assert np.array_equal(got["state"], want["state"])
     assert want["is_collide"].sum() >= 3
+
+
+def test_double_crossings_on_the_arc_are_all_candidates(pre, ref_table):
+    """A straight vehicle path can cut the quarter turn of the ego path (rows 40-59 of the table) twice.  The reference
+    tries every intersection point shapely returns (agents/pure_mpc.py:635-654); device code and numpy mirror enumerate
+    both crossings, in the ego's direction of travel (GEOS's own order of a MultiPoint is that of a hash map and cannot
+    be reproduced), and agree with each other; each candidate lies on both polylines."""
+    from host_preamble import path_crossings
+    ego = np.ascontiguousarray(ref_table[30:70, :2])            # straight - arc - straight
+    rng = np.random.default_rng(5)
+    two = 0
+    for _ in range(400):
+        c = np.array([-4.0, 3.0]) + rng.uniform(-3, 3, 2)       # a chord through the inside of the turn
+        ang = rng.uniform(0, np.pi)
+        d = np.array([np.cos(ang), np.sin(ang)])
+        ag = np.stack([c + (t - 15) * 1.2 * d for t in range(31)])
+        want = path_crossings(ego, ag)
+        out = np.zeros((4, 2))
+        n = pre.preamble_path_crossings(ego.ctypes.data_as(ctypes.c_void_p), len(ego), ag.ctypes.data_as(ctypes.c_void_p),
+                                        len(ag), out.ctypes.data_as(ctypes.c_void_p), 4)
+        assert n == len(want)
+        for q in range(n):
+            assert np.allclose(out[q], want[q], rtol=0, atol=1e-12)
+            # on the agent's straight line and on an ego segment
+            r = out[q] - ag[0]
+            assert abs(r[0] * d[1] - r[1] * d[0]) < 1e-9
+            seg = np.linalg.norm(ego[1:] - ego[:-1], axis=1)
+            on = [abs(np.linalg.norm(out[q] - ego[i]) + np.linalg.norm(out[q] - ego[i + 1]) - seg[i]) < 1e-9
+                  for i in range(len(ego) - 1)]
+            assert any(on)
+        if n == 2:
+            two += 1
+            # ordered along the ego path: the first candidate is met first
+            first = [int(np.argmin(np.linalg.norm(ego - out[q], axis=1))) for q in range(2)]
+            assert first[0] <= first[1]
+    assert two >= 20
+    # hand-made: the horizontal line y = 9.2 cuts the straight approach (x = 2, at row 10) and nothing else; the diagonal
+    # through (2, 6.0) and (-8, -1.5) cuts the arc twice
+    ag = np.stack([np.array([3.0, 6.75]) + t * np.array([-0.4, -0.3]) for t in range(31)])
+    got = path_crossings(ego, ag)
+    assert len(got) == 2 and got[0][1] > got[1][1]               # travelling down and then left: higher point first
