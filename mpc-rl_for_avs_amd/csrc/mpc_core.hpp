@@ -122,13 +122,51 @@ MPC_HD double atan_b(double t) {
 #endif
 }
 
+// sin and cos of the two angles of the bicycle model, the steering angle |delta| <= pi/3 (1 + 1e-8) and the heading
+// |theta| <= pi (1 + 1e-8) (the bounds of the NLP), without range reduction or quadrant logic: the fdlibm kernel
+// polynomials (valid on |x| <= pi/4) are evaluated at delta/2 and theta/4 - four independent Horner chains that share
+// every coefficient, so a lone wave overlaps their latencies and each 64-bit literal is materialised once - followed
+// by one resp. two angle doublings (sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a; absolute error < 1e-15).
+// Measured on MI355X: the generic two-argument version (reduction, quadrant selects on 64-bit values) was ~190
+// instructions of the ~330 of a rollout stage, this one is ~50.
+MPC_HD void sincos_delta_theta(double delta, double theta, double &sd, double &cd, double &st, double &ct) {
+    const double rx = 0.5 * delta, ry = 0.25 * theta;
+    const double zx = rx * rx, zy = ry * ry;
+    double psx = fma(zx, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double psy = fma(zy, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pcx = fma(zx, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    double pcy = fma(zy, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    psx = fma(zx, psx, 2.75573137070700676789e-06);
+    psy = fma(zy, psy, 2.75573137070700676789e-06);
+    pcx = fma(zx, pcx, -2.75573143513906633035e-07);
+    pcy = fma(zy, pcy, -2.75573143513906633035e-07);
+    psx = fma(zx, psx, -1.98412698298579493134e-04);
+    psy = fma(zy, psy, -1.98412698298579493134e-04);
+    pcx = fma(zx, pcx, 2.48015872894767294178e-05);
+    pcy = fma(zy, pcy, 2.48015872894767294178e-05);
+    psx = fma(zx, psx, 8.33333333332248946124e-03);
+    psy = fma(zy, psy, 8.33333333332248946124e-03);
+    pcx = fma(zx, pcx, -1.38888888888741095749e-03);
+    pcy = fma(zy, pcy, -1.38888888888741095749e-03);
+    psx = fma(zx, psx, -1.66666666666666324348e-01);
+    psy = fma(zy, psy, -1.66666666666666324348e-01);
+    pcx = fma(zx, pcx, 4.16666666666666019037e-02);
+    pcy = fma(zy, pcy, 4.16666666666666019037e-02);
+    const double sx = fma(zx * rx, psx, rx), sy = fma(zy * ry, psy, ry);
+    const double cx = fma(zx * zx, pcx, fma(-0.5, zx, 1.0)), cy = fma(zy * zy, pcy, fma(-0.5, zy, 1.0));
+    sd = 2.0 * sx * cx;
+    cd = fma(-2.0 * sx, sx, 1.0);
+    const double s2 = 2.0 * sy * cy, c2 = fma(-2.0 * sy, sy, 1.0);     // theta / 2
+    st = 2.0 * s2 * c2;
+    ct = fma(-2.0 * s2, s2, 1.0);
+}
+
 // kinematic bicycle model (agents/pure_mpc.py:220-228): beta = atan(LENGTH_REAR/LENGTH * tan(delta)).
 // tan and atan are eliminated algebraically: with q = (4 cos^2 delta + sin^2 delta)^-1/2,
 //   cos(beta) = 2 cos(delta) q,  sin(beta) = sin(delta) q,  sin/cos(theta+beta) by the addition theorems.
 MPC_HD void dyn_eval(double theta, double delta, double &S, double &C, double &sb, double &cb) {
     double sd, cd, st, ct;
-    sincos_b(delta, sd, cd);
-    sincos_b(theta, st, ct);
+    sincos_delta_theta(delta, theta, sd, cd, st, ct);
     const double q = frsqrt(fma(3.0 * cd, cd, 1.0));
     cb = 2.0 * cd * q;
     sb = sd * q;

@@ -86,8 +86,14 @@ MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
     T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_L2, T_RIC_2X2, T_RIC_L4, T_LINEAR,
-    T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD, T_COUNT
+    T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD,
+    // finer attribution inside one rollout stage (only a profiling context with kFine = true ticks these)
+    T_R_FEEDBACK, T_R_CLAMP, T_R_DYN, T_R_STORE, T_R_CHECK, T_COUNT
 };
+template <class CTX, class = void>
+struct fine_ticks { static constexpr bool value = false; };
+template <class CTX>
+struct fine_ticks<CTX, decltype((void)CTX::kFine)> { static constexpr bool value = CTX::kFine; };
 
 // A value that differs per lane and lives across phases: one register per lane on the device; the host emulation,
 // which runs the lanes of a phase one after the other, keeps all 64.
@@ -169,6 +175,7 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //   void take(PerLane<double>& dst, PerLane<double>& src, PerLane<int>& from)   dst[l] = src[from[l]]
 //   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
 //   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
+//   void sched_fence()                           the compiler schedules no instruction across this point
 //   int opaque(int v)                            v, but the compiler cannot see that (keeps recomputable per-lane tables
 //                                                from being hoisted out of the iteration loop and held in registers)
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
@@ -444,19 +451,22 @@ struct Solver {
             bool feas = true;
 #pragma unroll 1
             for (int k = 0; k < N; ++k) {
-                const double e0 = x_0 - S(k, CB + W_X + 0), e1 = x_1 - S(k, CB + W_X + 1);
-                const double e2 = x_2 - S(k, CB + W_X + 2), e3 = x_3 - S(k, CB + W_X + 3);
+                // everything the stage reads from LDS first, in one batch (one wait instead of eight: the loads do not
+                // depend on the recursion, the arithmetic below does)
+                const double xc0 = S(k, CB + W_X + 0), xc1 = S(k, CB + W_X + 1), xc2 = S(k, CB + W_X + 2), xc3 = S(k, CB + W_X + 3);
                 const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
-                double s0 = alpha * S(k, W_KF + 0) + S(k, W_KX + 0) * e0 + S(k, W_KX + 1) * e1 + S(k, W_KX + 2) * e2 +
-                            S(k, W_KX + 3) * e3;
-                double s1 = alpha * S(k, W_KF + 1) + S(k, W_KX + 4) * e0 + S(k, W_KX + 5) * e1 + S(k, W_KX + 6) * e2 +
-                            S(k, W_KX + 7) * e3;
-                if (k >= 1) {
-                    const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);
-                    s0 += kp00 * dup0 + kp01 * dup1;
-                    s1 += kp01 * dup0 + kp11 * dup1;
-                }
+                const double kf0 = S(k, W_KF + 0), kf1 = S(k, W_KF + 1);
+                const double k00 = S(k, W_KX + 0), k01 = S(k, W_KX + 1), k02 = S(k, W_KX + 2), k03 = S(k, W_KX + 3);
+                const double k10 = S(k, W_KX + 4), k11 = S(k, W_KX + 5), k12 = S(k, W_KX + 6), k13 = S(k, W_KX + 7);
+                const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);   // zero at stage 0
                 const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+                c.sched_fence();
+                const double e0 = x_0 - xc0, e1 = x_1 - xc1, e2 = x_2 - xc2, e3 = x_3 - xc3;
+                double s0 = alpha * kf0 + k00 * e0 + k01 * e1 + k02 * e2 + k03 * e3;
+                double s1 = alpha * kf1 + k10 * e0 + k11 * e1 + k12 * e2 + k13 * e3;
+                s0 += kp00 * dup0 + kp01 * dup1;
+                s1 += kp01 * dup0 + kp11 * dup1;
+                if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
                 const double ulo0 = ulo_r(0) + fracu * (c0 - ulo_r(0)), uhi0 = uhi_r(0) - fracu * (uhi_r(0) - c0);
                 const double ulo1 = ulo_r(1) + fracu * (c1 - ulo_r(1)), uhi1 = uhi_r(1) - fracu * (uhi_r(1) - c1);
                 double u0 = fmin2(fmax2(c0 + s0, ulo0), uhi0);
@@ -467,9 +477,14 @@ struct Solver {
                     const double a = fmin2(fmax2(u0, (vlo - x_3) * idt), (vhi - x_3) * idt);
                     u0 = fmin2(fmax2(a, ulo0), uhi0);
                 }
+                if (fine_ticks<CTX>::value) c.tick(T_R_CLAMP);
                 double Sn, Cn, sb, cb_;
                 dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
                 double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+                // both trigonometric chains (delta and theta) stay in front of the branch below, where the scheduler
+                // interleaves them; without the fence the theta chain sinks behind the branch and runs on its own
+                c.sched_fence();
+                if (fine_ticks<CTX>::value) c.tick(T_R_DYN);
                 {
                     // theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
                     // node's box, take the delta that puts it on the edge of the box
@@ -495,6 +510,7 @@ struct Solver {
                 const double n0 = x_0 + dt * (x_3 * Cn);
                 const double n1 = x_1 + dt * (x_3 * Sn);
                 const double n3 = x_3 + dt * u0;
+                if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                 if (n2 - xlo_r(0) < frac * (o2 - xlo_r(0)) || xhi_r(0) - n2 < frac * (xhi_r(0) - o2) ||
                     n3 - xlo_r(1) < frac * (o3 - xlo_r(1)) || xhi_r(1) - n3 < frac * (xhi_r(1) - o3)) {
                     feas = false;
@@ -514,6 +530,7 @@ struct Solver {
                 x_1 = n1;
                 x_2 = n2;
                 x_3 = n3;
+                if (fine_ticks<CTX>::value) c.tick(T_R_CHECK);
             }
             if (feas) {
                 const int o = base + N * stride;
@@ -1021,7 +1038,8 @@ struct Solver {
                     for (int k = N - 1; k >= 0; --k) {
                         const double rdk = (k >= 1) ? rd_full : 0.0;
                         // operands that do not depend on the recursion: F in its four block arrangements, the stage
-                        // Hessian / gradient as accumulator inputs (prefetching them one stage ahead measured neutral)
+                        // Hessian / gradient as accumulator inputs (prefetching them one stage ahead measured slower,
+                        // rounds 1 and 2: 45.7 -> 48.2 us per lone-wave iteration, and it spills)
                         PerLane<double> FA0, FA1, FB0, FB1, Hm, hv;
                         load_stage_operands(k, AB, rdk, FA0, FA1, FB0, FB1, Hm, hv);
                         c.tick(T_RIC_SCALARS);
@@ -1173,18 +1191,19 @@ struct Solver {
                 double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
 #pragma unroll 1
                 for (int k = 0; k < N; ++k) {
-                    double du0 = S(k, W_KF + 0) + S(k, W_KX + 0) * d0 + S(k, W_KX + 1) * d1 + S(k, W_KX + 2) * d2 +
-                                 S(k, W_KX + 3) * d3;
-                    double du1 = S(k, W_KF + 1) + S(k, W_KX + 4) * d0 + S(k, W_KX + 5) * d1 + S(k, W_KX + 6) * d2 +
-                                 S(k, W_KX + 7) * d3;
-                    if (k >= 1) {
-                        const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);
-                        du0 += kp00 * dp0 + kp01 * dp1;
-                        du1 += kp01 * dp0 + kp11 * dp1;
-                    }
+                    // all LDS reads of the stage in one batch (they do not depend on the recursion)
+                    const double kf0 = S(k, W_KF + 0), kf1 = S(k, W_KF + 1);
+                    const double k00 = S(k, W_KX + 0), k01 = S(k, W_KX + 1), k02 = S(k, W_KX + 2), k03 = S(k, W_KX + 3);
+                    const double k10 = S(k, W_KX + 4), k11 = S(k, W_KX + 5), k12 = S(k, W_KX + 6), k13 = S(k, W_KX + 7);
+                    const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);   // zero at stage 0
                     const double a02 = S(k, W_LIN + 0), a03 = S(k, W_LIN + 1), a12 = S(k, W_LIN + 2), a13 = S(k, W_LIN + 3),
                                  a23 = S(k, W_LIN + 4);
                     const double b01 = S(k, W_LIN + 5), b11 = S(k, W_LIN + 6), b21 = S(k, W_LIN + 7);
+                    c.sched_fence();
+                    double du0 = kf0 + k00 * d0 + k01 * d1 + k02 * d2 + k03 * d3;
+                    double du1 = kf1 + k10 * d0 + k11 * d1 + k12 * d2 + k13 * d3;
+                    du0 += kp00 * dp0 + kp01 * dp1;
+                    du1 += kp01 * dp0 + kp11 * dp1;
                     const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
                     const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
                     const double n2 = d2 + a23 * d3 + b21 * du1;

@@ -80,6 +80,7 @@ struct WaveOps {
     // register pair it costs none (and when scalar registers run out the compiler parks them in lanes of a vector
     // register, 32 doubles per register, instead of spilling vector registers to scratch memory).
     __device__ __forceinline__ double uni(double v) const { return readlane_first_f64(v); }
+    __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ int opaque(int v) const {
         asm volatile("" : "+v"(v));
         return v;

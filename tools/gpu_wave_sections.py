@@ -13,7 +13,7 @@ from mpc_rl_for_avs_amd import synth
 from mpc_rl_for_avs_amd.reference_path import reference_states
 
 NAMES = ["prep", "adjoint", "dualres", "ric_assembly", "ric_operands", "ric_T", "ric_H", "ric_2x2", "ric_schur",
-         "linear", "ratios", "roll_dyn", "roll_cost", "dualupd"]
+         "linear", "ratios", "roll_dyn", "roll_cost", "dualupd", "r_feedback", "r_clamp", "r_dyn", "r_store", "r_check"]
 lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libwave_sections.so"))
 assert lib.wave_sections_count() == len(NAMES)
 dev = torch.device("cuda", 0)
@@ -49,10 +49,12 @@ def run(inp, idx, cc, V, label):
     for n, s, q in zip(NAMES, share, per_it):
         print(f"   {n:12s} {100 * s:5.1f} %   {q:8.1f} ticks/iteration")
     ric = share[3:9].sum()
-    print(f"   riccati total {100 * ric:.1f} %, rollout total {100 * share[11:13].sum():.1f} %")
+    print(f"   riccati total {100 * ric:.1f} %, rollout total {100 * (share[11:13].sum() + share[14:].sum()):.1f} % "
+          f"(the r_* rows are the parts of the rollout stages, timed in lane 0; roll_dyn is what is left of that phase)")
 
 
 inp = synth.solver_inputs(4096, 8, seed=0, N=20)
 run(inp, np.array([0]), True, 8, "typical instance alone")
 run(inp, np.array([77]), True, 8, "straggler (instance 77) alone")
-run(inp, np.arange(4096), True, 8, "whole batch (config 3)")
+if "--batch" in sys.argv:
+    run(inp, np.arange(4096), True, 8, "whole batch (config 3)")

@@ -13,12 +13,15 @@ namespace {
 
 struct ProfCtx : mpc::wave::WaveOps {
     static constexpr int kN = 20;
+    static constexpr bool kFine = true;     // also attribute the parts of a rollout stage
     const double *table;
     int e0, M;
-    unsigned long long *acc;   // [T_COUNT] of this instance (lane 0 writes)
+    unsigned long long *acc;   // [T_COUNT] accumulators of this instance in LDS, behind the solver's words (lane 0 adds)
     unsigned long long last;
     __device__ __forceinline__ ProfCtx(mpc::wave::lds_double_t *l, const double *t, int e, int m, unsigned long long *a)
         : mpc::wave::WaveOps{l}, table(t), e0(e), M(m), acc(a), last(0ull) {}
+    // LDS accumulation: a tick is the counter read plus one LDS add (a global read-modify-write per tick would cost
+    // hundreds of cycles and land in whichever section waits for memory next)
     __device__ __forceinline__ void tick(int s) {
         const unsigned long long now = __builtin_readcyclecounter();
         if (threadIdx.x == 0) acc[s] += now - last;
@@ -43,7 +46,9 @@ __global__ __launch_bounds__(64, 2) void prof_kernel(mpc::SolveParams P, int B, 
     constexpr int N = 20;
     const int b = blockIdx.x, lane = threadIdx.x;
     constexpr int SL = mpc::wave::stage_slots(CC);
-    ProfCtx ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M, cycles + (size_t)b * mpc::wave::T_COUNT);
+    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(smem + mpc::wave::lds_doubles(CC, N, P.V));
+    if (lane < mpc::wave::T_COUNT) lacc[lane] = 0ull;
+    ProfCtx ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M, lacc);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
     if (lane <= N) ctx.st(lane * SL + mpc::wave::W_RV, vref[(size_t)b * (N + 1) + lane]);
     if (CC && lane < P.V) {
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(64, 2) void prof_kernel(mpc::SolveParams P, int B, 
         status_out[b] = status;
         iters_out[b] = iters;
     }
+    if (lane < mpc::wave::T_COUNT) cycles[(size_t)b * mpc::wave::T_COUNT + lane] = lacc[lane];
 }
 }  // namespace
 
@@ -87,7 +93,7 @@ extern "C" int wave_sections(int B, int V, int cc, int max_iter, const double *r
     P.tol = 1e-8;
     P.mu_init = 0.1;
     P.w_distance = 10.0;
-    const size_t lds = (size_t)mpc::wave::lds_doubles(cc != 0, 20, P.V) * sizeof(double);
+    const size_t lds = (size_t)(mpc::wave::lds_doubles(cc != 0, 20, P.V) + mpc::wave::T_COUNT) * sizeof(double);
     if (cc) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prof_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(prof_kernel<true>, dim3(B), dim3(64), lds, 0, P, B, ref5, M, state, ego_index, vref, weights,
