@@ -100,20 +100,39 @@ MPC_HD void sincos_b(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -ca : ca;
 }
 
-// atan(t) for |t| <= ~4 (the steering angle whose tangent is t; used on the rare path that projects a rollout back
-// into the theta bounds): rational first guess, then Newton steps on sin(d) - t cos(d) = 0, whose update
-// (sin d - t cos d) / (cos d + t sin d) = tan(d - atan t) converges cubically
+// sin and cos of |x| <= pi/2 (1 + tiny) without range reduction: the fdlibm kernel polynomials at x/2 and one angle
+// doubling (absolute error < 5e-16)
+MPC_HD void sincos_half(double x, double &s, double &c) {
+    const double r = 0.5 * x, z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double sh = fma(z * r, ps, r), ch = fma(z * z, pc, fma(-0.5, z, 1.0));
+    s = 2.0 * sh * ch;
+    c = fma(-2.0 * sh, sh, 1.0);
+}
+
+// atan(t) for |t| <= ~4 (the steering angle whose tangent is t; used on the path that projects a rollout back into the
+// theta bounds): rational first guess (error < 5e-3), then two Newton steps on sin(d) - t cos(d) = 0, whose update
+// (sin d - t cos d) / (cos d + t sin d) = tan(d - atan t) converges cubically (5e-3 -> 4e-8 -> 2e-23)
 MPC_HD double atan_b(double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double at = fabs(t);
-    // |t| <= 1: t / (1 + 0.28125 t^2) (error < 5e-3); above: pi/2 - the same in 1/t
+    // |t| <= 1: t / (1 + 0.28125 t^2); above: pi/2 - the same in 1/t
     const double r = at <= 1.0 ? at : frcp(at);
     const double g = r * frcp(fma(0.28125 * r, r, 1.0));
     double d = at <= 1.0 ? g : 1.57079632679489655800e+00 - g;
 #pragma unroll 1
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 2; ++i) {
         double sd, cd;
-        sincos_b(d, sd, cd);
+        sincos_half(d, sd, cd);
         d -= fma(-at, cd, sd) * frcp(fma(at, sd, cd));
     }
     return t < 0.0 ? -d : d;

@@ -88,7 +88,7 @@ enum : int {
     T_PREP = 0, T_ADJOINT, T_DUALRES, T_RIC_INIT, T_RIC_SCALARS, T_RIC_L1, T_RIC_L2, T_RIC_2X2, T_RIC_L4, T_LINEAR,
     T_RATIOS, T_ROLL_DYN, T_ROLL_COST, T_DUALUPD,
     // finer attribution inside one rollout stage (only a profiling context with kFine = true ticks these)
-    T_R_FEEDBACK, T_R_CLAMP, T_R_DYN, T_R_STORE, T_R_CHECK, T_COUNT
+    T_R_FEEDBACK, T_R_CLAMP, T_R_DYN, T_R_STORE, T_R_CHECK, T_R_PROJ, T_R_LDSW, T_COUNT
 };
 template <class CTX, class = void>
 struct fine_ticks { static constexpr bool value = false; };
@@ -176,6 +176,7 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
 //   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
 //   void sched_fence()                           the compiler schedules no instruction across this point
+//   double keep(double v)                        v, computed by this point (an opaque use: the value cannot sink below)
 //   int opaque(int v)                            v, but the compiler cannot see that (keeps recomputable per-lane tables
 //                                                from being hoisted out of the iteration loop and held in registers)
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
@@ -483,6 +484,9 @@ struct Solver {
                 double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
                 // both trigonometric chains (delta and theta) stay in front of the branch below, where the scheduler
                 // interleaves them; without the fence the theta chain sinks behind the branch and runs on its own
+                Sn = c.keep(Sn);
+                Cn = c.keep(Cn);
+                n2 = c.keep(n2);
                 c.sched_fence();
                 if (fine_ticks<CTX>::value) c.tick(T_R_DYN);
                 {
@@ -490,14 +494,17 @@ struct Solver {
                     // node's box, take the delta that puts it on the edge of the box
                     const double tlo = xlo_r(0) + kProjKeep * (o2 - xlo_r(0)), thi = xhi_r(0) - kProjKeep * (xhi_r(0) - o2);
                     if ((n2 < tlo || n2 > thi) && x_3 > 1e-6) {
+                        if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                         const double sreq = ((n2 < tlo ? tlo : thi) - x_2) * (1.0 / kInvWheelbase) * frcp(dt * x_3);
                         if (fabs(sreq) < 0.9) {
                             u1 = fmin2(fmax2(atan_b(2.0 * sreq * frsqrt(1.0 - sreq * sreq)), ulo1), uhi1);
                             dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
                             n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
                         }
+                        if (fine_ticks<CTX>::value) c.tick(T_R_PROJ);
                     }
                 }
+                if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                 dup0 = u0 - c0;
                 dup1 = u1 - c1;
                 const int o = base + k * stride;
@@ -507,6 +514,7 @@ struct Solver {
                 c.st(o + 3, x_3);
                 c.st(o + 4, u0);
                 c.st(o + 5, u1);
+                if (fine_ticks<CTX>::value) c.tick(T_R_LDSW);
                 const double n0 = x_0 + dt * (x_3 * Cn);
                 const double n1 = x_1 + dt * (x_3 * Sn);
                 const double n3 = x_3 + dt * u0;

@@ -81,6 +81,10 @@ struct WaveOps {
     // register, 32 doubles per register, instead of spilling vector registers to scratch memory).
     __device__ __forceinline__ double uni(double v) const { return readlane_first_f64(v); }
     __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ double keep(double v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
     __device__ __forceinline__ int opaque(int v) const {
         asm volatile("" : "+v"(v));
         return v;

@@ -61,6 +61,7 @@ struct HostCtx {
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
     int opaque(int v) const { return v; }
     void sched_fence() const {}
+    double keep(double v) const { return v; }
     double uni(double v) const { return v; }
     double wave_sum(mpc::wave::PerLane<double> &p) const {
         return mpc::wave::host_reduce(p, [](double a, double b) { return a + b; });
