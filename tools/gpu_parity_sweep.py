@@ -23,13 +23,13 @@ for seed in range(1, 7):
         want = oracle_lib.solve_batch(ref, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
                                       vref=inp["vref"], others=inp["others"], collision_cost=cc, max_iter=100,
                                       xy_bounds=False)
-        both = (got["status"] == 0) & (want["status"] == 0)
+        both = ((got["status"] == 0) | (got["status"] == 5)) & ((want["status"] == 0) | (want["status"] == 5))
         err = np.abs(got["u0"] - want["u0"]).max(axis=1) / np.maximum(1.0, np.abs(want["u0"]).max(axis=1))
         bad = int((err[both] > 1e-4).sum())
         worst = max(worst, float(np.percentile(err[both], 99)))
         print(f"seed {seed} V={V} cc={int(cc)}: both converged {both.mean():.4f}, status equal {(got['status'] == want['status']).mean():.4f}, "
               f"iterations equal {(got['iters'] == want['iters'])[both].mean():.4f}, beyond 1e-4: {bad}, p99 err {np.percentile(err[both], 99):.2e}, "
-              f"gpu status {np.bincount(got['status'], minlength=5)}, finite {np.isfinite(got['u0']).all()}", flush=True)
+              f"gpu status {np.bincount(got['status'], minlength=6)}, finite {np.isfinite(got['u0']).all()}", flush=True)
 print("worst p99", worst)
 
 # ---- the iterative-linear agent's QP: first call and two re-linearised rounds per seed
