@@ -49,13 +49,16 @@ enum : int {
     W_KP = 40,   // 3
     W_KF = 43,   // 2
     W_RV = 45,   // 1
-    W_SLOTS = 46,
+    // The stage stride is kept ODD: lane k of a stage-parallel phase addresses word k * stride + slot, and with 64 LDS
+    // banks of 4 bytes an even number of doubles per stage puts every 4th (56 slots) or 16th (46, 54 slots) stage on the
+    // same banks - measured with 56 slots: SQ_LDS_BANK_CONFLICT 17 % of the LDS cycles, against 3 % in round 1.
+    W_SLOTS = 47,
     W_LX = 46,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
     W_Q = 48,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
     W_QG = 51,   // 3  its Gauss-Newton part; after the line search slot 0: vehicle a rejected trial took across d = 1
     W_ZW = 54,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
     W_WJ = 55,   // 1  its vehicle j (as a double), -1: none
-    W_SLOTS_CC = 56
+    W_SLOTS_CC = 57   // one pad slot: odd stride
 };
 // parked values (valid between the factorisation and the next preparation phase)
 enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1, W_CROSS = W_QG };

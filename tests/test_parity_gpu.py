@@ -225,7 +225,7 @@ def test_limits_of_the_interface(oracle):
     e.close()
     # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (44 KB of LDS)
     e = engine.MPCEngine(horizon=64, max_iter=100)
-    assert e.workspace_bytes(1, 16) == (56 * 65 + 4 + 64 + 3 * 6 * 65) * 8
+    assert e.workspace_bytes(1, 16) == (57 * 65 + 4 + 64 + 3 * 6 * 65) * 8
     sub = {k: (v[:24] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
     vref64 = np.concatenate([sub["vref"], np.repeat(sub["vref"][:, -1:], 44, axis=1)], axis=1)
     got = e.solve_batch(sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=vref64, others=oth16[:24],
