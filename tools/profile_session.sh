@@ -14,3 +14,12 @@ bash tools/pmc_one.sh > $O/pmc_lone_wave.txt 2>&1
 python3 tools/gpu_predict_timing.py > $O/predict.txt 2>&1
 python3 tools/gpu_parity_sweep.py > $O/parity_sweep.txt 2>&1
 ls $O
+python3 tools/gpu_ltv_timing.py > $O/ltv_timing.txt 2>&1
+python3 tools/bench_rollout.py --envs 256 --steps 64 > $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 2048 --steps 64 >> $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 8192 --steps 32 >> $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 >> $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 8192 --steps 32 --graph --groups 4 >> $O/rollout.jsonl 2>> $O/rollout.err
+BENCH_FORCE_DIST=1 python3 bench.py --steps 10 --no-side --no-cpu-baseline > $O/bench_rccl_1rank.json 2>> $O/rollout.err
+python3 tools/run_pure_mpc.py > $O/run_pure_mpc.txt 2>&1
+ls $O
