@@ -33,7 +33,11 @@
  * augmented with the previous control to carry the input-rate cost), nonlinear
  * feedback rollouts with an Armijo line search on the barrier objective,
  * fraction-to-the-boundary rule, split dual step.  The dynamics hold exactly at
- * every iterate; X[0] is pinned by X[0] = state.
+ * every iterate; X[0] is pinned by X[0] = state.  Round 2: a rollout that would take theta or v of the
+ * next node out of its bounds gets the control that decides it pulled back (PROJ_KEEP); a vehicle that a
+ * rejected trial took across the d = 1 discontinuity of the collision cost becomes a wall constraint
+ * |p - o|^2 >= 1 of that node (status 5 when it ends with a multiplier); four line-search trials.
+ * oracle_last_work() reports the iterations / sweeps / rollouts of the last call and their flops.
  */
 #include <math.h>
 #include <stdint.h>
