@@ -143,22 +143,24 @@ inline T host_reduce(PerLane<T> &p, OP op) {
 // linearised about a nominal trajectory - is made of 0, 1, dt and eight stored values a02 a03 a12 a13 a23 b01 b11 b21
 // (slots lin .. lin + 7 of the stage): LDS word of element (r, c), stage-relative (>= 0) or, for the three constants,
 // the absolute word encoded as -(word + 1).  Shared by the NLP solver and the LTV-QP solver (mpc_ltv.hpp).
+// (written as one chain of selects on the key 8 r + c: the role tables are recomputed every iteration in every lane,
+// and a per-lane `if` / `switch` cascade costs an exec-mask save / restore and a branch per case)
 MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int one, int dtw) {
-    if (r >= 6) return zero;
-    if (r == 4) return c == 6 ? one : zero;
-    if (r == 5) return c == 7 ? one : zero;
-    if (c < 4) {
-        if (r == c) return one;
-        if (r == 0 && c == 2) return lin + 0;
-        if (r == 0 && c == 3) return lin + 1;
-        if (r == 1 && c == 2) return lin + 2;
-        if (r == 1 && c == 3) return lin + 3;
-        if (r == 2 && c == 3) return lin + 4;
-        return zero;
-    }
-    if (c == 6) return r == 3 ? dtw : zero;
-    if (c == 7) return r == 0 ? lin + 5 : (r == 1 ? lin + 6 : (r == 2 ? lin + 7 : zero));
-    return zero;
+    const int key = 8 * r + c;
+    int w = zero;
+    w = (r < 4 && r == c) ? one : w;
+    w = key == 8 * 4 + 6 ? one : w;
+    w = key == 8 * 5 + 7 ? one : w;
+    w = key == 8 * 0 + 2 ? lin + 0 : w;
+    w = key == 8 * 0 + 3 ? lin + 1 : w;
+    w = key == 8 * 1 + 2 ? lin + 2 : w;
+    w = key == 8 * 1 + 3 ? lin + 3 : w;
+    w = key == 8 * 2 + 3 ? lin + 4 : w;
+    w = key == 8 * 3 + 6 ? dtw : w;
+    w = key == 8 * 0 + 7 ? lin + 5 : w;
+    w = key == 8 * 1 + 7 ? lin + 6 : w;
+    w = key == 8 * 2 + 7 ? lin + 7 : w;
+    return w;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -265,25 +267,19 @@ struct Solver {
             m_fb0.at(lane) = f_word(0 + hi, 4 * J + lo);
             m_fb1.at(lane) = f_word(4 + hi, 4 * J + lo);
             const int a = row < col ? row : col, b = row < col ? col : row;
+            const int key = a * 8 + b;
             int slot = -1;
-            double cst = 0.0;
-            switch (a * 8 + b) {
-                case 0 * 8 + 0: slot = A_L00; break;
-                case 0 * 8 + 1: slot = A_L01; break;
-                case 1 * 8 + 1: slot = A_L11; break;
-                case 2 * 8 + 2: slot = A_H22; break;
-                case 2 * 8 + 3: slot = A_H23; break;
-                case 3 * 8 + 3: slot = A_H33; break;
-                case 2 * 8 + 7: slot = A_WTD; break;
-                case 3 * 8 + 7: slot = A_WVD; break;
-                case 6 * 8 + 6: slot = A_H66; break;
-                case 7 * 8 + 7: slot = A_H77; break;
-                case 4 * 8 + 4: cst = 1.0; break;
-                case 5 * 8 + 5: cst = 1.0; break;
-                case 4 * 8 + 6: cst = -1.0; break;
-                case 5 * 8 + 7: cst = -1.0; break;
-                default: break;
-            }
+            slot = key == 0 * 8 + 0 ? A_L00 : slot;
+            slot = key == 0 * 8 + 1 ? A_L01 : slot;
+            slot = key == 1 * 8 + 1 ? A_L11 : slot;
+            slot = key == 2 * 8 + 2 ? A_H22 : slot;
+            slot = key == 2 * 8 + 3 ? A_H23 : slot;
+            slot = key == 3 * 8 + 3 ? A_H33 : slot;
+            slot = key == 2 * 8 + 7 ? A_WTD : slot;
+            slot = key == 3 * 8 + 7 ? A_WVD : slot;
+            slot = key == 6 * 8 + 6 ? A_H66 : slot;
+            slot = key == 7 * 8 + 7 ? A_H77 : slot;
+            const double cst = (key == 4 * 8 + 4 || key == 5 * 8 + 5) ? 1.0 : ((key == 4 * 8 + 6 || key == 5 * 8 + 7) ? -1.0 : 0.0);
             m_lslot.at(lane) = slot;
             m_lcst.at(lane) = cst;
             // gradient: column-0 lanes carry element `row`
@@ -496,7 +492,7 @@ struct Solver {
                     // theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
                     // node's box, take the delta that puts it on the edge of the box
                     const double tlo = xlo_r(0) + kProjKeep * (o2 - xlo_r(0)), thi = xhi_r(0) - kProjKeep * (xhi_r(0) - o2);
-                    if ((n2 < tlo || n2 > thi) && x_3 > 1e-6) {
+                    if (feas & ((n2 < tlo) | (n2 > thi)) & (x_3 > 1e-6)) {
                         if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                         const double sreq = ((n2 < tlo ? tlo : thi) - x_2) * (1.0 / kInvWheelbase) * frcp(dt * x_3);
                         if (fabs(sreq) < 0.9) {
@@ -522,19 +518,17 @@ struct Solver {
                 const double n1 = x_1 + dt * (x_3 * Sn);
                 const double n3 = x_3 + dt * u0;
                 if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
-                if (n2 - xlo_r(0) < frac * (o2 - xlo_r(0)) || xhi_r(0) - n2 < frac * (xhi_r(0) - o2) ||
-                    n3 - xlo_r(1) < frac * (o3 - xlo_r(1)) || xhi_r(1) - n3 < frac * (xhi_r(1) - o3)) {
-                    feas = false;
-                    break;
-                }
+                // a trial that leaves the fraction-to-the-boundary box is infeasible; it is integrated to the end all the
+                // same (its lane would idle otherwise): a uniform trip count and a flag instead of a per-lane `break` keep
+                // the exec-mask bookkeeping out of the loop.  Whatever an infeasible lane computes from here on is never
+                // looked at (no trap can come of it: bounded polynomials, rsq / rcp of garbage give NaN at worst).
+                feas = feas & !((n2 - xlo_r(0) < frac * (o2 - xlo_r(0))) | (xhi_r(0) - n2 < frac * (xhi_r(0) - o2)) |
+                                (n3 - xlo_r(1) < frac * (o3 - xlo_r(1))) | (xhi_r(1) - n3 < frac * (xhi_r(1) - o3)));
                 if (CC && any_wall && k + 1 < N) {
                     const double wjv = S(k + 1, W_WJ);
                     if (wjv >= 0.0) {
                         double nx, ny;
-                        if (wall_slack(k + 1, n0, n1, (int)wjv, nx, ny) < frac * S(k + 1, W_GW)) {
-                            feas = false;
-                            break;
-                        }
+                        feas = feas & !(wall_slack(k + 1, n0, n1, (int)wjv, nx, ny) < frac * S(k + 1, W_GW));
                     }
                 }
                 x_0 = n0;
@@ -543,7 +537,7 @@ struct Solver {
                 x_3 = n3;
                 if (fine_ticks<CTX>::value) c.tick(T_R_CHECK);
             }
-            if (feas) {
+            {
                 const int o = base + N * stride;
                 c.st(o + 0, x_0);
                 c.st(o + 1, x_1);
@@ -1147,20 +1141,27 @@ struct Solver {
                         //      computed while the matrix core works and scales the other operand afterwards);
                         //      P = H - H(., u) W / det;  p = h + H(., u) kf
                         PerLane<double> G, nHA, W, kfB;
-                        c.lanes([&](int lane) {
+                        // (selects between wave-uniform doubles by lane position are written as 0/1 weights: the compiler
+                        // turns `cond ? scalar_a : scalar_b` on scalar-register doubles into a branch cascade)
+                        c.lanes([&](int lane_) {
+                            const int lane = c.opaque(lane_);     // weights recomputed per stage, not kept in registers
                             const int hi = lane >> 4, lo = lane & 3;
-                            G.at(lane) = (hi == 2 && lo == 2) ? hc : ((hi == 3 && lo == 3) ? ha : ((hi >= 2 && lo >= 2) ? -hb : 0.0));
-                            W.at(lane) = 0.0;
+                            const double w22 = (hi == 2 && lo == 2) ? 1.0 : 0.0, w33 = (hi == 3 && lo == 3) ? 1.0 : 0.0;
+                            const double wof = ((hi == 2 && lo == 3) || (hi == 3 && lo == 2)) ? 1.0 : 0.0;
+                            G.at(lane_) = w22 * hc + w33 * ha - wof * hb;
+                            W.at(lane_) = 0.0;
                         });
                         c.mfma(G, HB, W);
                         const double idet = frcp(det);
                         const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
                         const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
                         dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
-                        c.lanes([&](int lane) {
-                            const int hi = lane >> 4;
-                            nHA.at(lane) = -idet * HA.at(lane);
-                            kfB.at(lane) = (m_col.at(lane) == 0) ? (hi == 2 ? kf0 : (hi == 3 ? kf1 : 0.0)) : 0.0;
+                        c.lanes([&](int lane_) {
+                            const int lane = c.opaque(lane_);
+                            const int hi = lane >> 4, col0 = (lane & 7) == 0;      // column 0 of the block: J = 0, lo = 0
+                            nHA.at(lane_) = -idet * HA.at(lane_);
+                            const double w2 = (col0 && hi == 2) ? 1.0 : 0.0, w3 = (col0 && hi == 3) ? 1.0 : 0.0;
+                            kfB.at(lane_) = w2 * kf0 + w3 * kf1;
                         });
                         c.mfma(nHA, W, Hm);      // Hm <- H - H(., u) Huu^-1 H(u, .)
                         c.mfma(HA, kfB, hv);     // hv <- h + H(., u) kf
