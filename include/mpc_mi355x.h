@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 1
+#define MPC_ABI_VERSION 2
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -73,6 +73,9 @@ typedef struct mpc_config {
     double tol;          /* scaled KKT tolerance (reference: ipopt.tol 1e-6, agents/pure_mpc.py:295); default 1e-8 */
     double w_distance;   /* cfg key weight_distance  (config/cfg.yaml:105), used with MPC_FLAG_COLLISION_COST */
     double w_collision;  /* cfg key weight_collision (config/cfg.yaml:106), used with MPC_FLAG_COLLISION_COST */
+    int32_t ltv_passes;  /* iterative-linear agent: linearisation passes per call, the trip count of the loop at
+                            agents/pure_mpc_linear.py:189 (`for _ in range(1)`); default 1 */
+    int32_t reserved0;   /* 0 */
 } mpc_config;
 
 /* ABI version of the loaded library (MPC_ABI_VERSION it was built with). */

@@ -208,15 +208,24 @@ __global__ __launch_bounds__(kBlock, 2) void mpc_ltv_kernel(
     }
     __syncthreads();
     ltv::Solver<WaveCtx<0>> solver(P, ctx, x0);
-    int status, iters;
-    solver.solve(status, iters);
-    __syncthreads();
-    const bool ok = status == ltv::ST_CONVERGED;
-    if (lane < 2) u0_out[(size_t)b * 2 + lane] = ok ? ctx.ld(ltv::L_U + lane) : 0.0;
-    if (ok && lane < N) {
-        U[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 0);
-        U[((size_t)b * N + lane) * 2 + 1] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 1);
+    // the loop of :189: every pass re-simulates the profile the previous one stored and solves the QP linearised
+    // about it; the first pass that fails ends the call with the action (0, 0) and the profile stored so far
+    int status = ltv::ST_MAX_ITER, iters = 0;
+    bool ok = false;
+#pragma unroll 1
+    for (int pass = 0; pass < P.passes; ++pass) {
+        int it = 0;
+        solver.solve(status, it);
+        iters += it;
+        __syncthreads();
+        ok = status == ltv::ST_CONVERGED;
+        if (!ok) break;
+        if (lane < N) {
+            U[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 0);
+            U[((size_t)b * N + lane) * 2 + 1] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 1);
+        }
     }
+    if (lane < 2) u0_out[(size_t)b * 2 + lane] = ok ? ctx.ld(ltv::L_U + lane) : 0.0;
     if (X_out && status != ltv::ST_INFEASIBLE)
         for (int node = lane; node <= N; node += kBlock) {
             double *o = X_out + ((size_t)b * (N + 1) + node) * 4;
@@ -429,6 +438,7 @@ void mpc_default_config(mpc_config *cfg) {
     cfg->tol = 1e-8;
     cfg->w_distance = 10.0;
     cfg->w_collision = 1.0;
+    cfg->ltv_passes = 1;
 }
 
 int mpc_create(const mpc_config *cfg, mpc_handle **out) {
@@ -439,6 +449,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
         return fail(MPC_ERR_INVALID_ARG, "mpc_create: horizon out of range");
     if (!(cfg->dt > 0.0) || cfg->max_iter < 0 || !(cfg->tol > 0.0))
         return fail(MPC_ERR_INVALID_ARG, "mpc_create: dt, max_iter and tol must be positive");
+    if (cfg->ltv_passes < 1 || cfg->ltv_passes > 16 || cfg->reserved0 != 0)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_create: ltv_passes must be 1..16 and reserved0 zero");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -738,6 +750,7 @@ static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_
     mpc::ltv::LtvParams P;
     P.N = h->cfg.horizon;
     P.max_iter = h->cfg.max_iter;
+    P.passes = h->cfg.ltv_passes;
     P.dt = h->cfg.dt;
     const size_t lds = (size_t)mpc::ltv::lds_doubles(P.N) * sizeof(double);
     static std::atomic<size_t> lds_set[kMaxDevices];

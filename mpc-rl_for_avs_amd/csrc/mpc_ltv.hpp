@@ -80,6 +80,7 @@ MPC_HD constexpr int lds_doubles(int N) { return L_SLOTS * (N + 1) + SC_SIZE; }
 struct LtvParams {
     int N;
     int max_iter;
+    int passes;   // linearisation passes per call (the loop at agents/pure_mpc_linear.py:189)
     double dt;
 };
 

@@ -39,7 +39,8 @@ class EngineError(RuntimeError):
 class _Config(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dt", ctypes.c_double),
                 ("max_iter", ctypes.c_int32), ("device", ctypes.c_int32), ("tol", ctypes.c_double),
-                ("w_distance", ctypes.c_double), ("w_collision", ctypes.c_double)]
+                ("w_distance", ctypes.c_double), ("w_collision", ctypes.c_double),
+                ("ltv_passes", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
 _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_create", "mpc_destroy",
@@ -124,13 +125,15 @@ class MPCEngine:
     """One engine per (process, GPU).  `solve_batch` replaces B calls of `PureMPC_Agent._solve`."""
 
     def __init__(self, horizon: int = 20, dt: float = 0.1, max_iter: int = 100, tol: float = 1e-8,
-                 w_distance: float = 10.0, w_collision: float = 1.0, device: int = 0, ref_table=None):
+                 w_distance: float = 10.0, w_collision: float = 1.0, device: int = 0, ref_table=None,
+                 ltv_passes: int = 1):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         cfg = _Config()
         self._lib.mpc_default_config(ctypes.byref(cfg))
         cfg.horizon, cfg.dt, cfg.max_iter, cfg.tol = int(horizon), float(dt), int(max_iter), float(tol)
         cfg.w_distance, cfg.w_collision, cfg.device = float(w_distance), float(w_collision), int(device)
+        cfg.ltv_passes = int(ltv_passes)     # iterative-linear agent only: trip count of agents/pure_mpc_linear.py:189
         rc = self._lib.mpc_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc != 0:
             self._h = ctypes.c_void_p()

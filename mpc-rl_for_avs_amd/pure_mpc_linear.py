@@ -61,8 +61,11 @@ class IterativeLinearMPC_Agent:
         if float(self.wheelbase) != 2.5:
             raise ValueError("the engine is built for the reference's wheelbase of 2.5 m (agents/pure_mpc_linear.py:131)")
         self.target_ind = 0
+        # trip count of the linearisation loop (agents/pure_mpc_linear.py:189 hard-codes 1); cfg key of this package
+        self.linearization_passes = int(self.config.get("linearization_passes", 1))
         self._engine = engine if engine is not None else MPCEngine(
-            horizon=self.horizon, dt=self.dt, max_iter=max_iter, device=device, ref_table=self.global_reference_states)
+            horizon=self.horizon, dt=self.dt, max_iter=max_iter, device=device, ref_table=self.global_reference_states,
+            ltv_passes=self.linearization_passes)
         self.last_solve = None
 
     def __str__(self):
@@ -106,10 +109,10 @@ class IterativeLinearMPC_Agent:
         out = self._engine.ltv_solve_batch(state, U)
         self.last_solve = out
         self.target_ind = int(out["target_index"][0])
-        if out["status"][0] != 0:                               # :193-196 solver failed => fallback, profile kept
+        self.oa = out["U"][0, :, 0].copy()                      # the profile of the last pass that solved (:197-198);
+        self.od = out["U"][0, :, 1].copy()                      # the stored one if the first pass failed
+        if out["status"][0] != 0:                               # :193-196 solver failed => fallback
             return MPC_Action(0.0, 0.0)
-        self.oa = out["U"][0, :, 0].copy()
-        self.od = out["U"][0, :, 1].copy()
         return MPC_Action(self.oa[0], self.od[0])
 
     # ------------------------------------------------------------------ batched API

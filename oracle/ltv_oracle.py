@@ -236,33 +236,48 @@ def _max_step_unbounded(v, dv):
     return r.min(axis=1)
 
 
-def solve_batch(ref_table, state, u_nominal, dt=0.1, max_iter=50, wheelbase=WHEELBASE):
+def solve_batch(ref_table, state, u_nominal, dt=0.1, max_iter=50, wheelbase=WHEELBASE, passes=1):
     """One call of IterativeLinearMPC_Agent._solve (pure_mpc_linear.py:153-203) for B instances.
 
     state [B,4] = (x, y, v, yaw) of the ego vehicle; u_nominal [B,T,2] = the stored profile (oa, od) (zeros on the
-    first call, :190-192).  Returns dict(u0 [B,2], U [B,T,2] new profile (unchanged where the solve failed), X [B,T+1,4],
-    status, iters, target_index, z multipliers)."""
+    first call, :190-192); passes = trip count of the loop at :189 (1 in the reference): every pass re-simulates the
+    profile the previous one stored and solves the QP linearised about it, the first failing pass ends the call with
+    the action (0, 0) and the profile stored so far (:193-196).  Returns dict(u0 [B,2], U [B,T,2] new profile, X
+    [B,T+1,4], status, iters (summed over the passes), target_index, z multipliers, u_raw, xref, and xbar of the last
+    pass each instance ran)."""
     ref_table = np.asarray(ref_table, dtype=np.float64)
     state = np.asarray(state, dtype=np.float64)
-    u_nominal = np.asarray(u_nominal, dtype=np.float64)
-    Bn, T = u_nominal.shape[0], u_nominal.shape[1]
+    U = np.array(u_nominal, dtype=np.float64, copy=True)
+    Bn, T = U.shape[0], U.shape[1]
     target = nearest_index(state[:, 0], state[:, 1], ref_table)
     xref = reference_window(ref_table, target, T)[:, :, [0, 1, 2, 3]]
-    xbar = nominal_rollout(state, u_nominal[:, :, 0], u_nominal[:, :, 1], dt, wheelbase)
     infeasible = (state[:, 2] < 0.0) | (state[:, 2] > MAX_SPEED)        # x[2, 0] == v0 against :252-256
     x0 = state.copy()
     x0[infeasible, 2] = np.clip(x0[infeasible, 2], 0.0, MAX_SPEED)    # keeps the batch finite; their result is discarded
-    qp = build_qp(x0, xref, xbar, dt, wheelbase)
-    u_start = np.zeros((Bn, 2 * T))     # the nominal profile fixes the model only; the minimiser does not depend on the start
-    u, z, status, iters = solve_qp(qp["H"], qp["g"], qp["C"], qp["c0"], u_start, max_iter=max_iter)
-    status[infeasible] = STATUS_INFEASIBLE
-    iters[infeasible] = 0
-    ok = status == STATUS_CONVERGED
-    U = np.where(ok[:, None, None], u.reshape(Bn, T, 2), u_nominal)
-    X = qp["xfree"] + np.einsum("btik,bk->bti", qp["M"], u)
-    u0 = np.where(ok[:, None], U[:, 0], 0.0)
-    return dict(u0=u0, U=U, X=X, status=status, iters=iters, target_index=target, z=z, u_raw=u.reshape(Bn, T, 2),
-                xref=xref, xbar=xbar)
+    status = np.full(Bn, STATUS_CONVERGED, dtype=np.int32)
+    iters = np.zeros(Bn, dtype=np.int32)
+    live = np.ones(Bn, dtype=bool)                                      # no pass has failed yet
+    X = np.zeros((Bn, T + 1, 4))
+    xbar = np.zeros((Bn, T + 1, 4))
+    z = u_raw = None
+    for _ in range(passes):
+        xbar_p = nominal_rollout(state, U[:, :, 0], U[:, :, 1], dt, wheelbase)
+        qp = build_qp(x0, xref, xbar_p, dt, wheelbase)
+        u_start = np.zeros((Bn, 2 * T))  # the nominal profile fixes the model only; the minimiser does not depend on the start
+        u, z_p, st_p, it_p = solve_qp(qp["H"], qp["g"], qp["C"], qp["c0"], u_start, max_iter=max_iter)
+        st_p[infeasible] = STATUS_INFEASIBLE
+        it_p[infeasible] = 0
+        if z is None:
+            z, u_raw = z_p.copy(), u.reshape(Bn, T, 2).copy()
+        z[live], u_raw[live], xbar[live] = z_p[live], u.reshape(Bn, T, 2)[live], xbar_p[live]
+        X[live] = (qp["xfree"] + np.einsum("btik,bk->bti", qp["M"], u))[live]
+        status[live] = st_p[live]
+        iters[live] += it_p[live]
+        ok = live & (st_p == STATUS_CONVERGED)
+        U[ok] = u.reshape(Bn, T, 2)[ok]
+        live = ok
+    u0 = np.where(live[:, None], U[:, 0], 0.0)
+    return dict(u0=u0, U=U, X=X, status=status, iters=iters, target_index=target, z=z, u_raw=u_raw, xref=xref, xbar=xbar)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@
 // state [B][4] = x, y, v, yaw (interface order of the reference); U [B][N][2] in: stored profile, out: new profile
 // (unchanged unless status 0); u0 [B][2] ((0, 0) unless status 0); X [B][N+1][4] predicted states (x, y, v, yaw)
 extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state, int max_iter,
-                               double *u0, double *U, double *X, int32_t *status, int32_t *iters, int32_t *target) {
+                               int passes, double *u0, double *U, double *X, int32_t *status, int32_t *iters, int32_t *target) {
     if (N > mpc::wave::kMaxHorizon || N < 1) return -1;
     std::vector<double> table((size_t)M * mpc::REF_COLS), speeds((size_t)M);
     for (int i = 0; i < M; ++i) {
@@ -25,6 +25,7 @@ extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table,
     mpc::ltv::LtvParams P;
     P.N = N;
     P.max_iter = max_iter;
+    P.passes = passes;
     P.dt = dt;
     const int nd = mpc::ltv::lds_doubles(N);
     for (int b = 0; b < B; ++b) {
@@ -46,13 +47,18 @@ extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table,
             for (int i = 0; i < 2; ++i) L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_U + i] = U[((size_t)b * N + k) * 2 + i];
         const double x0[4] = {state[4 * b + 0], state[4 * b + 1], state[4 * b + 3], state[4 * b + 2]};
         mpc::ltv::Solver<HostCtx> solver(P, ctx, x0);
-        int st, it;
-        solver.solve(st, it);
-        const bool ok = st == mpc::ltv::ST_CONVERGED;
-        for (int i = 0; i < 2; ++i) u0[2 * b + i] = ok ? L[mpc::ltv::L_U + i] : 0.0;
-        if (ok)
+        int st = mpc::ltv::ST_MAX_ITER, it = 0;
+        bool ok = false;
+        for (int pass = 0; pass < passes; ++pass) {   // the loop of agents/pure_mpc_linear.py:189, as mpc_ltv_kernel runs it
+            int it1 = 0;
+            solver.solve(st, it1);
+            it += it1;
+            ok = st == mpc::ltv::ST_CONVERGED;
+            if (!ok) break;
             for (int k = 0; k < N; ++k)
                 for (int i = 0; i < 2; ++i) U[((size_t)b * N + k) * 2 + i] = L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_U + i];
+        }
+        for (int i = 0; i < 2; ++i) u0[2 * b + i] = ok ? L[mpc::ltv::L_U + i] : 0.0;
         if (X)
             for (int k = 0; k <= N; ++k) {
                 const double *x = &L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_X];

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
             "mpc_version", "mpc_default_config", "mpc_workspace_bytes"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpc_mi355x.h but not exported"
-    assert lib.mpc_version() == 1
+    assert lib.mpc_version() == 2
     assert sorted(engine._EXPORTS) == names
 
 

@@ -96,3 +96,79 @@ def test_golden_solutions(cpu_ltv, ltv_oracle, ref_table):
     rec = np.isfinite(g["slsqp_objective"])
     assert rec.sum() >= 4
     assert (g["oracle_objective"][rec] <= g["slsqp_objective"][rec] + 1e-6 * np.abs(g["slsqp_objective"][rec])).all()
+
+
+def test_independent_fixtures(cpu_ltv, ref_table):
+    """The kernel solver against exact solutions of the QP from an independent method (Goldfarb-Idnani active set on the
+    loop transcription of the cvxpy statements, tests/golden/make_ltv_independent.py) - no interior point, no oracle."""
+    fx = np.load(os.path.join(GOLDEN, "ltv_independent_solutions.npz"))
+    for T in (20, 12):
+        st, nom, U = fx[f"state_T{T}"], fx[f"nominal_T{T}"], fx[f"U_T{T}"]
+        got = cpu_ltv(ref_table, st, nom, N=T)
+        assert (got["status"] == 0).all() and np.array_equal(got["target_index"], fx[f"target_index_T{T}"])
+        err = np.abs(got["U"] - U).reshape(len(st), -1).max(axis=1)
+        assert err.max() <= 5e-5 and np.percentile(err, 90) <= 1e-6     # see tests/test_ltv_oracle.py for the measured values
+        assert rel_u0_err(got["u0"], U[:, 0]).max() <= 1e-5
+
+
+def test_linearisation_passes(cpu_ltv, ltv_oracle, ref_table):
+    """LtvParams.passes = the trip count of the loop at agents/pure_mpc_linear.py:189."""
+    st = ltv_states(32, seed=17)
+    nom = np.zeros((32, 20, 2))
+    got = cpu_ltv(ref_table, st, nom, passes=3)
+    want = ltv_oracle.solve_batch(ref_table, st, nom, passes=3)
+    ok = want["status"] == 0
+    assert np.array_equal(got["status"], want["status"]) and ok.mean() > 0.8
+    assert rel_u0_err(got["u0"], want["u0"])[ok].max() <= TOL and np.abs(got["iters"] - want["iters"])[ok].max() <= 6
+    # the same as three calls feeding the profile back, bit for bit
+    u, its = nom, np.zeros(32, dtype=np.int64)
+    for _ in range(3):
+        o = cpu_ltv(ref_table, st, u)
+        u, its = o["U"], its + o["iters"]
+    assert np.array_equal(got["U"], o["U"]) and np.array_equal(got["u0"], o["u0"]) and np.array_equal(got["iters"], its)
+    # first pass solved, second one capped: action (0, 0), the first pass's profile stays stored
+    one = cpu_ltv(ref_table, st, nom)
+    cap = int(one["iters"][ok].max())
+    two = cpu_ltv(ref_table, st, nom, passes=2, max_iter=cap)
+    second = cpu_ltv(ref_table, st, one["U"], max_iter=cap)
+    failed = ok & (second["status"] != 0)
+    assert failed.any()
+    assert np.array_equal(two["U"][failed], one["U"][failed]) and not two["u0"][failed].any()
+    assert (two["status"][failed] == 1).all()
+
+
+def same_stage_cases(ltv_oracle, ref_table, B=24):
+    """A reference speed above MAX_SPEED and ego speeds 0.2 k below it: the optimum accelerates at the input bound for k
+    stages and lands exactly on the speed bound - acceleration bound and speed bound active in the same stage, and the
+    speed bound of the LAST node degenerate (multiplier exactly 0: the terminal cost has no speed term, Qf[2] = 0).
+    Returns the table, states and the exact minimisers (Goldfarb-Idnani on the condensed QP)."""
+    import qp_active_set as Q
+    L = ltv_oracle
+    ref = np.array(ref_table, copy=True)
+    ref[:, 2] = 15.0
+    st = ltv_states(B, seed=91)
+    st[:, 2] = np.clip(L.MAX_SPEED - 0.2 * np.random.default_rng(3).integers(0, 16, B), 0.0, L.MAX_SPEED)
+    nom = np.zeros((B, 20, 2))
+    tgt = L.nearest_index(st[:, 0], st[:, 1], ref)
+    qp = L.build_qp(st, L.reference_window(ref, tgt, 20), L.nominal_rollout(st, nom[:, :, 0], nom[:, :, 1], 0.1), 0.1)
+    exact = np.stack([Q.solve(qp["H"][b], qp["g"][b], qp["C"][b], -qp["c0"][b])[0].reshape(20, 2) for b in range(B)])
+    return ref, st, nom, exact
+
+
+def check_same_stage(got, exact, L):
+    assert (got["status"] == 0).all() and got["iters"].max() <= 30
+    a, v = got["U"][:, :, 0], got["X"][:, 1:, 2]
+    both = (np.abs(a - L.MAX_ACCEL) < 1e-6) & (v > L.MAX_SPEED - 1e-6)
+    assert both.any(axis=1).mean() > 0.8                          # the case is present
+    err = np.abs(got["U"] - exact)
+    # everything but the last acceleration is exact to rounding; that one sits sqrt(s z / H_aa) below its degenerate
+    # bound (measured 2.6e-4 ... 5.9e-4, the same in the dense-LU oracle): the central path, not the factorisation
+    assert err[:, :-1].max() <= 1e-9 and err[:, -1, 1].max() <= 1e-9
+    assert err[:, -1, 0].max() <= 1e-3
+    assert np.abs(got["u0"] - exact[:, 0]).max() <= 1e-9
+
+
+def test_bounds_active_in_the_same_stage(cpu_ltv, ltv_oracle, ref_table):
+    ref, st, nom, exact = same_stage_cases(ltv_oracle, ref_table)
+    check_same_stage(cpu_ltv(ref, st, nom), exact, ltv_oracle)
+    check_same_stage(ltv_oracle.solve_batch(ref, st, nom), exact, ltv_oracle)

@@ -199,3 +199,108 @@ def test_golden_solutions(eng):
     ok2 = g["status_second"] == 0
     assert np.array_equal(got2["status"], g["status_second"])
     assert rel_u0_err(got2["u0"], g["u0_second"])[ok2].max() <= TOL
+
+
+def test_independent_fixtures(eng, ref_table):
+    """The engine against exact solutions of the QP from an independent method (Goldfarb-Idnani active set on the loop
+    transcription of the cvxpy statements of agents/pure_mpc_linear.py:205-257, tests/golden/make_ltv_independent.py):
+    168 instances at T = 20 (first calls, random stored profiles, second calls), 48 at T = 12."""
+    from mpc_rl_for_avs_amd import engine
+    fx = np.load(os.path.join(GOLDEN, "ltv_independent_solutions.npz"))
+    for T in (20, 12):
+        e = eng if T == 20 else engine.MPCEngine(horizon=T, max_iter=50)
+        st, nom, U = fx[f"state_T{T}"], fx[f"nominal_T{T}"], fx[f"U_T{T}"]
+        got = e.ltv_solve_batch(st, nom)
+        assert (got["status"] == 0).all() and np.array_equal(got["target_index"], fx[f"target_index_T{T}"])
+        err = np.abs(got["U"] - U).reshape(len(st), -1).max(axis=1)
+        assert err.max() <= 5e-5 and np.percentile(err, 90) <= 1e-6
+        assert rel_u0_err(got["u0"], U[:, 0]).max() <= 1e-5
+        if T != 20:
+            e.close()
+
+
+def test_full_batch_certified(eng, ltv_oracle, ref_table):
+    """Every solved instance of a 4096 batch (first call, then the call linearised about its result) carries a KKT
+    certificate whose multipliers are fitted independently of the solver (NNLS on the rows within 1e-5 of their bound):
+    feasible to 1e-9, stationarity <= 1e-6 relative - for a strictly convex QP that pins the minimiser."""
+    import qp_active_set as Q
+    L = ltv_oracle
+    B = 4096
+    st = ltv_states(B, seed=77)
+    nom = np.zeros((B, 20, 2))
+    for call in range(2):
+        got = eng.ltv_solve_batch(st, nom)
+        ok = got["status"] == 0
+        assert ((got["status"] == 0) | (got["status"] == L.STATUS_INFEASIBLE)).all() and ok.mean() > 0.85
+        tgt = L.nearest_index(st[:, 0], st[:, 1], ref_table)
+        assert np.array_equal(tgt, got["target_index"])
+        worst_s = worst_v = 0.0
+        for lo in range(0, B, 512):
+            sl = slice(lo, lo + 512)
+            xref = L.reference_window(ref_table, tgt[sl], 20)
+            xbar = L.nominal_rollout(st[sl], nom[sl, :, 0], nom[sl, :, 1], 0.1)
+            x0 = st[sl].copy()
+            x0[:, 2] = np.clip(x0[:, 2], 0.0, L.MAX_SPEED)
+            qp = L.build_qp(x0, xref, xbar, 0.1)
+            for i in np.nonzero(ok[sl])[0]:
+                s, v, _ = Q.certify(qp["H"][i], qp["g"][i], qp["C"][i], qp["c0"][i], got["U"][lo + i].ravel())
+                worst_s, worst_v = max(worst_s, s), max(worst_v, v)
+        print(f"LTV call {call + 1}: {int(ok.sum())} of {B} certified, stationarity max {worst_s:.2e}, violation max {worst_v:.2e}")
+        assert worst_s <= 1e-6 and worst_v <= 1e-9
+        nom = got["U"]
+
+
+def test_linearisation_passes(ltv_oracle, ref_table):
+    """mpc_config.ltv_passes = the trip count of the loop at agents/pure_mpc_linear.py:189."""
+    from mpc_rl_for_avs_amd import engine
+    from mpc_rl_for_avs_amd.pure_mpc_linear import IterativeLinearMPC_Agent
+    st = ltv_states(256, seed=17)
+    nom = np.zeros((256, 20, 2))
+    e1 = engine.MPCEngine(horizon=20, max_iter=50)
+    e3 = engine.MPCEngine(horizon=20, max_iter=50, ltv_passes=3)
+    got = e3.ltv_solve_batch(st, nom)
+    want = ltv_oracle.solve_batch(ref_table, st, nom, passes=3)
+    ok = want["status"] == 0
+    assert np.array_equal(got["status"], want["status"]) and ok.mean() > 0.8
+    assert rel_u0_err(got["u0"], want["u0"])[ok].max() <= TOL
+    u, its = nom, np.zeros(256, dtype=np.int64)
+    for _ in range(3):
+        o = e1.ltv_solve_batch(st, u)
+        u, its = o["U"], its + o["iters"]
+    assert np.array_equal(got["U"], o["U"]) and np.array_equal(got["u0"], o["u0"]) and np.array_equal(got["iters"], its)
+    # a capped second pass: action (0, 0), the first pass's profile stays stored
+    one = e1.ltv_solve_batch(st, nom)
+    cap = int(one["iters"][ok].max())
+    ec1 = engine.MPCEngine(horizon=20, max_iter=cap)
+    ec2 = engine.MPCEngine(horizon=20, max_iter=cap, ltv_passes=2)
+    two = ec2.ltv_solve_batch(st, nom)
+    second = ec1.ltv_solve_batch(st, one["U"])
+    failed = ok & (second["status"] != 0)
+    assert failed.any()
+    assert np.array_equal(two["U"][failed], one["U"][failed]) and not two["u0"][failed].any()
+    with pytest.raises(engine.EngineError):
+        engine.MPCEngine(horizon=20, ltv_passes=0)
+
+    class Env:
+        config = {"simulation_frequency": 30, "policy_frequency": 10, "observation": {"vehicles_count": 10}}
+    agent = IterativeLinearMPC_Agent(Env, dict(horizon=20, render=False, linearization_passes=3))
+    s1 = st[ok][:1].copy()
+    s1[:, 2] = min(s1[0, 2], 10.5)
+    act = agent.predict(_obs_from_state(s1)[0])
+    parsed = np.array([[agent.ego_vehicle.position[0], agent.ego_vehicle.position[1], agent.ego_vehicle.speed,
+                        agent.ego_vehicle.heading]], dtype=np.float64)
+    want1 = ltv_oracle.solve_batch(ref_table, parsed, np.zeros((1, 20, 2)), passes=3)
+    assert rel_u0_err(act[None], want1["u0"]).max() <= TOL and np.abs(np.stack([agent.oa, agent.od], 1) - want1["U"][0]).max() <= 1e-3
+    for e in (e1, e3, ec1, ec2):
+        e.close()
+
+
+def test_bounds_active_in_the_same_stage(ltv_oracle, ref_table):
+    """Acceleration bound and speed bound active in the same stage (and a degenerate speed bound at the last node)
+    against the exact minimiser; see tests/test_ltv_cpu.py."""
+    from mpc_rl_for_avs_amd import engine
+    from test_ltv_cpu import same_stage_cases, check_same_stage
+    ref, st, nom, exact = same_stage_cases(ltv_oracle, ref_table, B=64)
+    e = engine.MPCEngine(horizon=20, max_iter=50, ref_table=ref)
+    check_same_stage(e.ltv_solve_batch(st, nom, want_traj=True), exact, ltv_oracle)
+    e.close()
