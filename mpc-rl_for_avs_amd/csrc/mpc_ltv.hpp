@@ -102,7 +102,7 @@ struct Solver {
     PerLane<double> red_a, red_b, red_c, red_d, red_e;
     PerLane<double> s_[8], z_[8], rp_[8], pr_[8];   // slack, multiplier, primal residual, predictor product per inequality
     // matrix-core roles, as in mpc_wave.hpp: lane l = 16 hi + 4 (2 I + J) + lo holds element (4 I + hi, 4 J + lo)
-    PerLane<int> m_row, m_col, m_s1a, m_s1b, m_s2a, m_s2b, m_fa0, m_fa1, m_fb0, m_fb1, m_lslot, m_gslot, m_kx;
+    PerLane<int> m_row, m_col, m_fa0, m_fa1, m_fb0, m_fb1, m_lslot, m_gslot, m_kx;
     PerLane<double> m_lsgn;
 
     // reference columns of node k: window row min(target + k, M - 1) (:178-187)
@@ -123,11 +123,6 @@ struct Solver {
             const int row = 4 * I + hi, col = 4 * J + lo;
             m_row.at(lane) = row;
             m_col.at(lane) = col;
-            const int rest = lane & ~12;
-            m_s1a.at(lane) = rest | ((0 + I) << 2);
-            m_s1b.at(lane) = rest | ((2 + I) << 2);
-            m_s2a.at(lane) = rest | ((0 + J) << 2);
-            m_s2b.at(lane) = rest | ((2 + J) << 2);
             m_fa0.at(lane) = f_word(0 + hi, 4 * I + lo);
             m_fa1.at(lane) = f_word(4 + hi, 4 * I + lo);
             m_fb0.at(lane) = f_word(0 + hi, 4 * J + lo);
@@ -262,24 +257,24 @@ struct Solver {
             });
             // T = P F   (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
             PerLane<double> PA0, PA1, Tm;
-            c.take(PA0, Pd, m_s1a);
-            c.take(PA1, Pd, m_s1b);
+            c.template take_blocks<wave::BM_K0_I>(PA0, Pd);
+            c.template take_blocks<wave::BM_K1_I>(PA1, Pd);
             c.lanes([&](int lane) { Tm.at(lane) = 0.0; });
             c.mfma(PA0, FB0, Tm);
             c.mfma(PA1, FB1, Tm);
             // H = L + F' T,  h = l + F' p   (F in the C/D layout is F' as A operand)
             PerLane<double> TB0, TB1, pB0, pB1;
-            c.take(TB0, Tm, m_s2a);
-            c.take(TB1, Tm, m_s2b);
-            c.take(pB0, pvd, m_s2a);
-            c.take(pB1, pvd, m_s2b);
+            c.template take_blocks<wave::BM_K0_J>(TB0, Tm);
+            c.template take_blocks<wave::BM_K1_J>(TB1, Tm);
+            c.template take_blocks<wave::BM_K0_J>(pB0, pvd);
+            c.template take_blocks<wave::BM_K1_J>(pB1, pvd);
             c.mfma(FA0, TB0, Hm);
             c.mfma(FA1, TB1, Hm);
             c.mfma(FA0, pB0, hv);
             c.mfma(FA1, pB1, hv);
             PerLane<double> HB, HA;
-            c.take(HB, Hm, m_s2b);
-            c.take(HA, Hm, m_s1b);
+            c.template take_blocks<wave::BM_K1_J>(HB, Hm);
+            c.template take_blocks<wave::BM_K1_I>(HA, Hm);
             // control block: elements (6,6) (6,7) (7,6) (7,7) in lanes 46 47 62 63, gradient rows 6, 7 in lanes 40, 56
             const double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
                          hc = c.lane_get(Hm, 63);

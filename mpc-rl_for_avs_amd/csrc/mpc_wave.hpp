@@ -29,6 +29,9 @@ namespace mpc {
 namespace wave {
 
 constexpr int kLanes = 64;
+// block moves of the 8x8 stage matrix (2x2 blocks of 4x4, lane = 16 hi + 4 (2 I + J) + lo): block (I, J) of the result is
+// block (K, I) [BM_K0_I, BM_K1_I] or block (K, J) [BM_K0_J, BM_K1_J] of the source
+enum : int { BM_K0_I = 0, BM_K1_I = 1, BM_K0_J = 2, BM_K1_J = 3 };
 constexpr int kTrials = 4;   // step lengths tried by the line search: a_pr * 4^-t (six gained nothing: 4083 against 4084
                              // of 4096 config-3 instances converged in the oracle, and cost 2 KB of LDS per instance)
 // A rollout that would take theta or v of the next node out of its bounds gets the one control that decides it (delta
@@ -177,7 +180,7 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //   void lanes(F f)                              f(lane) for the 64 lanes, no barrier (register-only work)
 //   void mfma(PerLane<double>& a, PerLane<double>& b, PerLane<double>& cd)   cd += a x b, v_mfma_f64_4x4x4f64:
 //        lane l = 16 hi + 4 blk + lo holds A_blk[row lo][k hi], B_blk[k hi][col lo], C/D_blk[row hi][col lo]
-//   void take(PerLane<double>& dst, PerLane<double>& src, PerLane<int>& from)   dst[l] = src[from[l]]
+//   void take_blocks<MOVE>(PerLane<double>& dst, PerLane<double>& src)   block (I, J) of dst <- block MOVE of src
 //   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
 //   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
 //   void sched_fence()                           the compiler schedules no instruction across this point
@@ -211,7 +214,6 @@ struct Solver {
     // MFMA sweep (kMfmaSweep): the 8x8 stage block lives in the C/D layout of v_mfma_f64_4x4x4f64 as 2x2 blocks of
     // 4x4: lane l = 16 hi + 4 (2 I + J) + lo holds element (row 4 I + hi, col 4 J + lo)
     PerLane<int> m_row, m_col;                     // element of this lane
-    PerLane<int> m_s1a, m_s1b, m_s2a, m_s2b;       // source lanes: block (I,J) <- block (K,I) [K = 0, 1], <- block (K,J)
     PerLane<int> m_fa0, m_fa1, m_fb0, m_fb1;       // where F[4K+hi][4I+lo] / F[4K+hi][4J+lo] sit in LDS (>= 0: stage slot)
     PerLane<int> m_lslot, m_hvslot, m_hvab, m_kx;  // stage-Hessian slot, gradient slot (column-0 lanes), gain slot to store
     PerLane<double> m_lcst;
@@ -257,11 +259,6 @@ struct Solver {
             const int row = 4 * I + hi, col = 4 * J + lo;
             m_row.at(lane) = row;
             m_col.at(lane) = col;
-            const int rest = lane & ~12;
-            m_s1a.at(lane) = rest | ((0 + I) << 2);
-            m_s1b.at(lane) = rest | ((2 + I) << 2);
-            m_s2a.at(lane) = rest | ((0 + J) << 2);
-            m_s2b.at(lane) = rest | ((2 + J) << 2);
             m_fa0.at(lane) = f_word(0 + hi, 4 * I + lo);
             m_fa1.at(lane) = f_word(4 + hi, 4 * I + lo);
             m_fb0.at(lane) = f_word(0 + hi, 4 * J + lo);
@@ -1050,18 +1047,18 @@ struct Solver {
                         c.tick(T_RIC_SCALARS);
                         // ---- T = P F  (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
                         PerLane<double> PA0, PA1, T;
-                        c.take(PA0, Pd, m_s1a);
-                        c.take(PA1, Pd, m_s1b);
+                        c.template take_blocks<BM_K0_I>(PA0, Pd);
+                        c.template take_blocks<BM_K1_I>(PA1, Pd);
                         c.lanes([&](int lane) { T.at(lane) = 0.0; });
                         c.mfma(PA0, FB0, T);
                         c.mfma(PA1, FB1, T);
                         c.tick(T_RIC_L1);
                         // ---- H = L + F' T,  h = l + F' p   (F in the C/D layout is F' as A operand)
                         PerLane<double> TB0, TB1, pB0, pB1;
-                        c.take(TB0, T, m_s2a);
-                        c.take(TB1, T, m_s2b);
-                        c.take(pB0, pvd, m_s2a);
-                        c.take(pB1, pvd, m_s2b);
+                        c.template take_blocks<BM_K0_J>(TB0, T);
+                        c.template take_blocks<BM_K1_J>(TB1, T);
+                        c.template take_blocks<BM_K0_J>(pB0, pvd);
+                        c.template take_blocks<BM_K1_J>(pB1, pvd);
                         c.mfma(FA0, TB0, Hm);
                         c.mfma(FA1, TB1, Hm);
                         c.mfma(FA0, pB0, hv);
@@ -1070,8 +1067,8 @@ struct Solver {
                         // the control rows / columns of H in the block positions the Schur complement needs them; issued
                         // before the scalar work on the 2x2 block so that the permutations overlap with it
                         PerLane<double> HB, HA;
-                        c.take(HB, Hm, m_s2b);
-                        c.take(HA, Hm, m_s1b);
+                        c.template take_blocks<BM_K1_J>(HB, Hm);
+                        c.template take_blocks<BM_K1_I>(HA, Hm);
                         // ---- 2x2 control block (uniform): elements (6,6) (6,7) (7,6) (7,7) sit in lanes 46 47 62 63,
                         //      gradient elements 6, 7 in lanes 40, 56
                         double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
@@ -1125,8 +1122,8 @@ struct Solver {
                                 }
                                 Hm.at(lane) += corr;
                             });
-                            c.take(HB, Hm, m_s2b);
-                            c.take(HA, Hm, m_s1b);
+                            c.template take_blocks<BM_K1_J>(HB, Hm);
+                            c.template take_blocks<BM_K1_I>(HA, Hm);
                             ha = c.lane_get(Hm, 46);
                             hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62));
                             hc = c.lane_get(Hm, 63);

@@ -53,9 +53,15 @@ struct HostCtx {
         }
         for (int l = 0; l < mpc::wave::kLanes; ++l) cd.v[l] = out[l];
     }
-    void take(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src, mpc::wave::PerLane<int> &from) const {
+    template <int MOVE>
+    void take_blocks(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src) const {
         double out[mpc::wave::kLanes];
-        for (int l = 0; l < mpc::wave::kLanes; ++l) out[l] = src.v[from.v[l]];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) {
+            const int blk = (l >> 2) & 3, I = blk >> 1, J = blk & 1;
+            const int K = (MOVE == mpc::wave::BM_K1_I || MOVE == mpc::wave::BM_K1_J) ? 1 : 0;
+            const int from = (MOVE == mpc::wave::BM_K0_I || MOVE == mpc::wave::BM_K1_I) ? 2 * K + I : 2 * K + J;
+            out[l] = src.v[(l & ~12) | (from << 2)];
+        }
         for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
     }
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
