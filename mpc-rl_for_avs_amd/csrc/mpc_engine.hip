@@ -43,10 +43,11 @@ int fail(int code, const std::string &msg) {
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
 constexpr int kMaxDevices = 64;
-// Waves per SIMD the wave-cooperative kernel is compiled for: 3 (168 VGPRs, 32 B/lane of scratch).  LDS (14.4 KB per
-// wave at N = 20 with the collision cost) allows 11 waves per CU.  Same box: 2 waves (209 VGPRs, no scratch) 620 k
-// solves/s for one batch of 4096, 1.58 M at B = 65536; 3 waves 645 k and 1.75 M; a 4-wave build is slower.
-constexpr int kWaveOcc = 3;
+// Waves per SIMD the wave-cooperative kernel is compiled for.  The compile-time-horizon builds fit 128 VGPRs without
+// scratch (the constants of the solve live in an LDS table, not in registers: mpc_wave.hpp) and an instance needs 9.9 KB
+// of LDS at N = 20 with the collision cost and 8 vehicles, so 16 waves share a CU: all 4096 waves of a BASELINE batch
+// are resident at once and a straggler never starts late.  The runtime-horizon build would spill at 128 and stays at 3.
+constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
@@ -409,11 +410,11 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
     if (cc) {
         if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOcc);       /* BASELINE horizon */
         else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOcc);  /* reference cfg.yaml default */
-        else MPC_LAUNCH_W(true, 0, kWaveOcc);
+        else MPC_LAUNCH_W(true, 0, kWaveOccGeneric);
     } else {
         if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOcc);
         else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOcc);
-        else MPC_LAUNCH_W(false, 0, kWaveOcc);
+        else MPC_LAUNCH_W(false, 0, kWaveOccGeneric);
     }
 #undef MPC_LAUNCH_W
     return rc;

@@ -55,21 +55,41 @@ enum : int {
     // The stage stride is kept ODD: lane k of a stage-parallel phase addresses word k * stride + slot, and with 64 LDS
     // banks of 4 bytes an even number of doubles per stage puts every 4th (56 slots) or 16th (46, 54 slots) stage on the
     // same banks - measured with 56 slots: SQ_LDS_BANK_CONFLICT 17 % of the LDS cycles, against 3 % in round 1.
-    W_SLOTS = 47,
+    W_TE = 46,   // 4  (variant without the collision cost) states of line-search trial 2, see trial_x / trial_u
+    W_SLOTS = 51,
     W_LX = 46,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
     W_Q = 48,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
-    W_QG = 51,   // 3  its Gauss-Newton part; after the line search slot 0: vehicle a rejected trial took across d = 1
+    W_QG = 51,   // 3  its Gauss-Newton part
     W_ZW = 54,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
     W_WJ = 55,   // 1  its vehicle j (as a double), -1: none
-    W_SLOTS_CC = 57   // one pad slot: odd stride
+    W_CROSS = 56,  // 1  after the line search: vehicle a rejected trial took across d = 1 (also keeps the stride odd)
+    W_SLOTS_CC = 57
 };
 // parked values (valid between the factorisation and the next preparation phase)
-enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1, W_CROSS = W_QG };
+enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1 };
+// The four trial trajectories of the line search (x 4, u 2 per node, stage stride like everything else) live in slots
+// that are dead while the line search runs, so that an instance fits in 10 KB of LDS and 16 waves share a CU:
+//   trial 0  the spare trajectory buffer (the accepted trial ends up there)
+//   trial 1  W_LIN + 0..5          the linearisation is recomputed by the next preparation phase
+//   trial 2  x: W_Q + 2 .. W_QG + 2 (collision-cost variant: curvatures, recomputed likewise) resp. W_TE; u: W_LIN + 6, 7
+//   trial 3  W_KX + 0..5           the gains of stage k have been read by all four trials (one wave, program order) when
+//                                  the stage's results are stored; nothing after the rollout reads gains
+// trial_x(t) is the slot of element 0, trial_u(t) the slot of element 4 minus 4: element e of node k sits at
+// k * stride + (e < 4 ? trial_x : trial_u) + e.  (The host model runs the lanes of a phase one after the other: trial 3,
+// the only one that overwrites something the others read, is the last lane.)
+static_assert(kTrials == 4, "the trial areas below are laid out for four trials");
+MPC_HD constexpr int trial_x(bool cc, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? (cc ? W_Q + 2 : W_TE) : W_KX)); }
+MPC_HD constexpr int trial_u(bool cc, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 2 : W_KX)); }
 // scratch behind the stage arrays: the three constants the F operands are made of besides the linearisation values
 enum : int {
     SC_SPARE = 0,  // 0.0, 1.0, dt
-    SC_SIZE = 4
+    SC_TRIG = 4,   // the sine / cosine kernel coefficients (mpc_core.hpp TrigCoef), loaded per phase
+    SC_LOG = SC_TRIG + kTrigWords,   // coefficients of log_pos
+    SC_BND = SC_LOG + kLogWords,     // the bounds of the NLP: xlo(0), xhi(0), xlo(1), xhi(1), ulo(0), uhi(0), ulo(1), uhi(1)
+    SC_K = SC_BND + 8,               // constants of this solve: objective scale and what is derived from it (K_* below)
+    SC_SIZE = SC_K + 6
 };
+enum : int { K_SF = 0, K_RD, K_RC, K_QTT, K_Q33, K_MUMIN };
 constexpr int kMaxHorizon = kLanes;   // lane k = stage k in the stage-parallel phases
 // compact stage cost Hessian / gradient, assembled for all stages before a sweep into slots that are free during it:
 // the stage's gain slots (overwritten by the gains once the stage is done) and the trial trajectory buffer
@@ -82,12 +102,8 @@ enum : int {
 };
 
 MPC_HD constexpr int stage_slots(bool cc) { return cc ? W_SLOTS_CC : W_SLOTS; }
-// doubles of one line-search trial area: (x 4, u 2) per node
-MPC_HD constexpr int trial_doubles(int N) { return 6 * (N + 1); }
-// doubles of LDS one instance needs: stage arrays + constants + other vehicles + trial areas
-MPC_HD constexpr int lds_doubles(bool cc, int N, int V) {
-    return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0) + (kTrials - 1) * trial_doubles(N);
-}
+// doubles of LDS one instance needs: stage arrays + constants + other vehicles
+MPC_HD constexpr int lds_doubles(bool cc, int N, int V) { return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0); }
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
@@ -185,6 +201,8 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
 //   void sched_fence()                           the compiler schedules no instruction across this point
 //   double keep(double v)                        v, computed by this point (an opaque use: the value cannot sink below)
+//   double fresh(double v)                       a wave-uniform v, but the compiler cannot see where it comes from (keeps
+//                                                loop-invariant expressions of solve constants out of vector registers)
 //   int opaque(int v)                            v, but the compiler cannot see that (keeps recomputable per-lane tables
 //                                                from being hoisted out of the iteration loop and held in registers)
 // The caller has already stored W_RV (all stages) and the other vehicles (x, y, dx, dy per vehicle).
@@ -193,15 +211,22 @@ template <bool CC, class CTX>
 struct Solver {
     const SolveParams &P;
     CTX &c;
-    const int N, SL, SCR, OTH, TRL;
+    const int N, SL, SCR, OTH;
     const double dt;
     double x0[4];
-    double ws_, wc_, wd_, wcoll;
+    double ws_, wc_, wd_, wcoll;   // read through WS() ... WCOLL(), SF()
     double sf = 1.0;
+    MPC_HD double SF() const { return sc(SC_K + K_SF); }
+    MPC_HD double RD() const { return sc(SC_K + K_RD); }
+    MPC_HD double RC() const { return sc(SC_K + K_RC); }
+    MPC_HD double WS() const { return c.fresh(ws_); }
+    MPC_HD double WC() const { return c.fresh(wc_); }
+    MPC_HD double WD() const { return c.fresh(wd_); }
+    MPC_HD double WCOLL() const { return c.fresh(wcoll); }
 
     MPC_HD Solver(const SolveParams &P_, CTX &c_, const double *x0_, double ws, double wc, double wd, double wcl)
-        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE), TRL(OTH + (CC ? 4 * P_.V : 0)),
-          dt(P_.dt), ws_(ws), wc_(wc), wd_(wd), wcoll(wcl) {
+        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
+          dt(P_.dt), ws_(c_.uni(ws)), wc_(c_.uni(wc)), wd_(c_.uni(wd)), wcoll(c_.uni(wcl)) {
         x0[0] = x0_[0]; x0[1] = x0_[1]; x0[2] = x0_[2]; x0[3] = x0_[3];
     }
     MPC_HD double S(int k, int slot) const { return c.ld(k * SL + slot); }
@@ -209,6 +234,27 @@ struct Solver {
     MPC_HD double sc(int i) const { return c.ld(SCR + i); }
     MPC_HD void sc(int i, double v) { c.st(SCR + i, v); }
     MPC_HD double oth(int j, int q) const { return c.ld(OTH + j * 4 + q); }
+    // Bounds and function coefficients come from a table in LDS, not from literals: a 64-bit literal that is used in
+    // more than one place gets hoisted out of the iteration loop into a register pair for the whole solve, and two dozen
+    // of those are the difference between 3 and 4 resident waves per SIMD.  A table entry is loaded where it is used
+    // (one broadcast ds_read), or once in front of a serial loop.
+    MPC_HD double xlo(int i) const { return sc(SC_BND + 0 + 2 * i); }
+    MPC_HD double xhi(int i) const { return sc(SC_BND + 1 + 2 * i); }
+    MPC_HD double ulo(int i) const { return sc(SC_BND + 4 + 2 * i); }
+    MPC_HD double uhi(int i) const { return sc(SC_BND + 5 + 2 * i); }
+    MPC_HD double flog(double x) const {
+        double K[kLogWords];
+        for (int i = 0; i < kLogWords; ++i) K[i] = sc(SC_LOG + i);
+        return log_pos(K, x);
+    }
+    MPC_HD TrigCoef trig() const {
+        TrigCoef K;
+        for (int i = 0; i < 6; ++i) {
+            K.s[i] = sc(SC_TRIG + i);
+            K.c[i] = sc(SC_TRIG + 6 + i);
+        }
+        return K;
+    }
 
     PerLane<double> red_a, red_b, red_c, red_w;   // per-lane operands of the wave reductions
     // MFMA sweep (kMfmaSweep): the 8x8 stage block lives in the C/D layout of v_mfma_f64_4x4x4f64 as 2x2 blocks of
@@ -299,9 +345,9 @@ struct Solver {
             g[0] = 10.0 * (8.0 * perp * s + 4.0 * para * cc);
             g[1] = 10.0 * (-8.0 * perp * cc + 4.0 * para * s);
             g[2] = 10.0 * dth;
-            g[3] = 20.0 * ws_ * dv;
+            g[3] = 20.0 * WS() * dv;
         }
-        return 10.0 * (4.0 * perp * perp + 2.0 * para * para + ws_ * dv * dv + 0.5 * dth * dth);
+        return 10.0 * (4.0 * perp * perp + 2.0 * para * para + WS() * dv * dv + 0.5 * dth * dth);
     }
     MPC_HD double dist(int k, double x_0, double x_1, double *d8) const {
         double J = 0.0, g0 = 0, g1 = 0, h00 = 0, h01 = 0, h11 = 0, c00 = 0, c01 = 0, c11 = 0;
@@ -310,8 +356,8 @@ struct Solver {
             const double py = x_1 - (oth(j, 1) + k * oth(j, 3));
             const double d2 = fma(px, px, py * py);
             const double rd = frsqrt(d2), d = d2 * rd;
-            const double cst = (d2 < 1.0 ? 1000.0 : 100.0) * P.w_distance;   // same expression as wall_slack() + 1
-            const double rde = frcp(d + 1e-6);
+            const double cst = (d2 < 1.0 ? c.fresh(1000.0) : c.fresh(100.0)) * P.w_distance;   // same expression as wall_slack() + 1
+            const double rde = frcp(d + c.fresh(1e-6));
             const double inv2 = rde * rde;
             J += cst * inv2;
             if (d8) {
@@ -348,35 +394,37 @@ struct Solver {
         const double x_3 = S(k, B + W_X + 3);
         double g[4];
         track(k, S(k, B + W_X + 0), S(k, B + W_X + 1), S(k, B + W_X + 2), x_3, g);
-        lx[0] = sf * g[0];
-        lx[1] = sf * g[1];
-        lx[2] = sf * g[2];
-        lx[3] = sf * g[3];
+        lx[0] = SF() * g[0];
+        lx[1] = SF() * g[1];
+        lx[2] = SF() * g[2];
+        lx[3] = SF() * g[3];
         if (CC) {
             lx[0] += S(k, W_LX + 0);
             lx[1] += S(k, W_LX + 1);
-            lx[3] += sf * 2.0 * wcoll * x_3;
+            lx[3] += SF() * 2.0 * WCOLL() * x_3;
         }
     }
 
-    // ---- objective / barrier terms of one stage of a trajectory stored at L[base + k * stride + e],
-    //      e = 0..3 state of node k, 4..5 control of stage k: control cost of stage k, tracking / collision cost and
-    //      barrier of node k + 1
-    MPC_HD void stage_terms(int base, int stride, int k, double &Jk, double &bark) const {
+    // ---- objective / barrier terms of one stage of a trajectory stored at L[k * SL + (e < 4 ? bx : bu) + e],
+    //      e = 0..3 state of node k, 4..5 control of stage k (trial_x / trial_u): control cost of stage k, tracking /
+    //      collision cost and barrier of node k + 1
+    MPC_HD void stage_terms(int bx, int bu, int k, double &Jk, double &bark) const {
+        const int stride = SL, base = bu;
         const double u0 = c.ld(base + k * stride + 4), u1 = c.ld(base + k * stride + 5);
-        double J = 0.01 * sf * wc_ * (u0 * u0 + u1 * u1);
+        const double hundredth = c.fresh(0.01);
+        double J = hundredth * SF() * WC() * (u0 * u0 + u1 * u1);
         if (k >= 1) {
             const double d0 = u0 - c.ld(base + (k - 1) * stride + 4), d1 = u1 - c.ld(base + (k - 1) * stride + 5);
-            J += 0.01 * sf * wd_ * (d0 * d0 + d1 * d1);
+            J += hundredth * SF() * WD() * (d0 * d0 + d1 * d1);
         }
-        const int nb = base + (k + 1) * stride;
+        const int nb = bx + (k + 1) * stride;
         const double y0 = c.ld(nb + 0), y1 = c.ld(nb + 1), y2 = c.ld(nb + 2), y3 = c.ld(nb + 3);
-        double slack = (((u0 - ulo_r(0)) * (uhi_r(0) - u0)) * ((u1 - ulo_r(1)) * (uhi_r(1) - u1))) *
-                       (((y2 - xlo_r(0)) * (xhi_r(0) - y2)) * ((y3 - xlo_r(1)) * (xhi_r(1) - y3)));
+        double slack = (((u0 - ulo(0)) * (uhi(0) - u0)) * ((u1 - ulo(1)) * (uhi(1) - u1))) *
+                       (((y2 - xlo(0)) * (xhi(0) - y2)) * ((y3 - xlo(1)) * (xhi(1) - y3)));
         if (k + 1 < N) {
-            J += sf * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
+            J += SF() * track(k + 1, y0, y1, y2, y3, (double *)nullptr);
             if (CC) {
-                J += sf * (dist(k + 1, y0, y1, (double *)nullptr) + wcoll * y3 * y3);
+                J += SF() * (dist(k + 1, y0, y1, (double *)nullptr) + WCOLL() * y3 * y3);
                 if (any_wall) {
                     const double wjv = S(k + 1, W_WJ);
                     if (wjv >= 0.0) {
@@ -387,12 +435,14 @@ struct Solver {
             }
         }
         Jk = J;
-        bark = -log(slack);
+        bark = -flog(slack);
     }
 
     // ---- initial rollout of the controls already in buffer 0: serial dynamics (uniform) + stage-parallel cost
     MPC_HD bool rollout_init(double &Jout, double &barout) {
         double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
+        const TrigCoef K = trig();
+        const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
             const double u0 = S(k, W_U + 0), u1 = S(k, W_U + 1);
@@ -401,12 +451,12 @@ struct Solver {
             S(k, W_X + 2, x_2);
             S(k, W_X + 3, x_3);
             double Sn, Cn, sb, cb_;
-            dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+            dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
             const double n0 = x_0 + dt * (x_3 * Cn);
             const double n1 = x_1 + dt * (x_3 * Sn);
             const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
             const double n3 = x_3 + dt * u0;
-            if (!(n2 > xlo_r(0)) || !(n2 < xhi_r(0)) || !(n3 > xlo_r(1)) || !(n3 < xhi_r(1))) return false;
+            if (!(n2 > tlo_) || !(n2 < thi_) || !(n3 > vlo_) || !(n3 < vhi_)) return false;
             x_0 = n0;
             x_1 = n1;
             x_2 = n2;
@@ -420,7 +470,7 @@ struct Solver {
             red_a.at(lane) = 0.0;
             red_b.at(lane) = 0.0;
             if (lane >= N) return;
-            stage_terms(0, SL, lane, red_a.at(lane), red_b.at(lane));
+            stage_terms(0, 0, lane, red_a.at(lane), red_b.at(lane));
         });
         Jout = c.wave_sum(red_a);
         barout = c.wave_sum(red_b);
@@ -435,17 +485,21 @@ struct Solver {
     MPC_HD bool line_search(int cur, double a_pr, double frac, double phi0, double dV1, double mu_, double &Jn,
                             double &barn, int &acc_out) {
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
-        const double fracu = 2.0 * frac, idt = 1.0 / dt;
-        const int TSZ = 6 * (N + 1);
+        const double fracu = 2.0 * frac, idt = frcp(c.fresh(dt));
         c.phase([&](int lane) {
             ls_feas.at(lane) = 0;
             if (lane >= kTrials) return;
             double alpha = a_pr;
             for (int q = 0; q < lane; ++q) alpha *= 0.25;
-            const int base = lane == 0 ? TB : TRL + (lane - 1) * TSZ, stride = lane == 0 ? SL : 6;
+            const int bx = trial_x(CC, lane, TB), bu = trial_u(CC, lane, TB);
             double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
             double dup0 = 0.0, dup1 = 0.0;
             bool feas = true;
+            const TrigCoef K = trig();
+            // the bounds, read from the table once (theta, v, a, delta)
+            const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
+            const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
+            const double keep_ = c.fresh(kProjKeep), vmin_ = c.fresh(1e-6);
 #pragma unroll 1
             for (int k = 0; k < N; ++k) {
                 // everything the stage reads from LDS first, in one batch (one wait instead of eight: the loads do not
@@ -464,19 +518,19 @@ struct Solver {
                 s0 += kp00 * dup0 + kp01 * dup1;
                 s1 += kp01 * dup0 + kp11 * dup1;
                 if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
-                const double ulo0 = ulo_r(0) + fracu * (c0 - ulo_r(0)), uhi0 = uhi_r(0) - fracu * (uhi_r(0) - c0);
-                const double ulo1 = ulo_r(1) + fracu * (c1 - ulo_r(1)), uhi1 = uhi_r(1) - fracu * (uhi_r(1) - c1);
+                const double ulo0 = alo_ + fracu * (c0 - alo_), uhi0 = ahi_ - fracu * (ahi_ - c0);
+                const double ulo1 = dlo_ + fracu * (c1 - dlo_), uhi1 = dhi_ - fracu * (dhi_ - c1);
                 double u0 = fmin2(fmax2(c0 + s0, ulo0), uhi0);
                 double u1 = fmin2(fmax2(c1 + s1, ulo1), uhi1);
                 {
                     // v of node k+1 is decided by a_k alone: keep it inside the node's box (kProjKeep of its slack)
-                    const double vlo = xlo_r(1) + kProjKeep * (o3 - xlo_r(1)), vhi = xhi_r(1) - kProjKeep * (xhi_r(1) - o3);
+                    const double vlo = vlo_ + keep_ * (o3 - vlo_), vhi = vhi_ - keep_ * (vhi_ - o3);
                     const double a = fmin2(fmax2(u0, (vlo - x_3) * idt), (vhi - x_3) * idt);
                     u0 = fmin2(fmax2(a, ulo0), uhi0);
                 }
                 if (fine_ticks<CTX>::value) c.tick(T_R_CLAMP);
                 double Sn, Cn, sb, cb_;
-                dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+                dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
                 double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
                 // both trigonometric chains (delta and theta) stay in front of the branch below, where the scheduler
                 // interleaves them; without the fence the theta chain sinks behind the branch and runs on its own
@@ -488,13 +542,13 @@ struct Solver {
                 {
                     // theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
                     // node's box, take the delta that puts it on the edge of the box
-                    const double tlo = xlo_r(0) + kProjKeep * (o2 - xlo_r(0)), thi = xhi_r(0) - kProjKeep * (xhi_r(0) - o2);
-                    if (feas & ((n2 < tlo) | (n2 > thi)) & (x_3 > 1e-6)) {
+                    const double tlo = tlo_ + keep_ * (o2 - tlo_), thi = thi_ - keep_ * (thi_ - o2);
+                    if (feas & ((n2 < tlo) | (n2 > thi)) & (x_3 > vmin_)) {
                         if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                         const double sreq = ((n2 < tlo ? tlo : thi) - x_2) * (1.0 / kInvWheelbase) * frcp(dt * x_3);
                         if (fabs(sreq) < 0.9) {
-                            u1 = fmin2(fmax2(atan_b(2.0 * sreq * frsqrt(1.0 - sreq * sreq)), ulo1), uhi1);
-                            dyn_eval(x_2, u1, Sn, Cn, sb, cb_);
+                            u1 = fmin2(fmax2(atan_b(K, 2.0 * sreq * frsqrt(1.0 - sreq * sreq)), ulo1), uhi1);
+                            dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
                             n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
                         }
                         if (fine_ticks<CTX>::value) c.tick(T_R_PROJ);
@@ -503,13 +557,13 @@ struct Solver {
                 if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                 dup0 = u0 - c0;
                 dup1 = u1 - c1;
-                const int o = base + k * stride;
+                const int o = bx + k * SL, ou = bu + k * SL;
                 c.st(o + 0, x_0);
                 c.st(o + 1, x_1);
                 c.st(o + 2, x_2);
                 c.st(o + 3, x_3);
-                c.st(o + 4, u0);
-                c.st(o + 5, u1);
+                c.st(ou + 4, u0);
+                c.st(ou + 5, u1);
                 if (fine_ticks<CTX>::value) c.tick(T_R_LDSW);
                 const double n0 = x_0 + dt * (x_3 * Cn);
                 const double n1 = x_1 + dt * (x_3 * Sn);
@@ -519,8 +573,8 @@ struct Solver {
                 // same (its lane would idle otherwise): a uniform trip count and a flag instead of a per-lane `break` keep
                 // the exec-mask bookkeeping out of the loop.  Whatever an infeasible lane computes from here on is never
                 // looked at (no trap can come of it: bounded polynomials, rsq / rcp of garbage give NaN at worst).
-                feas = feas & !((n2 - xlo_r(0) < frac * (o2 - xlo_r(0))) | (xhi_r(0) - n2 < frac * (xhi_r(0) - o2)) |
-                                (n3 - xlo_r(1) < frac * (o3 - xlo_r(1))) | (xhi_r(1) - n3 < frac * (xhi_r(1) - o3)));
+                feas = feas & !((n2 - tlo_ < frac * (o2 - tlo_)) | (thi_ - n2 < frac * (thi_ - o2)) |
+                                (n3 - vlo_ < frac * (o3 - vlo_)) | (vhi_ - n3 < frac * (vhi_ - o3)));
                 if (CC && any_wall && k + 1 < N) {
                     const double wjv = S(k + 1, W_WJ);
                     if (wjv >= 0.0) {
@@ -535,7 +589,7 @@ struct Solver {
                 if (fine_ticks<CTX>::value) c.tick(T_R_CHECK);
             }
             {
-                const int o = base + N * stride;
+                const int o = bx + N * SL;
                 c.st(o + 0, x_0);
                 c.st(o + 1, x_1);
                 c.st(o + 2, x_2);
@@ -557,18 +611,17 @@ struct Solver {
                     red_b.at(lane) = 0.0;
                     const int h = lane >> 5, k = lane & 31, t = 2 * p + h;
                     if (k >= N || !(h ? f1 : f0)) return;
-                    const int base = t == 0 ? TB : TRL + (t - 1) * TSZ, stride = t == 0 ? SL : 6;
-                    stage_terms(base, stride, k, red_a.at(lane), red_b.at(lane));
+                    stage_terms(trial_x(CC, t, TB), trial_u(CC, t, TB), k, red_a.at(lane), red_b.at(lane));
                 });
                 double J0, J1, b0, b1;
                 c.wave_sum2(red_a, J0, J1);
                 c.wave_sum2(red_b, b0, b1);
                 const double a1 = alpha * 0.25;
-                if (f0 && J0 + mu_ * b0 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                if (f0 && J0 + mu_ * b0 <= phi0 + c.fresh(1e-4) * alpha * 2.0 * dV1 + c.fresh(1e-12) * fabs(phi0)) {
                     acc = 2 * p;
                     Jn = J0;
                     barn = b0;
-                } else if (f1 && J1 + mu_ * b1 <= phi0 + 1e-4 * a1 * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                } else if (f1 && J1 + mu_ * b1 <= phi0 + c.fresh(1e-4) * a1 * 2.0 * dV1 + c.fresh(1e-12) * fabs(phi0)) {
                     acc = 2 * p + 1;
                     Jn = J1;
                     barn = b1;
@@ -584,11 +637,10 @@ struct Solver {
                     red_a.at(lane) = 0.0;
                     red_b.at(lane) = 0.0;
                     if (lane >= N) return;
-                    const int base = t == 0 ? TB : TRL + (t - 1) * TSZ, stride = t == 0 ? SL : 6;
-                    stage_terms(base, stride, lane, red_a.at(lane), red_b.at(lane));
+                    stage_terms(trial_x(CC, t, TB), trial_u(CC, t, TB), lane, red_a.at(lane), red_b.at(lane));
                 });
                 const double J0 = c.wave_sum(red_a), b0 = c.wave_sum(red_b);
-                if (J0 + mu_ * b0 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
+                if (J0 + mu_ * b0 <= phi0 + c.fresh(1e-4) * alpha * 2.0 * dV1 + c.fresh(1e-12) * fabs(phi0)) {
                     acc = t;
                     Jn = J0;
                     barn = b0;
@@ -614,7 +666,7 @@ struct Solver {
                     bool crossed = false;
                     for (int t = 0; t < nrej; ++t) {
                         if (!fe[t]) continue;
-                        const int o = (t == 0 ? TB + k * SL : TRL + (t - 1) * TSZ + k * 6);
+                        const int o = trial_x(CC, t, TB) + k * SL;
                         if (wall_slack(k, c.ld(o + 0), c.ld(o + 1), j, nx, ny) < 0.0) crossed = true;
                     }
                     if (crossed) {
@@ -626,10 +678,10 @@ struct Solver {
             });
         }
         if (acc >= 1) {
-            const int base = TRL + (acc - 1) * TSZ;
+            const int bx = trial_x(CC, acc, TB), bu = trial_u(CC, acc, TB);
             c.phase([&](int lane) {
                 for (int node = lane; node <= N; node += kLanes)
-                    for (int e = 0; e < (node < N ? 6 : 4); ++e) S(node, TB + e, c.ld(base + node * 6 + e));
+                    for (int e = 0; e < (node < N ? 6 : 4); ++e) S(node, TB + e, c.ld(node * SL + (e < 4 ? bx : bu) + e));
             });
         }
         c.tick(T_ROLL_COST);
@@ -649,6 +701,15 @@ struct Solver {
         sc(SC_SPARE + 0, 0.0);   // the constants F is made of besides the linearisation values (fetched by address)
         sc(SC_SPARE + 1, 1.0);
         sc(SC_SPARE + 2, dt);
+        for (int i = 0; i < kTrigWords; ++i) sc(SC_TRIG + i, trig_coef(i));
+        for (int i = 0; i < kLogWords; ++i) sc(SC_LOG + i, log_coef(i));
+        sc(SC_K + K_SF, 1.0);            // until the objective scale is known (below)
+        for (int i = 0; i < 2; ++i) {
+            sc(SC_BND + 0 + 2 * i, xlo_r(i));
+            sc(SC_BND + 1 + 2 * i, xhi_r(i));
+            sc(SC_BND + 4 + 2 * i, ulo_r(i));
+            sc(SC_BND + 5 + 2 * i, uhi_r(i));
+        }
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;
@@ -694,16 +755,20 @@ struct Solver {
                 }
                 red_a.at(lane) = g;
             });
-            const double gmax = fmax2(0.02 * (wc_ + wd_) * fabs(S(0, W_U + 0)), c.wave_max(red_a));
+            const double gmax = fmax2(0.02 * (WC() + WD()) * fabs(S(0, W_U + 0)), c.wave_max(red_a));
             sf = c.uni(100.0 / fmin2(fmax2(100.0, gmax), 1e4));
             Jcur = c.uni(Jcur * sf);
             barcur = c.uni(barcur);
         }
         // wave-uniform doubles that live across the whole solve: in scalar registers (CTX::uni), not in vector registers
-        const double rd_full = c.uni(0.02 * sf * wd_), rc = c.uni(0.02 * sf * wc_), qtt = c.uni(10.0 * sf);
-        const double q33 = c.uni(sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0)));
+        // wave-uniform constants of the solve: in the LDS table (read where they are used), not in registers
+        sc(SC_K + K_SF, sf);
+        sc(SC_K + K_RD, 0.02 * sf * wd_);
+        sc(SC_K + K_RC, 0.02 * sf * wc_);
+        sc(SC_K + K_QTT, 10.0 * sf);
+        sc(SC_K + K_Q33, sf * (20.0 * ws_ + (CC ? 2.0 * wcoll : 0.0)));
+        sc(SC_K + K_MUMIN, P.tol / 10.0);
         double mu = P.mu_init;
-        const double mu_min = c.uni(P.tol / 10.0);
         int iter = 0, nfail = 0;
         double reg = 0.0;
 
@@ -726,7 +791,7 @@ struct Solver {
                              xk3 = S(k, CB + W_X + 3);
                 {
                     double Sn, Cn, sb, cb_, bp, bpp;
-                    dyn_eval(xk2, u1, Sn, Cn, sb, cb_);
+                    dyn_eval(trig(), xk2, u1, Sn, Cn, sb, cb_);
                     beta_derivs(sb, cb_, bp, bpp);
                     S(k, W_LIN + 0, -dt * xk3 * Sn);
                     S(k, W_LIN + 1, dt * Cn);
@@ -743,21 +808,21 @@ struct Solver {
                 if (k >= 1) {
                     double g[4];
                     track(k, xk0, xk1, xk2, xk3, g);
-                    double lx0 = sf * g[0], lx1 = sf * g[1], lx2 = sf * g[2], lx3 = sf * g[3];
+                    double lx0 = SF() * g[0], lx1 = SF() * g[1], lx2 = SF() * g[2], lx3 = SF() * g[3];
                     if (CC) {
                         double d8[8];
                         dist(k, xk0, xk1, d8);
-                        S(k, W_LX + 0, sf * d8[0]);
-                        S(k, W_LX + 1, sf * d8[1]);
-                        S(k, W_Q + 0, sf * d8[2]);
-                        S(k, W_Q + 1, sf * d8[3]);
-                        S(k, W_Q + 2, sf * d8[4]);
-                        S(k, W_QG + 0, sf * d8[5]);
-                        S(k, W_QG + 1, sf * d8[6]);
-                        S(k, W_QG + 2, sf * d8[7]);
-                        lx0 += sf * d8[0];
-                        lx1 += sf * d8[1];
-                        lx3 += sf * 2.0 * wcoll * xk3;
+                        S(k, W_LX + 0, SF() * d8[0]);
+                        S(k, W_LX + 1, SF() * d8[1]);
+                        S(k, W_Q + 0, SF() * d8[2]);
+                        S(k, W_Q + 1, SF() * d8[3]);
+                        S(k, W_Q + 2, SF() * d8[4]);
+                        S(k, W_QG + 0, SF() * d8[5]);
+                        S(k, W_QG + 1, SF() * d8[6]);
+                        S(k, W_QG + 2, SF() * d8[7]);
+                        lx0 += SF() * d8[0];
+                        lx1 += SF() * d8[1];
+                        lx3 += SF() * 2.0 * WCOLL() * xk3;
                         if (any_wall) {
                             const double wjv = S(k, W_WJ);
                             if (wjv >= 0.0) {
@@ -783,15 +848,15 @@ struct Solver {
                 const double zul0 = S(k, W_ZUL + 0), zul1 = S(k, W_ZUL + 1), zuu0 = S(k, W_ZUU + 0), zuu1 = S(k, W_ZUU + 1);
                 double cmx, cmn, sz = zul0 + zul1 + zuu0 + zuu1;
                 {
-                    const double c0 = (u0 - ulo_r(0)) * zul0, c1 = (uhi_r(0) - u0) * zuu0;
-                    const double c2 = (u1 - ulo_r(1)) * zul1, c3 = (uhi_r(1) - u1) * zuu1;
+                    const double c0 = (u0 - ulo(0)) * zul0, c1 = (uhi(0) - u0) * zuu0;
+                    const double c2 = (u1 - ulo(1)) * zul1, c3 = (uhi(1) - u1) * zuu1;
                     cmx = fmax2(fmax2(c0, c1), fmax2(c2, c3));
                     cmn = fmin2(fmin2(c0, c1), fmin2(c2, c3));
                 }
                 for (int i = 0; i < 2; ++i) {
                     const double xi = S(k + 1, CB + W_X + 2 + i);
                     const double zl = S(k + 1, W_ZXL + i), zu = S(k + 1, W_ZXU + i);
-                    const double c0 = (xi - xlo_r(i)) * zl, c1 = (xhi_r(i) - xi) * zu;
+                    const double c0 = (xi - xlo(i)) * zl, c1 = (xhi(i) - xi) * zu;
                     cmx = fmax2(cmx, fmax2(c0, c1));
                     cmn = fmin2(cmn, fmin2(c0, c1));
                     sz += zl + zu;
@@ -869,6 +934,7 @@ struct Solver {
                     return;
                 }
                 const int k = lane;
+                const double rd_full = RD(), rc = RC();
                 const double rdk = (k >= 1) ? rd_full : 0.0;
                 const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
                 double um0 = 0.0, um1 = 0.0;
@@ -893,8 +959,8 @@ struct Solver {
             for (;;) {
                 const double ec = fmax2(cmax - mu, mu - cmin);
                 const double E_mu = fmax2(err_d / s_d, ec / s_c);
-                if (E_mu <= 10.0 * mu && mu > mu_min) {
-                    mu = c.uni(fmax2(mu_min, fmin2(0.2 * mu, mu * sqrt(mu))));
+                if (E_mu <= 10.0 * mu && mu > sc(SC_K + K_MUMIN)) {
+                    mu = c.uni(fmax2(sc(SC_K + K_MUMIN), fmin2(c.fresh(0.2) * mu, mu * sqrt(mu))));
                     continue;
                 }
                 break;
@@ -902,7 +968,7 @@ struct Solver {
             const double E0 = fmax2(err_d / s_d, cmax / s_c);
             kkt_out = E0;
             if (E0 <= P.tol) {
-                status_out = (CC && zw_max > 1e-6 * sf) ? 5 : 0;
+                status_out = (CC && zw_max > c.fresh(1e-6) * SF()) ? 5 : 0;
                 break;
             }
             if (iter == P.max_iter) break;
@@ -925,7 +991,8 @@ struct Solver {
                     if (lane >= N) return;
                     // ---- stage cost Hessian / gradient of stage k = lane (compact: the 10 distinct entries + 8 gradients)
                     const int k = lane;
-                    const double rdk = (k >= 1) ? rd_full : 0.0;
+                    const double rc = RC(), qtt = sc(SC_K + K_QTT), q33 = sc(SC_K + K_Q33);
+                    const double rdk = (k >= 1) ? RD() : 0.0;
                     const double v = S(k, CB + W_X + 3);
                     const double u0 = S(k, CB + W_U + 0), u1 = S(k, CB + W_U + 1);
                     double sig[4], sgr[4];
@@ -933,7 +1000,7 @@ struct Solver {
                         const bool isx = q < 2;
                         const int b = isx ? q : q - 2;
                         const double val = isx ? S(k, CB + W_X + 2 + b) : (b == 0 ? u0 : u1);
-                        const double lo = isx ? xlo_r(b) : ulo_r(b), hi = isx ? xhi_r(b) : uhi_r(b);
+                        const double lo = isx ? xlo(b) : ulo(b), hi = isx ? xhi(b) : uhi(b);
                         const double zl = isx ? S(k, W_ZXL + b) : S(k, W_ZUL + b);
                         const double zu = isx ? S(k, W_ZXU + b) : S(k, W_ZUU + b);
                         const double rl = frcp(val - lo), ru = frcp(hi - val);
@@ -943,7 +1010,7 @@ struct Solver {
                     double wdd = 0.0, wtt = 0.0, wtv = 0.0, wtd = 0.0, wvd = 0.0;
                     if (!gn) {
                         double Sn, Cn, sb, cb_, bp, bpp;
-                        dyn_eval(S(k, CB + W_X + 2), u1, Sn, Cn, sb, cb_);
+                        dyn_eval(trig(), S(k, CB + W_X + 2), u1, Sn, Cn, sb, cb_);
                         beta_derivs(sb, cb_, bp, bpp);
                         const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
                         const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
@@ -959,9 +1026,9 @@ struct Solver {
                         double lx[4];
                         cost_grad(cur, k, lx);
                         const double s = c.ref(k, R_SIN), cc = c.ref(k, R_COS);
-                        l00 = sf * 10.0 * (8.0 * s * s + 4.0 * cc * cc) + delta_w;
-                        l01 = sf * 10.0 * (-8.0 * s * cc + 4.0 * cc * s);
-                        l11 = sf * 10.0 * (8.0 * cc * cc + 4.0 * s * s) + delta_w;
+                        l00 = SF() * 10.0 * (8.0 * s * s + 4.0 * cc * cc) + delta_w;
+                        l01 = SF() * 10.0 * (-8.0 * s * cc + 4.0 * cc * s);
+                        l11 = SF() * 10.0 * (8.0 * cc * cc + 4.0 * s * s) + delta_w;
                         if (CC) {
                             const int QS = gn ? W_QG : W_Q;
                             l00 += S(k, QS + 0);
@@ -1023,7 +1090,7 @@ struct Solver {
                     double tsig[2], tgr[2];
                     for (int i = 0; i < 2; ++i) {
                         const double xi = S(N, CB + W_X + 2 + i);
-                        const double rl = frcp(xi - xlo_r(i)), ru = frcp(xhi_r(i) - xi);
+                        const double rl = frcp(xi - xlo(i)), ru = frcp(xhi(i) - xi);
                         tsig[i] = S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w;
                         tgr[i] = mu * (ru - rl);
                     }
@@ -1036,6 +1103,7 @@ struct Solver {
                         pvd.at(lane) = cl == 0 ? (r == 2 ? tgr[0] : (r == 3 ? tgr[1] : 0.0)) : 0.0;
                     });
                     c.tick(T_RIC_INIT);
+                    const double rd_full = RD();
 #pragma unroll 1
                     for (int k = N - 1; k >= 0; --k) {
                         const double rdk = (k >= 1) ? rd_full : 0.0;
@@ -1075,7 +1143,7 @@ struct Solver {
                                hc = c.lane_get(Hm, 63);
                         const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
                         double det = ha * hc - hb * hb;
-                        if ((!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) && !gn) {
+                        if ((!(ha > 0.0) || !(hc > 0.0) || !(det > c.fresh(1e-12) * ha * hc)) && !gn) {
                             // not positive definite with the exact Hessian: this stage alone falls back to its
                             // Gauss-Newton terms (constraint curvature off, radial part of the collision potential) -
                             // they are taken out of H, the products with P stay
@@ -1083,7 +1151,7 @@ struct Solver {
                             {
                                 const double v = S(k, CB + W_X + 3);
                                 double Sn, Cn, sb, cb_, bp, bpp;
-                                dyn_eval(S(k, CB + W_X + 2), S(k, CB + W_U + 1), Sn, Cn, sb, cb_);
+                                dyn_eval(trig(), S(k, CB + W_X + 2), S(k, CB + W_U + 1), Sn, Cn, sb, cb_);
                                 beta_derivs(sb, cb_, bp, bpp);
                                 const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
                                 const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
@@ -1129,7 +1197,7 @@ struct Solver {
                             hc = c.lane_get(Hm, 63);
                             det = ha * hc - hb * hb;
                         }
-                        if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-12 * ha * hc)) {
+                        if (!(ha > 0.0) || !(hc > 0.0) || !(det > c.fresh(1e-12) * ha * hc)) {
                             ok = false;
                             break;
                         }
@@ -1183,7 +1251,7 @@ struct Solver {
                     if (!gn) {
                         gn = true;
                     } else {
-                        delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
+                        delta_w = (delta_w == 0.0) ? c.fresh(1e-8) : c.fresh(100.0) * delta_w;
                     }
                     if (delta_w > 1e40) break;
                 }
@@ -1243,7 +1311,7 @@ struct Solver {
                 for (int i = 0; i < 4; ++i) {
                     const bool isu = i < 2;
                     const int j = isu ? i : i - 2;
-                    const double lo = isu ? ulo_r(j) : xlo_r(j), hi = isu ? uhi_r(j) : xhi_r(j);
+                    const double lo = isu ? ulo(j) : xlo(j), hi = isu ? uhi(j) : xhi(j);
                     const int kk = isu ? k : k + 1;
                     const double val = isu ? S(kk, CB + W_U + j) : S(kk, CB + W_X + 2 + j);
                     const double d = S(kk, W_Y + i);
@@ -1308,7 +1376,7 @@ struct Solver {
                     for (int i = 0; i < 4; ++i) {
                         const bool isu = i < 2;
                         const int j = isu ? i : i - 2;
-                        const double lo = isu ? ulo_r(j) : xlo_r(j), hi = isu ? uhi_r(j) : xhi_r(j);
+                        const double lo = isu ? ulo(j) : xlo(j), hi = isu ? uhi(j) : xhi(j);
                         const int kk = isu ? k : k + 1;
                         const int sv = isu ? (W_U + j) : (W_X + 2 + j);
                         const int szl = isu ? (W_ZUL + j) : (W_ZXL + j), szu = isu ? (W_ZUU + j) : (W_ZXU + j);
@@ -1317,8 +1385,8 @@ struct Solver {
                         const double dzl = (mu - zl * d) * frcp(val - lo) - zl, dzu = (mu + zu * d) * frcp(hi - val) - zu;
                         const double vn = S(kk, NB + sv);
                         const double ml = mu * frcp(vn - lo), mh = mu * frcp(hi - vn);
-                        S(kk, szl, fmax2(fmin2(zl + (dzl > 0.0 ? 1.0 : a_du) * dzl, 1e10 * ml), 1e-10 * ml));
-                        S(kk, szu, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : a_du) * dzu, 1e10 * mh), 1e-10 * mh));
+                        S(kk, szl, fmax2(fmin2(zl + (dzl > 0.0 ? 1.0 : a_du) * dzl, c.fresh(1e10) * ml), c.fresh(1e-10) * ml));
+                        S(kk, szu, fmax2(fmin2(zu + (dzu > 0.0 ? 1.0 : a_du) * dzu, c.fresh(1e10) * mh), c.fresh(1e-10) * mh));
                     }
                 });
                 // wall constraints: dual step of the active ones; a vehicle that a rejected trial took across d = 1
@@ -1335,7 +1403,7 @@ struct Solver {
                         if (wjv >= 0.0) {
                             gcur = wall_slack(kn, xn0, xn1, (int)wjv, nx, ny);
                             const double zw = S(kn, W_ZW), dzw = S(kn, W_DZW), ml = mu * frcp(gcur);
-                            S(kn, W_ZW, fmax2(fmin2(zw + (dzw > 0.0 ? 1.0 : a_du) * dzw, 1e10 * ml), 1e-10 * ml));
+                            S(kn, W_ZW, fmax2(fmin2(zw + (dzw > 0.0 ? 1.0 : a_du) * dzw, c.fresh(1e10) * ml), c.fresh(1e-10) * ml));
                             flag = 1.0;
                         }
                         if (cr >= 0.0 && cr != wjv) {
@@ -1344,7 +1412,7 @@ struct Solver {
                                 S(kn, W_WJ, cr);
                                 S(kn, W_ZW, mu * frcp(gc));
                                 // the barrier value carried for the current point changes with the constraint set
-                                red_b.at(lane) = (wjv >= 0.0 ? log(gcur) : 0.0) - log(gc);
+                                red_b.at(lane) = (wjv >= 0.0 ? flog(gcur) : 0.0) - flog(gc);
                                 flag = 3.0;
                             }
                         }

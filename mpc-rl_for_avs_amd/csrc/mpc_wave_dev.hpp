@@ -110,6 +110,15 @@ struct WaveOps {
         asm volatile("" : "+v"(v));
         return v;
     }
+    // A wave-uniform double (or a literal) as a value the compiler cannot trace back: whatever is computed from it is
+    // computed where it is used.  Otherwise every loop-invariant product of solve constants (0.01 sf wc, 1/dt, ...) and
+    // every 64-bit literal used twice is hoisted out of the iteration loop into a vector register pair for the whole
+    // solve - 40 registers of the 128 a wave may hold if four waves are to share a SIMD.
+    __device__ __forceinline__ double fresh(double v) const {
+        v = readlane_first_f64(v);       // folds away for a value that already lives in scalar registers
+        asm volatile("" : "+s"(v));
+        return v;
+    }
     __device__ __forceinline__ int opaque(int v) const {
         asm volatile("" : "+v"(v));
         return v;

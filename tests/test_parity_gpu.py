@@ -223,9 +223,14 @@ def test_limits_of_the_interface(oracle):
         e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
                       others=np.concatenate([oth16, far[:, :1]], axis=1), collision_cost=True)      # 17 vehicles
     e.close()
-    # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (44 KB of LDS)
+    # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (30 KB of LDS):
+    # 57 slots per node, the table of constants (3 + 1, 12 trig, 10 log, 8 bounds, 6 solve constants), 4 per vehicle;
+    # the BASELINE shape (horizon 20, 8 vehicles) is 9.9 KB, i.e. 16 instances per CU
     e = engine.MPCEngine(horizon=64, max_iter=100)
-    assert e.workspace_bytes(1, 16) == (57 * 65 + 4 + 64 + 3 * 6 * 65) * 8
+    assert e.workspace_bytes(1, 16) == (57 * 65 + 40 + 64) * 8
+    e20 = engine.MPCEngine(horizon=20, max_iter=100)
+    assert e20.workspace_bytes(1, 8) == (57 * 21 + 40 + 32) * 8 <= 10240
+    e20.close()
     sub = {k: (v[:24] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
     vref64 = np.concatenate([sub["vref"], np.repeat(sub["vref"][:, -1:], 44, axis=1)], axis=1)
     got = e.solve_batch(sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=vref64, others=oth16[:24],
