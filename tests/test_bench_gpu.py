@@ -1,0 +1,46 @@
+"""bench.py on the GPU box: the single-process line and the launch the driver uses for N > 1 (torch.distributed.run, one
+rank per GPU, RCCL) rehearsed with one rank - process-group init on the nccl backend, the barrier / max-over-ranks timing
+around the engine's own stream, the rank-0 JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _line(cmd, env=None):
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(d, steps):
+    assert d["metric"] == "MPC solves/sec (horizon=20, batch=4096)" and d["unit"] == "solves/s"
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["higher_is_better"] is True and d["dtype"] == "f64"
+    assert d["value"] > 1e5 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
+    assert d["config"]["workload"] and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["solver"]["converged_frac"] >= 0.99 and d["solver"]["iters_max"] <= d["config"]["max_iter"]
+    assert d["ms_per_step"] * 1e-3 * d["value"] == pytest.approx(d["config"]["batch_per_gpu"], rel=1e-9)
+
+
+def test_single_process_line():
+    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-side"])
+    _check(d, 3)
+
+
+def test_one_rank_over_rccl():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-side"], env=env)
+    _check(d, 3)
+    assert "x1" in d["config"]["parallelism"]
