@@ -37,6 +37,8 @@ constexpr int kTrials = 4;   // step lengths tried by the line search: a_pr * 4^
 // A rollout that would take theta or v of the next node out of its bounds gets the one control that decides it (delta
 // resp. a) pulled back so that the node keeps this fraction of its slack
 constexpr double kProjKeep = 0.2;
+// how far inside its heading bound the cold start puts a node that zero controls would leave on or outside it (rad)
+constexpr double kInitPush = 1e-2;
 
 // per-stage slots in LDS (doubles); trajectory buffer b lives at b*6
 enum : int {
@@ -438,23 +440,41 @@ struct Solver {
         bark = -flog(slack);
     }
 
-    // ---- initial rollout of the controls already in buffer 0: serial dynamics (uniform) + stage-parallel cost
-    MPC_HD bool rollout_init(double &Jout, double &barout) {
+    // ---- initial rollout of the controls already in buffer 0: serial dynamics (uniform) + stage-parallel cost.
+    // project (cold start only): a node whose heading would sit on or outside its bound - an ego that drives along the
+    // exit straight has theta_0 = -pi to float32 rounding, 5.6e-8 OUTSIDE [-pi, pi] (1 + 1e-8), and zero controls keep
+    // every node there - gets the steering angle that puts it kInitPush inside (less when the vehicle is slow).  IPOPT
+    // does the same to its starting point (bound_push) and accepts the 5.6e-8 at node 0 as a constraint violation below
+    // its tolerance; without this such an ego was answered with status 3 and the action (0, 0) step after step.
+    MPC_HD bool rollout_init(double &Jout, double &barout, bool project) {
         double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
         const TrigCoef K = trig();
         const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
-            const double u0 = S(k, W_U + 0), u1 = S(k, W_U + 1);
+            const double u0 = S(k, W_U + 0);
+            double u1 = S(k, W_U + 1);
             S(k, W_X + 0, x_0);
             S(k, W_X + 1, x_1);
             S(k, W_X + 2, x_2);
             S(k, W_X + 3, x_3);
             double Sn, Cn, sb, cb_;
             dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
+            double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+            if (project && (!(n2 > tlo_) || !(n2 < thi_)) && x_3 > 1e-6) {
+                const double reach = dt * x_3 * kInvWheelbase;             // |theta_{k+1} - theta_k| <= reach sin(beta)
+                const double push = fmin2(kInitPush, 0.25 * reach);
+                const double target = !(n2 > tlo_) ? tlo_ + push : thi_ - push;
+                const double sreq = (target - x_2) / reach;
+                if (fabs(sreq) < 0.9) {
+                    u1 = warm_clamp(atan_b(K, 2.0 * sreq * frsqrt(1.0 - sreq * sreq)), 1);
+                    S(k, W_U + 1, u1);
+                    dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
+                    n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
+                }
+            }
             const double n0 = x_0 + dt * (x_3 * Cn);
             const double n1 = x_1 + dt * (x_3 * Sn);
-            const double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
             const double n3 = x_3 + dt * u0;
             if (!(n2 > tlo_) || !(n2 < thi_) || !(n3 > vlo_) || !(n3 < vhi_)) return false;
             x_0 = n0;
@@ -726,14 +746,14 @@ struct Solver {
         });
         any_wall = 0;
         double Jcur = 0.0, barcur = 0.0;
-        if (!(warm && rollout_init(Jcur, barcur))) {
+        if (!(warm && rollout_init(Jcur, barcur, false))) {
             c.phase([&](int lane) {
                 if (lane >= N) return;
                 S(lane, W_U + 0, 0.0);
                 S(lane, W_U + 1, 0.0);
             });
             if (x0[3] < 0.01) S(0, W_U + 0, (0.01 - x0[3]) / dt);
-            if (!rollout_init(Jcur, barcur)) {
+            if (!rollout_init(Jcur, barcur, true)) {
                 status_out = 3;
                 return;
             }

@@ -269,6 +269,23 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         for (int k = 0; k < N; ++k) {
             dyn_t d;
             dyn_eval(it->x[k], it->u[k], &d);
+            double n2 = it->x[k][2] + dt * d.f[2];
+            /* cold start only: a node whose heading would sit on or outside its bound (theta_0 = -pi to float32 rounding
+             * is 5.6e-8 outside the relaxed bound, and zero controls keep every node there) gets the steering angle that
+             * puts it INIT_PUSH inside, less for a slow vehicle - IPOPT's bound_push on its starting point; the 5.6e-8
+             * at node 0 are below its constraint tolerance */
+            if (!warm && (!(n2 > xlo_r(2)) || !(n2 < xhi_r(2))) && it->x[k][3] > 1e-6) {
+                const double INIT_PUSH = 1e-2;
+                const double reach = dt * it->x[k][3] / WHEELBASE;
+                const double push = fmin(INIT_PUSH, 0.25 * reach);
+                const double target = !(n2 > xlo_r(2)) ? xlo_r(2) + push : xhi_r(2) - push;
+                const double sreq = (target - it->x[k][2]) / reach;
+                if (fabs(sreq) < 0.9) {
+                    const double m = 1e-3 * (UHI[1] - ULO[1]);
+                    it->u[k][1] = fmin(fmax(atan(2.0 * sreq / sqrt(1.0 - sreq * sreq)), ULO[1] + m), UHI[1] - m);
+                    dyn_eval(it->x[k], it->u[k], &d);
+                }
+            }
             for (int i = 0; i < 4; ++i) it->x[k + 1][i] = it->x[k][i] + dt * d.f[i];
             for (int i = 0; i < 2; ++i) it->zul[k][i] = it->zuu[k][i] = 1.0;
             for (int i = p->i0; i < 4; ++i) it->zxl[k + 1][i] = it->zxu[k + 1][i] = 1.0;

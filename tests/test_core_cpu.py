@@ -69,3 +69,35 @@ def test_wave_core_warm_start_matches_oracle(cpu_wave, oracle, ref_table):
     assert (rel_u0_err(got["u0"], want["u0"])[both] <= 1e-4).mean() >= 0.99
     assert (got["iters"] == want["iters"])[both].mean() > 0.95
     assert want["iters"][both].mean() < cold["iters"][both].mean()
+
+
+def heading_on_the_bound_inputs(ref_table):
+    """An ego on the exit straight (reference heading -pi, rows 62.. of the table) whose observed heading is +-pi to
+    float32 rounding: 5.6e-8 outside the NLP's relaxed bound [-pi, pi] (1 + 1e-8).  IPOPT accepts that at node 0 as a
+    constraint violation below its tolerance and pushes its start inside; zero controls keep every node of a
+    single-shooting start on the bound."""
+    rows = np.array([64, 66, 70, 74, 78, 80, 66, 70])
+    th = np.float64(np.float32(-np.pi)) * np.ones(len(rows))
+    th[-2:] = np.float64(np.float32(np.pi))                 # the same heading, wrapped to the other side
+    v = np.array([10.0, 9.9, 8.0, 5.0, 2.0, 0.5, 10.0, 6.0])
+    state = np.stack([ref_table[rows, 0], ref_table[rows, 1] + 0.05, th, v], axis=1)
+    return dict(state=state, ego_index=rows.astype(np.int32), weights=np.ones((len(rows), 3)),
+                is_collide=np.zeros(len(rows), np.uint8), vref=None, others=None)
+
+
+def test_heading_on_the_bound(cpu_core, oracle, ref_table):
+    import kkt_batch as kb
+    import nlp_batch as nb
+    inp = heading_on_the_bound_inputs(ref_table)
+    assert (np.abs(inp["state"][:, 2]) > np.pi * (1 + 1e-8)).all()
+    want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], max_iter=100,
+                              xy_bounds=False)
+    got = cpu_core(ref_table, inp)
+    assert np.array_equal(got["status"], want["status"]) and (want["status"][:6] == 0).all()      # was 3 for all of them
+    assert rel_u0_err(got["u0"], want["u0"])[want["status"] == 0].max() < 1e-7
+    # every later node is strictly inside, and the points are KKT points of the reference NLP (theta_0 itself is data)
+    ok = want["status"] == 0
+    assert (np.abs(want["X"][ok][:, 1:, 2]) < np.pi * (1 + 1e-8)).all()
+    p = nb.Batch.build(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"])
+    cert = kb.certify(p.take(np.nonzero(ok)[0]), want["X"][ok], want["U"][ok])
+    assert cert["stationarity"].max() <= 1e-8 and cert["feasibility"].max() <= 1e-10
