@@ -90,7 +90,39 @@ def cpu_baseline(inp):
     work = oracle_lib.last_work()
     n1 = 1024
     dt1 = min(run(n1, 1)[0] for _ in range(2))
-    return dict(value=BATCH / dt, unit="solves/s", cores=cores, kind="port",
+    # independent solvers on one thread: scipy SLSQP on the loop restatement of the NLP (analytic
+    # reduced gradient, dense BFGS) and the dense restatement of IPOPT's algorithm - the closest thing to "what the
+    # reference's solver does per instance" that can run here; CasADi's graph build + nlpsol construction, which the
+    # reference pays on top at every step, is not included (tools/time_reference_casadi.py times it where CasADi exists)
+    import warnings
+    import ipopt_restated as ipr
+    import nlp_batch as nb
+    import nlp_spec as S
+    import scipy_crosscheck as X
+    n_ind = 16
+    t0 = time.perf_counter()
+    ok_s = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for b in range(n_ind):
+            p = S.Problem.build(HORIZON, 0.1, inp["state"][b], inp["ego_index"][b], ref.copy(), inp["weights"][b],
+                                inp["is_collide"][b], collision_cost=True, others=inp["others"][b])
+            p.ref[:, 2] = inp["vref"][b]
+            ok_s += bool(X.solve_slsqp(p)["success"])
+    dt_s = time.perf_counter() - t0
+    pb = nb.Batch.build(ref, inp["state"][:n_ind], inp["ego_index"][:n_ind], inp["weights"][:n_ind],
+                        inp["is_collide"][:n_ind], vref=inp["vref"][:n_ind], others=inp["others"][:n_ind], collision_cost=True)
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):          # one BLAS thread: dense 208 x 208 factorisations do not want more
+        t0 = time.perf_counter()
+        ok_i = sum(int(ipr.solve(pb.take([b]), tol=1e-6, max_iter=1000, sf_min=1e-2)["status"] == 0) for b in range(n_ind))
+        dt_i = time.perf_counter() - t0
+    independent = {"scipy_slsqp": {"value": n_ind / dt_s, "unit": "solves/s", "cores": 1, "succeeded": ok_s,
+                                   "sample": f"first {n_ind} instances, oracle/scipy_crosscheck.py, {dt_s:.1f} s"},
+                   "ipopt_restated": {"value": n_ind / dt_i, "unit": "solves/s", "cores": 1, "succeeded": ok_i,
+                                      "sample": f"first {n_ind} instances, oracle/ipopt_restated.py (dense numpy, tol 1e-6 "
+                                                f"like the reference), {dt_i:.1f} s"}}
+    return dict(value=BATCH / dt, unit="solves/s", cores=cores, kind="port", independent_solvers=independent,
                 sample=f"all {BATCH} instances of the same batch, oracle/mpc_oracle.c, OpenMP over instances, {cores} of "
                        f"{ncpu} hardware threads (best of the thread counts tried, best of 3 runs: {dt:.3f} s), "
                        f"mean {float(out['iters'].mean()):.1f} iterations",
