@@ -8,14 +8,17 @@
 //   * the Riccati / DDP factorisation stage works on the 8x8 stage KKT block [Hxx Hxp Hxu; . Hpp Hpu; . . Huu]
 //     (state 4 + previous control 2 + control 2) held in registers in the C/D layout of v_mfma_f64_4x4x4f64 (2x2 blocks
 //     of 4x4): T = P F, H = L + F'T, W = Huu^-1 H(u,.), P' = H - H(.,u) W and the gradient recursion are nine FP64
-//     matrix-core instructions per stage; blocks move between operand positions by lane permutation, nothing is
+//     matrix-core instructions per stage; blocks move between operand positions by DPP row shifts, nothing is
 //     exchanged through LDS;
-//   * the line search integrates all six trial step lengths at once, lane t = trial t;
+//   * the line search integrates all four trial step lengths at once, lane t = trial t;
 //   * the adjoint recursion is three suffix sums over the stages (A' = I + strictly triangular): wave scans;
 //   * only the true recursions (linearised step, one lane's rollout, the Riccati sweep itself) are serial.
 // Why: measured on MI355X, a one-lane-per-instance kernel (the first design, since removed) is bound by the serial
 // FP64 instruction stream of its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4
 // SIMDs per CU usable because the per-instance state has to sit in LDS.
+// Resources: 128 VGPRs, no scratch, 9.9 KB of LDS at N = 20 with 8 vehicles (16 instances per CU): no constant of the
+// solve lives in a register across the iteration loop (LDS table, CTX::fresh) and the trial trajectories of the line
+// search live in slots that are dead while it runs (trial_x / trial_u below).
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
 // (f(lane) per lane; other lanes may read afterwards what a lane wrote to LDS); tests/cpu_wave_harness.cpp runs the
