@@ -179,3 +179,41 @@ def test_synth_generator_shapes():
     assert np.all(inp["weights"] >= 0) and np.all(np.abs(inp["state"][:, 2]) <= np.pi)
     again = synth.solver_inputs(33, 8, seed=0)
     assert all(np.array_equal(inp[k], again[k]) for k in ("state", "vref", "others", "weights"))
+
+
+def test_config1_closed_loop_with_the_oracle(oracle, ref_table):
+    """BASELINE configs[0] (the reference's stand-alone loop main/run_pure_mpc.py:10-40: one ego, one other vehicle,
+    horizon 20) on the CPU: the numpy mirror of the agent with the C oracle as its solver against the synthetic
+    intersection.  The ego must arrive, and every solve along the way - including the exit straight, where the observed
+    heading is -pi to float32 rounding, i.e. just outside the NLP's heading bound - must be a real solve, as it is for
+    the reference's IPOPT (no status 3)."""
+    import torch
+    from conftest import converged
+    from host_preamble import HostPreambleAgent
+    from mpc_rl_for_avs_amd import rollout
+
+    class OracleEngine:
+        def solve_batch(self, state, ego_index, weights, is_collide, vref=None, others=None, collision_cost=False,
+                        want_trajectories=False):
+            return oracle.solve_batch(ref_table, state, ego_index, weights, is_collide, vref=vref, others=others,
+                                      collision_cost=collision_cost, max_iter=100, xy_bounds=False)
+
+    cfg = dict(horizon=20, render=False, ttc_threshold=3, weight_speed=1, weight_control=1, weight_input_diff=1,
+               speed_override=0)
+    env = rollout.SyntheticIntersectionEnv(1, device="cpu", seed=0, n_others=1)
+    agent = HostPreambleAgent(Env(), cfg, engine=OracleEngine())
+    obs = env.reset()
+    status, headings, outcome = [], [], "timeout"
+    for _ in range(150):
+        o = obs[0].numpy()
+        a = agent.predict(o, False)
+        status.append(int(agent.last_solve["status"][0]))
+        headings.append(float(agent.last_inputs["state"][0, 2]))
+        obs, _, done, info = env.step(torch.tensor([[a.acceleration, a.steer]], dtype=torch.float64))
+        if bool(done[0]):
+            outcome = "crashed" if bool(info["crashed"][0]) else ("arrived" if bool(info["arrived"][0]) else "timeout")
+            break
+    status = np.array(status)
+    assert outcome == "arrived"
+    assert (np.abs(np.array(headings)) > np.pi * (1 + 1e-8)).any()          # the case does occur on the way
+    assert (status != 3).all() and converged(status).mean() >= 0.95
