@@ -9,6 +9,7 @@ bash tools/pmc_run.sh r02_bulk python3 tools/gpu_bulk.py > $O/pmc_bulk.log 2>&1
 python3 tools/pmc_summary.py r02_bulk >> $O/pmc_bulk.log 2>&1
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/gpu_lat.py --bulk > $O/latency.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/ubench/libwave_sections.so tools/ubench/wave_sections.hip 2> $O/wave_sections_build.err
 python3 tools/gpu_wave_sections.py --batch > $O/wave_sections.txt 2>&1
 bash tools/pmc_one.sh > $O/pmc_lone_wave.txt 2>&1
 python3 tools/gpu_predict_timing.py > $O/predict.txt 2>&1
