@@ -182,14 +182,14 @@ def main():
     out = dict(u0=torch.empty((BATCH, 2), dtype=torch.float64, device=dev),
                status=torch.empty(BATCH, dtype=torch.int32, device=dev),
                iters=torch.empty(BATCH, dtype=torch.int32, device=dev))
-    gathered = None
+    gathered = gathered_st = None
 
     n_str = max(1, a.streams)
     side = [torch.cuda.Stream(dev) for _ in range(n_str)] if n_str > 1 else [torch.cuda.current_stream(dev)]
     outs_s = [out] + [dict((k, torch.empty_like(v)) for k, v in out.items()) for _ in range(n_str - 1)]
 
     def step(i, ev=None):
-        nonlocal gathered
+        nonlocal gathered, gathered_st
         with torch.cuda.stream(side[i % n_str]):
             if ev is not None:
                 ev[0].record()
@@ -197,7 +197,7 @@ def main():
             if ev is not None:
                 ev[1].record()
             if use_dist:
-                gathered = sharding.all_gather_actions(outs_s[i % n_str]["u0"])
+                gathered, gathered_st = sharding.all_gather_results(outs_s[i % n_str]["u0"], outs_s[i % n_str]["status"])
 
     for i in range(max(a.warmup, n_str if n_str > 1 else 0)):
         step(i)
@@ -215,8 +215,16 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    dist_info = None
     if use_dist:
-        assert gathered.shape == (world * BATCH, 2)
+        assert gathered.shape == (world * BATCH, 2) and gathered_st.shape == (world * BATCH,)
+        lo = rank * BATCH
+        last = outs_s[(a.steps - 1) % n_str]
+        dist_info = {"backend": dist.get_backend(), "world_size": world, "gathered_actions_shape": list(gathered.shape),
+                     "gathered_status_shape": list(gathered_st.shape),
+                     "own_block_equals_local": bool(torch.equal(gathered[lo:lo + BATCH], last["u0"]) and
+                                                    torch.equal(gathered_st[lo:lo + BATCH], last["status"])),
+                     "bytes_per_rank_per_step": BATCH * 24}
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -253,6 +261,7 @@ def main():
                        "parallelism": f"instance-sharded x{world}, all-gather of actions" +
                                       (f", {n_str} batches in flight on {n_str} streams" if n_str > 1 else "")},
             "roofline": roof,
+            "distributed": dist_info,
             "solver": {"converged_frac": float(conv.mean()), "smooth_kkt_frac": float((status == 0).mean()),
                        "on_kink_frac": float((status == 5).mean()), "iters_mean": float(iters.mean()),
                        "iters_p99": float(np.percentile(iters, 99)), "iters_max": int(iters.max()),

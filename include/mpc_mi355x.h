@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 2
+#define MPC_ABI_VERSION 3
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -48,6 +48,14 @@ extern "C" {
                                       mpc_predict_batch: each environment starts from its previous solution advanced by
                                       one stage (kept in the handle, forgotten by the reset calls);
                                       mpc_reset_env_mask: forget only that memory, keep the detector state */
+
+/* mpc_predict_batch only: the reference's call sequence _parse_obs -> _check_collision -> _solve as separate calls
+ * (agents/pure_mpc.py:68-78).  Without either flag one call does all of it. */
+#define MPC_FLAG_DETECT_ONLY 16u   /* _check_collision alone (agents/pure_mpc.py:552-676): advance the detector records of
+                                      the B environments for this observation, solve nothing (weights, act may be NULL);
+                                      mpc_get_env_state then serves is_collide, conflict_index, ... */
+#define MPC_FLAG_DETECTED 32u      /* _solve after such a call for the SAME observation: the records are not advanced
+                                      again; ego index, speed profile (agents/pure_mpc.py:678-724) and the solve only */
 
 /* per-instance solver status written to status[] */
 #define MPC_STATUS_CONVERGED 0
@@ -84,8 +92,14 @@ int mpc_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char *mpc_last_error(void);
 
-/* Fill *cfg with the defaults (horizon 20, dt 0.1, max_iter 100, tol 1e-8, weights 10 / 1, device 0). */
+/* Fill *cfg with the defaults (horizon 20, dt 0.1, max_iter 100, tol 1e-8, weights 10 / 1, device 0).
+ * Writes sizeof(mpc_config) bytes of THIS header's layout: only for callers compiled against this header. */
 void mpc_default_config(mpc_config *cfg);
+
+/* The same for bindings that declare the struct themselves (ctypes, cgo, ...): `size` is the size of the caller's
+ * object.  Nothing is written and MPC_ERR_INVALID_ARG is returned unless it equals the library's sizeof(mpc_config),
+ * so a binding built for an older layout fails loudly instead of being overrun. */
+int mpc_default_config_sized(mpc_config *cfg, int32_t size);
 
 /* Create an engine bound to cfg->device.  Replaces PureMPC_Agent.__init__ (agents/pure_mpc.py:24-63). */
 int mpc_create(const mpc_config *cfg, mpc_handle **out);
@@ -130,7 +144,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
  *   weights        [B][3] weight_speed, weight_control, weight_input_diff (RL action or the cfg defaults)
  *   ref_speed      [B] RL reference-speed override (agents/pure_mpc.py:683-688) or NULL
  *   flags          MPC_FLAG_COLLISION_COST: distance/collision terms over the observed vehicles; MPC_FLAG_DEVICE_PTRS,
- *                  MPC_FLAG_NO_SYNC as for mpc_solve_batch
+ *                  MPC_FLAG_NO_SYNC as for mpc_solve_batch; MPC_FLAG_DETECT_ONLY / MPC_FLAG_DETECTED (above)
  *   act            [B][2] acceleration, steer;  status/iters [B] optional
  */
 int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicles_count, const double *weights,
@@ -182,7 +196,10 @@ int mpc_get_env_state(mpc_handle *h, int32_t B, int32_t *is_collide, int32_t *eg
 /* Checkpoint / resume of the per-environment detector records (the reference never saves them: its agent state is lost
  * with the process, agents/pure_mpc.py:38-43).  mpc_env_state_bytes(): size of one opaque record;
  * mpc_save_env_state copies records 0..B-1 to a host buffer of B * that size; mpc_set_env_state puts them back (into
- * this or another handle of the same library version), growing the handle's capacity if needed.  Both synchronise. */
+ * this or another handle of the same library version), growing the handle's capacity if needed (not while a captured
+ * hipGraph still addresses the old buffers: size the handle with mpc_reserve_envs first).  Every record is validated
+ * (counts, indices against the reference table) and a bad one refuses the whole call; the restored environments lose
+ * their warm-start controls and stored LTV profile (those belong to the episode that was running).  Both synchronise. */
 int64_t mpc_env_state_bytes(void);
 int mpc_save_env_state(mpc_handle *h, int32_t B, void *records);
 int mpc_set_env_state(mpc_handle *h, int32_t B, const void *records);

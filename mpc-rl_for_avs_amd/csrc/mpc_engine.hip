@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     int B, const float *__restrict__ obs, int rows, const double *__restrict__ ref5, int M, int N, double dt,
     const double *__restrict__ ref_speed, mpc::pre::EnvState *__restrict__ env, double *__restrict__ state,
     int32_t *__restrict__ ego_index, double *__restrict__ vref, uint8_t *__restrict__ is_collide,
-    double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh) {
+    double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh, int advance) {
     namespace pre = mpc::pre;
     __shared__ pre::P2 s_ego[kPreEnvs][pre::kPredHorizon + 1];
     __shared__ int s_ne[kPreEnvs];
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     const float *ob = obs + (size_t)b * rows * pre::kObsCols;
     const pre::Parsed p = pre::parse_obs(ob, rows);
     // surplus groups (live == false) only keep the barriers company: no detector work on possibly changing state
-    const bool replay = !live || (env[b].collision_memory > 0 && env[b].has_memorized);
+    const bool replay = !live || !advance || (env[b].collision_memory > 0 && env[b].has_memorized);
     if (!replay && l == 0)
         s_ne[g] = pre::ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, s_ego[g]);
     __syncthreads();
@@ -285,7 +285,8 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     for (int j = p.observed; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
     int32_t e = 0;
     uint8_t c = 0;
-    pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], s_cpt[g], st, e, vref + (size_t)b * (N + 1), c);
+    pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], s_cpt[g], st, e, vref + (size_t)b * (N + 1), c,
+                    advance != 0);
     ego_index[b] = e;
     is_collide[b] = c;
     nveh[b] = p.observed;
@@ -440,6 +441,15 @@ void mpc_default_config(mpc_config *cfg) {
     cfg->w_distance = 10.0;
     cfg->w_collision = 1.0;
     cfg->ltv_passes = 1;
+}
+
+int mpc_default_config_sized(mpc_config *cfg, int32_t size) {
+    if (!cfg) return fail(MPC_ERR_INVALID_ARG, "mpc_default_config_sized: null argument");
+    if (size != (int32_t)sizeof(mpc_config))
+        return fail(MPC_ERR_INVALID_ARG, "mpc_default_config_sized: the caller's mpc_config has " + std::to_string(size) +
+                                         " bytes, this library's has " + std::to_string(sizeof(mpc_config)));
+    mpc_default_config(cfg);
+    return MPC_OK;
 }
 
 int mpc_create(const mpc_config *cfg, mpc_handle **out) {
@@ -648,7 +658,10 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
                       const double *ref_speed, uint32_t flags, double *act, int32_t *status, int32_t *iters,
                       void *stream_) {
     if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: null handle");
-    if (B < 0 || !obs || !weights || !act)
+    const bool detect_only = (flags & MPC_FLAG_DETECT_ONLY) != 0, detected = (flags & MPC_FLAG_DETECTED) != 0;
+    if (detect_only && detected)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: MPC_FLAG_DETECT_ONLY and MPC_FLAG_DETECTED exclude each other");
+    if (B < 0 || !obs || (!detect_only && (!weights || !act)))
         return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: null required pointer or negative batch");
     if (vehicles_count < 1 || vehicles_count > MPC_MAX_OTHERS + 1)
         return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: vehicles_count out of range");
@@ -711,7 +724,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         char *sb = static_cast<char *>(h->d_stage);
         HIP_TRY(hipMemcpyAsync(sb + o_obs, obs, (size_t)B * rows * mpc::pre::kObsCols * 4, hipMemcpyHostToDevice,
                                stream));
-        HIP_TRY(hipMemcpyAsync(sb + o_w, weights, (size_t)B * 3 * 8, hipMemcpyHostToDevice, stream));
+        if (weights) HIP_TRY(hipMemcpyAsync(sb + o_w, weights, (size_t)B * 3 * 8, hipMemcpyHostToDevice, stream));
         d_obs = reinterpret_cast<float *>(sb + o_obs);
         d_weights = reinterpret_cast<double *>(sb + o_w);
         if (ref_speed) {
@@ -725,9 +738,14 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
 
     hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)((B + kPreEnvs - 1) / kPreEnvs)), dim3(kBlock), 0, stream,
                        (int)B, d_obs, rows, h->d_ref, h->M, N, h->cfg.dt, d_rs, h->d_env, h->p_state, h->p_ego,
-                       h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh);
+                       h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh, detected ? 0 : 1);
     HIP_TRY(hipGetLastError());
     const bool warm = (flags & MPC_FLAG_WARM_START) != 0;
+    if (detect_only) {
+        // _check_collision on its own (agents/pure_mpc.py:552-676): the records are advanced, nothing is solved
+        if (!dev || !(flags & MPC_FLAG_NO_SYNC)) HIP_TRY(hipStreamSynchronize(stream));
+        return MPC_OK;
+    }
     if (int rc = dispatch_solve(h, B, cc, V, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
                                 h->p_others, h->p_nveh, warm ? h->d_warm : nullptr, 1, warm ? h->d_warm_valid : nullptr,
                                 d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters))
@@ -976,10 +994,30 @@ int mpc_save_env_state(mpc_handle *h, int32_t B, void *records) {
 int mpc_set_env_state(mpc_handle *h, int32_t B, const void *records) {
     if (!h || B < 0 || (!records && B > 0)) return fail(MPC_ERR_INVALID_ARG, "mpc_set_env_state: bad argument");
     if (B == 0) return MPC_OK;
+    // the records are opaque to the caller but not trusted: the device code uses the counts as loop bounds and the
+    // indices as subscripts of the reference table
+    if (!h->d_ref) return fail(MPC_ERR_NO_REFERENCE, "mpc_set_env_state: call mpc_set_reference first (indices are checked against it)");
+    {
+        const auto *rec = static_cast<const mpc::pre::EnvState *>(records);
+        const int M = h->M, K = mpc::pre::kMaxOthers;
+        for (int b = 0; b < B; ++b) {
+            const mpc::pre::EnvState &s = rec[b];
+            bool ok = s.collision_memory >= 0 && s.collision_memory <= 10 && (s.has_memorized == 0 || s.has_memorized == 1) &&
+                      s.n_memorized >= 0 && s.n_memorized <= K && s.n_conflict >= 0 && s.n_conflict <= K &&
+                      (s.is_collide == 0 || s.is_collide == 1) && s.ego_index >= 0 && s.ego_index < M &&
+                      s.stop_index1 >= 0 && s.stop_index1 <= M && s.last_valid_stop1 >= 0 && s.last_valid_stop1 <= M;
+            for (int j = 0; ok && j < K; ++j)
+                ok = s.conflict[j] >= -1 && s.conflict[j] < M && s.memorized[j] >= -1 && s.memorized[j] < M;
+            if (!ok) return fail(MPC_ERR_INVALID_ARG, "mpc_set_env_state: record " + std::to_string(b) + " is not a valid detector state");
+        }
+    }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     if (int rc = ensure_env(h, B, nullptr)) return rc;
     HIP_TRY(hipMemcpy(h->d_env, records, (size_t)B * sizeof(mpc::pre::EnvState), hipMemcpyHostToDevice));
+    // a restored environment is not the episode whose controls the handle remembers: no warm start, no stored LTV profile
+    HIP_TRY(hipMemset(h->d_warm_valid, 0, (size_t)B));
+    HIP_TRY(hipMemset(h->d_ltv_u, 0, (size_t)B * h->cfg.horizon * 2 * sizeof(double)));
     return MPC_OK;
 }
 

@@ -406,9 +406,14 @@ MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable 
 
 // part 3 - detector state machine (agents/pure_mpc.py:558-563, 661-676), a6 ego index, a5 speed profile
 // (agents/pure_mpc.py:678-724).  conflict: the part-2 results of vehicles 0..observed-1 (unused when replaying).
+// advance = false: the state machine has already seen this observation (the caller ran _check_collision on its own,
+// MPC_FLAG_DETECTED): only the ego index and the speed profile are derived, from the record as it stands.
 MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *ref_speed, const int32_t *conflict,
-                       const P2 *conflict_pt, EnvState &st, int32_t &ego_index_out, double *vref, uint8_t &collide_out) {
-    if (replays_memory(st)) {
+                       const P2 *conflict_pt, EnvState &st, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
+                       bool advance = true) {
+    if (!advance) {
+        // nothing: st.is_collide, the conflict indices and the memory are those of the detection call
+    } else if (replays_memory(st)) {
         st.n_conflict = st.n_memorized;
         for (int j = 0; j < kMaxOthers; ++j) {
             st.conflict[j] = st.memorized[j];
@@ -507,18 +512,18 @@ MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *
 // ego_index, is_collide.  ref_speed: RL override or nullptr.
 MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, double dt, const double *ref_speed,
                          EnvState &st, double *state, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
-                         double *others, int32_t &nveh_out) {
+                         double *others, int32_t &nveh_out, bool advance = true) {
     const Parsed p = parse_obs(obs, rows);
     write_vehicles(obs, p, state, others);
     nveh_out = p.observed;
     int32_t conflict[kMaxOthers];
     P2 cpt[kMaxOthers];
-    if (!replays_memory(st)) {
+    if (advance && !replays_memory(st)) {
         P2 ego[kPredHorizon + 1];
         const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, ego);
         for (int j = 0; j < p.observed; ++j) conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt, cpt[j]);
     }
-    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out);
+    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out, advance);
 }
 
 }  // namespace pre

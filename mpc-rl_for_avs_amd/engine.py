@@ -18,6 +18,8 @@ FLAG_COLLISION_COST = 1
 FLAG_DEVICE_PTRS = 2
 FLAG_NO_SYNC = 4
 FLAG_WARM_START = 8      # not in the reference: start from given / previous controls instead of zeros
+FLAG_DETECT_ONLY = 16    # mpc_predict_batch: _check_collision alone (advance the detector records, no solve)
+FLAG_DETECTED = 32       # mpc_predict_batch: _solve after such a call for the same observation
 
 STATUS_CONVERGED = 0
 STATUS_MAX_ITER = 1
@@ -43,7 +45,7 @@ class _Config(ctypes.Structure):
                 ("ltv_passes", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
 
-_EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_create", "mpc_destroy",
+_EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_config_sized", "mpc_create", "mpc_destroy",
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
@@ -80,6 +82,8 @@ def load_library(path: str | None = None):
     lib.mpc_last_error.restype = ctypes.c_char_p
     lib.mpc_default_config.argtypes = [ctypes.POINTER(_Config)]
     lib.mpc_default_config.restype = None
+    lib.mpc_default_config_sized.argtypes = [ctypes.POINTER(_Config), ctypes.c_int32]
+    lib.mpc_default_config_sized.restype = ctypes.c_int
     lib.mpc_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(vp)]
     lib.mpc_create.restype = ctypes.c_int
     lib.mpc_destroy.argtypes = [vp]
@@ -130,7 +134,10 @@ class MPCEngine:
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         cfg = _Config()
-        self._lib.mpc_default_config(ctypes.byref(cfg))
+        # the sized variant: a _Config that no longer matches the library's mpc_config is refused, not overrun
+        rc = self._lib.mpc_default_config_sized(ctypes.byref(cfg), ctypes.sizeof(cfg))
+        if rc != 0:
+            raise EngineError(f"mpc_default_config_sized failed ({rc}): {self._lib.mpc_last_error().decode()}")
         cfg.horizon, cfg.dt, cfg.max_iter, cfg.tol = int(horizon), float(dt), int(max_iter), float(tol)
         cfg.w_distance, cfg.w_collision, cfg.device = float(w_distance), float(w_collision), int(device)
         cfg.ltv_passes = int(ltv_passes)     # iterative-linear agent only: trip count of agents/pure_mpc_linear.py:189
@@ -228,10 +235,21 @@ class MPCEngine:
         return out
 
     # ------------------------------------------------------------------ observation-level path
-    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False, warm_start=False):
+    def detect_batch(self, obs):
+        """`_check_collision` alone (agents/pure_mpc.py:552-676) for obs[B, vehicles_count, 8]: advances the detector
+        records; `env_state` serves the result.  Follow with `predict_batch(..., detected=True)` for the same obs."""
+        obs = np.ascontiguousarray(obs, dtype=np.float32)
+        if obs.ndim != 3 or obs.shape[2] != 8:
+            raise ValueError(f"obs must be [B, vehicles_count, 8], got {obs.shape}")
+        B, rows = obs.shape[:2]
+        rc = self._lib.mpc_predict_batch(self._h, B, _ptr(obs), rows, None, None, FLAG_DETECT_ONLY, None, None, None, None)
+        self._check(rc, "mpc_predict_batch")
+
+    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False, warm_start=False, detected=False):
         """obs[B, vehicles_count, 8] float32 -> dict(act[B, 2], status, iters): parsing, collision detector (with the
         per-environment memory kept inside the engine), speed-profile rewrite and solve, all on the device.
-        warm_start (not in the reference): each environment starts from its previous solution advanced one stage."""
+        warm_start (not in the reference): each environment starts from its previous solution advanced one stage.
+        detected: `detect_batch` has already advanced the records for this observation."""
         obs = np.ascontiguousarray(obs, dtype=np.float32)
         if obs.ndim != 3 or obs.shape[2] != 8:
             raise ValueError(f"obs must be [B, vehicles_count, 8], got {obs.shape}")
@@ -241,7 +259,8 @@ class MPCEngine:
         act = np.empty((B, 2))
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
-        flags = (FLAG_COLLISION_COST if collision_cost else 0) | (FLAG_WARM_START if warm_start else 0)
+        flags = (FLAG_COLLISION_COST if collision_cost else 0) | (FLAG_WARM_START if warm_start else 0) | \
+            (FLAG_DETECTED if detected else 0)
         rc = self._lib.mpc_predict_batch(self._h, B, _ptr(obs), rows, _ptr(weights), _ptr(rs), flags, _ptr(act),
                                          _ptr(status), _ptr(iters), None)
         self._check(rc, "mpc_predict_batch")

@@ -36,11 +36,16 @@ SAFETY_BUFFER_POINTS = 5    # agents/pure_mpc.py:681
 
 
 class MPC_Action:
-    """agents/utils.py:4-12"""
+    """agents/utils.py:4-12, plus what the reference only prints (`solver.stats()['success']`, agents/pure_mpc.py:303-305):
+    `success` (solved to tolerance), the engine's `status` code and iteration count - for callers that hold nothing but
+    the action (trainer.predict-style code)."""
 
-    def __init__(self, acceleration, steer) -> None:
+    def __init__(self, acceleration, steer, success=True, status=0, iters=0) -> None:
         self.acceleration = acceleration
         self.steer = steer
+        self.success = bool(success)
+        self.status = int(status)
+        self.iters = int(iters)
 
     def numpy(self) -> np.ndarray:
         return np.array([self.acceleration, self.steer])
@@ -108,6 +113,7 @@ class PureMPC_Agent:
             w_collision=float(self.config.get("weight_collision", 1.0)), device=device,
             ref_table=self.global_reference_states)
         self._obs = None
+        self._detected = False     # the detector has already seen self._obs (a stand-alone _check_collision or a _solve)
         self._env0 = None          # detector record of environment 0 after the last predict()
         self.last_acc = 0          # agents/pure_mpc.py:63
         self.last_solve = None
@@ -193,7 +199,7 @@ class PureMPC_Agent:
     def predict(self, obs, return_numpy=True, weights_from_RL=None, ref_speed=None):
         """agents/pure_mpc.py:68-78"""
         self._parse_obs(obs)
-        self._check_collision()
+        self._check_collision(_within_predict=True)
         mpc_action = self._solve(weights_from_RL, ref_speed)
         return mpc_action.numpy() if return_numpy else mpc_action
 
@@ -206,6 +212,7 @@ class PureMPC_Agent:
             raise ValueError(
                 f"Expect observation's shape of ({(self.total_vehicles_count, 8)}), but got {obs.shape}")
         self._obs = obs
+        self._detected = False
         self.ego_vehicle, self.agent_vehicles = self._vehicles_from_obs(obs)
         self.observed_vehicles_count = len(self.agent_vehicles)
         self.agent_vehicles_mpc = [Vehicle(v.index, v.position.copy(), v.vectorized_speed, v.heading, v.sinh, v.cosh)
@@ -218,10 +225,28 @@ class PureMPC_Agent:
                   for i in range(max(observed, 0))]
         return ego, others
 
-    def _check_collision(self):
-        """agents/pure_mpc.py:552-676.  The detector and its memory live in the engine and run in the same device call
-        as the solve (`_solve`); this step of the reference's sequence has nothing left to do on the host."""
+    def _check_collision(self, _within_predict=False):
+        """agents/pure_mpc.py:552-676.  The detector and its memory live in the engine.  Inside `predict()` it runs in
+        the same device call as the solve (`_solve`), so this step has nothing to do there.  Called on its own - the
+        reference's sequence `_parse_obs -> _check_collision -> read is_collide -> _solve` - it runs the detector for
+        the parsed observation now (`MPC_FLAG_DETECT_ONLY`), refreshes `is_collide`, `conflict_index`, ... and tells
+        the following `_solve` not to advance the detector a second time (`MPC_FLAG_DETECTED`)."""
+        if _within_predict or self._detected:
+            return None
+        if self._obs is None:
+            raise RuntimeError("_check_collision: call _parse_obs(obs) first")
+        self._engine.detect_batch(np.ascontiguousarray(self._obs, dtype=np.float32)[None])
+        self._detected = True
+        self._read_env0()
         return None
+
+    def _read_env0(self):
+        rec = self._engine.env_state(1)
+        n = self.observed_vehicles_count
+        self._env0 = dict(is_collide=rec["is_collide"][0], ego_index=rec["ego_index"][0],
+                          collision_memory=rec["collision_memory"][0], stop_index=rec["stop_index"][0],
+                          conflict_index=rec["conflict_index"][0, :n].copy(),
+                          conflict_points=rec["conflict_points"][0, :n].copy())
 
     def _solve(self, weights_from_RL=None, ref_speed_from_RL=None) -> MPC_Action:
         """agents/pure_mpc.py:80-318 for the environment parsed by `_parse_obs`: one `mpc_predict_batch` with B = 1."""
@@ -229,15 +254,14 @@ class PureMPC_Agent:
             raise RuntimeError("_solve: call _parse_obs(obs) first")
         w = None if weights_from_RL is None else np.asarray(weights_from_RL, dtype=np.float64).reshape(1, -1)[:, :3]
         rs = None if ref_speed_from_RL is None else np.asarray(ref_speed_from_RL, dtype=np.float64).reshape(1, 1)
-        act = self._predict_device(np.ascontiguousarray(self._obs, dtype=np.float32)[None], w, rs)
-        rec = self._engine.env_state(1)
-        n = self.observed_vehicles_count
-        self._env0 = dict(is_collide=rec["is_collide"][0], ego_index=rec["ego_index"][0],
-                          collision_memory=rec["collision_memory"][0], stop_index=rec["stop_index"][0],
-                          conflict_index=rec["conflict_index"][0, :n].copy(),
-                          conflict_points=rec["conflict_points"][0, :n].copy())
+        act = self._predict_device(np.ascontiguousarray(self._obs, dtype=np.float32)[None], w, rs,
+                                   detected=self._detected)
+        self._detected = True          # a second _solve for the same observation must not advance the detector either
+        self._read_env0()
         self.last_acc = act[0, 0]
-        return MPC_Action(acceleration=act[0, 0], steer=act[0, 1])
+        st = int(self.last_solve["status"][0])
+        return MPC_Action(acceleration=act[0, 0], steer=act[0, 1], success=bool(converged(np.int32(st))), status=st,
+                          iters=int(self.last_solve["iters"][0]))
 
     # ------------------------------------------------------------------ batched API
     def predict_batch(self, obs, weights_from_RL=None, ref_speed=None) -> np.ndarray:
@@ -250,12 +274,12 @@ class PureMPC_Agent:
         obs, w, rs = self._check_batch_args(obs, weights_from_RL, ref_speed)
         return self._predict_device(obs, w, rs)
 
-    def _predict_device(self, obs, w, rs):
+    def _predict_device(self, obs, w, rs, detected=False):
         B = obs.shape[0]
         if w is None:
             w = np.tile([float(self.default_weights[f"weight_{k}"]) for k in PureMPC_Agent.weight_components], (B, 1))
         out = self._engine.predict_batch(obs, w, None if rs is None else rs[:, 0], collision_cost=self.collision_cost,
-                                         warm_start=self.warm_start)
+                                         warm_start=self.warm_start, detected=detected)
         self.last_solve = out
         bad = int(np.count_nonzero(~converged(out["status"])))
         if bad:                                             # agents/pure_mpc.py:303-305

@@ -303,6 +303,7 @@ class BatchedCollector:
         self.last_mpc = None
         self._mpc_out = None
         self.gathered_actions = None
+        self.gathered_status = None
         self.use_graph = bool(use_graph)
         self._graph = None
         if self.use_graph:
@@ -337,7 +338,8 @@ class BatchedCollector:
         mpc_action = self.last_mpc["act"]
         if self.gather_actions:
             from . import sharding
-            self.gathered_actions = sharding.all_gather_actions(mpc_action)
+            # every rank sees every environment's action and whether its solve converged
+            self.gathered_actions, self.gathered_status = sharding.all_gather_results(mpc_action, self.last_mpc["status"])
         new_obs, rewards, dones, info = self.env.step(mpc_action)
         if self.algorithm == "ppo":                      # agents/ppo_mpc.py:451-461
             tv = self.policy.predict_values(info["terminal_obs"])

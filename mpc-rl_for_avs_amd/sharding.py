@@ -29,6 +29,16 @@ def all_gather_actions(local_u0, group=None):
     return out
 
 
+def all_gather_results(local_u0, local_status, group=None):
+    """The path's one exchange as SURVEY section 8(e) states it: actions [b, 2] float64 AND solver status [b] int32 of
+    every rank, in ONE collective (the status rides as a third float64 column; 24 B per instance, latency-bound).
+    Returns (actions [world*b, 2] float64, status [world*b] int32) on every rank."""
+    import torch
+    packed = torch.cat([local_u0, local_status.to(local_u0.dtype).unsqueeze(1)], dim=1)
+    full = all_gather_actions(packed, group)
+    return full[:, :2], full[:, 2].to(torch.int32)
+
+
 def all_gather_ragged(local_u0, total: int, group=None):
     """Gather blocks made by `shard_range` (sizes may differ by one) into the full [total, 2] array."""
     import torch

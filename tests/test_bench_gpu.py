@@ -37,10 +37,38 @@ def test_single_process_line():
     _check(d, 3)
 
 
+def test_single_process_line_has_no_process_group():
+    """Without torchrun / BENCH_FORCE_DIST the line says so: `distributed` is null (what test_one_rank_over_rccl's
+    assertions would catch if that test silently ran this path)."""
+    d = _line([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-side"])
+    assert d["distributed"] is None
+
+
 def test_one_rank_over_rccl():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    """The launch the driver uses for N > 1 with one rank: init_process_group("nccl") = RCCL, barrier, the all-gather of
+    actions + status after every solve, max-over-ranks timing.  BENCH_FORCE_DIST makes a world of 1 take that path."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_FORCE_DIST="1")
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1",
                "--no-cpu-baseline", "--no-side"], env=env)
     _check(d, 3)
     assert "x1" in d["config"]["parallelism"]
+    g = d["distributed"]                         # only the process-group path fills this in
+    assert g["backend"] == "nccl" and g["world_size"] == 1
+    assert g["gathered_actions_shape"] == [4096, 2] and g["gathered_status_shape"] == [4096]
+    assert g["own_block_equals_local"] is True
+
+
+def test_config5_shape_rollout_over_rccl():
+    """BASELINE config 5 at its per-step workload on the one GPU there is: 2048 environments, MPC in the loop
+    (agents/a2c_mpc.py:138-153 is the call being sharded), a 1-rank RCCL group, actions AND status all-gathered every
+    step and equal to the local ones.  (8 ranks x 256 environments is the driver's to launch.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_FORCE_DIST="1")
+    d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", "29643", "tools/bench_rollout.py", "--envs", "2048", "--steps", "16",
+               "--algorithm", "a2c"], env=env)
+    assert d["envs"] == 2048 and d["n_gpus"] == 1 and d["steps_per_env"] == 16
+    g = d["distributed"]
+    assert g["backend"] == "nccl" and g["gathered_actions_shape"] == [2048, 2] and g["gathered_status_shape"] == [2048]
+    assert g["own_block_equals_local"] is True
+    assert d["env_steps_per_s"] > 1e5 and d["converged_frac"] > 0.99

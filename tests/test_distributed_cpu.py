@@ -79,7 +79,9 @@ class _RankEngine:
         act = torch.zeros((B, 2), dtype=torch.float64)
         act[:, 0] = -1.0
         act[:, 1] = 1e-3 * (self.offset + torch.arange(B, dtype=torch.float64))
-        return dict(act=act, status=torch.zeros(B, dtype=torch.int32), iters=torch.zeros(B, dtype=torch.int32))
+        # status encodes the global id too (values a real solve can return: 0, 1, 4, 5)
+        status = torch.tensor([0, 1, 4, 5], dtype=torch.int32)[(self.offset + torch.arange(B)) % 4]
+        return dict(act=act, status=status, iters=torch.zeros(B, dtype=torch.int32))
 
 
 def _rollout_worker(rank, world, port, total, q):
@@ -94,13 +96,14 @@ def _rollout_worker(rank, world, port, total, q):
     col = rollout.BatchedCollector(env, rollout.ActorCritic(1), _RankEngine(lo), version="v0", n_steps=3,
                                    gather_actions=True)
     col.collect_rollouts()
-    q.put((rank, col.gathered_actions.numpy(), col.buffer.mpc_actions[-1].numpy()))
+    q.put((rank, col.gathered_actions.numpy(), col.buffer.mpc_actions[-1].numpy(), col.gathered_status.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_sharded_rollout_gathers_every_ranks_actions():
-    """Config-5 shape: environments sharded over ranks, MPC actions all-gathered each step (gloo stands in for RCCL)."""
+    """Config-5 shape: environments sharded over ranks, MPC actions and solver status all-gathered each step in one
+    collective (gloo stands in for RCCL)."""
     total = 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -108,7 +111,7 @@ def test_sharded_rollout_gathers_every_ranks_actions():
     procs = [ctx.Process(target=_rollout_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = {r: (g, l) for r, g, l in (q.get(timeout=120) for _ in range(2))}
+    got = {r: (g, l, s) for r, g, l, s in (q.get(timeout=120) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -116,3 +119,4 @@ def test_sharded_rollout_gathers_every_ranks_actions():
     for r in range(2):
         assert np.array_equal(got[r][0], want)
         assert np.array_equal(got[r][1], want[r * 6:(r + 1) * 6])
+        assert got[r][2].dtype == np.int32 and np.array_equal(got[r][2], np.array([0, 1, 4, 5])[np.arange(total) % 4])

@@ -275,6 +275,42 @@ def test_warm_start_flag(oracle, ref_table):
     assert cw.mean() > cc_.mean() - 0.03
 
 
+def test_reference_call_sequence_with_separate_check_collision():
+    """The reference's own sequence `_parse_obs -> _check_collision -> (read is_collide) -> _solve`
+    (agents/pure_mpc.py:68-78 spelled out by a caller) equals `predict()`: the stand-alone `_check_collision` refreshes
+    the flag BEFORE the solve and the detector is advanced once per observation, not twice."""
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    a, b = PureMPC_Agent(Env(), dict(CFG)), PureMPC_Agent(Env(), dict(CFG))
+    obs = np.zeros((10, 8), np.float32)
+    obs[0] = [1, 2.0, 30.0, 0.0, -10.0, -np.pi / 2, -1.0, 0.0]
+    obs[1] = [1, -15.0, 12.0, 8.0, 0.0, 0.0, 0.0, 1.0]              # crosses the ego path ahead
+    gone = obs.copy()
+    gone[1:] = 0
+    for step, o in enumerate([obs, gone, gone, gone, obs, gone]):
+        want = a.predict(o, return_numpy=False)
+        b._parse_obs(o)
+        assert b._detected is False
+        b._check_collision()
+        flag_before_solve = (b.is_collide, b.collision_memory, list(b.conflict_index))
+        got = b._solve()
+        assert flag_before_solve == (a.is_collide, a.collision_memory, list(a.conflict_index)), step
+        assert (b.is_collide, b.collision_memory) == (a.is_collide, a.collision_memory), step
+        assert got.acceleration == want.acceleration and got.steer == want.steer, step
+        assert got.success and got.status in (0, 5) and got.iters > 0
+        again = b._solve()                                           # a second _solve never touches the detector
+        assert b.collision_memory == a.collision_memory and again.acceleration == want.acceleration
+    # an RL speed override given to _solve after a stand-alone detection is honoured (the profile is derived in _solve,
+    # agents/pure_mpc.py:113-117, and takes precedence over the collision profile, :683-688)
+    c, d = PureMPC_Agent(Env(), dict(CFG)), PureMPC_Agent(Env(), dict(CFG))
+    rs = np.array([[0.7]])
+    want = c.predict(obs, ref_speed=rs)
+    d._parse_obs(obs)
+    d._check_collision()
+    assert d.is_collide
+    got = d._solve(ref_speed_from_RL=rs)
+    assert got.acceleration == want[0] and got.steer == want[1] and want[0] < -1.0
+
+
 def test_single_agent_attributes_and_checkpoint():
     """`predict()` of the product agent (one device call, B = 1) leaves the attributes the reference's callers and plots
     read (agents/pure_mpc.py:38-43, 589-593), equal to the numpy mirror's; the detector record can be saved and put back
@@ -314,6 +350,13 @@ def test_single_agent_attributes_and_checkpoint():
     a.load_env_state(saved)
     run2 = [a.predict(obs2).copy() for _ in range(9)]
     assert all(np.array_equal(x, y) for x, y in zip(run1, run2)) and a.collision_memory == mem1
+    # a corrupted record is refused as a whole (counts are loop bounds, indices subscripts on the device)
+    from mpc_rl_for_avs_amd.engine import EngineError
+    for word, val in ((3, 99), (5, 85), (8, 10 ** 6), (0, -1)):      # n_conflict, ego_index, conflict[0], collision_memory
+        bad = saved.copy()
+        bad.view(np.int32)[0, word] = val
+        with pytest.raises(EngineError, match="not a valid detector state"):
+            a.load_env_state(bad)
     # into another engine
     b = PureMPC_Agent(Env(), dict(CFG))
     b.load_env_state(saved)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--others", type=int, default=4)
     ap.add_argument("--version", default="v0")
+    ap.add_argument("--algorithm", default="ppo", choices=("ppo", "a2c"))
     ap.add_argument("--graph", action="store_true", help="replay the rollout step as a captured hipGraph")
     ap.add_argument("--groups", type=int, default=1,
                     help="split this rank's environments into G groups stepped on G HIP streams (PipelinedCollector)")
@@ -50,7 +51,7 @@ def main():
             e_g = engine.MPCEngine(horizon=20, max_iter=100, device=local)
             env = rollout.SyntheticIntersectionEnv(ghi - glo, device=dev, seed=rank * 97 + g, n_others=a.others)
             engs.append(e_g)
-            cols.append(rollout.BatchedCollector(env, pol, e_g, version=a.version, algorithm="ppo", n_steps=a.steps,
+            cols.append(rollout.BatchedCollector(env, pol, e_g, version=a.version, algorithm=a.algorithm, n_steps=a.steps,
                                                  collision_cost=False, gather_actions=use_dist and G == 1 and not a.graph,
                                                  seed=g, use_graph=a.graph))
         col = cols[0] if G == 1 else rollout.PipelinedCollector(cols)
@@ -83,14 +84,20 @@ def main():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-            if G == 1 and not a.graph:
-                assert col.gathered_actions.shape == (total, 2)
+        dist_info = None
+        if use_dist and G == 1 and not a.graph:
+            assert col.gathered_actions.shape == (total, 2) and col.gathered_status.shape == (total,)
+            dist_info = dict(backend=dist.get_backend(), world_size=world,
+                             gathered_actions_shape=list(col.gathered_actions.shape),
+                             gathered_status_shape=list(col.gathered_status.shape),
+                             own_block_equals_local=bool(torch.equal(col.gathered_actions[lo:hi], col.last_mpc["act"]) and
+                                                         torch.equal(col.gathered_status[lo:hi], col.last_mpc["status"])))
         dm = sum(e0.elapsed_time(e1) for e0, e1 in events) * 1e-3
         st = torch.cat([c.last_mpc["status"] for c in cols]).cpu().numpy()
         if rank == 0:
-            print(json.dumps(dict(config=f"{total} envs on {world} GPU(s), {a.others} other vehicles, {a.version}/ppo, "
+            print(json.dumps(dict(config=f"{total} envs on {world} GPU(s), {a.others} other vehicles, {a.version}/{a.algorithm}, "
                                          f"horizon 20" + (f", {G} groups on {G} streams" if G > 1 else "") + (", hipGraph step" if a.graph else ""),
-                              envs=total, n_gpus=world, groups=G, graph=bool(a.graph),
+                              envs=total, n_gpus=world, distributed=dist_info, groups=G, graph=bool(a.graph),
                               steps_per_env=a.steps, env_steps_per_s=total * a.steps / dt, ms_per_step=dt / a.steps * 1e3,
                               mpc_ms_per_step=dm / a.steps * 1e3, episodes=stats["episodes"], crashed=stats["crashed"],
                               arrived=stats["arrived"], converged_frac=float(((st == 0) | (st == 5)).mean()))), flush=True)
