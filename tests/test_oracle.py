@@ -135,3 +135,23 @@ def test_oracle_warm_start_reaches_the_same_solution_in_fewer_iterations(oracle,
     wild = np.full_like(cold["U"], 50.0)
     out = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], u_init=wild, **kw)
     assert (out["status"] == 0).mean() > 0.85
+
+
+def test_closed_loop_fixtures_agreement_is_what_the_profile_says(oracle, ref_table):
+    """tests/golden/closed_loop_ipopt.npz (make_closed_loop.py): the engine's algorithm (this oracle) against the
+    independent IPOPT restatement at the reference's settings on closed-loop problem data - the counts that
+    profiles/r03_parity_vs_ipopt.txt reports and the GPU test repeats on the device."""
+    import os
+    from conftest import GOLDEN, converged, rel_u0_err
+    g = np.load(os.path.join(GOLDEN, "closed_loop_ipopt.npz"))
+    want = {"c1": (121, 112), "c1cc": (118, 113), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 150)}
+    for name, counts in want.items():
+        d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
+        assert d["state"].shape[0] == 160 and d["others"].shape[1] in (1, 4)
+        o = oracle.solve_batch(ref_table, d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"],
+                               others=d["others"], collision_cost=name.endswith("cc"), max_iter=1000, xy_bounds=False)
+        assert np.array_equal(o["status"], g[f"{name}_oracle_status"])
+        assert rel_u0_err(o["u0"], g[f"{name}_oracle_u0"]).max() < 1e-9
+        both = (g[f"{name}_status"] == 0) & converged(o["status"])
+        agree = both & (rel_u0_err(o["u0"], g[f"{name}_u0"]) <= 1e-4)
+        assert (int(both.sum()), int(agree.sum())) == counts, name

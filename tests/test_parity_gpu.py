@@ -352,6 +352,51 @@ def test_independent_solver_fixtures(eng, ref_table):
             assert theirs["stationarity"].max() <= 1e-6       # the fixture's own points are KKT points too
 
 
+# scenario -> (both converged, of those within 1e-4) measured with the engine's algorithm on the CPU
+# (profiles/r03_parity_vs_ipopt.txt, tools/parity_vs_ipopt.py); the GPU must reproduce the agreement, not approach it
+CLOSED_LOOP_AGREEMENT = {"c1": (121, 112), "c1cc": (118, 113), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 150)}
+
+
+def test_closed_loop_fixtures_vs_independent_solver(ref_table):
+    """tests/golden/closed_loop_ipopt.npz: problem data recorded from closed-loop runs (BASELINE config 1 and the
+    config-4 rollout, collision cost off / on, RL speed override / none; generator tests/golden/make_closed_loop.py)
+    solved by oracle/ipopt_restated.py at the REFERENCE's settings (tol 1e-6, max_iter 1000, agents/pure_mpc.py:294-295).
+    The engine at its reference-like settings (max_iter 1000) must return the same action to 1e-4 on exactly the set
+    the analysis in profiles/r03_parity_vs_ipopt.txt found (97.2 % overall; 100 % under the RL speed override), and
+    where it does not its own point must be a certified KKT point (a different local minimiser: the 20 cases are
+    classified one by one in that file - end of the route with the reference window clamped, spawn transients with the
+    heading off the path and steering almost free, one stop profile)."""
+    import kkt_batch as kb
+    import nlp_batch as nb
+    from mpc_rl_for_avs_amd import engine
+    g = np.load(os.path.join(GOLDEN, "closed_loop_ipopt.npz"))
+    e = engine.MPCEngine(horizon=20, max_iter=1000)
+    tot_both = tot_agree = 0
+    for name, (n_both, n_agree) in CLOSED_LOOP_AGREEMENT.items():
+        cc = name.endswith("cc")
+        d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
+        got = e.solve_batch(d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"], others=d["others"],
+                            collision_cost=cc)
+        assert converged(got["status"]).all(), (name, np.bincount(got["status"], minlength=6))
+        # the device against the CPU run of the same algorithm that the analysis used
+        assert rel_u0_err(got["u0"], g[f"{name}_oracle_u0"]).max() < 1e-6, name
+        both = (g[f"{name}_status"] == 0) & converged(got["status"])
+        err = rel_u0_err(got["u0"], g[f"{name}_u0"])
+        agree = both & (err <= TOL)
+        assert (int(both.sum()), int(agree.sum())) == (n_both, n_agree), (name, both.sum(), agree.sum())
+        assert np.median(err[agree]) < 1e-7          # the proxy stops at tol 1e-6
+        other = np.nonzero(both & ~agree)[0]
+        if other.size:
+            p = nb.Batch.build(ref_table, d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"],
+                               others=d["others"], collision_cost=cc).take(other)
+            mine = kb.certify(p, got["X"][other], got["U"][other])
+            assert mine["stationarity"].max() <= 1e-8 and mine["feasibility"].max() <= 1e-10, name
+        tot_both += int(both.sum())
+        tot_agree += int(agree.sum())
+    assert tot_agree / tot_both >= 0.97
+    e.close()
+
+
 def test_config4_rollout_256_envs_against_oracle(oracle, ref_table):
     """BASELINE config 4: 256 parallel intersection environments, MPC in the loop (v0: the policy's action is the
     reference speed).  Every step's MPC actions against the oracle fed with the problem data the device preamble
