@@ -48,17 +48,22 @@ constexpr int kMaxDevices = 64;
 // of LDS at N = 20 with the collision cost and 8 vehicles, so 16 waves share a CU: all 4096 waves of a BASELINE batch
 // are resident at once and a straggler never starts late.  The runtime-horizon build would spill at 128 and stays at 3.
 constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
+// Builds of the same solver for batches that do not fill the SIMDs four deep (WaveOpsT<RELAX = true>, mpc_wave_dev.hpp):
+// up to two waves per SIMD (B <= 2048 on 256 CUs: BASELINE configs 2, 4, 5 and every single-environment predict) the
+// 201-register build, up to four the 168-register build for three resident waves (the rest of a 4096 batch is dispatched
+// as slots free, which also balances the SIMDs better than four static residents: 3.97 against 4.25 ms at cap 60).
+constexpr int kWaveOccLat = 2, kWaveOccMid = 3;
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
 // ---------------------------------------------------------------------------------------------------
-template <int NC>
-struct WaveCtx : mpc::wave::WaveOps {
+template <int NC, bool RELAX = false>
+struct WaveCtx : mpc::wave::WaveOpsT<RELAX> {
     static constexpr int kN = NC;
     const double *table;  // [M][REF_COLS] in global memory (wave-uniform index in the serial parts -> scalar loads)
     int e0, M;
     __device__ __forceinline__ WaveCtx(mpc::wave::lds_double_t *l, const double *t, int e, int m)
-        : mpc::wave::WaveOps{l}, table(t), e0(e), M(m) {}
+        : mpc::wave::WaveOpsT<RELAX>{l}, table(t), e0(e), M(m) {}
     __device__ __forceinline__ void tick(int) const {}  // section timing hook, used by tools/ubench only
     __device__ __forceinline__ double ref(int k, int c) const {
         int idx = e0 + k;
@@ -74,7 +79,7 @@ struct WaveCtx : mpc::wave::WaveOps {
     }
 };
 
-template <bool CC, int NC, int OCC>
+template <bool CC, int NC, int OCC, bool RELAX>
 __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     const int lane = threadIdx.x;
     constexpr int SL = mpc::wave::stage_slots(CC);
-    WaveCtx<NC> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
+    WaveCtx<NC, RELAX> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
     // inputs -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j)
     for (int node = lane; node <= N; node += kBlock) {
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     const bool collide = is_collide[b] != 0;
     const double ws_ = collide ? 100.0 : weights[(size_t)b * 3 + 0];  // agents/pure_mpc.py:143-147
     const double wcoll = (CC && collide) ? 3000.0 * w_collision : 0.0;
-    mpc::wave::Solver<CC, WaveCtx<NC>> solver(P, ctx, x0, ws_, weights[(size_t)b * 3 + 1], weights[(size_t)b * 3 + 2],
+    mpc::wave::Solver<CC, WaveCtx<NC, RELAX>> solver(P, ctx, x0, ws_, weights[(size_t)b * 3 + 1], weights[(size_t)b * 3 + 2],
                                              wcoll);
     int status, iters, cur;
     double kkt;
@@ -347,12 +352,12 @@ size_t carve(size_t &off, size_t bytes) {
     return o;
 }
 
-template <bool CC, int NC, int OCC>
+template <bool CC, int NC, int OCC, bool RELAX>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
                 const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
                 uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
-    auto kern = mpc_solve_wave_kernel<CC, NC, OCC>;
+    auto kern = mpc_solve_wave_kernel<CC, NC, OCC, RELAX>;
     // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
     // capture (hipGraph) of the launch
     static std::atomic<size_t> lds_set[kMaxDevices];      // zero-initialised; concurrent callers at worst both set it
@@ -405,18 +410,26 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
     if (wlds > h->lds_per_cu)
         return fail(MPC_ERR_INVALID_ARG, "horizon / vehicle count too large for the LDS workspace of one instance");
     int rc;
-#define MPC_LAUNCH_W(CCV, NCV, OCCV)                                                                              \
-    rc = launch_wave<CCV, NCV, OCCV>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
-                                     d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters)
+#define MPC_LAUNCH_W(CCV, NCV, OCCV, RLX)                                                                              \
+    rc = launch_wave<CCV, NCV, OCCV, RLX>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
+                                          d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters)
+    // which build: by how deep the batch fills the SIMDs (see kWaveOccLat / kWaveOccMid above)
+    const int simds = 4 * h->num_cu;
+    const int depth = B <= kWaveOccLat * simds ? kWaveOccLat : (B <= kWaveOcc * simds ? kWaveOccMid : kWaveOcc);
+#define MPC_LAUNCH_N(CCV, NCV)                                                         \
+    if (depth == kWaveOccLat) MPC_LAUNCH_W(CCV, NCV, kWaveOccLat, true);               \
+    else if (depth == kWaveOccMid) MPC_LAUNCH_W(CCV, NCV, kWaveOccMid, true);          \
+    else MPC_LAUNCH_W(CCV, NCV, kWaveOcc, false)
     if (cc) {
-        if (N == 20) MPC_LAUNCH_W(true, 20, kWaveOcc);       /* BASELINE horizon */
-        else if (N == 16) MPC_LAUNCH_W(true, 16, kWaveOcc);  /* reference cfg.yaml default */
-        else MPC_LAUNCH_W(true, 0, kWaveOccGeneric);
+        if (N == 20) { MPC_LAUNCH_N(true, 20); }       /* BASELINE horizon */
+        else if (N == 16) { MPC_LAUNCH_N(true, 16); }  /* reference cfg.yaml default */
+        else MPC_LAUNCH_W(true, 0, kWaveOccGeneric, false);
     } else {
-        if (N == 20) MPC_LAUNCH_W(false, 20, kWaveOcc);
-        else if (N == 16) MPC_LAUNCH_W(false, 16, kWaveOcc);
-        else MPC_LAUNCH_W(false, 0, kWaveOccGeneric);
+        if (N == 20) { MPC_LAUNCH_N(false, 20); }
+        else if (N == 16) { MPC_LAUNCH_N(false, 16); }
+        else MPC_LAUNCH_W(false, 0, kWaveOccGeneric, false);
     }
+#undef MPC_LAUNCH_N
 #undef MPC_LAUNCH_W
     return rc;
 }

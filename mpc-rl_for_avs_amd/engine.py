@@ -59,6 +59,8 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is None and os.environ.get("MPC_EXPERIMENT_LIB"):
+        path = os.environ["MPC_EXPERIMENT_LIB"]     # development aid: an experimental build of the same ABI (tools/)
     if path is None:
         path = _build.LIB_PATH
         if _build.is_stale():

@@ -163,6 +163,10 @@ static double stage_cost_raw(const prob_t *p, int k, const double *x, double *lx
 
 /* optional work counters (ORACLE_COUNT=1, single thread): iterations, backward sweeps, rollouts */
 static long g_cnt_iter, g_cnt_sweep, g_cnt_roll, g_cnt_solve;
+/* per-thread tallies of the instance being solved (no shared counters inside solve_one: with 32+ threads the atomics on
+ * three global words were a measurable part of the run); summed by the OpenMP reduction of the batch loop */
+static _Thread_local long t_cnt_iter, t_cnt_sweep, t_cnt_roll;
+static int g_trace, g_trace2; /* ORACLE_TRACE / ORACLE_TRACE2, read once per batch call */
 static int g_cnt_N, g_cnt_V, g_cnt_cc;
 
 typedef struct {
@@ -448,11 +452,9 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
          * multiple of the identity is added. */
         double dV1 = 0.0, delta_w = reg;
         int nmod = 0, ok = 0, gn = 0;
-#pragma omp atomic
-        ++g_cnt_iter;
+        ++t_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
-#pragma omp atomic
-            ++g_cnt_sweep;
+            ++t_cnt_sweep;
             ok = 1;
             dV1 = 0.0;
             double Pxx[4][4], Pxp[4][2], Ppp[2][2] = {{0, 0}, {0, 0}}, px[4], pp[2] = {0, 0};
@@ -644,8 +646,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         for (int k = 0; k <= N; ++k) cross[k] = -1;
         for (nls = 0; nls < MAXLS; ++nls, alpha *= BTF) {
             int feas = 1;
-#pragma omp atomic
-            ++g_cnt_roll;
+            ++t_cnt_roll;
             trial = *it;
             for (int k = 0; k < N && feas; ++k) {
                 for (int i = 0; i < 2; ++i) {
@@ -697,10 +698,10 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     wall_slack(p, k + 1, trial.x[k + 1], it->wj[k + 1]) < 0.5 * (1.0 - tau) * gw[k + 1])
                     feas = 0;
             }
-            if (getenv("ORACLE_TRACE2")) fprintf(stderr, "   trial %d alpha %.3e feas %d\n", nls, alpha, feas);
+            if (g_trace2) fprintf(stderr, "   trial %d alpha %.3e feas %d\n", nls, alpha, feas);
             if (!feas) continue;
             phi1 = barrier_objective(p, &trial, mu);
-            if (getenv("ORACLE_TRACE2")) fprintf(stderr, "      phi1-phi0 %.6e need %.6e\n", phi1 - phi0, 1e-4 * alpha * 2.0 * dV1);
+            if (g_trace2) fprintf(stderr, "      phi1-phi0 %.6e need %.6e\n", phi1 - phi0, 1e-4 * alpha * 2.0 * dV1);
             if (phi1 <= phi0 + 1e-4 * alpha * 2.0 * dV1 + 1e-12 * fabs(phi0)) {
                 accepted = 1;
                 break;
@@ -714,7 +715,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                             cross[k] = j;
                     }
         }
-        if (getenv("ORACLE_TRACE"))
+        if (g_trace)
             fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
                     iter, nmod, gn, mu, delta_w, err_d, err_c0, E0, a_pr, alpha, a_du, nls, dV1, phi0, phi1, accepted);
         if (!accepted) trial = *it; /* keep the primal point; the dual step below still moves z */
@@ -813,11 +814,15 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
     g_cnt_V = (flags & 1u) ? V : 0;
     g_cnt_cc = (flags & 1u) ? 1 : 0;
     opts_t o = {tol, 0.1, max_iter};
+    g_trace = getenv("ORACLE_TRACE") != NULL;
+    g_trace2 = getenv("ORACLE_TRACE2") != NULL;
+    long c_iter = 0, c_sweep = 0, c_roll = 0;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : c_iter, c_sweep, c_roll) proc_bind(close)
     for (int b = 0; b < B; ++b) {
+        t_cnt_iter = t_cnt_sweep = t_cnt_roll = 0;
         prob_t p;
         memset(&p, 0, sizeof(p));
         p.N = N;
@@ -870,7 +875,13 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
         iters[b] = its;
         if (kkt) kkt[b] = e;
         free(it);
+        c_iter += t_cnt_iter;
+        c_sweep += t_cnt_sweep;
+        c_roll += t_cnt_roll;
     }
+    g_cnt_iter = c_iter;
+    g_cnt_sweep = c_sweep;
+    g_cnt_roll = c_roll;
     if (getenv("ORACLE_COUNT"))
         fprintf(stderr, "oracle work: %ld iterations, %ld backward sweeps, %ld rollouts\n", g_cnt_iter, g_cnt_sweep, g_cnt_roll);
     return 0;
