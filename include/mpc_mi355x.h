@@ -62,7 +62,8 @@ extern "C" {
 #define MPC_STATUS_MAX_ITER 1       /* last iterate returned, like the reference (agents/pure_mpc.py:303-305) */
 #define MPC_STATUS_FACTORIZATION 2
 #define MPC_STATUS_INFEASIBLE_START 3 /* the initial state violates the state bounds of agents/pure_mpc.py:272-274 */
-#define MPC_STATUS_STALLED 4          /* no acceptable step in 3 consecutive iterations; last iterate returned */
+#define MPC_STATUS_STALLED 4          /* no acceptable step in 3 consecutive iterations, or (mpc_config.stall_window) no
+                                         halving of the KKT error within the window; last iterate returned */
 #define MPC_STATUS_CONVERGED_ON_KINK 5 /* converged, with the collision cost on, to a point that holds a vehicle exactly at
                                          the d = 1 m discontinuity of that cost (agents/archive/pure_mpc.py:189-196:
                                          100/d^2 outside, 1000/d^2 inside): a KKT point of the outer branch with
@@ -89,7 +90,12 @@ typedef struct mpc_config {
     double w_collision;  /* cfg key weight_collision (config/cfg.yaml:106), used with MPC_FLAG_COLLISION_COST */
     int32_t ltv_passes;  /* iterative-linear agent: linearisation passes per call, the trip count of the loop at
                             agents/pure_mpc_linear.py:189 (`for _ in range(1)`); default 1 */
-    int32_t reserved0;   /* 0 */
+    int32_t stall_window; /* 0 (default) = off.  W > 0: a solve whose scaled KKT error has not halved within W consecutive
+                            iterations ends with MPC_STATUS_STALLED instead of running on to max_iter - what makes the
+                            reference's max_iter 1000 affordable in a batch, whose time is that of its slowest instance
+                            (profiles/r03_tail.txt: one instance in a thousand never converges and costs 40 ms).  64
+                            gives up on 2 - 6 of 4096 BASELINE-config-3 instances that would converge after 100 - 440
+                            iterations.  Not an IPOPT option; the reference runs such instances to max_iter. */
 } mpc_config;
 
 /* ABI version of the loaded library (MPC_ABI_VERSION it was built with). */
@@ -220,6 +226,24 @@ int mpc_reserve_envs(mpc_handle *h, int32_t B);
  * Diagnostics / tests: these are exactly the arguments mpc_solve_batch would take. */
 int mpc_get_last_inputs(mpc_handle *h, int32_t B, double *state, int32_t *ego_index, double *vref,
                         uint8_t *is_collide, double *others, int32_t *nveh);
+
+/*
+ * Synthetic intersection environment for MPC-in-the-loop rollouts (BASELINE configs 4-5; highway-env, which the reference
+ * steps at agents/ppo_mpc.py:430-432, is not available offline): ONE launch per policy step for B environments - vehicle
+ * models, respawn, reward / termination shape of envs/intersection_env_Feb2025_v1.py:80-155, terminal observation,
+ * auto-reset and the next observation in the layout of config/config.py:10-26 (csrc/mpc_synth_env.hpp).  All pointers are
+ * DEVICE memory on `device`; the call only enqueues on `stream` (capturable in a hipGraph).  State arrays, updated in
+ * place: ego [B][4] x, y, heading, speed; opos [B][K'][2], ospeed / ohead [B][K'] f64, oactive [B][K'] u8 with
+ * K' = max(K, 1); t [B] steps of the episode; rng_counter [B] (zero-initialised; with `seed` and env_offset + b it keys a
+ * counter-based generator, so shards of one job draw distinct streams).  action [B][2] acceleration, steer.
+ * Outputs: obs [B][10][8] f32 what the policy sees next (after the auto-reset), terminal_obs the same before it, reward [B]
+ * f32, done / truncated / crashed / arrived [B] u8.  reset_all != 0: start fresh episodes everywhere and write obs only.
+ */
+int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double spawn_probability, uint64_t seed,
+                       int32_t env_offset, const double *ref_xy, int32_t M, const double *action, double *ego, double *opos,
+                       double *ospeed, double *ohead, uint8_t *oactive, int32_t *t, int64_t *rng_counter, float *obs,
+                       float *terminal_obs, float *reward, uint8_t *done, uint8_t *truncated, uint8_t *crashed,
+                       uint8_t *arrived, int32_t reset_all, void *stream);
 
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
  * collision-cost term (V = 0: term off); B is accepted for interface stability and does not matter.  The engine

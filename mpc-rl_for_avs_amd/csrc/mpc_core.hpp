@@ -29,6 +29,7 @@ struct SolveParams {
     double tol;
     double mu_init;
     double w_distance;  // weight_distance
+    int stall_window;   // mpc_config.stall_window: 0 = off
 };
 
 // single v_max_f64 / v_min_f64 on the device (a compare + two v_cndmask otherwise)

@@ -24,6 +24,7 @@
 #include "mpc_wave.hpp"
 #include "mpc_wave_dev.hpp"
 #include "mpc_preamble.hpp"
+#include "mpc_synth_env.hpp"
 
 namespace {
 
@@ -312,6 +313,40 @@ __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, con
         for (int i = 0; i < ltv_row; ++i) ltv_u[(size_t)b * ltv_row + i] = 0.0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// synthetic intersection environment (mpc_synth_env.hpp): one thread per environment; step + terminal observation +
+// auto-reset + next observation in ONE launch (the torch implementation of the same step is ~100 small kernels)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void mpc_synth_env_kernel(
+    int B, int K, double dt, double spawn_probability, uint64_t seed, int env_offset, const double *__restrict__ ref_xy,
+    int M, const double *__restrict__ action, double *__restrict__ ego, double *__restrict__ opos,
+    double *__restrict__ ospeed, double *__restrict__ ohead, uint8_t *__restrict__ oactive, int32_t *__restrict__ t,
+    int64_t *__restrict__ ctr, float *__restrict__ obs, float *__restrict__ terminal_obs, float *__restrict__ reward,
+    uint8_t *__restrict__ done, uint8_t *__restrict__ truncated, uint8_t *__restrict__ crashed,
+    uint8_t *__restrict__ arrived, int reset_all) {
+    namespace env = mpc::env;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int Ks = K > 0 ? K : 1;      // the arrays keep one slot per environment even without traffic
+    const env::View v{ego + (size_t)b * 4, opos + (size_t)b * Ks * 2, ospeed + (size_t)b * Ks, ohead + (size_t)b * Ks,
+                      oactive + (size_t)b * Ks, t + b, ctr + b};
+    float *o = obs + (size_t)b * env::kRows * env::kCols;
+    if (reset_all) {
+        const env::Rng r(seed, env_offset + b, *v.ctr);
+        *v.ctr += 1;
+        env::reset_env(v, K, r);
+        env::observe(v, K, o);
+        return;
+    }
+    const env::StepOut so = env::step_env(v, K, dt, spawn_probability, seed, env_offset + b, ref_xy, M, action + (size_t)b * 2,
+                                          terminal_obs + (size_t)b * env::kRows * env::kCols, o);
+    reward[b] = so.reward;
+    done[b] = so.done;
+    truncated[b] = so.truncated;
+    crashed[b] = so.crashed;
+    arrived[b] = so.arrived;
+}
+
 }  // namespace
 
 struct mpc_handle {
@@ -404,6 +439,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
     P.tol = h->cfg.tol;
     P.mu_init = 0.1;
     P.w_distance = h->cfg.w_distance;
+    P.stall_window = h->cfg.stall_window;
 
     static_assert(MPC_MAX_HORIZON <= mpc::wave::kMaxHorizon, "lane k = stage k needs the horizon to fit a wave");
     const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
@@ -473,8 +509,8 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
         return fail(MPC_ERR_INVALID_ARG, "mpc_create: horizon out of range");
     if (!(cfg->dt > 0.0) || cfg->max_iter < 0 || !(cfg->tol > 0.0))
         return fail(MPC_ERR_INVALID_ARG, "mpc_create: dt, max_iter and tol must be positive");
-    if (cfg->ltv_passes < 1 || cfg->ltv_passes > 16 || cfg->reserved0 != 0)
-        return fail(MPC_ERR_INVALID_ARG, "mpc_create: ltv_passes must be 1..16 and reserved0 zero");
+    if (cfg->ltv_passes < 1 || cfg->ltv_passes > 16 || cfg->stall_window < 0)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_create: ltv_passes must be 1..16 and stall_window non-negative");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -1031,6 +1067,27 @@ int mpc_set_env_state(mpc_handle *h, int32_t B, const void *records) {
     // a restored environment is not the episode whose controls the handle remembers: no warm start, no stored LTV profile
     HIP_TRY(hipMemset(h->d_warm_valid, 0, (size_t)B));
     HIP_TRY(hipMemset(h->d_ltv_u, 0, (size_t)B * h->cfg.horizon * 2 * sizeof(double)));
+    return MPC_OK;
+}
+
+int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double spawn_probability, uint64_t seed,
+                       int32_t env_offset, const double *ref_xy, int32_t M, const double *action, double *ego, double *opos,
+                       double *ospeed, double *ohead, uint8_t *oactive, int32_t *t, int64_t *rng_counter, float *obs,
+                       float *terminal_obs, float *reward, uint8_t *done, uint8_t *truncated, uint8_t *crashed,
+                       uint8_t *arrived, int32_t reset_all, void *stream_) {
+    if (B < 0 || K < 0 || K > mpc::env::kMaxOthers || !(dt > 0.0) || M < 1)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_synth_env_step: bad size");
+    if (!ref_xy || !ego || !opos || !ospeed || !ohead || !oactive || !t || !rng_counter || !obs)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_synth_env_step: null state pointer");
+    if (!reset_all && (!action || !terminal_obs || !reward || !done || !truncated || !crashed || !arrived))
+        return fail(MPC_ERR_INVALID_ARG, "mpc_synth_env_step: null output pointer");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(mpc_synth_env_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
+                       (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
+                       ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
+                       (int)reset_all);
+    HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
 

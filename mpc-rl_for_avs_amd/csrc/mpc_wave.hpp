@@ -794,6 +794,10 @@ struct Solver {
         double mu = P.mu_init;
         int iter = 0, nfail = 0;
         double reg = 0.0;
+        // progress guard (mpc_config.stall_window, off by default): the iteration at which the KKT error last fell below
+        // half of its value at the previous such mark
+        int i_mark = 0;
+        double e_mark = INFINITY;
 
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
@@ -995,6 +999,15 @@ struct Solver {
                 break;
             }
             if (iter == P.max_iter) break;
+            if (P.stall_window > 0) {
+                if (E0 < 0.5 * e_mark) {
+                    e_mark = c.uni(E0);
+                    i_mark = iter;
+                } else if (iter - i_mark >= P.stall_window) {
+                    status_out = 4;      // the KKT error has not halved within the window: stop burning the budget
+                    break;
+                }
+            }
 
             c.tick(T_DUALRES);
             // ============ Riccati / DDP factorisation: lane (i, j) = entry of the 8x8 stage block ============

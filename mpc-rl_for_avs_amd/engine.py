@@ -42,14 +42,14 @@ class _Config(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("horizon", ctypes.c_int32), ("dt", ctypes.c_double),
                 ("max_iter", ctypes.c_int32), ("device", ctypes.c_int32), ("tol", ctypes.c_double),
                 ("w_distance", ctypes.c_double), ("w_collision", ctypes.c_double),
-                ("ltv_passes", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("ltv_passes", ctypes.c_int32), ("stall_window", ctypes.c_int32)]
 
 
 _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_config_sized", "mpc_create", "mpc_destroy",
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
-            "mpc_set_env_state", "mpc_reserve_envs"]
+            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step"]
 MAX_OTHERS = 16
 _lib = None
 
@@ -117,6 +117,9 @@ def load_library(path: str | None = None):
     lib.mpc_set_env_state.restype = ctypes.c_int
     lib.mpc_reserve_envs.argtypes = [vp, ctypes.c_int32]
     lib.mpc_reserve_envs.restype = ctypes.c_int
+    lib.mpc_synth_env_step.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_uint64, ctypes.c_int32, dp, ctypes.c_int32] + [vp] * 15 + [ctypes.c_int32, vp]
+    lib.mpc_synth_env_step.restype = ctypes.c_int
     lib.mpc_get_last_inputs.argtypes = [vp, ctypes.c_int32, dp, ip, dp, vp, dp, ip]
     lib.mpc_get_last_inputs.restype = ctypes.c_int
     _lib = lib
@@ -132,7 +135,7 @@ class MPCEngine:
 
     def __init__(self, horizon: int = 20, dt: float = 0.1, max_iter: int = 100, tol: float = 1e-8,
                  w_distance: float = 10.0, w_collision: float = 1.0, device: int = 0, ref_table=None,
-                 ltv_passes: int = 1):
+                 ltv_passes: int = 1, stall_window: int = 0):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         cfg = _Config()
@@ -142,6 +145,7 @@ class MPCEngine:
             raise EngineError(f"mpc_default_config_sized failed ({rc}): {self._lib.mpc_last_error().decode()}")
         cfg.horizon, cfg.dt, cfg.max_iter, cfg.tol = int(horizon), float(dt), int(max_iter), float(tol)
         cfg.w_distance, cfg.w_collision, cfg.device = float(w_distance), float(w_collision), int(device)
+        cfg.stall_window = int(stall_window)  # 0 = off: see include/mpc_mi355x.h
         cfg.ltv_passes = int(ltv_passes)     # iterative-linear agent only: trip count of agents/pure_mpc_linear.py:189
         rc = self._lib.mpc_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc != 0:

@@ -44,18 +44,31 @@ WHEELBASE = 2.5
 
 
 class SyntheticIntersectionEnv:
-    """B independent intersection episodes stepped together on one device (auto-reset like an SB3 VecEnv)."""
+    """B independent intersection episodes stepped together on one device (auto-reset like an SB3 VecEnv).
+
+    Two implementations of the same step behind this class: on a GPU the fused HIP kernel `mpc_synth_env_step`
+    (csrc/mpc_synth_env.hpp: vehicle models, respawn, reward, termination, terminal observation, auto-reset and the next
+    observation in ONE launch, counter-based random numbers) - `backend="hip"`, the default there; on the CPU, or with
+    `backend="torch"`, the vectorised torch ops below (about a hundred small kernels per step on a GPU).  Same state
+    tensors, same return values; the two draw different random streams (as torch's CPU and GPU generators do), the
+    deterministic part of the step is identical (tests/test_rollout_cpu.py, tests/test_predict_gpu.py)."""
 
     def __init__(self, num_envs: int, device="cpu", seed: int = 0, n_others: int = 4, dt: float = 0.1,
-                 spawn_probability: float = 0.3):
+                 spawn_probability: float = 0.3, backend: str = "auto", env_offset: int = 0):
         assert 0 <= n_others <= VEHICLES_COUNT - 1
         self.num_envs, self.K, self.dt = int(num_envs), int(n_others), float(dt)
         self.device = torch.device(device)
         self.spawn_probability = float(spawn_probability)
+        if backend not in ("auto", "hip", "torch"):
+            raise ValueError("backend must be auto|hip|torch")
+        self.backend = ("hip" if self.device.type == "cuda" else "torch") if backend == "auto" else backend
+        if self.backend == "hip" and self.device.type != "cuda":
+            raise ValueError("the fused environment step needs a GPU device")
+        self.seed, self.env_offset = int(seed), int(env_offset)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
         ref = reference_states(dt)
-        self.ref_xy = torch.as_tensor(ref[:, :2], dtype=torch.float64, device=self.device)
+        self.ref_xy = torch.as_tensor(np.ascontiguousarray(ref[:, :2]), dtype=torch.float64, device=self.device)
         self.M = ref.shape[0]
         B, K = self.num_envs, max(self.K, 1)
         self.ego = torch.zeros((B, 4), dtype=torch.float64, device=self.device)      # x, y, heading, speed
@@ -65,6 +78,30 @@ class SyntheticIntersectionEnv:
         self.oactive = torch.zeros((B, K), dtype=torch.bool, device=self.device)
         self.t = torch.zeros(B, dtype=torch.int32, device=self.device)
         self._lane_h = torch.tensor([0.0, math.pi / 2, math.pi, -math.pi / 2], dtype=torch.float64, device=self.device)
+        if self.backend == "hip":
+            from . import engine as _engine
+            self._lib = _engine.load_library()
+            self.rng_counter = torch.zeros(B, dtype=torch.int64, device=self.device)
+            u8 = lambda: torch.zeros(B, dtype=torch.uint8, device=self.device)
+            # outputs of the step live at fixed addresses (a captured hipGraph replays against them)
+            self._out = dict(obs=torch.zeros((B, VEHICLES_COUNT, 8), dtype=torch.float32, device=self.device),
+                             terminal_obs=torch.zeros((B, VEHICLES_COUNT, 8), dtype=torch.float32, device=self.device),
+                             reward=torch.zeros(B, dtype=torch.float32, device=self.device),
+                             done=u8(), truncated=u8(), crashed=u8(), arrived=u8())
+
+    # ---- fused implementation (csrc/mpc_synth_env.hpp) ---------------------------------------------------------------
+    def _hip_call(self, action, reset_all):
+        import ctypes
+        o = self._out
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._lib.mpc_synth_env_step(
+            self.device.index or 0, self.num_envs, self.K, self.dt, self.spawn_probability, self.seed, self.env_offset,
+            p(self.ref_xy), self.M, p(action), p(self.ego), p(self.opos), p(self.ospeed), p(self.ohead), p(self.oactive),
+            p(self.t), p(self.rng_counter), p(o["obs"]), p(o["terminal_obs"]), p(o["reward"]), p(o["done"]),
+            p(o["truncated"]), p(o["crashed"]), p(o["arrived"]), 1 if reset_all else 0, stream)
+        if rc != 0:
+            raise RuntimeError(f"mpc_synth_env_step failed ({rc}): {self._lib.mpc_last_error().decode()}")
 
     # ---- random helpers ------------------------------------------------------------------------------------
     def _u(self, shape, lo, hi):
@@ -102,6 +139,7 @@ class SyntheticIntersectionEnv:
 
     # ---- observation (config/config.py:10-26) ------------------------------------------------------------------
     def observe(self) -> torch.Tensor:
+        """(torch implementation; also the independent check of the fused kernel's observation)"""
         B, K = self.num_envs, max(self.K, 1)
         obs = torch.zeros((B, VEHICLES_COUNT, 8), dtype=torch.float32, device=self.device)
         x, y, th, v = self.ego.unbind(dim=1)
@@ -125,6 +163,9 @@ class SyntheticIntersectionEnv:
         return obs
 
     def reset(self) -> torch.Tensor:
+        if self.backend == "hip":
+            self._hip_call(None, True)
+            return self._out["obs"]
         self._reset_where(torch.ones(self.num_envs, dtype=torch.bool, device=self.device))
         return self.observe()
 
@@ -133,6 +174,14 @@ class SyntheticIntersectionEnv:
         """action[B, 2] = acceleration [m/s^2], steering angle [rad] (what the RL wrappers hand to env.step,
         agents/ppo_mpc.py:430-432).  Returns obs, reward, done, info like an SB3 VecEnv with auto-reset:
         info = dict(terminal_obs, truncated, crashed, arrived)."""
+        if self.backend == "hip":
+            if action.dtype != torch.float64 or not action.is_contiguous():
+                action = action.to(torch.float64).contiguous()
+            self._hip_call(action, False)
+            o = self._out
+            b = lambda k: o[k].view(torch.bool)
+            return o["obs"], o["reward"], b("done"), dict(terminal_obs=o["terminal_obs"], truncated=b("truncated"),
+                                                          crashed=b("crashed"), arrived=b("arrived"))
         a = torch.clamp(action[:, 0].to(torch.float64), -5.0, 5.0)                      # config/config.py:31
         delta = torch.clamp(action[:, 1].to(torch.float64), -math.pi / 4, math.pi / 4)  # config/config.py:30
         x, y, th, v = self.ego.unbind(dim=1)
@@ -274,12 +323,15 @@ class BatchedCollector:
     episode boundaries; True forgets it (`mpc_reset_env_mask`) when an environment restarts.
     warm_start=True (not in the reference) starts every solve from the environment's previous solution advanced by
     one stage (`MPC_FLAG_WARM_START`).
+    use_graph: replay the step as one captured hipGraph (default on a GPU; `False` runs it eagerly, ~100 launches from
+    Python per step).
     """
 
     def __init__(self, env, policy: ActorCritic, engine, version: str = "v0", algorithm: str = "ppo",
                  n_steps: int = 64, gamma: float = 0.99, gae_lambda: float = 0.95,
                  default_weights=(1.0, 1.0, 1.0), collision_cost: bool = False, reset_mpc_on_done: bool = False,
-                 gather_actions: bool = False, seed: int = 0, warm_start: bool = False, use_graph: bool = False):
+                 gather_actions: bool = False, seed: int = 0, warm_start: bool = False,
+                 use_graph: bool | None = None):
         if version not in ("v0", "v1") or algorithm not in ("ppo", "a2c"):
             raise ValueError("version must be v0|v1 and algorithm ppo|a2c")
         if version == "v1" and policy.action_dim < 3:
@@ -304,6 +356,12 @@ class BatchedCollector:
         self._mpc_out = None
         self.gathered_actions = None
         self.gathered_status = None
+        # None = the default path: on a GPU with the real engine a step (policy -> MPC -> environment -> buffer row) is
+        # captured once as a hipGraph and replayed; eager on the CPU, with stand-in engines, and when the actions are
+        # all-gathered (the collective stays outside the graph)
+        if use_graph is None:
+            use_graph = (dev.type == "cuda" and hasattr(engine, "reserve_envs") and hasattr(engine, "predict_batch_torch")
+                         and not gather_actions)
         self.use_graph = bool(use_graph)
         self._graph = None
         if self.use_graph:

@@ -166,6 +166,7 @@ static long g_cnt_iter, g_cnt_sweep, g_cnt_roll, g_cnt_solve;
 /* per-thread tallies of the instance being solved (no shared counters inside solve_one: with 32+ threads the atomics on
  * three global words were a measurable part of the run); summed by the OpenMP reduction of the batch loop */
 static _Thread_local long t_cnt_iter, t_cnt_sweep, t_cnt_roll;
+static int g_stall_window; /* mpc_config.stall_window of the engine under test (0 = off); oracle_set_stall_window */
 static int g_trace, g_trace2; /* ORACLE_TRACE / ORACLE_TRACE2, read once per batch call */
 static int g_cnt_N, g_cnt_V, g_cnt_cc;
 
@@ -229,6 +230,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
     double mu = o->mu_init;
     const double mu_min = o->tol / 10.0;
     int status = 1, iter = 0, nfail = 0;
+    int i_mark = 0; /* progress guard: iteration at which the KKT error last fell below half of its value at the previous mark */
+    double e_mark = INFINITY;
     const double KSIG = 1e10; /* IPOPT kappa_Sigma */
     const int MAXLS = 4;      /* line-search trials per iteration */
     const double BTF = 0.25;  /* backtracking factor */
@@ -445,6 +448,15 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             break;
         }
         if (iter == o->max_iter) break;
+        if (g_stall_window > 0) {
+            if (E0 < 0.5 * e_mark) {
+                e_mark = E0;
+                i_mark = iter;
+            } else if (iter - i_mark >= g_stall_window) {
+                status = 4;
+                break;
+            }
+        }
 
         /* ---------------- backward (Riccati / DDP) sweep with the exact Lagrangian Hessian ------------------
          * If a control block Huu_k is not positive definite the sweep is repeated with the convex Gauss-Newton model
@@ -905,6 +917,9 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
  * out[0] = iterations, out[1] = sweeps, out[2] = rollouts, out[3] = solves, out[4] = arithmetic flops,
  * out[5] = transcendentals.
  * ------------------------------------------------------------------------------------------ */
+/* the engine's optional progress guard (include/mpc_mi355x.h: mpc_config.stall_window); applies to the calls that follow */
+void oracle_set_stall_window(int w) { g_stall_window = w > 0 ? w : 0; }
+
 void oracle_last_work(double out[6]) {
     const double N = g_cnt_N, V = g_cnt_V, cc = g_cnt_cc;
     const double per_iter = N * ((18 + 22 + 41 + 8 + cc * (V * 53 + 6)) + (22 + 8 + 40 + 18 + 40) + 50 + 128 + 64);

@@ -41,6 +41,8 @@ def _load():
             ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ip, dp, dp, bp, dp,
             ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
             dp, dp, dp, dp, dp, ip, ip, dp, ctypes.c_int]
+        _lib.oracle_set_stall_window.restype = None
+        _lib.oracle_set_stall_window.argtypes = [ctypes.c_int]
         _lib.oracle_last_work.restype = None
         _lib.oracle_last_work.argtypes = [dp]
     return _lib
@@ -60,13 +62,14 @@ def _p(a, ty):
 
 def solve_batch(ref_table, state, ego_index, weights, is_collide, vref=None, others=None, N=20, dt=0.1,
                 collision_cost=False, w_distance=10.0, w_collision=1.0, tol=1e-8, max_iter=200, nthreads=0,
-                xy_bounds=True, u_init=None):
+                xy_bounds=True, u_init=None, stall_window=0):
     """Solve B instances on the CPU. Returns dict(u0, U, X, lam, status, iters, kkt).
 
     xy_bounds=False drops the |x|,|y| <= 500 bounds of the reference NLP (agents/pure_mpc.py:272-274), which
     can never be active for a horizon of N*dt seconds starting inside the intersection; the GPU kernel does
     the same, tests/ check that both settings give the same controls."""
     lib = _load()
+    lib.oracle_set_stall_window(int(stall_window))      # the engine's optional progress guard (mpc_config.stall_window)
     ref_table = np.ascontiguousarray(ref_table, dtype=np.float64)
     state = np.ascontiguousarray(state, dtype=np.float64)
     B = state.shape[0]

@@ -15,7 +15,10 @@ void run(const mpc::SolveParams &P, HostCtx &ctx, const double *x0, double ws, d
     mpc::wave::Solver<CC, HostCtx> s(P, ctx, x0, ws, wc, wd, wcoll);
     s.solve(st, it, cur, e, warm);
 }
+int g_stall_window = 0;   // mpc_config.stall_window of the calls that follow (wave_set_stall_window)
 }  // namespace
+
+extern "C" void wave_set_stall_window(int w) { g_stall_window = w > 0 ? w : 0; }
 
 extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
                                      const int32_t *ego_index, const double *vref, const double *weights,
@@ -54,6 +57,7 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     mpc::SolveParams P;
     P.N = N; P.V = Vuse; P.max_iter = max_iter; P.dt = dt; P.tol = tol; P.mu_init = 0.1;
     P.w_distance = w_distance;
+    P.stall_window = g_stall_window;
     const int SL = mpc::wave::stage_slots(cc);
     const int nd = mpc::wave::lds_doubles(cc, N, Vuse);
     for (int b = 0; b < B; ++b) {

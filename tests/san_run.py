@@ -59,4 +59,17 @@ for rows in (1, 2, 10, 17):
             obs[:, 10:] = full[:, 1:rows - 9]
         o = dp(obs)
         assert o["state"].shape == (5, 4)
-print(f"sanitized run ok: {n} wave solves, LTV and preamble harnesses clean")
+# fused environment step (mpc_synth_env.hpp): every vehicle count, resets and respawns
+import ctypes  # noqa: E402
+import subprocess  # noqa: E402
+import test_synth_env_cpu as te  # noqa: E402
+out_env = os.path.join(conftest.BUILD_DIR, "libcpu_synth_env.so")
+subprocess.run(["g++"] + conftest.HOST_CXXFLAGS + ["-o", out_env, os.path.join(HERE, "cpu_synth_env_harness.cpp")], check=True)
+envlib = ctypes.CDLL(out_env)
+rng = np.random.default_rng(0)
+for K in (0, 1, 4, 9):
+    he = te.HostEnv(envlib, 33, K, seed=K)
+    he.reset()
+    for _ in range(220):
+        he.step(np.stack([rng.uniform(-6, 6, 33), rng.uniform(-0.1, 0.1, 33)], axis=1))
+print(f"sanitized run ok: {n} wave solves, LTV, preamble and environment harnesses clean")

@@ -61,7 +61,7 @@ def test_sized_default_config_refuses_a_short_struct():
     assert bytes(buf) == b"\xab" * 64                  # untouched, in particular behind the 48 bytes
     cfg = engine._Config()
     assert lib.mpc_default_config_sized(ctypes.byref(cfg), ctypes.sizeof(cfg)) == 0
-    assert cfg.struct_size == ctypes.sizeof(cfg) == 56 and cfg.ltv_passes == 1 and cfg.reserved0 == 0
+    assert cfg.struct_size == ctypes.sizeof(cfg) == 56 and cfg.ltv_passes == 1 and cfg.stall_window == 0
 
 
 def test_graft_entry_build_returns():

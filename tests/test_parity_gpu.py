@@ -377,9 +377,11 @@ def test_closed_loop_fixtures_vs_independent_solver(ref_table):
         d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
         got = e.solve_batch(d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"], others=d["others"],
                             collision_cost=cc)
-        assert converged(got["status"]).all(), (name, np.bincount(got["status"], minlength=6))
-        # the device against the CPU run of the same algorithm that the analysis used
-        assert rel_u0_err(got["u0"], g[f"{name}_oracle_u0"]).max() < 1e-6, name
+        # the device against the CPU run of the same algorithm that the analysis used (c1 holds two stalled solves)
+        assert np.array_equal(got["status"], g[f"{name}_oracle_status"]), (name, np.bincount(got["status"], minlength=6))
+        assert converged(got["status"]).mean() >= 0.98
+        ok = converged(got["status"])
+        assert rel_u0_err(got["u0"], g[f"{name}_oracle_u0"])[ok].max() < 1e-6, name
         both = (g[f"{name}_status"] == 0) & converged(got["status"])
         err = rel_u0_err(got["u0"], g[f"{name}_u0"])
         agree = both & (err <= TOL)

@@ -364,3 +364,56 @@ def test_single_agent_attributes_and_checkpoint():
     b.reset_env_state()
     b.predict(obs2)
     assert not b.is_collide and b.conflict_index == []
+
+
+def test_fused_environment_step_on_the_gpu_equals_its_host_build_and_the_torch_ops():
+    """`mpc_synth_env_step` (one launch per policy step: models, respawn, reward, termination, terminal observation,
+    auto-reset, next observation) against (a) the same source compiled for the host, same seed: same episodes, resets
+    and respawns included; (b) the torch implementation it replaces on the GPU, for the deterministic part."""
+    import ctypes
+    import torch
+    from mpc_rl_for_avs_amd import rollout
+    from test_synth_env_cpu import HostEnv
+    import subprocess, os
+    from conftest import BUILD_DIR, HOST_CXXFLAGS, ROOT
+    out = os.path.join(BUILD_DIR, "libcpu_synth_env.so")
+    if not os.path.exists(out):
+        os.makedirs(BUILD_DIR, exist_ok=True)
+        subprocess.run(["g++"] + HOST_CXXFLAGS + ["-o", out, os.path.join(ROOT, "tests", "cpu_synth_env_harness.cpp")], check=True)
+    hostlib = ctypes.CDLL(out)
+    B, K = 512, 4
+    dev = torch.device("cuda:0")
+    g = rollout.SyntheticIntersectionEnv(B, device=dev, seed=21, n_others=K, spawn_probability=0.3)
+    assert g.backend == "hip"
+    h = HostEnv(hostlib, B, K, seed=21, spawn_probability=0.3)
+    assert np.allclose(g.reset().cpu().numpy(), h.reset(), rtol=0, atol=1e-5)
+    rng = np.random.default_rng(0)
+    ended = 0
+    for step in range(150):
+        act = np.stack([rng.uniform(-3, 5, B), 0.03 * rng.uniform(-1, 1, B)], axis=1)
+        o_g, r_g, d_g, info = g.step(torch.as_tensor(act, device=dev))
+        o_h, r_h, d_h = h.step(act)
+        assert np.array_equal(d_g.cpu().numpy(), d_h), step
+        for k in ("crashed", "arrived", "truncated"):
+            assert np.array_equal(info[k].cpu().numpy(), h.flags[k].astype(bool)), (step, k)
+        assert np.allclose(r_g.cpu().numpy(), r_h, rtol=0, atol=1e-4)
+        assert np.allclose(o_g.cpu().numpy(), o_h, rtol=0, atol=1e-4) and np.allclose(info["terminal_obs"].cpu().numpy(), h.tobs, rtol=0, atol=1e-4)
+        assert np.allclose(g.ego.cpu().numpy(), h.ego, rtol=0, atol=1e-8) and np.array_equal(g.oactive.cpu().numpy(), h.oactive.astype(bool))
+        ended += int(d_h.sum())
+    assert ended >= 50 and np.array_equal(g.rng_counter.cpu().numpy(), h.ctr)
+    # (b) against the torch ops, no randomness in the step
+    gt = rollout.SyntheticIntersectionEnv(B, device=dev, seed=5, n_others=K, spawn_probability=0.0, backend="torch")
+    gh = rollout.SyntheticIntersectionEnv(B, device=dev, seed=5, n_others=K, spawn_probability=0.0, backend="hip")
+    gh.reset()
+    for a, b in ((gt.ego, gh.ego), (gt.opos, gh.opos), (gt.ospeed, gh.ospeed), (gt.ohead, gh.ohead), (gt.oactive, gh.oactive), (gt.t, gh.t)):
+        a.copy_(b)
+    alive = torch.ones(B, dtype=torch.bool, device=dev)
+    for step in range(60):
+        act = torch.as_tensor(np.stack([rng.uniform(-3, 5, B), 0.03 * rng.uniform(-1, 1, B)], axis=1), device=dev)
+        o1, r1, d1, i1 = gt.step(act)
+        o2, r2, d2, i2 = gh.step(act)
+        assert torch.equal(d1[alive], d2[alive]) and torch.allclose(r1[alive], r2[alive], rtol=0, atol=1e-4)
+        assert torch.allclose(i1["terminal_obs"][alive], i2["terminal_obs"][alive], rtol=0, atol=1e-4)
+        alive = alive & ~d2
+        assert torch.allclose(gt.ego[alive], gh.ego[alive], rtol=0, atol=1e-9)
+    assert int((~alive).sum()) >= 5

@@ -24,7 +24,11 @@ def main():
     ap.add_argument("--others", type=int, default=4)
     ap.add_argument("--version", default="v0")
     ap.add_argument("--algorithm", default="ppo", choices=("ppo", "a2c"))
-    ap.add_argument("--graph", action="store_true", help="replay the rollout step as a captured hipGraph")
+    ap.add_argument("--no-graph", dest="graph", action="store_false",
+                    help="run the step eagerly (launches from Python, MPC time measured with events) instead of replaying the "
+                         "captured hipGraph, which is the collector's default on a GPU")
+    ap.add_argument("--env-backend", default="auto", choices=("auto", "hip", "torch"),
+                    help="fused HIP environment step (default on a GPU) or the vectorised torch ops")
     ap.add_argument("--groups", type=int, default=1,
                     help="split this rank's environments into G groups stepped on G HIP streams (PipelinedCollector)")
     a = ap.parse_args()
@@ -49,11 +53,12 @@ def main():
         for g in range(G):
             glo, ghi = sharding.shard_range(B, g, G)
             e_g = engine.MPCEngine(horizon=20, max_iter=100, device=local)
-            env = rollout.SyntheticIntersectionEnv(ghi - glo, device=dev, seed=rank * 97 + g, n_others=a.others)
+            env = rollout.SyntheticIntersectionEnv(ghi - glo, device=dev, seed=rank * 97 + g, n_others=a.others,
+                                                   backend=a.env_backend, env_offset=lo + glo)
             engs.append(e_g)
             cols.append(rollout.BatchedCollector(env, pol, e_g, version=a.version, algorithm=a.algorithm, n_steps=a.steps,
-                                                 collision_cost=False, gather_actions=use_dist and G == 1 and not a.graph,
-                                                 seed=g, use_graph=a.graph))
+                                                 collision_cost=False, gather_actions=use_dist and G == 1,
+                                                 seed=g, use_graph=a.graph and not use_dist))
         col = cols[0] if G == 1 else rollout.PipelinedCollector(cols)
         col.collect_rollouts()                                   # warm-up (allocations, first launches)
         events = []
@@ -68,7 +73,8 @@ def main():
                 return out
             return call
 
-        if not a.graph:                                          # a replayed graph does not pass through Python
+        graph = a.graph and not use_dist                         # the all-gather stays outside a graph
+        if not graph:                                            # a replayed graph does not pass through Python
             for e_g in engs:
                 e_g.predict_batch_torch = timed(e_g.predict_batch_torch)
         torch.cuda.synchronize()
@@ -85,7 +91,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         dist_info = None
-        if use_dist and G == 1 and not a.graph:
+        if use_dist and G == 1:
             assert col.gathered_actions.shape == (total, 2) and col.gathered_status.shape == (total,)
             dist_info = dict(backend=dist.get_backend(), world_size=world,
                              gathered_actions_shape=list(col.gathered_actions.shape),
@@ -96,10 +102,10 @@ def main():
         st = torch.cat([c.last_mpc["status"] for c in cols]).cpu().numpy()
         if rank == 0:
             print(json.dumps(dict(config=f"{total} envs on {world} GPU(s), {a.others} other vehicles, {a.version}/{a.algorithm}, "
-                                         f"horizon 20" + (f", {G} groups on {G} streams" if G > 1 else "") + (", hipGraph step" if a.graph else ""),
-                              envs=total, n_gpus=world, distributed=dist_info, groups=G, graph=bool(a.graph),
+                                         f"horizon 20" + (f", {G} groups on {G} streams" if G > 1 else "") + (", hipGraph step" if graph else ", eager step") + f", {cols[0].env.backend} environment",
+                              envs=total, n_gpus=world, distributed=dist_info, groups=G, graph=bool(graph), env_backend=cols[0].env.backend,
                               steps_per_env=a.steps, env_steps_per_s=total * a.steps / dt, ms_per_step=dt / a.steps * 1e3,
-                              mpc_ms_per_step=dm / a.steps * 1e3, episodes=stats["episodes"], crashed=stats["crashed"],
+                              mpc_ms_per_step=(dm / a.steps * 1e3) if events else None, episodes=stats["episodes"], crashed=stats["crashed"],
                               arrived=stats["arrived"], converged_frac=float(((st == 0) | (st == 5)).mean()))), flush=True)
         for e_g in engs:
             e_g.close()
