@@ -81,6 +81,12 @@ def cpu_baseline(inp):
         ncpu = min(ncpu, len(os.sched_getaffinity(0)))          # what this process may actually use
     except AttributeError:
         pass
+    try:                                                         # ... and the container's CPU share (cgroup v2 quota)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
     ref = reference_states()
 
     def run(n, threads):
@@ -94,7 +100,7 @@ def cpu_baseline(inp):
     # `value` is the best median
     tried, best, out = [], None, None
     run(BATCH, ncpu)                                              # first touch: thread pool, page faults
-    for cores in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    for cores in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
         ts = []
         for _ in range(5):
             dt, out = run(BATCH, cores)

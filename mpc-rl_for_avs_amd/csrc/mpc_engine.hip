@@ -266,6 +266,8 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     __shared__ int s_ne[kPreEnvs];
     __shared__ int32_t s_conf[kPreEnvs][pre::kMaxOthers];
     __shared__ pre::P2 s_cpt[kPreEnvs][pre::kMaxOthers];
+    __shared__ float s_ag[kBlock][2 * (pre::kPredHorizon + 1)];    // each lane's vehicle path (31 float32 points)
+    __shared__ pre::P2 s_cand[kBlock][pre::kMaxCross];             // ... and its crossing candidates
     const int g = threadIdx.x / kPreGroup, l = threadIdx.x % kPreGroup;
     const int bq = blockIdx.x * kPreEnvs + g;
     const bool live = bq < B;
@@ -280,12 +282,12 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     __syncthreads();
     if (!replay) {
         pre::P2 cp{0.0, 0.0};
-        s_conf[g][l] = l < p.observed ? pre::detect_vehicle(ob + (l + 1) * pre::kObsCols, s_ego[g], s_ne[g], R, dt, cp) : -1;
+        s_conf[g][l] = l < p.observed ? pre::detect_vehicle(ob + (l + 1) * pre::kObsCols, s_ego[g], s_ne[g], R, dt, cp, s_ag[threadIdx.x], s_cand[threadIdx.x]) : -1;
         s_cpt[g][l] = cp;
     }
     __syncthreads();
     if (l != 0 || !live) return;
-    pre::EnvState st = env[b];
+    pre::EnvState &st = env[b];      // in place: a local copy of the 672-byte record is 672 bytes of scratch per lane
     double *oth = others + (size_t)b * Vslots * 4;
     pre::write_vehicles(ob, p, state + (size_t)b * 4, oth);
     for (int j = p.observed; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
@@ -296,7 +298,6 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     ego_index[b] = e;
     is_collide[b] = c;
     nveh[b] = p.observed;
-    env[b] = st;
 }
 
 __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, const uint8_t *__restrict__ mask,

@@ -240,16 +240,99 @@ MPC_HD int seg_intersections(P2 p, P2 q, P2 a, P2 b, Hit *h) {
     return 2;
 }
 
-// Intersections of the ego polyline with the (straight) agent polyline ag[0..na-1], as the candidate list the reference
+// The other vehicle's predicted path: 31 float32 points (the reference accumulates them in float32, agents/pure_mpc.py:
+// 529-550), kept as float pairs - 248 bytes, in LDS on the device - and widened to double where they are used.
+struct AgentPath {
+    const float *xy;   // [n][2]
+    int n;
+    MPC_HD P2 at(int m) const { return P2{(double)xy[2 * m], (double)xy[2 * m + 1]}; }
+};
+
+// Intersections of the ego polyline with the (straight) agent polyline, as the candidate list the reference
 // builds from shapely's result (agents/pure_mpc.py:615-633): every transversal crossing is a candidate, a collinear overlap
 // contributes the middle vertex of the overlapping stretch.  ORDER: along the ego's direction of travel.  shapely / GEOS
 // returns the members of a Multi* result in the iteration order of a hash map of its overlay graph, which cannot be
 // reproduced (or relied on); with a single crossing - a straight agent path meets the straight-arc-straight ego path
 // more than once only when it cuts the arc twice - there is nothing to order.  Returns the number of candidates (<= maxc).
+//
+// No per-lane arrays: the nodes of a collinear overlap (the overlap's ends on every ego segment it covers, and the
+// agent's own vertices inside it) are needed sorted along the ego's direction with duplicates dropped, and of that list
+// only the middle element.  Both families already come in that order - the ego-derived ones by construction, the agent's
+// vertices by index, ascending or descending - so the list is walked as a two-way merge, twice: once to count, once to
+// stop at the middle.  (Until round 3 the list was materialised and insertion-sorted in 1.5 KB of scratch per lane.)
 constexpr int kMaxCross = 4;
-MPC_HD int path_crossings(const P2 *ego, int ne, const P2 *ag, int na, P2 *out, int maxc) {
+
+struct OverlapWalk {
+    const P2 *ego;
+    int i, jend;          // ego segments i .. jend - 1 overlap the agent's line
+    P2 a, b;
+    AgentPath ag;
+    double klo, khi, sx, sy, ss, dx, dy;
+    bool asc;             // agent vertices by ascending index are ascending along the ego's direction
+    // ego-derived node q: 0, 1 = the ends of the overlap on segment i; q >= 2 = the far end on segment i + q - 1
+    MPC_HD P2 ego_node(int q) const {
+        Hit h[2];
+        if (q < 2) {
+            seg_intersections(ego[i], ego[i + 1], a, b, h);
+            return q == 0 ? h[0].p : h[1].p;
+        }
+        seg_intersections(ego[i + q - 1], ego[i + q], a, b, h);
+        return h[1].p;
+    }
+    MPC_HD double key(P2 p) const { return f64add(f64mul(p.x - ego[i].x, dx), f64mul(p.y - ego[i].y, dy)); }
+    MPC_HD bool agent_inside(int m) const {
+        const P2 v = ag.at(m);
+        const double kv = f64add(f64mul(v.x - a.x, sx), f64mul(v.y - a.y, sy));
+        return ss > 0 && klo <= kv && kv <= khi;
+    }
+    // (key, x, y) order of the reference's sort
+    MPC_HD static bool before(double ka, P2 pa, double kb, P2 pb) {
+        return ka < kb || (ka == kb && (pa.x < pb.x || (pa.x == pb.x && pa.y < pb.y)));
+    }
+    // walks the merged, de-duplicated list; returns its length, and in `out` its element number `want` (if want >= 0)
+    MPC_HD int walk(int want, P2 &out) const {
+        const int ne_nodes = 2 + (jend - (i + 1));
+        int qe = 0;                                   // next ego-derived node
+        int ma = asc ? 0 : ag.n - 1;                  // next agent vertex (index), skipping those outside the overlap
+        const int mstep = asc ? 1 : -1;
+        while (ma >= 0 && ma < ag.n && !agent_inside(ma)) ma += mstep;
+        int nu = 0;
+        P2 last{0.0, 0.0};
+        for (;;) {
+            const bool he = qe < ne_nodes, ha = ma >= 0 && ma < ag.n;
+            if (!he && !ha) break;
+            P2 pe{0.0, 0.0}, pa{0.0, 0.0};
+            double ke = 0.0, ka = 0.0;
+            if (he) {
+                pe = ego_node(qe);
+                ke = key(pe);
+            }
+            if (ha) {
+                pa = ag.at(ma);
+                ka = key(pa);
+            }
+            const bool take_e = he && (!ha || !before(ka, pa, ke, pe));
+            const P2 p = take_e ? pe : pa;
+            if (take_e) {
+                ++qe;
+            } else {
+                ma += mstep;
+                while (ma >= 0 && ma < ag.n && !agent_inside(ma)) ma += mstep;
+            }
+            if (nu == 0 || !close2(last, p)) {
+                if (nu == want) out = p;
+                last = p;
+                ++nu;
+            }
+        }
+        return nu;
+    }
+};
+
+MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, int maxc) {
+    const int na = ag.n;
     if (ne < 2 || na < 2) return 0;
-    const P2 a = ag[0], b = ag[na - 1];
+    const P2 a = ag.at(0), b = ag.at(na - 1);
     int nc = 0;
     for (int i = 0; i < ne - 1 && nc < maxc; ++i) {
         Hit h[2];
@@ -260,56 +343,44 @@ MPC_HD int path_crossings(const P2 *ego, int ne, const P2 *ag, int na, P2 *out, 
             if (nc == 0 || !close2(out[nc - 1], h[0].p)) out[nc++] = h[0].p;
             continue;
         }
-        // collinear overlap starting on ego segment i
-        constexpr int kMaxPts = 2 + kPredHorizon + kPredHorizon + 1;
-        P2 pts[kMaxPts];
-        double key[kMaxPts];
-        int np = 0;
-        pts[np++] = h[0].p;
-        pts[np++] = h[1].p;
+        // collinear overlap starting on ego segment i: it goes on over the following segments that overlap too
+        OverlapWalk w;
+        w.ego = ego;
+        w.i = i;
+        w.a = a;
+        w.b = b;
+        w.ag = ag;
         int j = i + 1;
+        P2 pl = h[1].p;
         for (; j < ne - 1; ++j) {
             Hit h2[2];
             if (seg_intersections(ego[j], ego[j + 1], a, b, h2) != 2) break;
-            pts[np++] = h2[1].p;
+            pl = h2[1].p;
         }
-        const double sx = b.x - a.x, sy = b.y - a.y;
-        const double ss = f64add(f64mul(sx, sx), f64mul(sy, sy));
-        const P2 pf = pts[0], pl = pts[np - 1];
-        const double k0 = f64add(f64mul(pf.x - a.x, sx), f64mul(pf.y - a.y, sy));
-        const double k1 = f64add(f64mul(pl.x - a.x, sx), f64mul(pl.y - a.y, sy));
-        const double klo = fmin(k0, k1) - 1e-12, khi = fmax(k0, k1) + 1e-12;
-        for (int m = 0; m < na && np < kMaxPts; ++m) {
-            const double kv = f64add(f64mul(ag[m].x - a.x, sx), f64mul(ag[m].y - a.y, sy));
-            if (ss > 0 && klo <= kv && kv <= khi) pts[np++] = ag[m];
-        }
-        const double dx = ego[i + 1].x - ego[i].x, dy = ego[i + 1].y - ego[i].y;
-        for (int m = 0; m < np; ++m) key[m] = f64add(f64mul(pts[m].x - ego[i].x, dx), f64mul(pts[m].y - ego[i].y, dy));
-        // sort by (key, x, y): insertion sort, <= 63 entries
-        for (int m = 1; m < np; ++m) {
-            const double km = key[m];
-            const P2 pm = pts[m];
-            int q = m - 1;
-            while (q >= 0 && (key[q] > km || (key[q] == km && (pts[q].x > pm.x || (pts[q].x == pm.x && pts[q].y > pm.y))))) {
-                key[q + 1] = key[q];
-                pts[q + 1] = pts[q];
-                --q;
-            }
-            key[q + 1] = km;
-            pts[q + 1] = pm;
-        }
-        int nu = 0;
-        for (int m = 0; m < np; ++m)
-            if (nu == 0 || !close2(pts[nu - 1], pts[m])) pts[nu++] = pts[m];
-        out[nc++] = pts[nu / 2];
+        w.jend = j;
+        w.sx = b.x - a.x;
+        w.sy = b.y - a.y;
+        w.ss = f64add(f64mul(w.sx, w.sx), f64mul(w.sy, w.sy));
+        const P2 pf = h[0].p;
+        const double k0 = f64add(f64mul(pf.x - a.x, w.sx), f64mul(pf.y - a.y, w.sy));
+        const double k1 = f64add(f64mul(pl.x - a.x, w.sx), f64mul(pl.y - a.y, w.sy));
+        w.klo = fmin(k0, k1) - 1e-12;
+        w.khi = fmax(k0, k1) + 1e-12;
+        w.dx = ego[i + 1].x - ego[i].x;
+        w.dy = ego[i + 1].y - ego[i].y;
+        w.asc = f64add(f64mul(w.sx, w.dx), f64mul(w.sy, w.dy)) >= 0.0;
+        P2 mid{0.0, 0.0}, dummy{0.0, 0.0};
+        const int nu = w.walk(-1, dummy);
+        w.walk(nu / 2, mid);
+        out[nc++] = mid;
         i = j - 1;      // go on behind the overlap
     }
     return nc;
 }
 // the first candidate (the only one in all but double-crossing scenes)
-MPC_HD bool first_crossing(const P2 *ego, int ne, const P2 *ag, int na, P2 &out) {
+MPC_HD bool first_crossing(const P2 *ego, int ne, const AgentPath &ag, P2 &out) {
     P2 c[1];
-    if (path_crossings(ego, ne, ag, na, c, 1) == 0) return false;
+    if (path_crossings(ego, ne, ag, c, 1) == 0) return false;
     out = c[0];
     return true;
 }
@@ -319,6 +390,19 @@ MPC_HD int argmin_dist(const P2 *pts, int n, P2 p) {
     double bd = dist2d(pts[0].x, pts[0].y, p.x, p.y);
     for (int i = 1; i < n; ++i) {
         const double d = dist2d(pts[i].x, pts[i].y, p.x, p.y);
+        if (d < bd) {
+            bd = d;
+            best = i;
+        }
+    }
+    return best;
+}
+MPC_HD int argmin_dist(const AgentPath &ag, P2 p) {
+    int best = 0;
+    double bd = dist2d(ag.at(0).x, ag.at(0).y, p.x, p.y);
+    for (int i = 1; i < ag.n; ++i) {
+        const P2 v = ag.at(i);
+        const double d = dist2d(v.x, v.y, p.x, p.y);
         if (d < bd) {
             bd = d;
             best = i;
@@ -373,27 +457,31 @@ MPC_HD bool replays_memory(const EnvState &st) { return st.collision_memory > 0 
 // part 2 - a4 for ONE other vehicle (agents/pure_mpc.py:575-660): reference index of the conflict point or -1.
 // o = its observation row; the constant-velocity polyline is float32 arithmetic (agents/pure_mpc.py:529-550:
 // step = speed * dt * [cos h, sin h], positions accumulate).
-MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt, P2 &pt_out) {
+// ag_xy (2 x 31 floats) and cand (kMaxCross points) are the caller's work space: LDS on the device, where a dynamically
+// indexed local array would be scratch memory.
+MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt, P2 &pt_out, float *ag_xy,
+                          P2 *cand) {
     const float sp = speed_f32(o[3], o[4]);
     const float sdt = f32mul(sp, (float)dt);
     const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
-    P2 ag[kPredHorizon + 1];
     float ax = o[1], ay = o[2];
-    ag[0] = P2{(double)ax, (double)ay};
+    ag_xy[0] = ax;
+    ag_xy[1] = ay;
     for (int m = 1; m <= kPredHorizon; ++m) {
         ax = f32add(ax, stx);
         ay = f32add(ay, sty);
-        ag[m] = P2{(double)ax, (double)ay};
+        ag_xy[2 * m] = ax;
+        ag_xy[2 * m + 1] = ay;
     }
+    const AgentPath ag{ag_xy, kPredHorizon + 1};
     // candidate loop of agents/pure_mpc.py:635-654: the first intersection point whose ego / agent sample indices differ
     // by less than TIME_THRESHOLD decides (with 31 samples that is every point except the pairing 0 / 30)
-    P2 cand[kMaxCross];
     pt_out = P2{0.0, 0.0};
-    const int nc = path_crossings(ego, ne, ag, kPredHorizon + 1, cand, kMaxCross);
+    const int nc = path_crossings(ego, ne, ag, cand, kMaxCross);
     for (int q = 0; q < nc; ++q) {
         const P2 pt = cand[q];
         const int ego_time = argmin_dist(ego, ne, pt);
-        const int agent_time = argmin_dist(ag, kPredHorizon + 1, pt);
+        const int agent_time = argmin_dist(ag, pt);
         int dtm = ego_time - agent_time;
         dtm = dtm < 0 ? -dtm : dtm;
         if (dtm < kTimeThreshold) {
@@ -521,7 +609,10 @@ MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, d
     if (advance && !replays_memory(st)) {
         P2 ego[kPredHorizon + 1];
         const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, ego);
-        for (int j = 0; j < p.observed; ++j) conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt, cpt[j]);
+        float ag_xy[2 * (kPredHorizon + 1)];
+        P2 cand[kMaxCross];
+        for (int j = 0; j < p.observed; ++j)
+            conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt, cpt[j], ag_xy, cand);
     }
     finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out, advance);
 }

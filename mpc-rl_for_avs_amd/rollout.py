@@ -444,6 +444,15 @@ class BatchedCollector:
             self._rollout_step(device_pos=True)
         self._graph = g
         self.buffer.reset()
+        # the warm-up steps must leave no trace: fresh episodes, fresh detector records and warm-start memory in the engine
+        # (an eager collector starts from exactly this state)
+        if hasattr(self.engine, "reset_env_state"):
+            self.engine.reset_env_state()
+        self._last_obs.copy_(self.env.reset())
+        self._last_episode_starts.fill_(1.0)
+        for k in ("ep_done", "crashed", "arrived", "unconverged"):
+            self._roll[k].zero_()
+        self._roll["dones"].zero_()
 
     def _step(self):
         if self._graph is not None:

@@ -56,11 +56,14 @@ extern "C" int preamble_ego_future(const double *ref_table, int M, float px, flo
 }
 
 extern "C" int preamble_first_crossing(const double *ego, int ne, const double *ag, int na, double *out) {
-    std::vector<mpc::pre::P2> e((size_t)ne), a((size_t)na);
+    // the agent path is float32 data (agents/pure_mpc.py:529-550 accumulates it in float32): callers pass values that are
+    // exactly representable
+    std::vector<mpc::pre::P2> e((size_t)ne);
+    std::vector<float> a((size_t)na * 2);
     for (int i = 0; i < ne; ++i) e[(size_t)i] = mpc::pre::P2{ego[i * 2], ego[i * 2 + 1]};
-    for (int i = 0; i < na; ++i) a[(size_t)i] = mpc::pre::P2{ag[i * 2], ag[i * 2 + 1]};
+    for (int i = 0; i < na * 2; ++i) a[(size_t)i] = (float)ag[i];
     mpc::pre::P2 p;
-    if (!mpc::pre::first_crossing(e.data(), ne, a.data(), na, p)) return 0;
+    if (!mpc::pre::first_crossing(e.data(), ne, mpc::pre::AgentPath{a.data(), na}, p)) return 0;
     out[0] = p.x;
     out[1] = p.y;
     return 1;
@@ -68,10 +71,11 @@ extern "C" int preamble_first_crossing(const double *ego, int ne, const double *
 
 // all candidates, in the order the detector tries them: out [maxc][2]; returns their number
 extern "C" int preamble_path_crossings(const double *ego, int ne, const double *ag, int na, double *out, int maxc) {
-    std::vector<mpc::pre::P2> e((size_t)ne), a((size_t)na), c((size_t)(maxc > 0 ? maxc : 1));
+    std::vector<mpc::pre::P2> e((size_t)ne), c((size_t)(maxc > 0 ? maxc : 1));
+    std::vector<float> a((size_t)na * 2);
     for (int i = 0; i < ne; ++i) e[(size_t)i] = mpc::pre::P2{ego[i * 2], ego[i * 2 + 1]};
-    for (int i = 0; i < na; ++i) a[(size_t)i] = mpc::pre::P2{ag[i * 2], ag[i * 2 + 1]};
-    const int n = mpc::pre::path_crossings(e.data(), ne, a.data(), na, c.data(), maxc);
+    for (int i = 0; i < na * 2; ++i) a[(size_t)i] = (float)ag[i];
+    const int n = mpc::pre::path_crossings(e.data(), ne, mpc::pre::AgentPath{a.data(), na}, c.data(), maxc);
     for (int i = 0; i < n; ++i) {
         out[i * 2] = c[(size_t)i].x;
         out[i * 2 + 1] = c[(size_t)i].y;

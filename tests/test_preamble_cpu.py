@@ -207,6 +207,7 @@ def test_double_crossings_on_the_arc_are_all_candidates(pre, ref_table):
         ang = rng.uniform(0, np.pi)
         d = np.array([np.cos(ang), np.sin(ang)])
         ag = np.stack([c + (t - 15) * 1.2 * d for t in range(31)])
+        ag = np.ascontiguousarray(ag.astype(np.float32).astype(np.float64))     # predicted paths are float32 data
         want = path_crossings(ego, ag)
         out = np.zeros((4, 2))
         n = pre.preamble_path_crossings(ego.ctypes.data_as(ctypes.c_void_p), len(ego), ag.ctypes.data_as(ctypes.c_void_p),
@@ -215,8 +216,8 @@ def test_double_crossings_on_the_arc_are_all_candidates(pre, ref_table):
         for q in range(n):
             assert np.allclose(out[q], want[q], rtol=0, atol=1e-12)
             # on the agent's straight line and on an ego segment
-            r = out[q] - ag[0]
-            assert abs(r[0] * d[1] - r[1] * d[0]) < 1e-9
+            r, dd = out[q] - ag[0], (ag[-1] - ag[0]) / np.linalg.norm(ag[-1] - ag[0])
+            assert abs(r[0] * dd[1] - r[1] * dd[0]) < 1e-9
             seg = np.linalg.norm(ego[1:] - ego[:-1], axis=1)
             on = [abs(np.linalg.norm(out[q] - ego[i]) + np.linalg.norm(out[q] - ego[i + 1]) - seg[i]) < 1e-9
                   for i in range(len(ego) - 1)]
@@ -232,3 +233,41 @@ def test_double_crossings_on_the_arc_are_all_candidates(pre, ref_table):
     ag = np.stack([np.array([3.0, 6.75]) + t * np.array([-0.4, -0.3]) for t in range(31)])
     got = path_crossings(ego, ag)
     assert len(got) == 2 and got[0][1] > got[1][1]               # travelling down and then left: higher point first
+
+
+def test_collinear_overlaps_stream_merge_equals_the_sorted_list(pre, ref_table):
+    """Same-lane traffic: the other vehicle's predicted path lies ON the ego's (collinear overlap, what shapely returns
+    as a LineString, agents/pure_mpc.py:619-622).  The device code finds the middle node of the overlap with a two-way
+    merge instead of materialising and sorting the node list; the numpy mirror sorts.  Randomised: both directions of
+    travel, standing vehicles, overlaps that start / end inside segments, on the approach straight and the exit straight."""
+    from host_preamble import path_crossings
+    rng = np.random.default_rng(11)
+    n_overlap = 0
+    for trial in range(600):
+        lane = trial % 2
+        v_ego = rng.uniform(0.5, 12.0)
+        steps = np.cumsum(np.full(30, v_ego * 0.1) + rng.uniform(0, 0.02, 30))
+        if lane == 0:       # approach straight x = 2, driving down
+            y0 = rng.uniform(20.0, 48.0)
+            ego = np.stack([np.full(31, 2.0), y0 - np.concatenate([[0.0], steps])], axis=1)
+            ay0, sp, sign = rng.uniform(5.0, 50.0), rng.choice([0.0, rng.uniform(0.2, 12.0)]), rng.choice([-1.0, 1.0])
+            ag = np.stack([np.full(31, 2.0), ay0 + sign * sp * 0.1 * np.arange(31)], axis=1)
+        else:               # exit straight y = -2.22585..., driving in -x
+            yy = float(ref_table[84, 1])
+            x0 = rng.uniform(-30.0, -8.0)
+            ego = np.stack([x0 - np.concatenate([[0.0], steps]), np.full(31, yy)], axis=1)
+            ax0, sp, sign = rng.uniform(-45.0, -5.0), rng.choice([0.0, rng.uniform(0.2, 12.0)]), rng.choice([-1.0, 1.0])
+            ag = np.stack([ax0 + sign * sp * 0.1 * np.arange(31), np.full(31, yy)], axis=1)
+        ego = np.ascontiguousarray(ego)
+        ag = np.ascontiguousarray(ag.astype(np.float32).astype(np.float64))
+        if lane == 1:
+            ego[:, 1] = ag[0, 1]         # exactly collinear with the float32 line
+        want = path_crossings(ego, ag)
+        out = np.zeros((4, 2))
+        n = pre.preamble_path_crossings(ego.ctypes.data_as(ctypes.c_void_p), len(ego), ag.ctypes.data_as(ctypes.c_void_p),
+                                        len(ag), out.ctypes.data_as(ctypes.c_void_p), 4)
+        assert n == len(want), trial
+        for q in range(n):
+            assert np.array_equal(out[q], want[q]), (trial, q, out[q], want[q])
+        n_overlap += n
+    assert n_overlap >= 300
