@@ -268,17 +268,57 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     __shared__ pre::P2 s_cpt[kPreEnvs][pre::kMaxOthers];
     __shared__ float s_ag[kBlock][2 * (pre::kPredHorizon + 1)];    // each lane's vehicle path (31 float32 points)
     __shared__ pre::P2 s_cand[kBlock][pre::kMaxCross];             // ... and its crossing candidates
+    // the reference table (85 rows x 6 doubles = 4 KB) is walked point by point several times per environment (nearest
+    // point, arc length): from LDS, not through the vector memory path
+    constexpr int kTabDoubles = 128 * (mpc::REF_COLS + 1);
+    __shared__ double s_tab[kTabDoubles];
+    __shared__ double s_nd[kBlock];
+    __shared__ int s_ni[kBlock];
     const int g = threadIdx.x / kPreGroup, l = threadIdx.x % kPreGroup;
     const int bq = blockIdx.x * kPreEnvs + g;
     const bool live = bq < B;
     const int b = live ? bq : B - 1;                    // surplus groups read the last environment, write nothing
-    const pre::RefTable R{ref5, M};
+    const bool staged = M * (mpc::REF_COLS + 1) <= kTabDoubles;
+    if (staged) {
+        for (int i = threadIdx.x; i < M * (mpc::REF_COLS + 1); i += kBlock) s_tab[i] = ref5[i];
+        __syncthreads();
+    }
+    const pre::RefTable R{staged ? (const double *)s_tab : ref5, M};
     const float *ob = obs + (size_t)b * rows * pre::kObsCols;
     const pre::Parsed p = pre::parse_obs(ob, rows);
+    // nearest reference point of the ego (first minimum, agents/pure_mpc.py:106-109, 567-570): the 16 lanes of the
+    // environment take every 16th point, lane 0 picks the first minimum of the 16 partial results; it serves the
+    // predicted path, the reference speed and the ego index alike
+    {
+        double bd = INFINITY;
+        int bi = M;
+        for (int i = l; i < M; i += kPreGroup) {
+            const double d = pre::dist2d(R.x(i), R.y(i), (double)p.ex, (double)p.ey);
+            if (d < bd) {
+                bd = d;
+                bi = i;
+            }
+        }
+        s_nd[threadIdx.x] = bd;
+        s_ni[threadIdx.x] = bi;
+    }
+    __syncthreads();
+    int e0 = 0;
+    {
+        double bd = s_nd[g * kPreGroup];
+        e0 = s_ni[g * kPreGroup];
+        for (int q = 1; q < kPreGroup; ++q) {
+            const double d = s_nd[g * kPreGroup + q];
+            const int i = s_ni[g * kPreGroup + q];
+            if (d < bd || (d == bd && i < e0)) {
+                bd = d;
+                e0 = i;
+            }
+        }
+    }
     // surplus groups (live == false) only keep the barriers company: no detector work on possibly changing state
     const bool replay = !live || !advance || (env[b].collision_memory > 0 && env[b].has_memorized);
-    if (!replay && l == 0)
-        s_ne[g] = pre::ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, s_ego[g]);
+    if (!replay && l == 0) s_ne[g] = pre::ego_future(R, p.ex, p.ey, p.ev, R.v(e0), dt, s_ego[g], e0);
     __syncthreads();
     if (!replay) {
         pre::P2 cp{0.0, 0.0};
@@ -294,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     int32_t e = 0;
     uint8_t c = 0;
     pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], s_cpt[g], st, e, vref + (size_t)b * (N + 1), c,
-                    advance != 0);
+                    advance != 0, e0);
     ego_index[b] = e;
     is_collide[b] = c;
     nveh[b] = p.observed;
@@ -326,6 +366,14 @@ __global__ __launch_bounds__(64) void mpc_synth_env_kernel(
     uint8_t *__restrict__ done, uint8_t *__restrict__ truncated, uint8_t *__restrict__ crashed,
     uint8_t *__restrict__ arrived, int reset_all) {
     namespace env = mpc::env;
+    // the route (85 x 2 doubles) is scanned point by point for the lane-centring term: from LDS
+    __shared__ double s_ref[2 * 128];
+    const bool staged = M <= 128;
+    if (staged) {
+        for (int i = threadIdx.x; i < 2 * M; i += blockDim.x) s_ref[i] = ref_xy[i];
+        __syncthreads();
+    }
+    const double *route = staged ? (const double *)s_ref : ref_xy;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int Ks = K > 0 ? K : 1;      // the arrays keep one slot per environment even without traffic
@@ -339,7 +387,7 @@ __global__ __launch_bounds__(64) void mpc_synth_env_kernel(
         env::observe(v, K, o);
         return;
     }
-    const env::StepOut so = env::step_env(v, K, dt, spawn_probability, seed, env_offset + b, ref_xy, M, action + (size_t)b * 2,
+    const env::StepOut so = env::step_env(v, K, dt, spawn_probability, seed, env_offset + b, route, M, action + (size_t)b * 2,
                                           terminal_obs + (size_t)b * env::kRows * env::kCols, o);
     reward[b] = so.reward;
     done[b] = so.done;

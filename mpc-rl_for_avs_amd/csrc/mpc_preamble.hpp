@@ -104,10 +104,11 @@ struct RefTable {
 
 // ---- a4: ego polyline, agents/pure_mpc.py:459-527 ------------------------------------------------------------
 // Returns the number of points written to out (<= kPredHorizon + 1).
-MPC_HD int ego_future(const RefTable &R, float px, float py, float speed, double reference_speed, double dt, P2 *out) {
+// start = R.nearest(px, py), which the caller has (it needs the same index for the reference speed and the ego index)
+MPC_HD int ego_future(const RefTable &R, float px, float py, float speed, double reference_speed, double dt, P2 *out,
+                      int start) {
     out[0] = P2{(double)px, (double)py};
     int n = 1;
-    const int start = R.nearest((double)px, (double)py);
     const int npts = R.M - start;
     if (npts < 2) return n;
     // current_speed / current_distance start as float32 (the observation's dtype) and become double once the ramp
@@ -498,7 +499,7 @@ MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable 
 // MPC_FLAG_DETECTED): only the ego index and the speed profile are derived, from the record as it stands.
 MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *ref_speed, const int32_t *conflict,
                        const P2 *conflict_pt, EnvState &st, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
-                       bool advance = true) {
+                       bool advance = true, int ego_nearest = -1) {
     if (!advance) {
         // nothing: st.is_collide, the conflict indices and the memory are those of the detection call
     } else if (replays_memory(st)) {
@@ -540,7 +541,7 @@ MPC_HD void finish_env(const Parsed &p, const RefTable &R, int N, const double *
 
     // a6: ego_index is refreshed by _solve in every call (agents/pure_mpc.py:106-109)
     const float ev = p.ev;
-    const int e = R.nearest((double)p.ex, (double)p.ey);
+    const int e = ego_nearest >= 0 ? ego_nearest : R.nearest((double)p.ex, (double)p.ey);
     st.ego_index = e;
     ego_index_out = e;
     collide_out = st.is_collide ? 1 : 0;
@@ -606,15 +607,16 @@ MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, d
     nveh_out = p.observed;
     int32_t conflict[kMaxOthers];
     P2 cpt[kMaxOthers];
+    const int e0 = R.nearest((double)p.ex, (double)p.ey);
     if (advance && !replays_memory(st)) {
         P2 ego[kPredHorizon + 1];
-        const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(R.nearest((double)p.ex, (double)p.ey)), dt, ego);
+        const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(e0), dt, ego, e0);
         float ag_xy[2 * (kPredHorizon + 1)];
         P2 cand[kMaxCross];
         for (int j = 0; j < p.observed; ++j)
             conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt, cpt[j], ag_xy, cand);
     }
-    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out, advance);
+    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out, advance, e0);
 }
 
 }  // namespace pre

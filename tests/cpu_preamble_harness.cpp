@@ -47,7 +47,7 @@ extern "C" int preamble_ego_future(const double *ref_table, int M, float px, flo
     }
     const mpc::pre::RefTable R{t.data(), M};
     mpc::pre::P2 pts[mpc::pre::kPredHorizon + 1];
-    const int n = mpc::pre::ego_future(R, px, py, speed, vref, dt, pts);
+    const int n = mpc::pre::ego_future(R, px, py, speed, vref, dt, pts, R.nearest((double)px, (double)py));
     for (int i = 0; i < n; ++i) {
         out[i * 2 + 0] = pts[i].x;
         out[i * 2 + 1] = pts[i].y;
