@@ -41,13 +41,15 @@ def test_engine_matches_oracle(eng, oracle, ref_table, B, V, cc, seed):
     inp = synth.solver_inputs(B, V, seed=seed)
     want = _oracle(oracle, ref_table, inp, cc)
     got = _gpu(eng, inp, cc)
-    both = (got["status"] == 0) & (want["status"] == 0)
-    assert both.mean() > (0.85 if cc else 0.97)
-    assert (got["status"] == want["status"]).mean() > 0.97
+    both = converged(got["status"]) & converged(want["status"])
+    # measured (round 3, all three builds of the kernel): 99.2 - 100 % converge within 100 iterations, statuses equal on
+    # >= 99.8 %, no instance of the 2638 beyond 1e-4 (worst 2e-9), iteration counts equal on >= 99.6 %
+    assert both.mean() >= 0.99
+    assert (got["status"] == want["status"]).mean() >= 0.995
     err = rel_u0_err(got["u0"], want["u0"])[both]
-    assert (err <= TOL).mean() >= 0.995, f"{(err > TOL).sum()} of {both.sum()} instances beyond {TOL}"
-    assert np.percentile(err, 95) < 1e-8
-    assert (got["iters"] == want["iters"])[both].mean() > 0.95
+    assert (err > TOL).sum() == 0, f"{(err > TOL).sum()} of {both.sum()} instances beyond {TOL}"
+    assert np.percentile(err, 99) < 1e-8
+    assert (got["iters"] == want["iters"])[both].mean() > 0.99
     # full trajectories of the agreeing instances
     ok = both.copy()
     ok[both] = err <= TOL
@@ -285,9 +287,11 @@ def _certified_full_batch(eng, oracle, ref_table, B, V, cc):
     assert (got["status"] == want["status"]).mean() >= 0.995
     both = conv & converged(want["status"])
     err = rel_u0_err(got["u0"], want["u0"])[both]
-    assert (err <= TOL).mean() >= 0.999, f"{(err > TOL).sum()} of {both.sum()} beyond {TOL}"
-    assert np.percentile(err, 99) < 1e-8
-    assert (got["iters"] == want["iters"])[both].mean() > 0.97
+    # measured: 0 of 4081 beyond 1e-4 (worst 2.1e-9); one instance landing in another minimum through a last-bit
+    # difference is the most this admits
+    assert (err > TOL).sum() <= 1, f"{(err > TOL).sum()} of {both.sum()} beyond {TOL}"
+    assert np.percentile(err, 99) < 1e-8 and np.percentile(err, 99.9) < 1e-6
+    assert (got["iters"] == want["iters"])[both].mean() > 0.99
     p = nb.Batch.build(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
                        others=inp["others"], collision_cost=cc)
     sel = np.nonzero(conv)[0]
