@@ -166,6 +166,8 @@ static long g_cnt_iter, g_cnt_sweep, g_cnt_roll, g_cnt_solve;
 /* per-thread tallies of the instance being solved (no shared counters inside solve_one: with 32+ threads the atomics on
  * three global words were a measurable part of the run); summed by the OpenMP reduction of the batch loop */
 static _Thread_local long t_cnt_iter, t_cnt_sweep, t_cnt_roll;
+/* experiment knobs of tools/portfolio_study.py (never changed by tests or the bench): barrier start and backtracking factor */
+static double g_exp_mu_init = 0.1, g_exp_btf = 0.25;
 static int g_stall_window; /* mpc_config.stall_window of the engine under test (0 = off); oracle_set_stall_window */
 static int g_trace, g_trace2; /* ORACLE_TRACE / ORACLE_TRACE2, read once per batch call */
 static int g_cnt_N, g_cnt_V, g_cnt_cc;
@@ -234,7 +236,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
     double e_mark = INFINITY;
     const double KSIG = 1e10; /* IPOPT kappa_Sigma */
     const int MAXLS = 4;      /* line-search trials per iteration */
-    const double BTF = 0.25;  /* backtracking factor */
+    const double BTF = g_exp_btf; /* backtracking factor, 0.25 (tools/portfolio_study.py may set another) */
     const double kap_eps = 10.0, kap_mu = 0.2;
     /* Levenberg-Marquardt term kept across iterations: added to the diagonal of the stage Hessians like delta_w.  Two or
      * more backtracks (or no acceptable step) multiply it by 4 (from 1e-3), a full first trial divides it by 4 (to 0
@@ -825,7 +827,7 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
     g_cnt_N = N;
     g_cnt_V = (flags & 1u) ? V : 0;
     g_cnt_cc = (flags & 1u) ? 1 : 0;
-    opts_t o = {tol, 0.1, max_iter};
+    opts_t o = {tol, g_exp_mu_init, max_iter};
     g_trace = getenv("ORACLE_TRACE") != NULL;
     g_trace2 = getenv("ORACLE_TRACE2") != NULL;
     long c_iter = 0, c_sweep = 0, c_roll = 0;
@@ -919,6 +921,12 @@ int oracle_solve_batch_warm(int B, int N, double dt, const double *ref_table, in
  * ------------------------------------------------------------------------------------------ */
 /* the engine's optional progress guard (include/mpc_mi355x.h: mpc_config.stall_window); applies to the calls that follow */
 void oracle_set_stall_window(int w) { g_stall_window = w > 0 ? w : 0; }
+
+/* tools/portfolio_study.py only: variants of the globalisation (what a portfolio of solver settings would race) */
+void oracle_set_experiment(double mu_init, double btf) {
+    g_exp_mu_init = mu_init > 0.0 ? mu_init : 0.1;
+    g_exp_btf = (btf > 0.0 && btf < 1.0) ? btf : 0.25;
+}
 
 void oracle_last_work(double out[6]) {
     const double N = g_cnt_N, V = g_cnt_V, cc = g_cnt_cc;
