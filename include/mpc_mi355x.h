@@ -57,6 +57,12 @@ extern "C" {
 #define MPC_FLAG_DETECTED 32u      /* _solve after such a call for the SAME observation: the records are not advanced
                                       again; ego index, speed profile (agents/pure_mpc.py:678-724) and the solve only */
 
+#define MPC_FLAG_THROUGHPUT 64u     /* the caller keeps several batches in flight on different streams: launch the build of the
+                                      solve kernel for four resident waves per SIMD whatever the batch size.  By default the
+                                      engine picks the build by how deep ONE batch fills the SIMDs (B <= 2 waves per SIMD: 201
+                                      registers, B <= 4: 168, else 128), which is the faster choice when batches run one at a
+                                      time and the slower one when six of them share the GPU (2.56 against 2.87 M solves/s). */
+
 /* per-instance solver status written to status[] */
 #define MPC_STATUS_CONVERGED 0
 #define MPC_STATUS_MAX_ITER 1       /* last iterate returned, like the reference (agents/pure_mpc.py:303-305) */

@@ -49,16 +49,20 @@ constexpr int kMaxDevices = 64;
 // of LDS at N = 20 with the collision cost and 8 vehicles, so 16 waves share a CU: all 4096 waves of a BASELINE batch
 // are resident at once and a straggler never starts late.  The runtime-horizon build would spill at 128 and stays at 3.
 constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
-// Builds of the same solver for batches that do not fill the SIMDs four deep (WaveOpsT<RELAX = true>, mpc_wave_dev.hpp):
+// Builds of the same solver for batches that do not fill the SIMDs four deep (WaveOpsT<RELAX>, mpc_wave_dev.hpp):
 // up to two waves per SIMD (B <= 2048 on 256 CUs: BASELINE configs 2, 4, 5 and every single-environment predict) the
-// 201-register build, up to four the 168-register build for three resident waves (the rest of a 4096 batch is dispatched
-// as slots free, which also balances the SIMDs better than four static residents: 3.97 against 4.25 ms at cap 60).
+// 201-register build (fresh() and opaque() both the identity: everything hoisted), 7 % less time per iteration for a wave
+// that has its SIMD to itself; up to four the 168-register build for three resident waves (opaque() the identity, constants
+// still fetched where they are used: with both relaxed it spills 9 registers - 6.6 MB of scratch writes per launch of
+// 4096 - for the same speed; the rest of a 4096 batch is dispatched as slots free, which also balances the SIMDs better
+// than four static residents: 3.9 against 4.25 ms at cap 60, profiles/r03_mid_builds.txt).
 constexpr int kWaveOccLat = 2, kWaveOccMid = 3;
+constexpr int kRelaxLat = 3, kRelaxMid = 2;
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
 // ---------------------------------------------------------------------------------------------------
-template <int NC, bool RELAX = false>
+template <int NC, int RELAX = 0>
 struct WaveCtx : mpc::wave::WaveOpsT<RELAX> {
     static constexpr int kN = NC;
     const double *table;  // [M][REF_COLS] in global memory (wave-uniform index in the serial parts -> scalar loads)
@@ -80,7 +84,7 @@ struct WaveCtx : mpc::wave::WaveOpsT<RELAX> {
     }
 };
 
-template <bool CC, int NC, int OCC, bool RELAX>
+template <bool CC, int NC, int OCC, int RELAX>
 __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
@@ -436,7 +440,7 @@ size_t carve(size_t &off, size_t bytes) {
     return o;
 }
 
-template <bool CC, int NC, int OCC, bool RELAX>
+template <bool CC, int NC, int OCC, int RELAX>
 int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
                 const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
@@ -474,7 +478,7 @@ int ensure_stage(mpc_handle *h, size_t bytes) {
 
 // Launch of the solve kernel for B instances whose data already sits in device memory (shared by mpc_solve_batch and
 // mpc_predict_batch).  d_nveh: vehicles present per instance or nullptr (= V for all).
-int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t stream, const double *d_state,
+int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, hipStream_t stream, const double *d_state,
                    const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
                    const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
                    double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
@@ -500,19 +504,20 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, hipStream_t strea
                                           d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters)
     // which build: by how deep the batch fills the SIMDs (see kWaveOccLat / kWaveOccMid above)
     const int simds = 4 * h->num_cu;
-    const int depth = B <= kWaveOccLat * simds ? kWaveOccLat : (B <= kWaveOcc * simds ? kWaveOccMid : kWaveOcc);
+    const int depth = throughput ? kWaveOcc
+                                 : (B <= kWaveOccLat * simds ? kWaveOccLat : (B <= kWaveOcc * simds ? kWaveOccMid : kWaveOcc));
 #define MPC_LAUNCH_N(CCV, NCV)                                                         \
-    if (depth == kWaveOccLat) MPC_LAUNCH_W(CCV, NCV, kWaveOccLat, true);               \
-    else if (depth == kWaveOccMid) MPC_LAUNCH_W(CCV, NCV, kWaveOccMid, true);          \
-    else MPC_LAUNCH_W(CCV, NCV, kWaveOcc, false)
+    if (depth == kWaveOccLat) MPC_LAUNCH_W(CCV, NCV, kWaveOccLat, kRelaxLat);                  \
+    else if (depth == kWaveOccMid) MPC_LAUNCH_W(CCV, NCV, kWaveOccMid, kRelaxMid); \
+    else MPC_LAUNCH_W(CCV, NCV, kWaveOcc, 0)
     if (cc) {
         if (N == 20) { MPC_LAUNCH_N(true, 20); }       /* BASELINE horizon */
         else if (N == 16) { MPC_LAUNCH_N(true, 16); }  /* reference cfg.yaml default */
-        else MPC_LAUNCH_W(true, 0, kWaveOccGeneric, false);
+        else MPC_LAUNCH_W(true, 0, kWaveOccGeneric, 0);
     } else {
         if (N == 20) { MPC_LAUNCH_N(false, 20); }
         else if (N == 16) { MPC_LAUNCH_N(false, 16); }
-        else MPC_LAUNCH_W(false, 0, kWaveOccGeneric, false);
+        else MPC_LAUNCH_W(false, 0, kWaveOccGeneric, 0);
     }
 #undef MPC_LAUNCH_N
 #undef MPC_LAUNCH_W
@@ -690,7 +695,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     if (warm && !U) return fail(MPC_ERR_INVALID_ARG, "mpc_solve_batch: MPC_FLAG_WARM_START needs U (initial controls in, solution out)");
     if (warm && !dev)
         HIP_TRY(hipMemcpyAsync(d_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
-    if (int rc = dispatch_solve(h, B, cc, V, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, nullptr,
+    if (int rc = dispatch_solve(h, B, cc, V, (flags & MPC_FLAG_THROUGHPUT) != 0, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, nullptr,
                                 warm ? d_U : nullptr, 0, nullptr, d_u0, d_U, d_X, d_status, d_iters))
         return rc;
 
@@ -844,7 +849,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         if (!dev || !(flags & MPC_FLAG_NO_SYNC)) HIP_TRY(hipStreamSynchronize(stream));
         return MPC_OK;
     }
-    if (int rc = dispatch_solve(h, B, cc, V, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
+    if (int rc = dispatch_solve(h, B, cc, V, (flags & MPC_FLAG_THROUGHPUT) != 0, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
                                 h->p_others, h->p_nveh, warm ? h->d_warm : nullptr, 1, warm ? h->d_warm_valid : nullptr,
                                 d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters))
         return rc;

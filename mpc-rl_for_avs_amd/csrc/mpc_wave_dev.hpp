@@ -48,12 +48,12 @@ __device__ __forceinline__ double row_reduce(double v, OP op) {
     return v;
 }
 
-// RELAX = false is the build for four resident waves per SIMD (128 registers): fresh() / opaque() hide where a constant or a
+// RELAX = 0 is the build for four resident waves per SIMD (128 registers): fresh() / opaque() hide where a constant or a
 // lane-derived table comes from, so that it is recomputed where it is used instead of living in registers across the
-// iteration loop.  RELAX = true lets the compiler hoist all of that: ~200 registers, two or three waves per SIMD, 7 % less
-// time per iteration for a wave that has its SIMD to itself (38.0 against 40.7 us, profiles/r03_latency_builds.txt) -
-// the build the engine launches when the batch leaves SIMDs that empty anyway (mpc_engine.hip: dispatch_solve).
-template <bool RELAX>
+// iteration loop.  The relaxed builds let the compiler hoist: with both relaxed ~200 registers (two waves per SIMD) and
+// 7 % less time per iteration for a wave that has its SIMD to itself (38.1 against 40.7 us, profiles/r03_latency.txt) -
+// the builds the engine launches when the batch leaves SIMDs that empty anyway (mpc_engine.hip: dispatch_solve).
+template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity
 struct WaveOpsT {
     lds_double_t *L;  // this instance's LDS words
     __device__ __forceinline__ double ld(int i) const { return L[i]; }
@@ -121,13 +121,13 @@ struct WaveOpsT {
     // every 64-bit literal used twice is hoisted out of the iteration loop into a vector register pair for the whole
     // solve - 40 registers of the 128 a wave may hold if four waves are to share a SIMD.
     __device__ __forceinline__ double fresh(double v) const {
-        if (RELAX) return v;
+        if (RELAX & 1) return v;
         v = readlane_first_f64(v);       // folds away for a value that already lives in scalar registers
         asm volatile("" : "+s"(v));
         return v;
     }
     __device__ __forceinline__ int opaque(int v) const {
-        if (RELAX) return v;
+        if (RELAX & 2) return v;
         asm volatile("" : "+v"(v));
         return v;
     }
@@ -194,7 +194,7 @@ struct WaveOpsT {
         rd = bd;
     }
 };
-using WaveOps = WaveOpsT<false>;
+using WaveOps = WaveOpsT<0>;
 
 }  // namespace wave
 }  // namespace mpc

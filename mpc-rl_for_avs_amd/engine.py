@@ -20,6 +20,7 @@ FLAG_NO_SYNC = 4
 FLAG_WARM_START = 8      # not in the reference: start from given / previous controls instead of zeros
 FLAG_DETECT_ONLY = 16    # mpc_predict_batch: _check_collision alone (advance the detector records, no solve)
 FLAG_DETECTED = 32       # mpc_predict_batch: _solve after such a call for the same observation
+FLAG_THROUGHPUT = 64     # several batches in flight: always the build for four resident waves per SIMD
 
 STATUS_CONVERGED = 0
 STATUS_MAX_ITER = 1
@@ -211,7 +212,7 @@ class MPCEngine:
 
     # ------------------------------------------------------------------ device (torch) path
     def solve_batch_torch(self, state, ego_index, weights, is_collide, vref=None, others=None,
-                          collision_cost=False, out=None, sync=False):
+                          collision_cost=False, out=None, sync=False, throughput=False):
         """Zero-copy solve on torch CUDA(=HIP) tensors, enqueued on torch's current stream.
 
         dtypes: state/weights/vref/others float64, ego_index int32, is_collide uint8; all contiguous and on
@@ -231,7 +232,8 @@ class MPCEngine:
                        status=torch.empty(B, dtype=torch.int32, device=dev),
                        iters=torch.empty(B, dtype=torch.int32, device=dev))
         V = 0 if others is None else int(others.shape[1])
-        flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC)
+        flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC) | \
+            (FLAG_THROUGHPUT if throughput else 0)     # throughput: several batches in flight (MPC_FLAG_THROUGHPUT)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = self._lib.mpc_solve_batch(self._h, B, p(state), p(ego_index), p(vref), p(weights), p(is_collide),

@@ -30,7 +30,8 @@ import nlp_batch as nb
 def certify(p: nb.Batch, X, U, eps_c=1e-6, wall_tol=1e-6, relax=1e-8, slack_max=10.0, chunk=512):
     """Certificates for all instances of `p` at (X[B,N+1,4], U[B,N,2]).
 
-    eps_c: complementarity allowed to the multipliers, z_i * slack_i <= eps_c * scale.  The default 1e-6 is what a
+    eps_c: complementarity allowed to the multipliers, z_i * slack_i <= eps_c * scale; a number or one value per instance
+    (`objective_scale` below gives the per-instance allowance that IPOPT's own criterion implies).  The default 1e-6 is what a
     solver stopping on IPOPT's scaled error at tol 1e-8 guarantees here: the objective is scaled by up to 1e-2
     (nlp_scaling_max_gradient: 100 / |grad f(start)|_inf), so z s <= 1e-8 in scaled units is 1e-6 in the units of
     `scale` = |grad f(solution)|_inf when the gradient has fallen to the order of 1 (the reference's own tol 1e-6 would
@@ -44,15 +45,39 @@ def certify(p: nb.Batch, X, U, eps_c=1e-6, wall_tol=1e-6, relax=1e-8, slack_max=
       scale
     """
     B, N = p.B, p.N
+    eps_c = np.broadcast_to(np.asarray(eps_c, dtype=np.float64), (B,))
     out = {k: np.zeros(B) for k in ("stationarity", "feasibility", "bound_violation", "scale")}
     out["n_active"] = np.zeros(B, dtype=np.int64)
     out["n_wall"] = np.zeros(B, dtype=np.int64)
     for s in range(0, B, chunk):
         sel = np.arange(s, min(B, s + chunk))
-        r = _certify_chunk(p.take(sel), X[sel], U[sel], eps_c, wall_tol, relax, slack_max)
+        r = _certify_chunk(p.take(sel), X[sel], U[sel], eps_c[sel], wall_tol, relax, slack_max)
         for k in out:
             out[k][sel] = r[k]
     return out
+
+
+def objective_scale(p: nb.Batch):
+    """IPOPT's gradient-based objective scaling (nlp_scaling_max_gradient 100) as the engines apply it, from the NLP data
+    alone: sf = 100 / clamp(|grad f|_inf along the cold-start rollout, 100, 1e4), in [0.01, 1].  A solver that stops on
+    IPOPT's scaled error at `tol` guarantees z s <= tol in units of the SCALED objective, i.e. tol / sf in the units of
+    this module: `certify(..., eps_c=tol / objective_scale(p))` is that criterion instance by instance."""
+    B, N, dt = p.B, p.N, p.dt
+    U0 = np.zeros((B, N, 2))
+    slow = p.state[:, 3] < 0.01                       # a standing vehicle starts with a_0 > 0 (strict interior of v >= 0)
+    U0[slow, 0, 0] = (0.01 - p.state[slow, 3]) / dt
+    X0 = np.zeros((B, N + 1, 4))
+    X0[:, 0] = p.state
+    for k in range(N):
+        f, _ = dyn(X0[:, k:k + 1], U0[:, k:k + 1])
+        X0[:, k + 1] = X0[:, k] + dt * f[:, 0]
+    gX, gU = nb.cost_grad(p, X0, U0)
+    gmax = np.maximum(np.abs(gX[:, 1:N]).max(axis=(1, 2)), np.abs(gU[:, 0, 0]))
+    return 100.0 / np.clip(gmax, 100.0, 1e4)
+
+
+def dyn(X, U):
+    return nb.dyn(X, U)
 
 
 def _certify_chunk(p, X, U, eps_c, wall_tol, relax, slack_max):
@@ -95,7 +120,7 @@ def _certify_chunk(p, X, U, eps_c, wall_tol, relax, slack_max):
     nwall = np.zeros(B, dtype=np.int64)
     for b in range(B):
         cols, ub = [], []
-        zmax = eps_c * scale[b]
+        zmax = eps_c[b] * scale[b]
         thr = slack_max      # a bound with more slack could hold a multiplier of at most eps_c / slack_max, relative
 
         def add(col, slack):

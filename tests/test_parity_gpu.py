@@ -295,12 +295,19 @@ def _certified_full_batch(eng, oracle, ref_table, B, V, cc):
     p = nb.Batch.build(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
                        others=inp["others"], collision_cost=cc)
     sel = np.nonzero(conv)[0]
-    cert = kb.certify(p.take(sel), got["X"][sel], got["U"][sel])
-    # stationarity relative to max(1, |grad f|_inf) with non-negative multipliers complementary to 1e-6 (what IPOPT's
-    # scaled error at tol 1e-8 guarantees, see kkt_batch.certify), dynamics to rounding, no bound violated
+    # stationarity relative to max(1, |grad f|_inf) with non-negative multipliers complementary to 1e-8 in the units of
+    # IPOPT's criterion (the objective scaled by sf = 100 / |grad f(start)|_inf, computed here from the NLP data alone),
+    # dynamics to rounding, no bound violated
+    sf = kb.objective_scale(p.take(sel))
+    cert = kb.certify(p.take(sel), got["X"][sel], got["U"][sel], eps_c=1e-8 / sf)
     assert cert["stationarity"].max() <= 1e-8, (cert["stationarity"].max(), sel[cert["stationarity"].argmax()])
     assert cert["feasibility"].max() <= 1e-10
     assert cert["bound_violation"].max() == 0.0
+    # SURVEY section 8(c) pin (1) literally - complementarity 1e-8 in UNSCALED units: holds for all but a handful, and
+    # every exception is an instance whose objective the scaling shrinks (measured: 3 of 4083, each with sf = 0.01)
+    plain = kb.certify(p.take(sel), got["X"][sel], got["U"][sel], eps_c=1e-8)
+    miss = plain["stationarity"] > 1e-8
+    assert miss.sum() <= 6 and (sf[miss] < 1.0).all(), (int(miss.sum()), sf[miss])
     # status 5 = a wall constraint carries a multiplier: nearly all of them hold a vehicle within 1e-6 of d^2 = 1 (the rest
     # have the multiplier large enough for the flag with a slack of mu / z just above that)
     if cc:
@@ -354,6 +361,58 @@ def test_independent_solver_fixtures(eng, ref_table):
             theirs = kb.certify(p, g[f"{name}_X"][other], g[f"{name}_U"][other])
             assert mine["stationarity"].max() <= 1e-8 and mine["feasibility"].max() <= 1e-10
             assert theirs["stationarity"].max() <= 1e-6       # the fixture's own points are KKT points too
+
+
+def test_three_builds_of_the_solve_kernel_agree(oracle, ref_table):
+    """The engine launches one of three builds of the same solver source by how deep the batch fills the SIMDs (201
+    registers up to two waves per SIMD, 168 up to four, 128 beyond / with MPC_FLAG_THROUGHPUT).  Same instances through
+    all three: statuses equal, actions equal to 1e-6 (a different build may contract a multiply-add differently; an
+    instance whose iterates are chaotic in the last bit may then take another path to the same point)."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, synth
+    dev = torch.device("cuda", 0)
+    inp = synth.solver_inputs(4096, 8, seed=3)
+    e = engine.MPCEngine(horizon=20, max_iter=100)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+
+    def run(n, throughput):
+        args = dict(state=t(inp["state"][:n], torch.float64), ego_index=t(inp["ego_index"][:n], torch.int32),
+                    weights=t(inp["weights"][:n], torch.float64), is_collide=t(inp["is_collide"][:n], torch.uint8),
+                    vref=t(inp["vref"][:n], torch.float64), others=t(inp["others"][:n], torch.float64), collision_cost=True)
+        o = e.solve_batch_torch(**args, sync=True, throughput=throughput)
+        return {k: v.cpu().numpy() for k, v in o.items()}
+    lat = run(1024, False)           # <= 2 waves per SIMD: 201-register build
+    mid = run(4096, False)           # <= 4: 168-register build
+    bulk = run(4096, True)           # 128-register build
+    for a, b, n in ((lat, mid, 1024), (mid, bulk, 4096), (lat, bulk, 1024)):
+        same = (a["status"][:n] == b["status"][:n])
+        assert same.mean() >= 0.998
+        ok = same & converged(a["status"][:n])
+        err = rel_u0_err(a["u0"][:n], b["u0"][:n])[ok]
+        assert (err <= 1e-6).mean() >= 0.999 and np.median(err) < 1e-12
+    want = _oracle(oracle, ref_table, {k: v[:1024] for k, v in inp.items() if isinstance(v, np.ndarray)}, True)
+    both = converged(lat["status"]) & converged(want["status"])
+    assert (rel_u0_err(lat["u0"], want["u0"])[both] <= TOL).all()
+    e.close()
+
+
+def test_stall_window_on_the_gpu(oracle, ref_table):
+    """mpc_config.stall_window = 64 with the reference's max_iter 1000: the batch no longer waits 40 ms for the instances
+    that never converge, the instances that converge quickly are untouched, and the engine agrees with the oracle run under
+    the same rule."""
+    from mpc_rl_for_avs_amd import engine, synth
+    inp = synth.solver_inputs(4096, 8, seed=0)
+    e = engine.MPCEngine(horizon=20, max_iter=1000, stall_window=64)
+    got = e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
+                        others=inp["others"], collision_cost=True)
+    want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
+                              others=inp["others"], collision_cost=True, max_iter=1000, xy_bounds=False, stall_window=64)
+    assert got["iters"].max() < 300 and (got["status"] == 1).sum() == 0
+    assert (got["status"] == want["status"]).mean() >= 0.998 and converged(got["status"]).mean() >= 0.996
+    assert 3 <= (got["status"] == 4).sum() <= 30
+    both = converged(got["status"]) & converged(want["status"])
+    assert (rel_u0_err(got["u0"], want["u0"])[both] > TOL).sum() <= 1
+    e.close()
 
 
 # scenario -> (both converged, of those within 1e-4) measured with the engine's algorithm on the CPU
