@@ -57,7 +57,7 @@ constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
 // 4096 - for the same speed; the rest of a 4096 batch is dispatched as slots free, which also balances the SIMDs better
 // than four static residents: 3.9 against 4.25 ms at cap 60, profiles/r03_mid_builds.txt).
 constexpr int kWaveOccLat = 2, kWaveOccMid = 3;
-constexpr int kRelaxLat = 3, kRelaxMid = 2;
+constexpr int kRelaxLat = 7, kRelaxMid = 2;   // LAT: + the linearised step fused into the rollout loop (bit 2)
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B

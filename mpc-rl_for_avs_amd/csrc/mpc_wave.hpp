@@ -122,6 +122,14 @@ struct fine_ticks { static constexpr bool value = false; };
 template <class CTX>
 struct fine_ticks<CTX, decltype((void)CTX::kFine)> { static constexpr bool value = CTX::kFine; };
 
+// CTX::kFuseLinear = true: the linearised Newton step runs inside the rollout loop of the line search (two independent
+// dependency chains in one instruction stream: for a wave that is alone on its SIMD); false / absent: in its own loop in
+// front of the line search (fewer live registers: for the builds that share a SIMD).  Same arithmetic either way.
+template <class CTX, class = void>
+struct fuse_linear { static constexpr bool value = false; };
+template <class CTX>
+struct fuse_linear<CTX, decltype((void)CTX::kFuseLinear)> { static constexpr bool value = CTX::kFuseLinear; };
+
 // A value that differs per lane and lives across phases: one register per lane on the device; the host emulation,
 // which runs the lanes of a phase one after the other, keeps all 64.
 template <class T>
@@ -505,8 +513,17 @@ struct Solver {
     // fraction-to-the-boundary box.  All step lengths are integrated at once - lane t runs the serial dynamics for
     // alpha_t into its own trial area (t = 0: the spare trajectory buffer) - and their costs are evaluated two trials
     // per pass (lanes 0..31 / 32..63 = stages of trial 2p / 2p + 1); the winner is copied into the spare buffer.
-    MPC_HD bool line_search(int cur, double a_pr, double frac, double phi0, double dV1, double mu_, double &Jn,
-                            double &barn, int &acc_out) {
+    // The linearised Newton step (a 6-dimensional recursion over the stages: the dual step and the dual step length need
+    // it) runs INSIDE the rollout loop: it reads the gains the rollout loads anyway, and its dependency chain is independent
+    // of the rollout's, so the two interleave in one instruction stream instead of paying their latencies one after the
+    // other (a wave alone on its SIMD is latency-bound).  That is possible because the trial step
+    // lengths do not depend on it: they are 1, 1/4, 1/16, 1/64 (a ladder anchored at the linearised fraction-to-the-boundary
+    // length was measured no better: 17.96 against 17.50 iterations on config 3), the trials' own state-bound tests decide
+    // what is feasible.  Its result is parked in the adjoint slots (du at W_Y + 0, 1 of the stage, d theta / d v at
+    // W_Y + 2, 3 of the next node; d x / d y at W_DXY when a wall needs them) by lane 0.
+    MPC_HD bool line_search(int cur, double frac, double phi0, double dV1, double mu_, double &Jn, double &barn,
+                            int &acc_out) {
+        const double a_pr = 1.0;
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
         const double fracu = 2.0 * frac, idt = frcp(c.fresh(dt));
         c.phase([&](int lane) {
@@ -517,6 +534,7 @@ struct Solver {
             const int bx = trial_x(CC, lane, TB), bu = trial_u(CC, lane, TB);
             double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
             double dup0 = 0.0, dup1 = 0.0;
+            double ld0 = 0.0, ld1 = 0.0, ld2 = 0.0, ld3 = 0.0, ldp0 = 0.0, ldp1 = 0.0;   // linearised step: d x_k, d u_{k-1}
             bool feas = true;
             const TrigCoef K = trig();
             // the bounds, read from the table once (theta, v, a, delta)
@@ -534,7 +552,37 @@ struct Solver {
                 const double k10 = S(k, W_KX + 4), k11 = S(k, W_KX + 5), k12 = S(k, W_KX + 6), k13 = S(k, W_KX + 7);
                 const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);   // zero at stage 0
                 const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+                // the stage linearisation, for the linearised step (the trial areas of this stage overwrite these slots
+                // at the end of the stage, after they have been read)
+                double a02 = 0, a03 = 0, a12 = 0, a13 = 0, a23 = 0, b01 = 0, b11 = 0, b21 = 0;
+                if (fuse_linear<CTX>::value) {
+                    a02 = S(k, W_LIN + 0); a03 = S(k, W_LIN + 1); a12 = S(k, W_LIN + 2); a13 = S(k, W_LIN + 3);
+                    a23 = S(k, W_LIN + 4); b01 = S(k, W_LIN + 5); b11 = S(k, W_LIN + 6); b21 = S(k, W_LIN + 7);
+                }
                 c.sched_fence();
+                if (fuse_linear<CTX>::value) {
+                    // linearised Newton step of stage k (same arithmetic in every lane; lane 0 stores)
+                    double du0 = kf0 + k00 * ld0 + k01 * ld1 + k02 * ld2 + k03 * ld3;
+                    double du1 = kf1 + k10 * ld0 + k11 * ld1 + k12 * ld2 + k13 * ld3;
+                    du0 += kp00 * ldp0 + kp01 * ldp1;
+                    du1 += kp01 * ldp0 + kp11 * ldp1;
+                    const double m0 = ld0 + a02 * ld2 + a03 * ld3 + b01 * du1;
+                    const double m1 = ld1 + a12 * ld2 + a13 * ld3 + b11 * du1;
+                    const double m2 = ld2 + a23 * ld3 + b21 * du1;
+                    const double m3 = ld3 + dt * du0;
+                    ld0 = m0; ld1 = m1; ld2 = m2; ld3 = m3;
+                    ldp0 = du0; ldp1 = du1;
+                    if (lane == 0) {
+                        S(k, W_Y + 0, du0);
+                        S(k, W_Y + 1, du1);
+                        S(k + 1, W_Y + 2, m2);
+                        S(k + 1, W_Y + 3, m3);
+                        if (CC && any_wall) {
+                            S(k + 1, W_DXY + 0, m0);
+                            S(k + 1, W_DXY + 1, m1);
+                        }
+                    }
+                }
                 const double e0 = x_0 - xc0, e1 = x_1 - xc1, e2 = x_2 - xc2, e3 = x_3 - xc3;
                 double s0 = alpha * kf0 + k00 * e0 + k01 * e1 + k02 * e2 + k03 * e3;
                 double s1 = alpha * kf1 + k10 * e0 + k11 * e1 + k12 * e2 + k13 * e3;
@@ -1298,9 +1346,10 @@ struct Solver {
             }
 
             c.tick(T_RIC_INIT);
-            // ============ linearised Newton step (serial recursion), parked in the adjoint slots
             const double tau = c.uni(fmax2(0.99, 1.0 - mu));
-            {
+            if (!fuse_linear<CTX>::value) {
+                // ============ linearised Newton step (serial recursion), parked in the adjoint slots; the fused builds run
+                //              the same statements inside the rollout loop of the line search
                 double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
 #pragma unroll 1
                 for (int k = 0; k < N; ++k) {
@@ -1334,16 +1383,35 @@ struct Solver {
                 }
             }
             c.tick(T_LINEAR);
-            // ============ step-length limits (stage-parallel)
+            // ============ wall constraints: slack at the current iterate, which the trials' feasibility test needs
+            if (CC && any_wall) {
+                c.phase([&](int lane) {
+                    const int kn = lane + 1;
+                    if (kn >= N) return;
+                    const double wjv = S(kn, W_WJ);
+                    if (wjv >= 0.0) {
+                        double nx, ny;
+                        S(kn, W_GW, wall_slack(kn, S(kn, CB + W_X + 0), S(kn, CB + W_X + 1), (int)wjv, nx, ny));
+                    }
+                });
+            }
+            // ============ line search on the barrier objective (Armijo, 4 trials, factor 1/4), with the linearised Newton
+            //              step computed alongside the rollouts
+            const double phi0 = c.uni(Jcur + mu * barcur);
+            const int tb = cur ^ 1;
+            double Jn = 0.0, barn = 0.0;
+            int acc_trial = -1;
+            const bool accepted = line_search(cur, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn, acc_trial);
+            const bool have_cross = CC && P.V > 0 && acc_trial != 0;
+            // ============ length of the dual step (stage-parallel, from the linearised step parked by the line search)
             c.phase([&](int lane) {
                 if (lane >= N) {
-                    red_a.at(lane) = 0.0;
                     red_b.at(lane) = 0.0;
                     red_c.at(lane) = 1.0;
                     return;
                 }
                 const int k = lane;
-                double rp = 0.0, rdn = 0.0, rdd = 1.0;
+                double rdn = 0.0, rdd = 1.0;
                 for (int i = 0; i < 4; ++i) {
                     const bool isu = i < 2;
                     const int j = isu ? i : i - 2;
@@ -1355,7 +1423,6 @@ struct Solver {
                     const double zu = isu ? S(kk, W_ZUU + j) : S(kk, W_ZXU + j);
                     const double rsl = frcp(val - lo), rsu = frcp(hi - val);
                     const double dzl = (mu - zl * d) * rsl - zl, dzu = (mu + zu * d) * rsu - zu;
-                    if (!isu) rp = fmax2(rp, fmax2(-d * rsl, d * rsu));
                     if (-dzl * rdd > rdn * zl) { rdn = -dzl; rdd = zl; }
                     if (-dzu * rdd > rdn * zu) { rdn = -dzu; rdd = zu; }
                 }
@@ -1363,35 +1430,24 @@ struct Solver {
                     const double wjv = S(k + 1, W_WJ);
                     if (wjv >= 0.0) {
                         double nx, ny;
-                        const double g = wall_slack(k + 1, S(k + 1, CB + W_X + 0), S(k + 1, CB + W_X + 1), (int)wjv, nx, ny);
+                        wall_slack(k + 1, S(k + 1, CB + W_X + 0), S(k + 1, CB + W_X + 1), (int)wjv, nx, ny);
+                        const double g = S(k + 1, W_GW);
                         const double d = nx * S(k + 1, W_DXY + 0) + ny * S(k + 1, W_DXY + 1), rg = frcp(g);
                         const double zw = S(k + 1, W_ZW), dzw = (mu - zw * d) * rg - zw;
-                        rp = fmax2(rp, -d * rg);
                         if (-dzw * rdd > rdn * zw) { rdn = -dzw; rdd = zw; }
-                        S(k + 1, W_GW, g);
                         S(k + 1, W_DZW, dzw);
                     }
                 }
-                red_a.at(lane) = rp;
                 red_b.at(lane) = rdn;
                 red_c.at(lane) = rdd;
             });
-            double a_pr, a_du;
+            double a_du;
             {
-                const double rp = c.wave_max(red_a);
                 double rdn, rdd;
                 c.wave_max_ratio(red_b, red_c, rdn, rdd);
-                a_pr = c.uni((rp > tau) ? tau / rp : 1.0);
                 a_du = c.uni((rdn > tau * rdd) ? tau * rdd / rdn : 1.0);
             }
             c.tick(T_RATIOS);
-            // ============ line search on the barrier objective (Armijo, <= 6 trials, factor 1/4)
-            const double phi0 = c.uni(Jcur + mu * barcur);
-            const int tb = cur ^ 1;
-            double Jn = 0.0, barn = 0.0;
-            int acc_trial = -1;
-            const bool accepted = line_search(cur, a_pr, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn, acc_trial);
-            const bool have_cross = CC && P.V > 0 && acc_trial != 0;
             bool newwall = false;
             double bar_shift = 0.0;
             // Levenberg-Marquardt term kept across iterations: two or more backtracks (or no acceptable step) multiply it

@@ -613,7 +613,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         const double tau = fmax(0.99, 1.0 - mu);
         static _Thread_local double dxl[NMAX + 1][4], dul[NMAX][2];
         static _Thread_local double dzxl[NMAX + 1][4], dzxu[NMAX + 1][4], dzul[NMAX][2], dzuu[NMAX][2], dzw[NMAX + 1];
-        double a_pr = 1.0, a_du = 1.0;
+        /* The trial step lengths are 1, 1/4, 1/16, 1/64: they do not depend on this linearised step (anchoring the ladder at its
+         * fraction-to-the-boundary length was measured no better: 17.96 against 17.50 iterations on BASELINE config 3), the
+         * trials' own state-bound tests decide what is feasible - which lets the kernel run this recursion inside its
+         * rollout loop.  The step is needed for the dual step and its length a_du. */
+        const double a_pr = 1.0;
+        double a_du = 1.0;
         memset(dxl[0], 0, sizeof(dxl[0]));
         for (int k = 0; k < N; ++k) {
             for (int i = 0; i < 2; ++i) {
@@ -638,8 +643,6 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             }
             for (int i = p->i0; i < 4; ++i) {
                 double sl = it->x[k + 1][i] - xlo_r(i), su = xhi_r(i) - it->x[k + 1][i], d = dxl[k + 1][i];
-                if (d < 0) a_pr = fmin(a_pr, -tau * sl / d);
-                if (d > 0) a_pr = fmin(a_pr, tau * su / d);
                 dzxl[k + 1][i] = (mu - it->zxl[k + 1][i] * d) / sl - it->zxl[k + 1][i];
                 dzxu[k + 1][i] = (mu + it->zxu[k + 1][i] * d) / su - it->zxu[k + 1][i];
                 if (dzxl[k + 1][i] < 0) a_du = fmin(a_du, -tau * it->zxl[k + 1][i] / dzxl[k + 1][i]);
@@ -647,7 +650,6 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             }
             if (k + 1 < N && it->wj[k + 1] >= 0) {
                 double d = wn[k + 1][0] * dxl[k + 1][0] + wn[k + 1][1] * dxl[k + 1][1];
-                if (d < 0) a_pr = fmin(a_pr, -tau * gw[k + 1] / d);
                 dzw[k + 1] = (mu - it->zw[k + 1] * d) / gw[k + 1] - it->zw[k + 1];
                 if (dzw[k + 1] < 0) a_du = fmin(a_du, -tau * it->zw[k + 1] / dzw[k + 1]);
             }

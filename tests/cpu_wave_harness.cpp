@@ -9,16 +9,24 @@
 #include "host_wave_ctx.hpp"
 
 namespace {
+int g_stall_window = 0;
+int g_split = 0;          // 1: the builds with the linearised step in its own loop (wave_set_split_linear)
 template <bool CC>
 void run(const mpc::SolveParams &P, HostCtx &ctx, const double *x0, double ws, double wc, double wd, double wcoll,
          int &st, int &it, int &cur, double &e, bool warm) {
+    if (g_split) {
+        HostCtxSplit &c2 = static_cast<HostCtxSplit &>(ctx);
+        mpc::wave::Solver<CC, HostCtxSplit> s(P, c2, x0, ws, wc, wd, wcoll);
+        s.solve(st, it, cur, e, warm);
+        return;
+    }
     mpc::wave::Solver<CC, HostCtx> s(P, ctx, x0, ws, wc, wd, wcoll);
     s.solve(st, it, cur, e, warm);
-}
-int g_stall_window = 0;   // mpc_config.stall_window of the calls that follow (wave_set_stall_window)
+}   // mpc_config.stall_window of the calls that follow (wave_set_stall_window)
 }  // namespace
 
 extern "C" void wave_set_stall_window(int w) { g_stall_window = w > 0 ? w : 0; }
+extern "C" void wave_set_split_linear(int on) { g_split = on ? 1 : 0; }
 
 extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
                                      const int32_t *ego_index, const double *vref, const double *weights,
@@ -62,7 +70,11 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     const int nd = mpc::wave::lds_doubles(cc, N, Vuse);
     for (int b = 0; b < B; ++b) {
         std::vector<double> L((size_t)nd, NAN);
-        HostCtx ctx{L.data(), table.data(), ego_index[b], M};
+        HostCtxSplit ctx{};
+        ctx.L = L.data();
+        ctx.table = table.data();
+        ctx.e0 = ego_index[b];
+        ctx.M = M;
         ctx.nwords = nd;   // the kernel source must stay inside lds_doubles() for every horizon / vehicle count
         for (int k = 0; k <= N; ++k) {
             int idx = ego_index[b] + k;

@@ -12,6 +12,7 @@
 
 struct HostCtx {
     static constexpr int kN = 0;
+    static constexpr bool kFuseLinear = true;    // the path of the 201-register build; HostCtxSplit below is the other
     double *L;
     const double *table;  // [M][REF_COLS]
     int e0, M;
@@ -134,3 +135,8 @@ struct HostCtx {
     }
 };
 
+
+// the same context for the builds that keep the linearised step in its own loop (mpc_wave.hpp: fuse_linear)
+struct HostCtxSplit : HostCtx {
+    static constexpr bool kFuseLinear = false;
+};

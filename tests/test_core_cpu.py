@@ -127,3 +127,21 @@ def test_stall_window_guard(cpu_wave, oracle, ref_table):
     assert (got["iters"] == guard["iters"]).mean() > 0.9
     both = converged(got["status"])
     assert np.abs(got["u0"] - guard["u0"])[both].max() < 1e-6
+
+
+def test_fused_and_split_linearised_step_are_the_same_solver(cpu_wave, oracle, ref_table):
+    """The 201-register build runs the linearised Newton step inside the rollout loop of the line search, the other builds
+    in its own loop (mpc_wave.hpp: fuse_linear): same statements, same iterates - bit for bit on the host, where no
+    compiler re-associates anything - and both equal to the oracle."""
+    from mpc_rl_for_avs_amd import synth
+    from conftest import converged, rel_u0_err
+    for V, cc, seed in ((8, True, 5), (4, False, 6)):
+        inp = synth.solver_inputs(96, V, seed=seed)
+        a = cpu_wave(ref_table, inp, collision_cost=cc)
+        b = cpu_wave(ref_table, inp, collision_cost=cc, split_linear=True)
+        assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"])
+        assert np.array_equal(a["U"], b["U"]) and np.array_equal(a["X"], b["X"])
+        want = oracle.solve_batch(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
+                                  others=inp["others"], collision_cost=cc, max_iter=100, xy_bounds=False)
+        both = converged(a["status"]) & converged(want["status"])
+        assert both.mean() > 0.95 and rel_u0_err(a["u0"], want["u0"])[both].max() < 1e-6
