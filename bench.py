@@ -193,9 +193,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
+    saved_stdout = None
     if use_dist:
-        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-            os.environ["NCCL_DEBUG"] = "WARN"        # keep RCCL's version banner off stdout: rank 0 prints ONE line
+        # RCCL writes its version banner and kernel-command-line warnings to STDOUT when the communicator is created (at the
+        # first collective): rank 0's stdout must carry ONE JSON line, so file descriptor 1 points at stderr until the timed
+        # region is over
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -261,6 +266,10 @@ def main():
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
 
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         conv = conv_mask(status)
         value_all = world * BATCH * a.steps / elapsed

@@ -13,11 +13,13 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _line(cmd, env=None):
+def _line(cmd, env=None, only_line=False):
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
+    if only_line:       # the driver reads rank 0's stdout: nothing but the JSON line may be on it (RCCL's banner is not)
+        assert [l for l in res.stdout.splitlines() if l.strip()] == lines, res.stdout[-2000:]
     return json.loads(lines[0])
 
 
@@ -35,7 +37,7 @@ def _check(d, steps):
 
 
 def test_single_process_line():
-    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-side"])
+    d = _line([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-side"], only_line=True)
     _check(d, 3)
 
 
@@ -52,7 +54,7 @@ def test_one_rank_over_rccl():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_FORCE_DIST="1")
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline", "--no-side"], env=env)
+               "--no-cpu-baseline", "--no-side"], env=env, only_line=True)
     _check(d, 3)
     assert "x1" in d["config"]["parallelism"]
     g = d["distributed"]                         # only the process-group path fills this in
