@@ -40,6 +40,11 @@ constexpr int kTrials = 4;   // step lengths tried by the line search: a_pr * 4^
 // A rollout that would take theta or v of the next node out of its bounds gets the one control that decides it (delta
 // resp. a) pulled back so that the node keeps this fraction of its slack
 constexpr double kProjKeep = 0.2;
+// No trial may bring a control or a bounded state nearer to its bound than this.  Late in a solve tau = 1 - mu lets a slack
+// shrink by the factor mu ~ 1e-9 per iteration; two such steps take a control at -5 below one ulp of its bound: slack
+// exactly 0, 1 / slack infinite, a NaN in the sweep that no regularisation repairs (status 2, seen on the GPU about once in
+// 4000 instances).  IPOPT corrects slacks that become too small likewise (Waechter & Biegler 2006, section 3.5).
+constexpr double kMinSlack = 1e-14;
 // how far inside its heading bound the cold start puts a node that zero controls would leave on or outside it (rad)
 constexpr double kInitPush = 1e-2;
 
@@ -540,7 +545,7 @@ struct Solver {
             // the bounds, read from the table once (theta, v, a, delta)
             const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
             const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
-            const double keep_ = c.fresh(kProjKeep), vmin_ = c.fresh(1e-6);
+            const double keep_ = c.fresh(kProjKeep), vmin_ = c.fresh(1e-6), ms_ = c.fresh(kMinSlack);
 #pragma unroll 1
             for (int k = 0; k < N; ++k) {
                 // everything the stage reads from LDS first, in one batch (one wait instead of eight: the loads do not
@@ -589,8 +594,8 @@ struct Solver {
                 s0 += kp00 * dup0 + kp01 * dup1;
                 s1 += kp01 * dup0 + kp11 * dup1;
                 if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
-                const double ulo0 = alo_ + fracu * (c0 - alo_), uhi0 = ahi_ - fracu * (ahi_ - c0);
-                const double ulo1 = dlo_ + fracu * (c1 - dlo_), uhi1 = dhi_ - fracu * (dhi_ - c1);
+                const double ulo0 = alo_ + fmax2(fracu * (c0 - alo_), ms_), uhi0 = ahi_ - fmax2(fracu * (ahi_ - c0), ms_);
+                const double ulo1 = dlo_ + fmax2(fracu * (c1 - dlo_), ms_), uhi1 = dhi_ - fmax2(fracu * (dhi_ - c1), ms_);
                 double u0 = fmin2(fmax2(c0 + s0, ulo0), uhi0);
                 double u1 = fmin2(fmax2(c1 + s1, ulo1), uhi1);
                 {
@@ -644,8 +649,8 @@ struct Solver {
                 // same (its lane would idle otherwise): a uniform trip count and a flag instead of a per-lane `break` keep
                 // the exec-mask bookkeeping out of the loop.  Whatever an infeasible lane computes from here on is never
                 // looked at (no trap can come of it: bounded polynomials, rsq / rcp of garbage give NaN at worst).
-                feas = feas & !((n2 - tlo_ < frac * (o2 - tlo_)) | (thi_ - n2 < frac * (thi_ - o2)) |
-                                (n3 - vlo_ < frac * (o3 - vlo_)) | (vhi_ - n3 < frac * (vhi_ - o3)));
+                feas = feas & !((n2 - tlo_ < fmax2(frac * (o2 - tlo_), ms_)) | (thi_ - n2 < fmax2(frac * (thi_ - o2), ms_)) |
+                                (n3 - vlo_ < fmax2(frac * (o3 - vlo_), ms_)) | (vhi_ - n3 < fmax2(frac * (vhi_ - o3), ms_)));
                 if (CC && any_wall && k + 1 < N) {
                     const double wjv = S(k + 1, W_WJ);
                     if (wjv >= 0.0) {

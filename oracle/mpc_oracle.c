@@ -250,6 +250,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * pure_mpc.py:273) is infeasible until the step is tiny (2048 instances of config 2: 66 -> 10 with 40 iterations
      * or more, none left at the cap) */
     const double PROJ_KEEP = 0.2;
+    /* no trial may bring a control or a bounded state nearer to its bound than this: late in a solve tau = 1 - mu lets a
+     * slack shrink by the factor mu ~ 1e-9 per iteration, two such steps take a control at -5 below one ulp of its bound -
+     * slack exactly 0, 1 / slack infinite, a NaN in the sweep that no regularisation repairs (status 2; seen on the GPU
+     * about once in 4000 instances).  IPOPT has the same safeguard (Waechter & Biegler 2006, section 3.5: slacks that
+     * become too small are corrected). */
+    const double MIN_SLACK = 1e-14;
     double reg = 0.0;
 
     static _Thread_local double A[NMAX][4][4], Bm[NMAX][4][2];
@@ -673,8 +679,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     trial.u[k][i] = it->u[k][i] + s;
                     /* control bounds: clamp each component to the fraction-to-the-boundary box instead of
                      * shortening the whole step (saturated accelerations would otherwise jam every iteration) */
-                    double lo_c = ulo_r(i) + (1.0 - tau) * (it->u[k][i] - ulo_r(i));
-                    double hi_c = uhi_r(i) - (1.0 - tau) * (uhi_r(i) - it->u[k][i]);
+                    double lo_c = ulo_r(i) + fmax((1.0 - tau) * (it->u[k][i] - ulo_r(i)), MIN_SLACK);
+                    double hi_c = uhi_r(i) - fmax((1.0 - tau) * (uhi_r(i) - it->u[k][i]), MIN_SLACK);
                     trial.u[k][i] = fmin(fmax(trial.u[k][i], lo_c), hi_c);
                 }
                 {
@@ -682,7 +688,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     const double *xo = it->x[k + 1];
                     double vlo = xlo_r(3) + PROJ_KEEP * (xo[3] - xlo_r(3)), vhi = xhi_r(3) - PROJ_KEEP * (xhi_r(3) - xo[3]);
                     double a = fmin(fmax(trial.u[k][0], (vlo - trial.x[k][3]) / dt), (vhi - trial.x[k][3]) / dt);
-                    double lo_c = ulo_r(0) + (1.0 - tau) * (it->u[k][0] - ulo_r(0)), hi_c = uhi_r(0) - (1.0 - tau) * (uhi_r(0) - it->u[k][0]);
+                    double lo_c = ulo_r(0) + fmax((1.0 - tau) * (it->u[k][0] - ulo_r(0)), MIN_SLACK),
+                           hi_c = uhi_r(0) - fmax((1.0 - tau) * (uhi_r(0) - it->u[k][0]), MIN_SLACK);
                     trial.u[k][0] = fmin(fmax(a, lo_c), hi_c);
                 }
                 dyn_t d;
@@ -697,7 +704,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                         double sreq = ((th1 < tlo ? tlo : thi) - trial.x[k][2]) * WHEELBASE / (dt * vk);
                         if (fabs(sreq) < 0.9) {
                             double del = atan(2.0 * sreq / sqrt(1.0 - sreq * sreq));
-                            double lo_d = ulo_r(1) + (1.0 - tau) * (it->u[k][1] - ulo_r(1)), hi_d = uhi_r(1) - (1.0 - tau) * (uhi_r(1) - it->u[k][1]);
+                            double lo_d = ulo_r(1) + fmax((1.0 - tau) * (it->u[k][1] - ulo_r(1)), MIN_SLACK),
+                                   hi_d = uhi_r(1) - fmax((1.0 - tau) * (uhi_r(1) - it->u[k][1]), MIN_SLACK);
                             trial.u[k][1] = fmin(fmax(del, lo_d), hi_d);
                             dyn_eval(trial.x[k], trial.u[k], &d);
                         }
@@ -706,8 +714,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 for (int i = 0; i < 4; ++i) {
                     trial.x[k + 1][i] = trial.x[k][i] + dt * d.f[i];
                     if (i < p->i0) continue;
-                    if (trial.x[k + 1][i] - xlo_r(i) < 0.5 * (1.0 - tau) * (it->x[k + 1][i] - xlo_r(i)) ||
-                        xhi_r(i) - trial.x[k + 1][i] < 0.5 * (1.0 - tau) * (xhi_r(i) - it->x[k + 1][i]))
+                    if (trial.x[k + 1][i] - xlo_r(i) < fmax(0.5 * (1.0 - tau) * (it->x[k + 1][i] - xlo_r(i)), MIN_SLACK) ||
+                        xhi_r(i) - trial.x[k + 1][i] < fmax(0.5 * (1.0 - tau) * (xhi_r(i) - it->x[k + 1][i]), MIN_SLACK))
                         feas = 0;
                 }
                 if (k + 1 < N && it->wj[k + 1] >= 0 &&

@@ -419,7 +419,7 @@ def test_stall_window_on_the_gpu(oracle, ref_table):
 
 # scenario -> (both converged, of those within 1e-4) measured with the engine's algorithm on the CPU
 # (profiles/r03_parity_vs_ipopt.txt, tools/parity_vs_ipopt.py); the GPU must reproduce the agreement, not approach it
-CLOSED_LOOP_AGREEMENT = {"c1": (120, 114), "c1cc": (119, 115), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 150)}
+CLOSED_LOOP_AGREEMENT = {"c1": (118, 112), "c1cc": (119, 115), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 150)}
 
 
 def test_closed_loop_fixtures_vs_independent_solver(ref_table):
@@ -442,9 +442,10 @@ def test_closed_loop_fixtures_vs_independent_solver(ref_table):
         d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
         got = e.solve_batch(d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"], others=d["others"],
                             collision_cost=cc)
-        # the device against the CPU run of the same algorithm that the analysis used (c1 holds two stalled solves; on the
-        # device one more instance of c1 - theta_0 on the heading bound, 40 iterations in the oracle - ends with status 2)
+        # the device against the CPU run of the same algorithm that the analysis used (c1 holds two stalled solves; at most
+        # one instance whose iterates are chaotic in the last bit may end differently on the device)
         assert (got["status"] == g[f"{name}_oracle_status"]).sum() >= 159, (name, np.bincount(got["status"], minlength=6))
+        assert (got["status"] == 2).sum() == 0, name      # the slack floor (kMinSlack) removed the NaN sweeps
         assert converged(got["status"]).mean() >= 0.98
         ok = converged(got["status"])
         assert rel_u0_err(got["u0"], g[f"{name}_oracle_u0"])[ok].max() < 1e-6, name

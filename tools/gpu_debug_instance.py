@@ -28,5 +28,9 @@ for n in range(1, top + 1):
         sub["others"] = None
     want = wave(ref, sub, collision_cost=cc, max_iter=n)
     du = np.abs(got["U"] - want["U"]).max()
+    U, X = got["U"][0], got["X"][0]
+    su = min((U[:, 0] + 5.0 * (1 + 1e-8)).min(), (5.0 * (1 + 1e-8) - U[:, 0]).min(), (U[:, 1] + np.pi / 3 * (1 + 1e-8)).min(),
+             (np.pi / 3 * (1 + 1e-8) - U[:, 1]).min())
+    sx = min((X[1:, 2] + np.pi * (1 + 1e-8)).min(), (np.pi * (1 + 1e-8) - X[1:, 2]).min(), (X[1:, 3] + 1e-8).min(), (30 * (1 + 1e-8) - X[1:, 3]).min())
     print(f"cap {n:3d}: gpu status {got['status'][0]} iters {got['iters'][0]:3d} | host status {want['status'][0]} iters {want['iters'][0]:3d} "
-          f"| max |dU| {du:.3e}  finite {np.isfinite(got['U']).all()}  u0 gpu {got['u0'][0]}")
+          f"| max |dU| {du:.3e}  min slack of a control {su:.3e} of a state {sx:.3e}")
