@@ -75,13 +75,13 @@ extern "C" {
                                          100/d^2 outside, 1000/d^2 inside): a KKT point of the outer branch with
                                          |p - o|^2 >= 1 as a constraint, i.e. a local minimiser of the discontinuous
                                          objective.  IPOPT has no such notion.  Observed with the restatement of its
-                                         algorithm at the reference's settings on the 154 such instances of BASELINE
-                                         config 3 (profiles/r03_parity_vs_ipopt.txt, part b): 102 end without success
-                                         (73 with steps below alpha_min, where IPOPT proper would try its restoration
+                                         algorithm at the reference's settings on the 148 such instances of BASELINE
+                                         config 3 (profiles/r03_parity_vs_ipopt.txt, part b): 99 end without success
+                                         (70 with steps below alpha_min, where IPOPT proper would try its restoration
                                          phase; 29 at max_iter 1000, half of them within 1e-3 of d = 1) and the reference
-                                         would act on that last iterate (agents/pure_mpc.py:303-305); 52 converge to a
-                                         smooth minimiser on one side of the jump (26 inside d < 1, 26 outside), a
-                                         different action than this status returns in 34 of them. */
+                                         would act on that last iterate (agents/pure_mpc.py:303-305); 49 converge to a
+                                         smooth minimiser on one side of the jump (26 inside d < 1, 23 outside), a
+                                         different action than this status returns in 35 of them. */
 
 typedef struct mpc_handle mpc_handle;
 

@@ -237,7 +237,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
     const double KSIG = 1e10; /* IPOPT kappa_Sigma */
     const int MAXLS = 4;      /* line-search trials per iteration */
     const double BTF = g_exp_btf; /* backtracking factor, 0.25 (tools/portfolio_study.py may set another) */
-    const double kap_eps = 10.0, kap_mu = 0.2;
+    const double kap_eps = 30.0, kap_mu = 0.2; /* kappa_epsilon: 10 in IPOPT and here until round 3 */
     /* Levenberg-Marquardt term kept across iterations: added to the diagonal of the stage Hessians like delta_w.  Two or
      * more backtracks (or no acceptable step) multiply it by 4 (from 1e-3), a full first trial divides it by 4 (to 0
      * below 1e-3).  Without it instances on the nonconvex side of the heading wrap crawl with 1/64-steps for the whole
@@ -249,7 +249,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * runs along theta = -pi (the reference heading of the exit straight IS the bound, base_agent.py:146-152 vs
      * pure_mpc.py:273) is infeasible until the step is tiny (2048 instances of config 2: 66 -> 10 with 40 iterations
      * or more, none left at the cap) */
-    const double PROJ_KEEP = 0.2;
+    const double PROJ_KEEP = 0.1;
     /* no trial may bring a control or a bounded state nearer to its bound than this: late in a solve tau = 1 - mu lets a
      * slack shrink by the factor mu ~ 1e-9 per iteration, two such steps take a control at -5 below one ulp of its bound -
      * slack exactly 0, 1 / slack infinite, a NaN in the sweep that no regularisation repairs (status 2; seen on the GPU

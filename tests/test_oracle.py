@@ -144,7 +144,7 @@ def test_closed_loop_fixtures_agreement_is_what_the_profile_says(oracle, ref_tab
     import os
     from conftest import GOLDEN, converged, rel_u0_err
     g = np.load(os.path.join(GOLDEN, "closed_loop_ipopt.npz"))
-    want = {"c1": (118, 112), "c1cc": (119, 115), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 150)}
+    want = {"c1": (117, 113), "c1cc": (117, 110), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 149)}
     for name, counts in want.items():
         d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
         assert d["state"].shape[0] == 160 and d["others"].shape[1] in (1, 4)
