@@ -170,7 +170,11 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
 // as agents/base_agent.py:96-102 does).  U holds the stored control profile (oa, od) on entry and, where the QP was
 // solved, the new one on exit; elsewhere it is left alone and the action is (0, 0) (pure_mpc_linear.py:193-196).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, 2) void mpc_ltv_kernel(
+// Two builds, as for the solve kernel: OCC 3 (<= 168 registers, nothing spilled; LDS admits 12 instances per CU at N = 20
+// anyway) keeps the role tables and uniform constants out of registers by recomputing them (opaque / fresh); OCC 2 with
+// both relaxed lets the compiler hoist them - 5 % less time per solve when the batch leaves the SIMDs that empty.
+template <int OCC, int RELAX>
+__global__ __launch_bounds__(kBlock, OCC) void mpc_ltv_kernel(
     mpc::ltv::LtvParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
     const float *__restrict__ obs, int rows, double *U, double *__restrict__ u0_out, double *__restrict__ X_out,
     int32_t *__restrict__ status_out, int32_t *__restrict__ iters_out, int32_t *__restrict__ target_out) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kBlock, 2) void mpc_ltv_kernel(
         x0[2] = state[(size_t)b * 4 + 3];
         x0[3] = state[(size_t)b * 4 + 2];
     }
-    WaveCtx<0> ctx((mpc::wave::lds_double_t *)smem, ref5, 0, M);
+    WaveCtx<0, RELAX> ctx((mpc::wave::lds_double_t *)smem, ref5, 0, M);
     // nearest reference point, first minimum of the squared distance (calc_nearest_index_in_direction, :38-60);
     // products and sum rounded separately like the Python expression
     {
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kBlock, 2) void mpc_ltv_kernel(
         ctx.st(lane * ltv::L_SLOTS + ltv::L_U + 1, U[((size_t)b * N + lane) * 2 + 1]);
     }
     __syncthreads();
-    ltv::Solver<WaveCtx<0>> solver(P, ctx, x0);
+    ltv::Solver<WaveCtx<0, RELAX>> solver(P, ctx, x0);
     // the loop of :189: every pass re-simulates the profile the previous one stored and solves the QP linearised
     // about it; the first pass that fails ends the call with the action (0, 0) and the profile stored so far
     int status = ltv::ST_MAX_ITER, iters = 0;
@@ -231,9 +235,10 @@ __global__ __launch_bounds__(kBlock, 2) void mpc_ltv_kernel(
         __syncthreads();
         ok = status == ltv::ST_CONVERGED;
         if (!ok) break;
-        if (lane < N) {
-            U[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 0);
-            U[((size_t)b * N + lane) * 2 + 1] = ctx.ld(lane * ltv::L_SLOTS + ltv::L_U + 1);
+        const int ul = ctx.opaque(lane);   // the row address is formed here, not carried in registers through the solve
+        if (ul < N) {
+            U[((size_t)b * N + ul) * 2 + 0] = ctx.ld(ul * ltv::L_SLOTS + ltv::L_U + 0);
+            U[((size_t)b * N + ul) * 2 + 1] = ctx.ld(ul * ltv::L_SLOTS + ltv::L_U + 1);
         }
     }
     if (lane < 2) u0_out[(size_t)b * 2 + lane] = ok ? ctx.ld(ltv::L_U + lane) : 0.0;
@@ -867,6 +872,10 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
 }
 
 // ---- iterative-linear MPC (reference agents/pure_mpc_linear.py) ---------------------------------------------
+// the two builds of mpc_ltv_kernel: waves per SIMD, and what the latency build may keep in registers (fresh / opaque the
+// identity, residuals kept, wave-uniform gain rows: mpc_ltv.hpp relax_bits).  Measured on one box (tools/gpu_ltv_ab.py):
+// per-lane gain rows cost a lone wave 5 % (0.633 against 0.603 ms at B = 1), recomputed residuals 2 %.
+constexpr int kLtvOcc = 3, kLtvOccLat = 2, kLtvRelaxLat = 1 | 2 | 8 | 16;
 static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_state, const float *d_obs, int rows,
                       double *d_U, double *d_u0, double *d_X, int32_t *d_status, int32_t *d_iters, int32_t *d_target) {
     mpc::ltv::LtvParams P;
@@ -877,15 +886,22 @@ static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_
     const size_t lds = (size_t)mpc::ltv::lds_doubles(P.N) * sizeof(double);
     static std::atomic<size_t> lds_set[kMaxDevices];
     if (h->device >= kMaxDevices || lds_set[h->device].load(std::memory_order_acquire) < lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel<kLtvOcc, 0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(mpc_ltv_kernel<kLtvOccLat, kLtvRelaxLat>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (h->device < kMaxDevices) {
             size_t cur = lds_set[h->device].load(std::memory_order_relaxed);
             while (cur < lds && !lds_set[h->device].compare_exchange_weak(cur, lds, std::memory_order_release)) {}
         }
     }
-    hipLaunchKernelGGL(mpc_ltv_kernel, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_obs,
-                       rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
+    // which build: by how deep the batch fills the SIMDs
+    if (B <= kLtvOccLat * 4 * h->num_cu)
+        hipLaunchKernelGGL((mpc_ltv_kernel<kLtvOccLat, kLtvRelaxLat>), dim3((unsigned)B), dim3(kBlock), lds, stream, P, B,
+                           h->d_ref, h->M, d_state, d_obs, rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
+    else
+        hipLaunchKernelGGL((mpc_ltv_kernel<kLtvOcc, 0>), dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M,
+                           d_state, d_obs, rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }

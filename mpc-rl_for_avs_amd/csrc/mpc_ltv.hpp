@@ -73,7 +73,7 @@ enum : int {
     L_T = 73,    // 2  t of the current right-hand side
     L_SLOTS = 75
 };
-enum : int { SC_ZERO = 0, SC_ONE = 1, SC_DT = 2, SC_SIZE = 4 };
+enum : int { SC_ZERO = 0, SC_ONE = 1, SC_DT = 2, SC_X0 = 4, SC_SIZE = 8 };   // SC_X0: the ego state x, y, yaw, v
 
 MPC_HD constexpr int lds_doubles(int N) { return L_SLOTS * (N + 1) + SC_SIZE; }
 
@@ -84,26 +84,40 @@ struct LtvParams {
     double dt;
 };
 
+// CTX::kRelax (absent: 0) - what the build may keep in registers (mpc_engine.hip: the two builds of mpc_ltv_kernel):
+//   bit 3: the primal residuals stay in registers from the residual phase to the predictor step instead of being recomputed
+//   bit 4: the gain rows g1, g2 of a Riccati stage are formed once as wave-uniform values instead of per lane
+template <class CTX, class = void>
+struct relax_bits { static constexpr int value = 0; };
+template <class CTX>
+struct relax_bits<CTX, decltype((void)CTX::kRelax)> { static constexpr int value = CTX::kRelax; };
+
 template <class CTX>
 struct Solver {
+    static constexpr bool kKeepResidual = (relax_bits<CTX>::value & 8) != 0;
+    static constexpr bool kUniformGains = (relax_bits<CTX>::value & 16) != 0;
     const LtvParams &P;
     CTX &c;
     const int N, SCR;
     const double dt;
-    double x0[4];   // x, y, yaw, v
 
+    // the ego state (x, y, yaw, v) is parked in LDS: it is read at the start of a pass only, and four wave-uniform doubles
+    // that the vector unit converted from the float32 observation would otherwise sit in eight vector registers for the
+    // whole kernel
     MPC_HD Solver(const LtvParams &P_, CTX &c_, const double *x0_)
         : P(P_), c(c_), N(P_.N), SCR(L_SLOTS * (P_.N + 1)), dt(P_.dt) {
-        x0[0] = x0_[0]; x0[1] = x0_[1]; x0[2] = x0_[2]; x0[3] = x0_[3];
+        for (int i = 0; i < 4; ++i) c.st(SCR + SC_X0 + i, x0_[i]);
+        c.phase([&](int) {});
     }
+    MPC_HD double X0(int i) const { return c.ld(SCR + SC_X0 + i); }
     MPC_HD double S(int k, int slot) const { return c.ld(k * L_SLOTS + slot); }
     MPC_HD void S(int k, int slot, double v) { c.st(k * L_SLOTS + slot, v); }
 
     PerLane<double> red_a, red_b, red_c, red_d, red_e;
     PerLane<double> s_[8], z_[8], rp_[8], pr_[8];   // slack, multiplier, primal residual, predictor product per inequality
     // matrix-core roles, as in mpc_wave.hpp: lane l = 16 hi + 4 (2 I + J) + lo holds element (4 I + hi, 4 J + lo)
-    PerLane<int> m_row, m_col, m_fa0, m_fa1, m_fb0, m_fb1, m_lslot, m_gslot, m_kx;
-    PerLane<double> m_lsgn;
+    PerLane<int> m_row, m_col, m_fa0, m_fa1, m_fb0, m_fb1;
+    PerLane<int> m_lslot;   // stage-Hessian slot of this lane's element, + 256 where it enters with a minus sign; -1: none
 
     // reference columns of node k: window row min(target + k, M - 1) (:178-187)
     MPC_HD double xr(int k) const { return c.ref(k, R_X); }
@@ -114,11 +128,11 @@ struct Solver {
     MPC_HD int f_word(int r, int cl) const {
         return wave::stage_transition_word(r, cl, L_LIN, -(SCR + SC_ZERO + 1), -(SCR + SC_ONE + 1), -(SCR + SC_DT + 1));
     }
+    // (pure functions of the lane id, recomputed at the start of every factorisation from a lane id the compiler cannot
+    // see through - as in mpc_wave.hpp - so that their 11 registers are live during the sweep only)
     MPC_HD void set_roles() {
-        c.st(SCR + SC_ZERO, 0.0);
-        c.st(SCR + SC_ONE, 1.0);
-        c.st(SCR + SC_DT, dt);
-        c.phase([&](int lane) {
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque(lane_);
             const int hi = lane >> 4, blk = (lane >> 2) & 3, I = blk >> 1, J = blk & 1, lo = lane & 3;
             const int row = 4 * I + hi, col = 4 * J + lo;
             m_row.at(lane) = row;
@@ -129,21 +143,10 @@ struct Solver {
             m_fb1.at(lane) = f_word(4 + hi, 4 * J + lo);
             const int a = row < col ? row : col, b = row < col ? col : row;
             int slot = -1;
-            double sgn = 0.0;
-            if (a == b && a >= 2) {
-                slot = L_H + (a - 2);
-                sgn = 1.0;
-            } else if (a == 4 && b == 6) {
-                slot = L_H + 2;
-                sgn = -1.0;
-            } else if (a == 5 && b == 7) {
-                slot = L_H + 3;
-                sgn = -1.0;
-            }
+            slot = (a == b && a >= 2) ? L_H + (a - 2) : slot;
+            slot = (a == 4 && b == 6) ? 256 + L_H + 2 : slot;
+            slot = (a == 5 && b == 7) ? 256 + L_H + 3 : slot;
             m_lslot.at(lane) = slot;
-            m_lsgn.at(lane) = sgn;
-            m_gslot.at(lane) = col == 0 ? L_G + row : -1;
-            m_kx.at(lane) = (I == 0 && J == 0 && hi >= 2) ? L_KX + (hi - 2) * 4 + lo : -1;
         });
     }
 
@@ -188,6 +191,13 @@ struct Solver {
         return i < 6 ? dr : dv;
     }
     MPC_HD static bool valid(int k, int i) { return k >= 1 || (i != 4 && i != 5); }
+    // primal residual c_i - s_i of inequality i of stage k; a residual below the rounding resolution of its constraint
+    // value is zero (kept, it would be multiplied by z / s).  Recomputed where it is needed - the iterate does not change
+    // between the residual phase and the predictor step - instead of being held in registers across the factorisation.
+    MPC_HD double presid(int k, int i, double s) const {
+        const double rr = cval(k, i) - s;
+        return fabs(rr) <= 8.0 * 2.220446049250313e-16 * kMaxSpeed ? 0.0 : rr;
+    }
 
     // stage gradient of stage k for the per-inequality right-hand-side terms q (g = grad f - C' q), own part: the
     // control and previous-control rows and the speed-bound term of node k + 1
@@ -228,6 +238,7 @@ struct Solver {
 
     // ---- Riccati factorisation + first solve on the matrix core (operands as in mpc_wave.hpp) -------------------
     MPC_HD bool factor_and_solve() {
+        set_roles();
         double pT[4];
         terminal_gradient(pT);
         const double T = (double)N;
@@ -250,10 +261,11 @@ struct Solver {
                 FB0.at(lane) = c.ld(w2 >= 0 ? base + w2 : -w2 - 1);
                 FB1.at(lane) = c.ld(w3 >= 0 ? base + w3 : -w3 - 1);
                 const int ls = m_lslot.at(lane);
-                Hm.at(lane) = m_lsgn.at(lane) * c.ld(base + (ls >= 0 ? ls : 0));
-                const int gs = m_gslot.at(lane);
-                const double gv = c.ld(base + (gs >= 0 ? gs : 0));
-                hv.at(lane) = gs >= 0 ? gv : 0.0;
+                const double lv = c.ld(base + (ls >= 0 ? (ls & 255) : 0));
+                Hm.at(lane) = ls < 0 ? 0.0 : (ls >= 256 ? -lv : lv);
+                const bool col0 = m_col.at(lane) == 0;
+                const double gv = c.ld(base + (col0 ? L_G + m_row.at(lane) : 0));
+                hv.at(lane) = col0 ? gv : 0.0;
             });
             // T = P F   (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
             PerLane<double> PA0, PA1, Tm;
@@ -320,48 +332,87 @@ struct Solver {
             c.mfma(HA, kfB, hv);     // hv <- h + H(., u) kf
             const double h44 = S(k, L_H + 2), h55 = S(k, L_H + 3);
             // base gains K0 = -G H(u, .): state columns from the matrix core's W = adj(Huu) H(u, .) (row 6 + a, column j
-            // sits in lane 16 (2 + a) + j), previous-control columns in closed form (H(u, p) = -diag(H44, H55))
-            double g1[6], g2[6], kx0[4], kx1[4];
+            // sits in lane 16 (2 + a) + j), previous-control columns in closed form (H(u, p) = -diag(H44, H55)).
+            // g1 = [dt K0(0, .) + e_v], g2 = [K0(1, .) - e_p1] (6 entries each) are needed per lane by row and by column:
+            // every lane selects its entries from the eight raw values of W (scalar registers) and scales them itself,
+            // instead of 20 wave-uniform doubles being kept in vector registers to the end of the stage.
+            if (kUniformGains) {
+                double g1[6], g2[6], kx0[4], kx1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    kx0[j] = -idet * c.lane_get(W, 32 + j);
+                    kx1[j] = -idet * c.lane_get(W, 48 + j);
+                    g1[j] = dt * kx0[j];
+                    g2[j] = kx1[j];
+                }
+                g1[3] += 1.0;
+                const double kp00 = i00 * h44, kp01 = i01 * h55, kp10 = i01 * h44, kp11 = i11 * h55;
+                g1[4] = dt * kp00;
+                g1[5] = dt * kp01;
+                g2[4] = kp10;
+                g2[5] = kp11 - 1.0;
+                const double z00 = y00 * k00 + y01 * k01, z01 = y00 * k01 + y01 * k11;      // Z = Y kap
+                const double z10 = y10 * k00 + y11 * k01, z11 = y10 * k01 + y11 * k11;
+                c.lanes([&](int lane) {
+                    const int r = m_row.at(lane), cl = m_col.at(lane);
+                    double g1r = 0.0, g2r = 0.0, g1c = 0.0, g2c = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        g1r = r == j ? g1[j] : g1r;
+                        g2r = r == j ? g2[j] : g2r;
+                        g1c = cl == j ? g1[j] : g1c;
+                        g2c = cl == j ? g2[j] : g2c;
+                    }
+                    const double add = g1r * (k00 * g1c + k01 * g2c) + g2r * (k01 * g1c + k11 * g2c);
+                    Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) + add : 0.0;
+                    const double padd = r == 3 ? t0 : (r == 5 ? -t1 : 0.0);                  // Fx (kap Fu' kf0)
+                    pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) + padd : 0.0;
+                    if (lane < 4) {
+                        S(k, L_KX + lane, kx0[lane] - (z00 * g1[lane] + z01 * g2[lane]));
+                        S(k, L_KX + 4 + lane, kx1[lane] - (z10 * g1[lane] + z11 * g2[lane]));
+                    }
+                    if (lane == 0) {
+                        S(k, L_KF + 0, kf0);
+                        S(k, L_KF + 1, kf1);
+                        S(k, L_KP + 0, kp00 - (z00 * g1[4] + z01 * g2[4]));
+                        S(k, L_KP + 1, kp01 - (z00 * g1[5] + z01 * g2[5]));
+                        S(k, L_KP + 2, kp10 - (z10 * g1[4] + z11 * g2[4]));
+                        S(k, L_KP + 3, kp11 - (z10 * g1[5] + z11 * g2[5]));
+                        S(k, L_IH + 0, i00 - (z00 * y00 + z01 * y01));
+                        S(k, L_IH + 1, i01 - (z00 * y10 + z01 * y11));
+                        S(k, L_IH + 2, i11 - (z10 * y10 + z11 * y11));
+                        S(k, L_Z + 0, z00);
+                        S(k, L_Z + 1, z01);
+                        S(k, L_Z + 2, z10);
+                        S(k, L_Z + 3, z11);
+                        S(k, L_T + 0, t0);
+                        S(k, L_T + 1, t1);
+                    }
+                    if (lane < 6) {
+                        S(k, L_M + lane, k00 * g1[lane] + k01 * g2[lane]);
+                        S(k, L_M + 6 + lane, k01 * g1[lane] + k11 * g2[lane]);
+                    }
+                });
+                continue;
+            }
+            double w0[4], w1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                kx0[j] = -idet * c.lane_get(W, 32 + j);
-                kx1[j] = -idet * c.lane_get(W, 48 + j);
-                g1[j] = dt * kx0[j];
-                g2[j] = kx1[j];
+                w0[j] = c.lane_get(W, 32 + j);
+                w1[j] = c.lane_get(W, 48 + j);
             }
-            g1[3] += 1.0;
             const double kp00 = i00 * h44, kp01 = i01 * h55, kp10 = i01 * h44, kp11 = i11 * h55;
-            g1[4] = dt * kp00;
-            g1[5] = dt * kp01;
-            g2[4] = kp10;
-            g2[5] = kp11 - 1.0;
             const double z00 = y00 * k00 + y01 * k01, z01 = y00 * k01 + y01 * k11;      // Z = Y kap
             const double z10 = y10 * k00 + y11 * k01, z11 = y10 * k01 + y11 * k11;
             c.lanes([&](int lane) {
-                const int r = m_row.at(lane), cl = m_col.at(lane);
-                double g1r = 0.0, g2r = 0.0, g1c = 0.0, g2c = 0.0;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    g1r = r == j ? g1[j] : g1r;
-                    g2r = r == j ? g2[j] : g2r;
-                    g1c = cl == j ? g1[j] : g1c;
-                    g2c = cl == j ? g2[j] : g2c;
-                }
-                const double add = g1r * (k00 * g1c + k01 * g2c) + g2r * (k01 * g1c + k11 * g2c);
-                Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) + add : 0.0;
-                const double padd = r == 3 ? t0 : (r == 5 ? -t1 : 0.0);                  // Fx (kap Fu' kf0)
-                pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) + padd : 0.0;
-                if (lane < 4) {
-                    S(k, L_KX + lane, kx0[lane] - (z00 * g1[lane] + z01 * g2[lane]));
-                    S(k, L_KX + 4 + lane, kx1[lane] - (z10 * g1[lane] + z11 * g2[lane]));
-                }
                 if (lane == 0) {
+                    const double g14 = dt * kp00, g15 = dt * kp01, g24 = kp10, g25 = kp11 - 1.0;
                     S(k, L_KF + 0, kf0);
                     S(k, L_KF + 1, kf1);
-                    S(k, L_KP + 0, kp00 - (z00 * g1[4] + z01 * g2[4]));
-                    S(k, L_KP + 1, kp01 - (z00 * g1[5] + z01 * g2[5]));
-                    S(k, L_KP + 2, kp10 - (z10 * g1[4] + z11 * g2[4]));
-                    S(k, L_KP + 3, kp11 - (z10 * g1[5] + z11 * g2[5]));
+                    S(k, L_KP + 0, kp00 - (z00 * g14 + z01 * g24));
+                    S(k, L_KP + 1, kp01 - (z00 * g15 + z01 * g25));
+                    S(k, L_KP + 2, kp10 - (z10 * g14 + z11 * g24));
+                    S(k, L_KP + 3, kp11 - (z10 * g15 + z11 * g25));
                     S(k, L_IH + 0, i00 - (z00 * y00 + z01 * y01));
                     S(k, L_IH + 1, i01 - (z00 * y10 + z01 * y11));
                     S(k, L_IH + 2, i11 - (z10 * y10 + z11 * y11));
@@ -372,12 +423,39 @@ struct Solver {
                     S(k, L_T + 0, t0);
                     S(k, L_T + 1, t1);
                 }
+            });
+            c.lanes([&](int lane) {
+                const int r = m_row.at(lane), cl = m_col.at(lane);
+                // entry j of g1 / g2 for j = row and j = column of this lane
+                double r0 = 0.0, r1 = 0.0, c0 = 0.0, c1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r0 = r == j ? w0[j] : r0;
+                    r1 = r == j ? w1[j] : r1;
+                    c0 = cl == j ? w0[j] : c0;
+                    c1 = cl == j ? w1[j] : c1;
+                }
+                const double kr0 = -idet * r0, kr1 = -idet * r1, kc0 = -idet * c0, kc1 = -idet * c1;   // K0(a, row / col)
+                const double g1r = r < 4 ? dt * kr0 + (r == 3 ? 1.0 : 0.0) : (r == 4 ? dt * kp00 : (r == 5 ? dt * kp01 : 0.0));
+                const double g2r = r < 4 ? kr1 : (r == 4 ? kp10 : (r == 5 ? kp11 - 1.0 : 0.0));
+                const double g1c = cl < 4 ? dt * kc0 + (cl == 3 ? 1.0 : 0.0) : (cl == 4 ? dt * kp00 : (cl == 5 ? dt * kp01 : 0.0));
+                const double g2c = cl < 4 ? kc1 : (cl == 4 ? kp10 : (cl == 5 ? kp11 - 1.0 : 0.0));
+                const double mc1 = k00 * g1c + k01 * g2c, mc2 = k01 * g1c + k11 * g2c;     // column cl of kap [g1 g2]'
+                const double add = g1r * mc1 + g2r * mc2;
+                Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) + add : 0.0;
+                const double padd = r == 3 ? t0 : (r == 5 ? -t1 : 0.0);                  // Fx (kap Fu' kf0)
+                pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) + padd : 0.0;
+                // lanes 0 .. 5 hold row 0, column = lane: their column entries are entry `lane` of g1, g2 and of K0
+                if (lane < 4) {
+                    S(k, L_KX + lane, kc0 - (z00 * g1c + z01 * g2c));
+                    S(k, L_KX + 4 + lane, kc1 - (z10 * g1c + z11 * g2c));
+                }
                 if (lane < 6) {
-                    S(k, L_M + lane, k00 * g1[lane] + k01 * g2[lane]);
-                    S(k, L_M + 6 + lane, k01 * g1[lane] + k11 * g2[lane]);
+                    S(k, L_M + lane, mc1);
+                    S(k, L_M + 6 + lane, mc2);
                 }
             });
-        }
+                }
         c.phase([&](int) {});
         return true;
     }
@@ -443,11 +521,13 @@ struct Solver {
     MPC_HD void solve(int &status_out, int &iters_out) {
         status_out = ST_MAX_ITER;
         iters_out = 0;
-        if (!(x0[3] >= 0.0) || !(x0[3] <= kMaxSpeed)) {   // x[2, 0] == v0 against 0 <= x[2, t] <= MAX_SPEED (:252-256)
+        if (!(X0(3) >= 0.0) || !(X0(3) <= kMaxSpeed)) {   // x[2, 0] == v0 against 0 <= x[2, t] <= MAX_SPEED (:252-256)
             status_out = ST_INFEASIBLE;
             return;
         }
-        set_roles();
+        c.st(SCR + SC_ZERO, 0.0);
+        c.st(SCR + SC_ONE, 1.0);
+        c.st(SCR + SC_DT, dt);
         // ---- nominal trajectory (predict_motion, :84-110); only its speed and yaw enter the model
         c.phase([&](int lane) {
             for (int k = lane; k < N; k += kLanes) {
@@ -457,7 +537,7 @@ struct Solver {
             }
         });
         {
-            double v = x0[3], yaw = x0[2];
+            double v = X0(3), yaw = X0(2);
 #pragma unroll 1
             for (int k = 0; k < N; ++k) {
                 S(k, L_G + 1, v);
@@ -487,7 +567,7 @@ struct Solver {
             }
         });
         {
-            double q0 = x0[0], q1 = x0[1], q2 = x0[2], q3 = x0[3];
+            double q0 = X0(0), q1 = X0(1), q2 = X0(2), q3 = X0(3);
 #pragma unroll 1
             for (int k = 0; k < N; ++k) {
                 S(k, L_X + 0, q0); S(k, L_X + 1, q1); S(k, L_X + 2, q2); S(k, L_X + 3, q3);
@@ -505,8 +585,6 @@ struct Solver {
                 const bool on = lane < N && valid(lane, i);
                 s_[i].at(lane) = on ? fmax2(cval(lane, i), kSInitMin) : 1.0;
                 z_[i].at(lane) = on ? kZInit : 0.0;
-                rp_[i].at(lane) = 0.0;
-                pr_[i].at(lane) = 0.0;
             }
         });
         const double m_ineq = (double)(8 * N - 2);
@@ -519,17 +597,21 @@ struct Solver {
             c.phase([&](int lane) {
                 red_a.at(lane) = 0.0;
                 red_b.at(lane) = 0.0;
-                if (lane >= N) return;
+                if (lane >= N) {
+                    if (kKeepResidual)
+                        for (int i = 0; i < 8; ++i) rp_[i].at(lane) = 0.0;
+                    return;
+                }
                 const int k = lane;
                 double rpm = 0.0, sz = 0.0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (!valid(k, i)) continue;
-                    // a residual below the rounding resolution of its constraint value is zero (kept, it would be
-                    // multiplied by z / s)
-                    const double cv = cval(k, i), rr = cv - s_[i].at(lane);
-                    const double r = fabs(rr) <= 8.0 * 2.220446049250313e-16 * kMaxSpeed ? 0.0 : rr;
-                    rp_[i].at(lane) = r;
+                    if (!valid(k, i)) {
+                        if (kKeepResidual) rp_[i].at(lane) = 0.0;
+                        continue;
+                    }
+                    const double r = presid(k, i, s_[i].at(lane));
+                    if (kKeepResidual) rp_[i].at(lane) = r;
                     rpm = fmax2(rpm, fabs(r));
                     sz += s_[i].at(lane) * z_[i].at(lane);
                 }
@@ -610,7 +692,7 @@ struct Solver {
                 for (int i = 0; i < 8; ++i) {
                     const double rs = frcp(s_[i].at(lane));
                     D[i] = z_[i].at(lane) * rs;            // 0 for the two absent rows of stage 0
-                    q[i] = -D[i] * rp_[i].at(lane);
+                    q[i] = kKeepResidual ? -D[i] * rp_[i].at(lane) : (valid(k, i) ? -D[i] * presid(k, i, s_[i].at(lane)) : 0.0);
                 }
                 put_own_gradient(k, q);
                 S(k + 1, L_DV, D[6] + D[7]);
@@ -639,15 +721,22 @@ struct Solver {
                 double rn, rd, sA, sB, sC;
                 c.phase([&](int lane) {
                     double bn = 0.0, bd = 1.0, a1 = 0.0, a2 = 0.0, a0 = 0.0;
+                    // (rp_ and pr_ are written on every path: they are live from here to the update of the iterate only)
                     if (lane < N) {
                         const int k = lane;
                         double dr, dv;
                         stiff_steps(k, dr, dv);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
-                            if (!valid(k, i)) continue;
+                            if (!valid(k, i)) {
+                                rp_[i].at(lane) = 0.0;
+                                pr_[i].at(lane) = 0.0;
+                                continue;
+                            }
                             const double s = s_[i].at(lane), z = z_[i].at(lane);
-                            const double ds = csign(i) * darg(k, i, dr, dv) + rp_[i].at(lane);
+                            const double rp = kKeepResidual ? rp_[i].at(lane) : presid(k, i, s);
+                            rp_[i].at(lane) = rp;
+                            const double ds = csign(i) * darg(k, i, dr, dv) + rp;
                             const double dz = -z - z * ds * frcp(s);
                             pr_[i].at(lane) = ds * dz;
                             if (wave::ratio_greater(-ds, s, bn, bd)) { bn = -ds; bd = s; }
@@ -655,6 +744,12 @@ struct Solver {
                             a0 += s * z;
                             a1 += s * dz + z * ds;
                             a2 += ds * dz;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            rp_[i].at(lane) = 0.0;
+                            pr_[i].at(lane) = 0.0;
                         }
                     }
                     red_a.at(lane) = bn;

@@ -56,6 +56,7 @@ __device__ __forceinline__ double row_reduce(double v, OP op) {
 template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity, bit 2: kFuseLinear
 struct WaveOpsT {
     static constexpr bool kFuseLinear = (RELAX & 4) != 0;   // mpc_wave.hpp: linearised step inside the rollout loop
+    static constexpr int kRelax = RELAX;                    // further bits: mpc_ltv.hpp (relax_bits)
     lds_double_t *L;  // this instance's LDS words
     __device__ __forceinline__ double ld(int i) const { return L[i]; }
     __device__ __forceinline__ void st(int i, double v) { L[i] = v; }

@@ -378,6 +378,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         /* ---------------- adjoint sweep: y_k = dL/dx_k with the current bound multipliers -------------
          * (y = -lam in IPOPT's sign convention); dual residual r_u and the constraint curvature terms */
         double err_d = 0.0, sum_lam = 0.0, sum_z = 0.0;
+        int dbg_k = 0, dbg_i = 0; /* where the dual infeasibility is largest (ORACLE_TRACE) */
         for (int i = 0; i < 4; ++i) {
             yv[N][i] = -it->zxl[N][i] + it->zxu[N][i];
             yv[N + 1][i] = 0.0;
@@ -387,6 +388,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             for (int i = 0; i < 2; ++i) {
                 double r = lus[k][i] - it->zul[k][i] + it->zuu[k][i] + ((k + 1 < N) ? lps[k + 1][i] : 0.0);
                 for (int j = 0; j < 4; ++j) r += Bm[k][j][i] * y[j];
+                if (fabs(r) > err_d) dbg_k = k, dbg_i = i;
                 err_d = fmax(err_d, fabs(r));
                 sum_z += it->zul[k][i] + it->zuu[k][i];
             }
@@ -739,6 +741,9 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                             cross[k] = j;
                     }
         }
+        if (g_trace)
+            fprintf(stderr, "   Ed at stage %d control %d: u %.12g zl %.3e zu %.3e wall %d zw %.3e\n", dbg_k, dbg_i, it->u[dbg_k][dbg_i],
+                    it->zul[dbg_k][dbg_i], it->zuu[dbg_k][dbg_i], it->wj[dbg_k], it->wj[dbg_k] >= 0 ? it->zw[dbg_k] : 0.0);
         if (g_trace)
             fprintf(stderr, "it %3d nmod %d gn %d mu %.2e dw %.1e Ed %.3e Ec %.3e E0 %.3e a_pr %.3e alpha %.3e a_du %.3e nls %d dV1 %.3e phi0 %.8e phi1 %.8e acc %d\n",
                     iter, nmod, gn, mu, delta_w, err_d, err_c0, E0, a_pr, alpha, a_du, nls, dV1, phi0, phi1, accepted);

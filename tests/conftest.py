@@ -116,10 +116,11 @@ def _ltv_solver():
         subprocess.run(["g++"] + HOST_CXXFLAGS + ["-o", out, src], check=True)
     lib = ctypes.CDLL(out)
     dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)
-    lib.ltv_solve_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ctypes.c_int,
-                                    ctypes.c_int, dp, dp, dp, ip, ip, ip]
+    for f in (lib.ltv_solve_batch, lib.ltv_solve_batch_relaxed):
+        f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, dp, ctypes.c_int, ctypes.c_int, dp, dp,
+                      dp, ip, ip, ip]
 
-    def solve(ref, state, U, N=20, dt=0.1, max_iter=50, passes=1):
+    def solve(ref, state, U, N=20, dt=0.1, max_iter=50, passes=1, relaxed=False):
         P = lambda a, t: a.ctypes.data_as(t)
         ref = np.ascontiguousarray(ref, dtype=np.float64)
         state = np.ascontiguousarray(state, dtype=np.float64)
@@ -128,8 +129,9 @@ def _ltv_solver():
         assert U.shape == (B, N, 2)
         u0 = np.zeros((B, 2)); X = np.zeros((B, N + 1, 4))
         st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); tg = np.zeros(B, np.int32)
-        rc = lib.ltv_solve_batch(B, N, dt, P(ref, dp), ref.shape[0], P(state, dp), max_iter, passes, P(u0, dp), P(U, dp),
-                                 P(X, dp), P(st, ip), P(it, ip), P(tg, ip))
+        fn = lib.ltv_solve_batch_relaxed if relaxed else lib.ltv_solve_batch   # the code paths of the kernel's two builds
+        rc = fn(B, N, dt, P(ref, dp), ref.shape[0], P(state, dp), max_iter, passes, P(u0, dp), P(U, dp), P(X, dp), P(st, ip),
+                P(it, ip), P(tg, ip))
         assert rc == 0
         return dict(u0=u0, U=U, X=X, status=st, iters=it, target_index=tg)
 

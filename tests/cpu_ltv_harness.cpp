@@ -10,8 +10,9 @@
 
 // state [B][4] = x, y, v, yaw (interface order of the reference); U [B][N][2] in: stored profile, out: new profile
 // (unchanged unless status 0); u0 [B][2] ((0, 0) unless status 0); X [B][N+1][4] predicted states (x, y, v, yaw)
-extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state, int max_iter,
-                               int passes, double *u0, double *U, double *X, int32_t *status, int32_t *iters, int32_t *target) {
+template <class CTX>
+static int ltv_solve_batch_t(int B, int N, double dt, const double *ref_table, int M, const double *state, int max_iter,
+                             int passes, double *u0, double *U, double *X, int32_t *status, int32_t *iters, int32_t *target) {
     if (N > mpc::wave::kMaxHorizon || N < 1) return -1;
     std::vector<double> table((size_t)M * mpc::REF_COLS), speeds((size_t)M);
     for (int i = 0; i < M; ++i) {
@@ -41,12 +42,12 @@ extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table,
                 best = i;
             }
         }
-        HostCtx ctx{L.data(), table.data(), best, M, speeds.data()};
+        CTX ctx{{L.data(), table.data(), best, M, speeds.data()}};
         ctx.nwords = nd;
         for (int k = 0; k < N; ++k)
             for (int i = 0; i < 2; ++i) L[k * mpc::ltv::L_SLOTS + mpc::ltv::L_U + i] = U[((size_t)b * N + k) * 2 + i];
         const double x0[4] = {state[4 * b + 0], state[4 * b + 1], state[4 * b + 3], state[4 * b + 2]};
-        mpc::ltv::Solver<HostCtx> solver(P, ctx, x0);
+        mpc::ltv::Solver<CTX> solver(P, ctx, x0);
         int st = mpc::ltv::ST_MAX_ITER, it = 0;
         bool ok = false;
         for (int pass = 0; pass < passes; ++pass) {   // the loop of agents/pure_mpc_linear.py:189, as mpc_ltv_kernel runs it
@@ -70,4 +71,17 @@ extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table,
         if (target) target[b] = best;
     }
     return 0;
+}
+
+struct HostCtxLtv : HostCtx {};   // the code path of the three-waves-per-SIMD build (relax_bits = 0)
+
+extern "C" int ltv_solve_batch(int B, int N, double dt, const double *ref_table, int M, const double *state, int max_iter,
+                               int passes, double *u0, double *U, double *X, int32_t *status, int32_t *iters, int32_t *target) {
+    return ltv_solve_batch_t<HostCtxLtv>(B, N, dt, ref_table, M, state, max_iter, passes, u0, U, X, status, iters, target);
+}
+// the same with the code path of the latency build (HostCtxLtvRelaxed)
+extern "C" int ltv_solve_batch_relaxed(int B, int N, double dt, const double *ref_table, int M, const double *state,
+                                       int max_iter, int passes, double *u0, double *U, double *X, int32_t *status,
+                                       int32_t *iters, int32_t *target) {
+    return ltv_solve_batch_t<HostCtxLtvRelaxed>(B, N, dt, ref_table, M, state, max_iter, passes, u0, U, X, status, iters, target);
 }

@@ -12,7 +12,7 @@
 
 struct HostCtx {
     static constexpr int kN = 0;
-    static constexpr bool kFuseLinear = true;    // the path of the 201-register build; HostCtxSplit below is the other
+    static constexpr bool kFuseLinear = true;    // the path of the latency build; HostCtxSplit below is the other
     double *L;
     const double *table;  // [M][REF_COLS]
     int e0, M;
@@ -139,4 +139,8 @@ struct HostCtx {
 // the same context for the builds that keep the linearised step in its own loop (mpc_wave.hpp: fuse_linear)
 struct HostCtxSplit : HostCtx {
     static constexpr bool kFuseLinear = false;
+};
+// mpc_ltv.hpp's code path of the latency build (residuals kept in registers, wave-uniform gain rows: relax_bits)
+struct HostCtxLtvRelaxed : HostCtx {
+    static constexpr int kRelax = 8 | 16;
 };

@@ -172,3 +172,17 @@ def test_bounds_active_in_the_same_stage(cpu_ltv, ltv_oracle, ref_table):
     ref, st, nom, exact = same_stage_cases(ltv_oracle, ref_table)
     check_same_stage(cpu_ltv(ref, st, nom), exact, ltv_oracle)
     check_same_stage(ltv_oracle.solve_batch(ref, st, nom), exact, ltv_oracle)
+
+
+def test_both_builds_take_the_same_path(cpu_ltv, ref_table):
+    """mpc_ltv_kernel ships in two builds (mpc_engine.hip: launch_ltv): the one for shallow batches keeps the primal
+    residuals in registers and forms the gain rows of a Riccati stage once per wave, the one for three waves per SIMD
+    recomputes the residuals and lets every lane select and scale its own entries (mpc_ltv.hpp: relax_bits).  Same
+    arithmetic in the same order: identical results."""
+    st = ltv_states(64, seed=321)
+    nom = np.zeros((len(st), 20, 2))
+    a = cpu_ltv(ref_table, st, nom, passes=2)
+    b = cpu_ltv(ref_table, st, nom, passes=2, relaxed=True)
+    assert (a["status"] == 0).mean() > 0.8
+    for k in ("status", "iters", "target_index", "u0", "U", "X"):
+        assert np.array_equal(a[k], b[k], equal_nan=k == "X"), k      # X is not written where no QP was posed (status 3)
