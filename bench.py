@@ -276,7 +276,7 @@ def main():
         value = value_all * float(conv.mean())        # solves to tolerance per second; rank 0's fraction stands for all ranks
         pmc, pmc_file = pmc_summary()
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "mpc_solve_wave_kernel<CC=true, N=20, OCC=3, RELAX=2> (the build for batches that fill the SIMDs "
+                "kernel": "mpc_solve_wave_kernel<CC=true, N=20, OCC=3, RELAX=10> (the build for batches that fill the SIMDs "
                           "three to four deep, mpc_engine.hip: dispatch_solve)", "kernel_ms": kern_ms,
                 "kernel_ms_median": float(np.median(kern)) if n_str == 1 else None,
                 "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,

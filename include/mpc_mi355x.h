@@ -252,8 +252,9 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
                        uint8_t *arrived, int32_t reset_all, void *stream);
 
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
- * collision-cost term (V = 0: term off); B is accepted for interface stability and does not matter.  The engine
- * keeps no per-instance solver state in HBM.  (diagnostics / capacity planning) */
+ * collision-cost term (V = 0: term off) in a batch of B (the builds for batches that leave LDS to spare keep 12 more
+ * words per stage: 12.1 instead of 10.2 KB at horizon 20 with 8 vehicles).  The engine keeps no per-instance solver
+ * state in HBM.  (diagnostics / capacity planning) */
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);
 
 #ifdef __cplusplus

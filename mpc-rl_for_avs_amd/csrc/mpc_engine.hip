@@ -57,7 +57,11 @@ constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
 // 4096 - for the same speed; the rest of a 4096 batch is dispatched as slots free, which also balances the SIMDs better
 // than four static residents: 3.9 against 4.25 ms at cap 60, profiles/r03_mid_builds.txt).
 constexpr int kWaveOccLat = 2, kWaveOccMid = 3;
-constexpr int kRelaxLat = 7, kRelaxMid = 2;   // LAT: + the linearised step fused into the rollout loop (bit 2)
+// LAT: + the linearised step fused into the rollout loop (bit 2).  Bit 3: trial bounds precomputed per line search (12
+// more LDS words per stage; same-box A/B: 2 % less time per lone-wave iteration and per config-3 batch) - not in the
+// MID build without the collision cost, which it costs a spilled register and 3 %.
+constexpr int kRelaxLat = 7 | 8;
+constexpr int relax_mid(bool cc) { return cc ? (2 | 8) : 2; }
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     if (b >= B) return;                          // grid = B workgroups of one wave
     if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     const int lane = threadIdx.x;
-    constexpr int SL = mpc::wave::stage_slots(CC);
+    constexpr int SL = mpc::wave::stage_slots(CC, (RELAX & 8) != 0);
     WaveCtx<NC, RELAX> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
     // inputs -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j)
@@ -446,11 +450,12 @@ size_t carve(size_t &off, size_t bytes) {
 }
 
 template <bool CC, int NC, int OCC, int RELAX>
-int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, size_t lds, hipStream_t stream,
+int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hipStream_t stream,
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
                 const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
                 uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC, RELAX>;
+    const size_t lds = (size_t)mpc::wave::lds_doubles(CC, P.N, P.V, (RELAX & 8) != 0) * sizeof(double);
     // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
     // capture (hipGraph) of the launch
     static std::atomic<size_t> lds_set[kMaxDevices];      // zero-initialised; concurrent callers at worst both set it
@@ -505,7 +510,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, 
         return fail(MPC_ERR_INVALID_ARG, "horizon / vehicle count too large for the LDS workspace of one instance");
     int rc;
 #define MPC_LAUNCH_W(CCV, NCV, OCCV, RLX)                                                                              \
-    rc = launch_wave<CCV, NCV, OCCV, RLX>(h, P, (int)B, (int)V, wlds, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
+    rc = launch_wave<CCV, NCV, OCCV, RLX>(h, P, (int)B, (int)V, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
                                           d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters)
     // which build: by how deep the batch fills the SIMDs (see kWaveOccLat / kWaveOccMid above)
     const int simds = 4 * h->num_cu;
@@ -513,7 +518,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, 
                                  : (B <= kWaveOccLat * simds ? kWaveOccLat : (B <= kWaveOcc * simds ? kWaveOccMid : kWaveOcc));
 #define MPC_LAUNCH_N(CCV, NCV)                                                         \
     if (depth == kWaveOccLat) MPC_LAUNCH_W(CCV, NCV, kWaveOccLat, kRelaxLat);                  \
-    else if (depth == kWaveOccMid) MPC_LAUNCH_W(CCV, NCV, kWaveOccMid, kRelaxMid); \
+    else if (depth == kWaveOccMid) MPC_LAUNCH_W(CCV, NCV, kWaveOccMid, relax_mid(CCV)); \
     else MPC_LAUNCH_W(CCV, NCV, kWaveOcc, 0)
     if (cc) {
         if (N == 20) { MPC_LAUNCH_N(true, 20); }       /* BASELINE horizon */
@@ -631,7 +636,10 @@ int mpc_set_reference(mpc_handle *h, const double *ref, int32_t M) {
 
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V) {
     if (!h || B < 0 || V < 0 || V > MPC_MAX_OTHERS) return -1;
-    return (int64_t)mpc::wave::lds_doubles(V > 0, h->cfg.horizon, V) * (int64_t)sizeof(double);
+    // the builds for batches up to kWaveOcc waves per SIMD deep keep 12 more words per stage (dispatch_solve, kPreBounds)
+    const int N = h->cfg.horizon;
+    const bool pre = (N == 20 || N == 16) && (B <= kWaveOccLat * 4 * h->num_cu || (V > 0 && B <= kWaveOcc * 4 * h->num_cu));
+    return (int64_t)mpc::wave::lds_doubles(V > 0, N, V, pre) * (int64_t)sizeof(double);
 }
 
 int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t *ego_index, const double *vref,

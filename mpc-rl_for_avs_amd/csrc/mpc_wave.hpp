@@ -114,9 +114,24 @@ enum : int {
     A_HV5 = W_U    // + trial buffer offset
 };
 
-MPC_HD constexpr int stage_slots(bool cc) { return cc ? W_SLOTS_CC : W_SLOTS; }
+// CTX::kPreBounds = true (the builds for batches that leave LDS to spare: up to 12 instances per CU): the bounds a trial
+// rollout applies at stage k that do not depend on the trial - the fraction-to-the-boundary box of the two controls, the
+// projection box of theta / v of the next node and the four feasibility margins, 40 FP64 operations per stage of the
+// serial loop - are computed once per line search, stage-parallel, into kPreSlots extra words per stage (B_* below) and
+// only loaded in the loop.  Same expressions, same results.
+constexpr int kPreSlots = 12;
+enum : int { B_ULO0 = 0, B_UHI0, B_ULO1, B_UHI1, B_VLO, B_VHI, B_TLO, B_THI, B_M2LO, B_M2HI, B_M3LO, B_M3HI };
+template <class CTX, class = void>
+struct pre_bounds { static constexpr bool value = false; };
+template <class CTX>
+struct pre_bounds<CTX, decltype((void)CTX::kPreBounds)> { static constexpr bool value = CTX::kPreBounds; };
+
+// (12 more words keep the stage stride odd: 57 -> 69, 51 -> 63)
+MPC_HD constexpr int stage_slots(bool cc, bool pre = false) { return (cc ? W_SLOTS_CC : W_SLOTS) + (pre ? kPreSlots : 0); }
 // doubles of LDS one instance needs: stage arrays + constants + other vehicles
-MPC_HD constexpr int lds_doubles(bool cc, int N, int V) { return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0); }
+MPC_HD constexpr int lds_doubles(bool cc, int N, int V, bool pre = false) {
+    return stage_slots(cc, pre) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0);
+}
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
@@ -246,7 +261,7 @@ struct Solver {
     MPC_HD double WCOLL() const { return c.fresh(wcoll); }
 
     MPC_HD Solver(const SolveParams &P_, CTX &c_, const double *x0_, double ws, double wc, double wd, double wcl)
-        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
+        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC, pre_bounds<CTX>::value)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
           dt(P_.dt), ws_(c_.uni(ws)), wc_(c_.uni(wc)), wd_(c_.uni(wd)), wcoll(c_.uni(wcl)) {
         x0[0] = x0_[0]; x0[1] = x0_[1]; x0[2] = x0_[2]; x0[3] = x0_[3];
     }
@@ -534,6 +549,32 @@ struct Solver {
         const double a_pr = 1.0;
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
         const double fracu = 2.0 * frac, idt = frcp(c.fresh(dt));
+        constexpr bool kPre = pre_bounds<CTX>::value;
+        constexpr int W_PRE = stage_slots(CC, false);
+        if (kPre) {
+            // what the trials' stages need of the current iterate and frac alone (see kPreBounds): stage-parallel, once
+            c.phase([&](int lane) {
+                if (lane >= N) return;
+                const int k = lane;
+                const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
+                const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
+                const double keep_ = c.fresh(kProjKeep), ms_ = c.fresh(kMinSlack);
+                const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
+                const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+                S(k, W_PRE + B_ULO0, alo_ + fmax2(fracu * (c0 - alo_), ms_));
+                S(k, W_PRE + B_UHI0, ahi_ - fmax2(fracu * (ahi_ - c0), ms_));
+                S(k, W_PRE + B_ULO1, dlo_ + fmax2(fracu * (c1 - dlo_), ms_));
+                S(k, W_PRE + B_UHI1, dhi_ - fmax2(fracu * (dhi_ - c1), ms_));
+                S(k, W_PRE + B_VLO, vlo_ + keep_ * (o3 - vlo_));
+                S(k, W_PRE + B_VHI, vhi_ - keep_ * (vhi_ - o3));
+                S(k, W_PRE + B_TLO, tlo_ + keep_ * (o2 - tlo_));
+                S(k, W_PRE + B_THI, thi_ - keep_ * (thi_ - o2));
+                S(k, W_PRE + B_M2LO, fmax2(frac * (o2 - tlo_), ms_));
+                S(k, W_PRE + B_M2HI, fmax2(frac * (thi_ - o2), ms_));
+                S(k, W_PRE + B_M3LO, fmax2(frac * (o3 - vlo_), ms_));
+                S(k, W_PRE + B_M3HI, fmax2(frac * (vhi_ - o3), ms_));
+            });
+        }
         c.phase([&](int lane) {
             ls_feas.at(lane) = 0;
             if (lane >= kTrials) return;
@@ -559,7 +600,15 @@ struct Solver {
                 const double k00 = S(k, W_KX + 0), k01 = S(k, W_KX + 1), k02 = S(k, W_KX + 2), k03 = S(k, W_KX + 3);
                 const double k10 = S(k, W_KX + 4), k11 = S(k, W_KX + 5), k12 = S(k, W_KX + 6), k13 = S(k, W_KX + 7);
                 const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);   // zero at stage 0
-                const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+                double o2 = 0, o3 = 0, ulo0, uhi0, ulo1, uhi1, vlo, vhi, tlo, thi, m2lo, m2hi, m3lo, m3hi;
+                if (kPre) {
+                    ulo0 = S(k, W_PRE + B_ULO0); uhi0 = S(k, W_PRE + B_UHI0); ulo1 = S(k, W_PRE + B_ULO1); uhi1 = S(k, W_PRE + B_UHI1);
+                    vlo = S(k, W_PRE + B_VLO); vhi = S(k, W_PRE + B_VHI); tlo = S(k, W_PRE + B_TLO); thi = S(k, W_PRE + B_THI);
+                    m2lo = S(k, W_PRE + B_M2LO); m2hi = S(k, W_PRE + B_M2HI); m3lo = S(k, W_PRE + B_M3LO); m3hi = S(k, W_PRE + B_M3HI);
+                } else {
+                    o2 = S(k + 1, CB + W_X + 2);
+                    o3 = S(k + 1, CB + W_X + 3);
+                }
                 // the stage linearisation, for the linearised step (the trial areas of this stage overwrite these slots
                 // at the end of the stage, after they have been read)
                 double a02 = 0, a03 = 0, a12 = 0, a13 = 0, a23 = 0, b01 = 0, b11 = 0, b21 = 0;
@@ -597,13 +646,18 @@ struct Solver {
                 s0 += kp00 * dup0 + kp01 * dup1;
                 s1 += kp01 * dup0 + kp11 * dup1;
                 if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
-                const double ulo0 = alo_ + fmax2(fracu * (c0 - alo_), ms_), uhi0 = ahi_ - fmax2(fracu * (ahi_ - c0), ms_);
-                const double ulo1 = dlo_ + fmax2(fracu * (c1 - dlo_), ms_), uhi1 = dhi_ - fmax2(fracu * (dhi_ - c1), ms_);
+                if (!kPre) {
+                    ulo0 = alo_ + fmax2(fracu * (c0 - alo_), ms_);
+                    uhi0 = ahi_ - fmax2(fracu * (ahi_ - c0), ms_);
+                    ulo1 = dlo_ + fmax2(fracu * (c1 - dlo_), ms_);
+                    uhi1 = dhi_ - fmax2(fracu * (dhi_ - c1), ms_);
+                    vlo = vlo_ + keep_ * (o3 - vlo_);
+                    vhi = vhi_ - keep_ * (vhi_ - o3);
+                }
                 double u0 = fmin2(fmax2(c0 + s0, ulo0), uhi0);
                 double u1 = fmin2(fmax2(c1 + s1, ulo1), uhi1);
                 {
                     // v of node k+1 is decided by a_k alone: keep it inside the node's box (kProjKeep of its slack)
-                    const double vlo = vlo_ + keep_ * (o3 - vlo_), vhi = vhi_ - keep_ * (vhi_ - o3);
                     const double a = fmin2(fmax2(u0, (vlo - x_3) * idt), (vhi - x_3) * idt);
                     u0 = fmin2(fmax2(a, ulo0), uhi0);
                 }
@@ -621,7 +675,10 @@ struct Solver {
                 {
                     // theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
                     // node's box, take the delta that puts it on the edge of the box
-                    const double tlo = tlo_ + keep_ * (o2 - tlo_), thi = thi_ - keep_ * (thi_ - o2);
+                    if (!kPre) {
+                        tlo = tlo_ + keep_ * (o2 - tlo_);
+                        thi = thi_ - keep_ * (thi_ - o2);
+                    }
                     if (feas & ((n2 < tlo) | (n2 > thi)) & (x_3 > vmin_)) {
                         if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
                         const double sreq = ((n2 < tlo ? tlo : thi) - x_2) * (1.0 / kInvWheelbase) * frcp(dt * x_3);
@@ -652,8 +709,13 @@ struct Solver {
                 // same (its lane would idle otherwise): a uniform trip count and a flag instead of a per-lane `break` keep
                 // the exec-mask bookkeeping out of the loop.  Whatever an infeasible lane computes from here on is never
                 // looked at (no trap can come of it: bounded polynomials, rsq / rcp of garbage give NaN at worst).
-                feas = feas & !((n2 - tlo_ < fmax2(frac * (o2 - tlo_), ms_)) | (thi_ - n2 < fmax2(frac * (thi_ - o2), ms_)) |
-                                (n3 - vlo_ < fmax2(frac * (o3 - vlo_), ms_)) | (vhi_ - n3 < fmax2(frac * (vhi_ - o3), ms_)));
+                if (!kPre) {
+                    m2lo = fmax2(frac * (o2 - tlo_), ms_);
+                    m2hi = fmax2(frac * (thi_ - o2), ms_);
+                    m3lo = fmax2(frac * (o3 - vlo_), ms_);
+                    m3hi = fmax2(frac * (vhi_ - o3), ms_);
+                }
+                feas = feas & !((n2 - tlo_ < m2lo) | (thi_ - n2 < m2hi) | (n3 - vlo_ < m3lo) | (vhi_ - n3 < m3hi));
                 if (CC && any_wall && k + 1 < N) {
                     const double wjv = S(k + 1, W_WJ);
                     if (wjv >= 0.0) {

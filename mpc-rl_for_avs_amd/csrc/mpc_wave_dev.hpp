@@ -53,10 +53,11 @@ __device__ __forceinline__ double row_reduce(double v, OP op) {
 // iteration loop.  The relaxed builds let the compiler hoist: with both relaxed ~200 registers (two waves per SIMD) and
 // 7 % less time per iteration for a wave that has its SIMD to itself (38.1 against 40.7 us, profiles/r03_latency.txt) -
 // the builds the engine launches when the batch leaves SIMDs that empty anyway (mpc_engine.hip: dispatch_solve).
-template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity, bit 2: kFuseLinear
+template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity, bit 2: kFuseLinear, bit 3: kPreBounds
 struct WaveOpsT {
     static constexpr bool kFuseLinear = (RELAX & 4) != 0;   // mpc_wave.hpp: linearised step inside the rollout loop
-    static constexpr int kRelax = RELAX;                    // further bits: mpc_ltv.hpp (relax_bits)
+    static constexpr bool kPreBounds = (RELAX & 8) != 0;    // mpc_wave.hpp: trial bounds precomputed per line search (12 more LDS words per stage)
+    static constexpr int kRelax = RELAX;                    // bits 3, 4 in mpc_ltv.hpp: relax_bits
     lds_double_t *L;  // this instance's LDS words
     __device__ __forceinline__ double ld(int i) const { return L[i]; }
     __device__ __forceinline__ void st(int i, double v) { L[i] = v; }

@@ -66,8 +66,9 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     P.N = N; P.V = Vuse; P.max_iter = max_iter; P.dt = dt; P.tol = tol; P.mu_init = 0.1;
     P.w_distance = w_distance;
     P.stall_window = g_stall_window;
-    const int SL = mpc::wave::stage_slots(cc);
-    const int nd = mpc::wave::lds_doubles(cc, N, Vuse);
+    const bool pre = !g_split;   // HostCtx (fused linear step, precomputed trial bounds) or HostCtxSplit (neither)
+    const int SL = mpc::wave::stage_slots(cc, pre);
+    const int nd = mpc::wave::lds_doubles(cc, N, Vuse, pre);
     for (int b = 0; b < B; ++b) {
         std::vector<double> L((size_t)nd, NAN);
         HostCtxSplit ctx{};

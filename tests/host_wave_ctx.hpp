@@ -13,6 +13,7 @@
 struct HostCtx {
     static constexpr int kN = 0;
     static constexpr bool kFuseLinear = true;    // the path of the latency build; HostCtxSplit below is the other
+    static constexpr bool kPreBounds = true;     // likewise: trial bounds precomputed per line search (12 more words per stage)
     double *L;
     const double *table;  // [M][REF_COLS]
     int e0, M;
@@ -139,6 +140,7 @@ struct HostCtx {
 // the same context for the builds that keep the linearised step in its own loop (mpc_wave.hpp: fuse_linear)
 struct HostCtxSplit : HostCtx {
     static constexpr bool kFuseLinear = false;
+    static constexpr bool kPreBounds = false;
 };
 // mpc_ltv.hpp's code path of the latency build (residuals kept in registers, wave-uniform gain rows: relax_bits)
 struct HostCtxLtvRelaxed : HostCtx {

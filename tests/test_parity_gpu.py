@@ -242,11 +242,14 @@ def test_limits_of_the_interface(oracle):
     e.close()
     # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (30 KB of LDS):
     # 57 slots per node, the table of constants (3 + 1, 12 trig, 10 log, 8 bounds, 6 solve constants), 4 per vehicle;
-    # the BASELINE shape (horizon 20, 8 vehicles) is 9.9 KB, i.e. 16 instances per CU
+    # the BASELINE shape (horizon 20, 8 vehicles) is 9.9 KB, i.e. 16 instances per CU, in the build for bulk batches and
+    # 12 words per node more (11.9 KB, up to 12 instances per CU) in the builds for batches up to four waves per SIMD deep
     e = engine.MPCEngine(horizon=64, max_iter=100)
     assert e.workspace_bytes(1, 16) == (57 * 65 + 40 + 64) * 8
     e20 = engine.MPCEngine(horizon=20, max_iter=100)
-    assert e20.workspace_bytes(1, 8) == (57 * 21 + 40 + 32) * 8 <= 10240
+    assert e20.workspace_bytes(65536, 8) == (57 * 21 + 40 + 32) * 8 <= 10240
+    assert e20.workspace_bytes(4096, 8) == e20.workspace_bytes(1, 8) == (69 * 21 + 40 + 32) * 8 <= 163840 // 12
+    assert e20.workspace_bytes(4096, 0) == (51 * 21 + 40) * 8 and e20.workspace_bytes(1024, 0) == (63 * 21 + 40) * 8
     e20.close()
     sub = {k: (v[:24] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
     vref64 = np.concatenate([sub["vref"], np.repeat(sub["vref"][:, -1:], 44, axis=1)], axis=1)
