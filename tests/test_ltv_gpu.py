@@ -70,6 +70,23 @@ def test_batch_of_one_and_permutation(eng):
     assert np.array_equal(shuf["u0"], full["u0"][perm]) and np.array_equal(shuf["U"], full["U"][perm])
 
 
+def test_two_builds_of_the_ltv_kernel_agree(eng):
+    """mpc_ltv_kernel ships in two builds (mpc_engine.hip: launch_ltv): up to two waves per SIMD deep (B <= 2048 on 256
+    CUs) the 215-register one, deeper the 165-register one that runs three waves per SIMD.  The same instances through
+    both: statuses and iteration counts equal, profiles equal to 1e-9 (same statements; the compiler may contract a
+    multiply-add differently in the two)."""
+    st = ltv_states(4096, seed=11)
+    nom = np.random.default_rng(4).uniform(-0.2, 0.2, (4096, 20, 2))
+    deep = eng.ltv_solve_batch(st, nom)                       # 4096 instances: the three-wave build
+    shallow = eng.ltv_solve_batch(st[:1024], nom[:1024])      # 1024: the latency build
+    assert np.array_equal(deep["status"][:1024], shallow["status"])
+    ok = shallow["status"] == 0
+    assert ok.mean() > 0.85
+    assert np.abs(deep["iters"][:1024] - shallow["iters"])[ok].max() <= 1
+    assert np.abs(deep["U"][:1024] - shallow["U"])[ok].max() <= 1e-9
+    assert np.array_equal(deep["u0"][:1024][~ok], shallow["u0"][~ok])
+
+
 def test_torch_zero_copy(eng):
     import torch
     st = ltv_states(128, seed=9)

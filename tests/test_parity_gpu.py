@@ -382,7 +382,7 @@ def test_independent_solver_fixtures(eng, ref_table):
 
 
 def test_three_builds_of_the_solve_kernel_agree(oracle, ref_table):
-    """The engine launches one of three builds of the same solver source by how deep the batch fills the SIMDs (201
+    """The engine launches one of three builds of the same solver source by how deep the batch fills the SIMDs (229
     registers up to two waves per SIMD, 168 up to four, 128 beyond / with MPC_FLAG_THROUGHPUT).  Same instances through
     all three: statuses equal, actions equal to 1e-6 (a different build may contract a multiply-add differently; an
     instance whose iterates are chaotic in the last bit may then take another path to the same point)."""
@@ -399,7 +399,7 @@ def test_three_builds_of_the_solve_kernel_agree(oracle, ref_table):
                     vref=t(inp["vref"][:n], torch.float64), others=t(inp["others"][:n], torch.float64), collision_cost=True)
         o = e.solve_batch_torch(**args, sync=True, throughput=throughput)
         return {k: v.cpu().numpy() for k, v in o.items()}
-    lat = run(1024, False)           # <= 2 waves per SIMD: 201-register build
+    lat = run(1024, False)           # <= 2 waves per SIMD: the latency build
     mid = run(4096, False)           # <= 4: 168-register build
     bulk = run(4096, True)           # 128-register build
     for a, b, n in ((lat, mid, 1024), (mid, bulk, 4096), (lat, bulk, 1024)):
