@@ -1297,7 +1297,10 @@ struct Solver {
                                hc = c.lane_get(Hm, 63);
                         const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
                         double det = ha * hc - hb * hb;
-                        if ((!(ha > 0.0) || !(hc > 0.0) || !(det > c.fresh(1e-12) * ha * hc)) && !gn) {
+                        // (one combined test, evaluated without short-circuit branches: the common case - positive definite -
+                        // then passes a single branch on the sweep's critical path instead of three)
+                        bool pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
+                        if (!pd && !gn) {
                             // not positive definite with the exact Hessian: this stage alone falls back to its
                             // Gauss-Newton terms (constraint curvature off, radial part of the collision potential) -
                             // they are taken out of H, the products with P stay
@@ -1350,8 +1353,9 @@ struct Solver {
                             hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62));
                             hc = c.lane_get(Hm, 63);
                             det = ha * hc - hb * hb;
+                            pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
                         }
-                        if (!(ha > 0.0) || !(hc > 0.0) || !(det > c.fresh(1e-12) * ha * hc)) {
+                        if (!pd) {
                             ok = false;
                             break;
                         }
