@@ -292,7 +292,8 @@ struct Solver {
                          hc = c.lane_get(Hm, 63);
             const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
             const double det = ha * hc - hb * hb;
-            if (!(ha > 0.0) || !(hc > 0.0) || !(det > 1e-14 * ha * hc)) return false;
+            // (one combined condition, no short-circuit branches: a single branch on the sweep's critical path)
+            if (!((ha > 0.0) & (hc > 0.0) & (det > 1e-14 * ha * hc))) return false;
             // W = adj(Huu) H(u, .) on the matrix core while the reciprocal of the determinant is computed
             PerLane<double> G, nHA, W, kfB;
             c.lanes([&](int lane) {
