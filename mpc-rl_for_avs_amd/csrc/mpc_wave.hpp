@@ -1263,7 +1263,8 @@ struct Solver {
                         const double rdk = (k >= 1) ? rd_full : 0.0;
                         // operands that do not depend on the recursion: F in its four block arrangements, the stage
                         // Hessian / gradient as accumulator inputs (prefetching them one stage ahead measured slower
-                        // three times: 45.7 -> 48.2 us per lone-wave iteration with spills, 41.1 -> 41.6 without)
+                        // four times: 45.7 -> 48.2 us per lone-wave iteration with spills, 41.1 -> 41.6 without, and in
+                        // round 3's latency build, issued behind the definiteness test with registers to spare, 32.9 -> 34.6)
                         PerLane<double> FA0, FA1, FB0, FB1, Hm, hv;
                         load_stage_operands(k, AB, rdk, FA0, FA1, FB0, FB1, Hm, hv);
                         c.tick(T_RIC_SCALARS);
