@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 PMC passes written by tools/pmc_run.sh into profiles/<tag>_pmc_summary.csv:
-one row per counter = mean over the launches of the solve kernel (all other kernels are dropped)."""
+one row per counter = mean over the launches of the solve kernel (all other kernels are dropped).
+usage: tools/pmc_summary.py [tag] [kernel-name substring, default mpc_solve]"""
 import collections
 import csv
 import glob
@@ -8,6 +9,7 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+kernel_pat = sys.argv[2] if len(sys.argv) > 2 else "mpc_solve"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"pmc_{tag}")
 rows = []
@@ -18,7 +20,7 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
     files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     for f in files[-1:]:            # gpurun_out/ keeps the files of earlier runs: only the newest pass counts
         for r in csv.DictReader(open(f)):
-            if "mpc_solve" not in r["Kernel_Name"]:
+            if kernel_pat not in r["Kernel_Name"]:
                 continue
             kern.add(r["Kernel_Name"].split("(")[0])
             acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
