@@ -255,6 +255,48 @@ class ActorCritic(torch.nn.Module):
     def predict_values(self, obs):
         return self.value_net(self.vf(obs.flatten(1)))[:, 0]
 
+    # ---- rollout-time forward (no gradients): both towers as ONE 80 -> 128 -> 128 -> (action_dim + 1) network (first
+    #      layers side by side, second layer block-diagonal, heads in one matrix) and the Gaussian sample / log-probability
+    #      written out - 3 GEMMs, 2 tanh and 6 small kernels instead of 6 + 4 + 12.  Same function as forward(); the fused
+    #      weights live in persistent buffers (a captured hipGraph reads them in place) refreshed by refresh_fused().
+    @torch.no_grad()
+    def refresh_fused(self):
+        A, H = self.action_dim, self.pi[0].out_features
+        dev, dt = self.log_std.device, self.log_std.dtype
+        if getattr(self, "_fz", None) is None or self._fz["w1"].device != dev:
+            z = lambda *shape: torch.zeros(shape, device=dev, dtype=dt)
+            self._fz = dict(w1=z(self.pi[0].in_features, 2 * H), b1=z(2 * H), w2=z(2 * H, 2 * H), b2=z(2 * H),
+                            wh=z(2 * H, A + 1), bh=z(A + 1), std=z(A), c0=z(1)[0])
+        f = self._fz
+        f["w1"][:, :H].copy_(self.pi[0].weight.t())
+        f["w1"][:, H:].copy_(self.vf[0].weight.t())
+        f["b1"][:H].copy_(self.pi[0].bias)
+        f["b1"][H:].copy_(self.vf[0].bias)
+        f["w2"][:H, :H].copy_(self.pi[2].weight.t())
+        f["w2"][H:, H:].copy_(self.vf[2].weight.t())
+        f["b2"][:H].copy_(self.pi[2].bias)
+        f["b2"][H:].copy_(self.vf[2].bias)
+        f["wh"][:H, :A].copy_(self.action_net.weight.t())
+        f["wh"][H:, A].copy_(self.value_net.weight[0])
+        f["bh"][:A].copy_(self.action_net.bias)
+        f["bh"][A:].copy_(self.value_net.bias)
+        f["std"].copy_(self.log_std.exp())
+        f["c0"].copy_(self.log_std.sum() + 0.5 * A * math.log(2.0 * math.pi))
+
+    @torch.no_grad()
+    def act(self, obs, generator=None):
+        """(actions, values, log_probs) like forward(obs), through the fused weights (call refresh_fused() after every
+        change of the parameters)."""
+        f, A = self._fz, self.action_dim
+        h = torch.tanh(torch.addmm(f["b1"], obs.flatten(1), f["w1"]))
+        h = torch.tanh(torch.addmm(f["b2"], h, f["w2"]))
+        out = torch.addmm(f["bh"], h, f["wh"])
+        mean = out[:, :A]
+        noise = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
+        actions = torch.addcmul(mean, noise, f["std"])
+        log_probs = (noise * noise).sum(dim=1).mul_(-0.5).sub_(f["c0"])
+        return actions, out[:, A], log_probs
+
     def evaluate_actions(self, obs, actions):
         d = self._dist(obs)
         return self.predict_values(obs), d.log_prob(actions).sum(dim=1), d.entropy().sum(dim=1)
@@ -272,6 +314,11 @@ class RolloutBuffer:
         self.episode_starts = z(T, B)
         self.advantages, self.returns = z(T, B), z(T, B)
         self.mpc_actions = z(T, B, 2, dt=torch.float64)
+        # PPO bootstraps truncated episodes with the value of their terminal observation (agents/ppo_mpc.py:451-461): the
+        # observations and flags are kept per step and the values are computed for the whole rollout at once at its end
+        # (bootstrap_truncated) - the policy does not change during a rollout - instead of one value tower per step
+        self.terminal_obs = None
+        self.truncated = None
         self.gamma, self.gae_lambda, self.n_steps, self.pos = float(gamma), float(gae_lambda), T, 0
         self.pos_dev = torch.zeros(1, dtype=torch.int64, device=device)     # the same counter for captured graphs
 
@@ -279,23 +326,45 @@ class RolloutBuffer:
         self.pos = 0
         self.pos_dev.zero_()
 
-    def add(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions=None):
+    def keep_terminal(self):
+        """allocate the per-step terminal observations / truncation flags (PPO collectors)"""
+        if self.terminal_obs is None:
+            self.terminal_obs = torch.zeros_like(self.obs)
+            self.truncated = torch.zeros_like(self.rewards)
+
+    def add(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions=None, terminal_obs=None,
+            truncated=None):
         i = self.pos
         self.obs[i], self.actions[i], self.rewards[i] = obs, actions, rewards
         self.episode_starts[i], self.values[i], self.log_probs[i] = episode_starts, values, log_probs
         if mpc_actions is not None:
             self.mpc_actions[i] = mpc_actions
+        if terminal_obs is not None:
+            self.terminal_obs[i], self.truncated[i] = terminal_obs, truncated
         self.pos += 1
         self.pos_dev.add_(1)
 
-    def add_at_device_pos(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions):
+    def add_at_device_pos(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions, terminal_obs=None,
+                          truncated=None):
         """`add` with the row taken from the device-side counter: no host value is baked into a captured graph."""
         i = self.pos_dev
-        for dst, src in ((self.obs, obs), (self.actions, actions), (self.rewards, rewards),
-                         (self.episode_starts, episode_starts), (self.values, values), (self.log_probs, log_probs),
-                         (self.mpc_actions, mpc_actions)):
+        rows = [(self.obs, obs), (self.actions, actions), (self.rewards, rewards), (self.episode_starts, episode_starts),
+                (self.values, values), (self.log_probs, log_probs), (self.mpc_actions, mpc_actions)]
+        if terminal_obs is not None:
+            rows += [(self.terminal_obs, terminal_obs), (self.truncated, truncated)]
+        for dst, src in rows:
             dst.index_copy_(0, i, src.to(dst.dtype).unsqueeze(0))
         self.pos_dev.add_(1)
+
+    @torch.no_grad()
+    def bootstrap_truncated(self, value_fn):
+        """rewards += gamma * V(terminal observation) where the episode was truncated, for the whole rollout in one
+        evaluation of the value tower"""
+        if self.terminal_obs is None:
+            return
+        T, B = self.rewards.shape
+        tv = value_fn(self.terminal_obs.reshape((T * B,) + self.terminal_obs.shape[2:])).reshape(T, B)
+        self.rewards += self.gamma * tv * self.truncated
 
     def compute_returns_and_advantage(self, last_values, dones):
         last_gae = torch.zeros_like(last_values)
@@ -343,14 +412,19 @@ class BatchedCollector:
         dev = env.device
         B = env.num_envs
         self.buffer = RolloutBuffer(n_steps, B, policy.action_dim, dev, gamma, gae_lambda)
+        if algorithm == "ppo":
+            self.buffer.keep_terminal()
         self.default_weights = torch.tensor(default_weights, dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
         self._last_obs = env.reset().clone()                 # persistent tensors, updated in place (graph replays)
         self._last_episode_starts = torch.ones(B, dtype=torch.float32, device=dev)
-        zi = lambda: torch.zeros((), dtype=torch.int64, device=dev)
-        self._roll = dict(ep_done=zi(), crashed=zi(), arrived=zi(), unconverged=zi(),
+        # episode counters of the rollout in one tensor (one reduction + one add per step): finished, crashed, arrived
+        # episodes and solves that did not converge
+        counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        self._roll = dict(counts=counts, ep_done=counts[0], crashed=counts[1], arrived=counts[2], unconverged=counts[3],
                           dones=torch.zeros(B, dtype=torch.bool, device=dev))
+        self.policy.refresh_fused()
         self.num_timesteps = 0
         self.last_mpc = None
         self._mpc_out = None
@@ -381,14 +455,14 @@ class BatchedCollector:
     @torch.no_grad()
     def _begin_rollout(self):
         self.policy.eval()
+        self.policy.refresh_fused()        # the parameters may have been updated since the last rollout
         self.buffer.reset()
-        for k in ("ep_done", "crashed", "arrived", "unconverged"):
-            self._roll[k].zero_()
+        self._roll["counts"].zero_()
 
     @torch.no_grad()
     def _rollout_step(self, device_pos: bool = False):
         obs = self._last_obs
-        actions, values, log_probs = self.policy(obs, generator=self.gen)
+        actions, values, log_probs = self.policy.act(obs, generator=self.gen)
         weights, ref_speed = self.mpc_inputs(actions)
         self._mpc_out = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
                                                         warm_start=self.warm_start, out=self._mpc_out)
@@ -399,28 +473,26 @@ class BatchedCollector:
             # every rank sees every environment's action and whether its solve converged
             self.gathered_actions, self.gathered_status = sharding.all_gather_results(mpc_action, self.last_mpc["status"])
         new_obs, rewards, dones, info = self.env.step(mpc_action)
-        if self.algorithm == "ppo":                      # agents/ppo_mpc.py:451-461
-            tv = self.policy.predict_values(info["terminal_obs"])
-            rewards = rewards + self.buffer.gamma * tv * info["truncated"].to(tv.dtype)
+        # (PPO, agents/ppo_mpc.py:451-461: a truncated episode's last reward is bootstrapped with the value of its terminal
+        # observation - kept here, applied for the whole rollout by _finish_rollout)
+        term = dict(terminal_obs=info["terminal_obs"], truncated=info["truncated"]) if self.algorithm == "ppo" else {}
         if self.reset_mpc_on_done:
-            self.engine.reset_env_mask_torch(dones.to(torch.uint8))
+            self.engine.reset_env_mask_torch(dones.view(torch.uint8))
         elif self.warm_start:            # a new episode must not start from the old one's plan
-            self.engine.reset_env_mask_torch(dones.to(torch.uint8), warm_only=True)
+            self.engine.reset_env_mask_torch(dones.view(torch.uint8), warm_only=True)
         if device_pos:
-            self.buffer.add_at_device_pos(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
+            self.buffer.add_at_device_pos(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action,
+                                          **term)
         else:
-            self.buffer.add(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action)
+            self.buffer.add(obs, actions, rewards, self._last_episode_starts, values, log_probs, mpc_action, **term)
         self._last_obs.copy_(new_obs)
-        self._last_episode_starts.copy_(dones.to(torch.float32))
+        self._last_episode_starts.copy_(dones)
         r = self._roll
         r["dones"].copy_(dones)
-        r["ep_done"] += dones.sum()
-        r["crashed"] += info["crashed"].sum()
-        r["arrived"] += info["arrived"].sum()
         # like the reference (agents/pure_mpc.py:303-305) an unconverged solve still acts with its last iterate; the
         # collector counts them so that a training run can see what fraction of its actions that was
         st = self.last_mpc["status"]
-        r["unconverged"] += ((st != 0) & (st != 5)).sum()
+        r["counts"] += torch.stack((dones, info["crashed"], info["arrived"], (st != 0) & (st != 5))).sum(dim=1)
 
     def _capture(self):
         """Capture one rollout step (policy -> mpc_predict_batch -> environment step -> buffer row) as a hipGraph: a step
@@ -450,8 +522,7 @@ class BatchedCollector:
             self.engine.reset_env_state()
         self._last_obs.copy_(self.env.reset())
         self._last_episode_starts.fill_(1.0)
-        for k in ("ep_done", "crashed", "arrived", "unconverged"):
-            self._roll[k].zero_()
+        self._roll["counts"].zero_()
         self._roll["dones"].zero_()
 
     def _step(self):
@@ -465,6 +536,7 @@ class BatchedCollector:
     @torch.no_grad()
     def _finish_rollout(self):
         last_values = self.policy.predict_values(self._last_obs)
+        self.buffer.bootstrap_truncated(self.policy.predict_values)
         self.buffer.compute_returns_and_advantage(last_values, self._roll["dones"])
 
     def _rollout_stats(self, n):

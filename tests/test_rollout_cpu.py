@@ -155,3 +155,24 @@ def test_policy_update_matches_the_published_losses_and_learns(algo):
     log = tr.learn(total_timesteps=col.num_timesteps + 3 * 128)
     assert len(log) == 3 and all(np.isfinite(list(r.values())).all() for r in log)
     assert log[-1]["timesteps"] == col.num_timesteps
+
+
+def test_fused_rollout_forward_is_the_policy():
+    """ActorCritic.act (both towers as one 80 -> 128 -> 128 network with a block-diagonal second layer, Gaussian sample and
+    log-probability written out: what the collector calls every step) against forward(): same noise, same actions, values
+    and log-probabilities; refresh_fused() follows a parameter update."""
+    torch.manual_seed(3)
+    pol = rollout.ActorCritic(3)
+    with torch.no_grad():
+        pol.log_std.copy_(torch.tensor([-0.3, 0.1, 0.4]))
+    obs = torch.randn(37, 10, 8)
+    for _ in range(2):
+        pol.refresh_fused()
+        g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            a0, v0, l0 = pol(obs, generator=g1)
+        a1, v1, l1 = pol.act(obs, generator=g2)
+        assert torch.allclose(a0, a1, atol=1e-5) and torch.allclose(v0, v1, atol=1e-5) and torch.allclose(l0, l1, atol=1e-4)
+        with torch.no_grad():                         # an optimiser step later the fused copy must follow
+            for p in pol.parameters():
+                p.add_(0.05 * torch.randn_like(p))
