@@ -168,6 +168,7 @@ static long g_cnt_iter, g_cnt_sweep, g_cnt_roll, g_cnt_solve;
 static _Thread_local long t_cnt_iter, t_cnt_sweep, t_cnt_roll;
 /* experiment knobs of tools/portfolio_study.py (never changed by tests or the bench): barrier start and backtracking factor */
 static double g_exp_mu_init = 0.1, g_exp_btf = 0.25;
+static double g_exp_warm_mu = 0.0; /* > 0 (warm-start study): barrier parameter a warm start begins with, multipliers mu / slack */
 static int g_stall_window; /* mpc_config.stall_window of the engine under test (0 = off); oracle_set_stall_window */
 static int g_trace, g_trace2; /* ORACLE_TRACE / ORACLE_TRACE2, read once per batch call */
 static int g_cnt_N, g_cnt_V, g_cnt_cc;
@@ -339,6 +340,20 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         rc *= p->sf;
     }
 
+    if (uinit && warm && g_exp_warm_mu > 0.0) {
+        /* warm-start study: start on the central path of a smaller barrier parameter at the warm point */
+        mu = g_exp_warm_mu;
+        for (int k = 0; k < N; ++k) {
+            for (int i = 0; i < 2; ++i) {
+                it->zul[k][i] = mu / (it->u[k][i] - ulo_r(i));
+                it->zuu[k][i] = mu / (uhi_r(i) - it->u[k][i]);
+            }
+            for (int i = p->i0; i < 4; ++i) {
+                it->zxl[k + 1][i] = mu / (it->x[k + 1][i] - xlo_r(i));
+                it->zxu[k + 1][i] = mu / (xhi_r(i) - it->x[k + 1][i]);
+            }
+        }
+    }
     for (iter = 0; iter <= o->max_iter; ++iter) {
         /* ---------------- stage derivatives along the current (feasible) trajectory ---------------- */
         for (int k = 0; k < N; ++k) {
@@ -942,6 +957,9 @@ void oracle_set_experiment(double mu_init, double btf) {
     g_exp_mu_init = mu_init > 0.0 ? mu_init : 0.1;
     g_exp_btf = (btf > 0.0 && btf < 1.0) ? btf : 0.25;
 }
+
+/* warm-start study (tools/warm_start_study.py): 0 = off */
+void oracle_set_warm_experiment(double warm_mu) { g_exp_warm_mu = warm_mu > 0.0 ? warm_mu : 0.0; }
 
 void oracle_last_work(double out[6]) {
     const double N = g_cnt_N, V = g_cnt_V, cc = g_cnt_cc;
