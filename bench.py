@@ -265,6 +265,19 @@ def main():
     kern_ms = float(kern.mean()) if n_str == 1 else None
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
+    n_conv_all = int(conv_mask(status).sum())
+    if use_dist:
+        # every rank solves its own batch (seed = rank): the converged count is summed over the ranks, and each rank's
+        # own kernel time / slowest instance is reported, because the step lasts as long as the rank whose batch holds
+        # the longest chain of iterations (the time is bound by that chain, not by the gather)
+        mine = torch.tensor([float(kern.mean()), float(iters.max()), float(n_conv_all)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
+        n_conv_all = int(per_rank[:, 2].sum())
+        dist_info.update({"per_rank_kernel_ms": [round(float(x), 4) for x in per_rank[:, 0]],
+                          "per_rank_iters_max": [int(x) for x in per_rank[:, 1]],
+                          "per_rank_converged": [int(x) for x in per_rank[:, 2]]})
 
     if saved_stdout is not None:
         sys.stdout.flush()
@@ -273,7 +286,7 @@ def main():
     if rank == 0:
         conv = conv_mask(status)
         value_all = world * BATCH * a.steps / elapsed
-        value = value_all * float(conv.mean())        # solves to tolerance per second; rank 0's fraction stands for all ranks
+        value = value_all * n_conv_all / float(world * BATCH)     # solves to tolerance per second, counted on every rank
         pmc, pmc_file = pmc_summary()
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "mpc_solve_wave_kernel<CC=true, N=20, OCC=3, RELAX=10> (the build for batches that fill the SIMDs "

@@ -61,6 +61,10 @@ def test_one_rank_over_rccl():
     assert g["backend"] == "nccl" and g["world_size"] == 1
     assert g["gathered_actions_shape"] == [4096, 2] and g["gathered_status_shape"] == [4096]
     assert g["own_block_equals_local"] is True
+    # every rank's own kernel time, slowest instance and converged count (the step lasts as long as the slowest rank)
+    assert len(g["per_rank_kernel_ms"]) == 1 and 0.5 < g["per_rank_kernel_ms"][0] < 50.0
+    assert g["per_rank_iters_max"] == [d["solver"]["iters_max"]]
+    assert abs(g["per_rank_converged"][0] / 4096 - d["solver"]["converged_frac"]) < 1e-9
 
 
 def test_config5_shape_rollout_over_rccl():
