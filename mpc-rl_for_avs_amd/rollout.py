@@ -303,22 +303,28 @@ class ActorCritic(torch.nn.Module):
 
 
 class RolloutBuffer:
-    """[n_steps, B, ...] device tensors + GAE (the arithmetic of SB3's RolloutBuffer, which the reference uses as is)."""
+    """[n_steps, B, ...] device tensors + GAE (the arithmetic of SB3's RolloutBuffer, which the reference uses as is).
 
-    def __init__(self, n_steps, num_envs, action_dim, device, gamma=0.99, gae_lambda=0.95):
-        T, B = int(n_steps), int(num_envs)
+    The float32 fields of a step (observation, action, reward, episode start, value, log-probability and - for PPO - the
+    terminal observation and the truncation flag) are columns of ONE [n_steps, B, F] tensor, so that a step writes its row
+    with one concatenation and one copy instead of eight; `obs`, `actions`, ... are views of it."""
+
+    def __init__(self, n_steps, num_envs, action_dim, device, gamma=0.99, gae_lambda=0.95, keep_terminal=False):
+        T, B, A, O = int(n_steps), int(num_envs), int(action_dim), VEHICLES_COUNT * 8
         z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=device)
-        self.obs = z(T, B, VEHICLES_COUNT, 8)
-        self.actions = z(T, B, action_dim)
-        self.rewards, self.values, self.log_probs = z(T, B), z(T, B), z(T, B)
-        self.episode_starts = z(T, B)
-        self.advantages, self.returns = z(T, B), z(T, B)
-        self.mpc_actions = z(T, B, 2, dt=torch.float64)
+        self._cols = O + A + 4 + ((O + 1) if keep_terminal else 0)
+        self._row = z(T, B, self._cols)
+        r, c = self._row, O + A
+        self.obs = r[..., :O].view(T, B, VEHICLES_COUNT, 8)
+        self.actions = r[..., O:c]
+        self.rewards, self.episode_starts, self.values, self.log_probs = r[..., c], r[..., c + 1], r[..., c + 2], r[..., c + 3]
         # PPO bootstraps truncated episodes with the value of their terminal observation (agents/ppo_mpc.py:451-461): the
         # observations and flags are kept per step and the values are computed for the whole rollout at once at its end
         # (bootstrap_truncated) - the policy does not change during a rollout - instead of one value tower per step
-        self.terminal_obs = None
-        self.truncated = None
+        self.terminal_obs = r[..., c + 4:c + 4 + O].view(T, B, VEHICLES_COUNT, 8) if keep_terminal else None
+        self.truncated = r[..., c + 4 + O] if keep_terminal else None
+        self.advantages, self.returns = z(T, B), z(T, B)
+        self.mpc_actions = z(T, B, 2, dt=torch.float64)
         self.gamma, self.gae_lambda, self.n_steps, self.pos = float(gamma), float(gae_lambda), T, 0
         self.pos_dev = torch.zeros(1, dtype=torch.int64, device=device)     # the same counter for captured graphs
 
@@ -326,21 +332,21 @@ class RolloutBuffer:
         self.pos = 0
         self.pos_dev.zero_()
 
-    def keep_terminal(self):
-        """allocate the per-step terminal observations / truncation flags (PPO collectors)"""
-        if self.terminal_obs is None:
-            self.terminal_obs = torch.zeros_like(self.obs)
-            self.truncated = torch.zeros_like(self.rewards)
+    def _pack(self, obs, actions, rewards, episode_starts, values, log_probs, terminal_obs, truncated):
+        f = lambda t: t.reshape(t.shape[0], -1)
+        cols = [f(obs), f(actions), f(rewards), f(episode_starts), f(values), f(log_probs)]
+        if self.terminal_obs is not None:
+            cols += [f(terminal_obs), f(truncated)]
+        row = torch.cat(cols, dim=1)
+        assert row.shape[1] == self._cols
+        return row
 
     def add(self, obs, actions, rewards, episode_starts, values, log_probs, mpc_actions=None, terminal_obs=None,
             truncated=None):
         i = self.pos
-        self.obs[i], self.actions[i], self.rewards[i] = obs, actions, rewards
-        self.episode_starts[i], self.values[i], self.log_probs[i] = episode_starts, values, log_probs
+        self._row[i] = self._pack(obs, actions, rewards, episode_starts, values, log_probs, terminal_obs, truncated)
         if mpc_actions is not None:
             self.mpc_actions[i] = mpc_actions
-        if terminal_obs is not None:
-            self.terminal_obs[i], self.truncated[i] = terminal_obs, truncated
         self.pos += 1
         self.pos_dev.add_(1)
 
@@ -348,12 +354,9 @@ class RolloutBuffer:
                           truncated=None):
         """`add` with the row taken from the device-side counter: no host value is baked into a captured graph."""
         i = self.pos_dev
-        rows = [(self.obs, obs), (self.actions, actions), (self.rewards, rewards), (self.episode_starts, episode_starts),
-                (self.values, values), (self.log_probs, log_probs), (self.mpc_actions, mpc_actions)]
-        if terminal_obs is not None:
-            rows += [(self.terminal_obs, terminal_obs), (self.truncated, truncated)]
-        for dst, src in rows:
-            dst.index_copy_(0, i, src.to(dst.dtype).unsqueeze(0))
+        row = self._pack(obs, actions, rewards, episode_starts, values, log_probs, terminal_obs, truncated)
+        self._row.index_copy_(0, i, row.unsqueeze(0))
+        self.mpc_actions.index_copy_(0, i, mpc_actions.to(self.mpc_actions.dtype).unsqueeze(0))
         self.pos_dev.add_(1)
 
     @torch.no_grad()
@@ -411,9 +414,7 @@ class BatchedCollector:
         self.warm_start = bool(warm_start)
         dev = env.device
         B = env.num_envs
-        self.buffer = RolloutBuffer(n_steps, B, policy.action_dim, dev, gamma, gae_lambda)
-        if algorithm == "ppo":
-            self.buffer.keep_terminal()
+        self.buffer = RolloutBuffer(n_steps, B, policy.action_dim, dev, gamma, gae_lambda, keep_terminal=algorithm == "ppo")
         self.default_weights = torch.tensor(default_weights, dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(int(seed))
