@@ -48,6 +48,7 @@ def main():
         lo, hi = sharding.shard_range(total, rank, world)
         B = hi - lo
         G = max(1, min(a.groups, B))
+        torch.manual_seed(1234)          # the same untrained policy in every run and on every rank: reproducible rows
         pol = rollout.ActorCritic(3 if a.version == "v1" else 1).to(dev)
         engs, cols = [], []
         for g in range(G):
