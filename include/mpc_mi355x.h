@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 3
+#define MPC_ABI_VERSION 4
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -232,6 +232,15 @@ int mpc_reserve_envs(mpc_handle *h, int32_t B);
  * Diagnostics / tests: these are exactly the arguments mpc_solve_batch would take. */
 int mpc_get_last_inputs(mpc_handle *h, int32_t B, double *state, int32_t *ego_index, double *vref,
                         uint8_t *is_collide, double *others, int32_t *nveh);
+
+/* Diagnostics for parity tests: with on != 0 every following mpc_predict_batch also keeps the polylines its detector
+ * worked on.  mpc_get_last_paths then returns (host arrays, any may be NULL; synchronises), for environments 0..B-1 of that
+ * call: ego_path [B][31][2] and ego_len [B] - what predict_ego_future_positions returns (agents/pure_mpc.py:459-527; 0
+ * points where the environment replayed its collision memory, :558-563, and predicted nothing) - and agent_paths
+ * [B][max(vehicles_count-1,1)][31][2] float32 - predict_future_positions per observed vehicle (:529-550; zeros for
+ * absent vehicles).  Costs one memset and B * (500 + 248 V) bytes per call; off by default. */
+int mpc_set_diagnostics(mpc_handle *h, int32_t on);
+int mpc_get_last_paths(mpc_handle *h, int32_t B, double *ego_path, int32_t *ego_len, float *agent_paths);
 
 /*
  * Synthetic intersection environment for MPC-in-the-loop rollouts (BASELINE configs 4-5; highway-env, which the reference

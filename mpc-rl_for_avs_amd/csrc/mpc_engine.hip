@@ -273,7 +273,8 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     int B, const float *__restrict__ obs, int rows, const double *__restrict__ ref5, int M, int N, double dt,
     const double *__restrict__ ref_speed, mpc::pre::EnvState *__restrict__ env, double *__restrict__ state,
     int32_t *__restrict__ ego_index, double *__restrict__ vref, uint8_t *__restrict__ is_collide,
-    double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh, int advance) {
+    double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh, int advance, double *__restrict__ dbg_ego,
+    int32_t *__restrict__ dbg_len, float *__restrict__ dbg_agents) {
     namespace pre = mpc::pre;
     __shared__ pre::P2 s_ego[kPreEnvs][pre::kPredHorizon + 1];
     __shared__ int s_ne[kPreEnvs];
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
     // predicted path, the reference speed and the ego index alike
     {
         double bd = INFINITY;
-        int bi = M;
+        int bi = 0;      // like RefTable::nearest: index 0 when no distance compares smaller (NaN / inf positions, M < 16)
         for (int i = l; i < M; i += kPreGroup) {
             const double d = pre::dist2d(R.x(i), R.y(i), (double)p.ex, (double)p.ey);
             if (d < bd) {
@@ -339,6 +340,19 @@ __global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
         s_cpt[g][l] = cp;
     }
     __syncthreads();
+    // diagnostics (mpc_set_diagnostics): the polylines the detector worked on, for the parity tests against the
+    // reference's predict_ego_future_positions / predict_future_positions
+    if (dbg_len && live) {
+        const int ne = replay ? 0 : s_ne[g];
+        if (l == 0) dbg_len[b] = ne;
+        for (int m = l; m < ne; m += kPreGroup) {
+            dbg_ego[((size_t)b * (pre::kPredHorizon + 1) + m) * 2 + 0] = s_ego[g][m].x;
+            dbg_ego[((size_t)b * (pre::kPredHorizon + 1) + m) * 2 + 1] = s_ego[g][m].y;
+        }
+        if (!replay && l < p.observed && l < Vslots)
+            for (int m = 0; m < 2 * (pre::kPredHorizon + 1); ++m)
+                dbg_agents[((size_t)b * Vslots + l) * 2 * (pre::kPredHorizon + 1) + m] = s_ag[threadIdx.x][m];
+    }
     if (l != 0 || !live) return;
     pre::EnvState &st = env[b];      // in place: a local copy of the 672-byte record is 672 bytes of scratch per lane
     double *oth = others + (size_t)b * Vslots * 4;
@@ -436,6 +450,14 @@ struct mpc_handle {
     double *p_state = nullptr, *p_vref = nullptr, *p_others = nullptr;
     int32_t *p_ego = nullptr, *p_nveh = nullptr;
     uint8_t *p_coll = nullptr;
+    // diagnostics (mpc_set_diagnostics): polylines of the last preamble launch
+    bool diag = false;
+    void *d_diag = nullptr;
+    size_t diag_bytes = 0;
+    int diag_B = 0, diag_V = 0;
+    double *g_ego = nullptr;
+    int32_t *g_len = nullptr;
+    float *g_agents = nullptr;
 };
 
 namespace {
@@ -610,6 +632,7 @@ void mpc_destroy(mpc_handle *h) {
     if (h->d_ltv_u) (void)hipFree(h->d_ltv_u);
     if (h->d_ids) (void)hipFree(h->d_ids);
     if (h->d_pre) (void)hipFree(h->d_pre);
+    if (h->d_diag) (void)hipFree(h->d_diag);
     delete h;
 }
 
@@ -852,9 +875,34 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         d_iters = reinterpret_cast<int32_t *>(sb + off_it);
     }
 
+    if (h->diag) {
+        size_t off = 0;
+        const size_t P = mpc::pre::kPredHorizon + 1, Vs = (size_t)(V > 0 ? V : 1);
+        const size_t o_ego = carve(off, (size_t)B * P * 2 * 8), o_len = carve(off, (size_t)B * 4);
+        const size_t o_ag = carve(off, (size_t)B * Vs * P * 2 * 4);
+        if (h->diag_bytes < off) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+                return fail(MPC_ERR_INVALID_ARG, "mpc_predict_batch: diagnostics buffers cannot grow inside a stream capture");
+            HIP_TRY(hipDeviceSynchronize());
+            if (h->d_diag) HIP_TRY(hipFree(h->d_diag));
+            h->d_diag = nullptr;
+            h->diag_bytes = 0;
+            HIP_TRY(hipMalloc(&h->d_diag, off));
+            h->diag_bytes = off;
+        }
+        char *db = static_cast<char *>(h->d_diag);
+        h->g_ego = reinterpret_cast<double *>(db + o_ego);
+        h->g_len = reinterpret_cast<int32_t *>(db + o_len);
+        h->g_agents = reinterpret_cast<float *>(db + o_ag);
+        h->diag_B = B;
+        h->diag_V = (int)Vs;
+        HIP_TRY(hipMemsetAsync(h->d_diag, 0, off, stream));
+    }
     hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)((B + kPreEnvs - 1) / kPreEnvs)), dim3(kBlock), 0, stream,
                        (int)B, d_obs, rows, h->d_ref, h->M, N, h->cfg.dt, d_rs, h->d_env, h->p_state, h->p_ego,
-                       h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh, detected ? 0 : 1);
+                       h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh, detected ? 0 : 1,
+                       h->diag ? h->g_ego : nullptr, h->diag ? h->g_len : nullptr, h->diag ? h->g_agents : nullptr);
     HIP_TRY(hipGetLastError());
     const bool warm = (flags & MPC_FLAG_WARM_START) != 0;
     if (detect_only) {
@@ -1166,6 +1214,27 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
                        ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
                        (int)reset_all);
     HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_set_diagnostics(mpc_handle *h, int32_t on) {
+    if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_set_diagnostics: null handle");
+    h->diag = on != 0;
+    if (!h->diag) h->diag_B = 0;
+    return MPC_OK;
+}
+
+int mpc_get_last_paths(mpc_handle *h, int32_t B, double *ego_path, int32_t *ego_len, float *agent_paths) {
+    if (!h || B < 0) return fail(MPC_ERR_INVALID_ARG, "mpc_get_last_paths: bad argument");
+    if (B == 0) return MPC_OK;
+    if (!h->diag || !h->d_diag || B > h->diag_B)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_get_last_paths: no diagnostics of that size (mpc_set_diagnostics, then mpc_predict_batch)");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t P = mpc::pre::kPredHorizon + 1;
+    if (ego_path) HIP_TRY(hipMemcpy(ego_path, h->g_ego, (size_t)B * P * 2 * 8, hipMemcpyDeviceToHost));
+    if (ego_len) HIP_TRY(hipMemcpy(ego_len, h->g_len, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (agent_paths) HIP_TRY(hipMemcpy(agent_paths, h->g_agents, (size_t)B * h->diag_V * P * 2 * 4, hipMemcpyDeviceToHost));
     return MPC_OK;
 }
 

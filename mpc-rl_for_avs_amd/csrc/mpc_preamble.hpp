@@ -335,13 +335,26 @@ MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, i
     if (ne < 2 || na < 2) return 0;
     const P2 a = ag.at(0), b = ag.at(na - 1);
     int nc = 0;
+    bool last_is_point = false;      // what out[nc - 1] came from
+    P2 line_end{0.0, 0.0};           // far end of the last collinear stretch
     for (int i = 0; i < ne - 1 && nc < maxc; ++i) {
         Hit h[2];
         const int nh = seg_intersections(ego[i], ego[i + 1], a, b, h);
         if (nh == 0) continue;
         if (nh == 1) {
             // a crossing exactly at an ego vertex is found by both segments that share it
-            if (nc == 0 || !close2(out[nc - 1], h[0].p)) out[nc++] = h[0].p;
+            bool dup = nc > 0 && last_is_point && close2(out[nc - 1], h[0].p);
+            // the intersection is a point SET: where the ego joins or leaves the other path's line at a vertex, the segment
+            // before / behind the collinear stretch touches the line in the stretch's end point, which is part of that piece
+            if (!dup && nc > 0 && !last_is_point && close2(line_end, h[0].p)) dup = true;
+            if (!dup && i + 2 < ne) {
+                Hit h2[2];
+                dup = seg_intersections(ego[i + 1], ego[i + 2], a, b, h2) == 2 && close2(h2[0].p, h[0].p);
+            }
+            if (!dup) {
+                out[nc++] = h[0].p;
+                last_is_point = true;
+            }
             continue;
         }
         // collinear overlap starting on ego segment i: it goes on over the following segments that overlap too
@@ -374,6 +387,8 @@ MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, i
         const int nu = w.walk(-1, dummy);
         w.walk(nu / 2, mid);
         out[nc++] = mid;
+        last_is_point = false;
+        line_end = pl;
         i = j - 1;      // go on behind the overlap
     }
     return nc;
@@ -416,10 +431,13 @@ MPC_HD int argmin_dist(const AgentPath &ag, P2 p) {
 MPC_HD float speed_f32(float vx, float vy) { return sqrtf(f32add(f32mul(vx, vx), f32mul(vy, vy))); }
 
 // heading wrap of the ego row (agents/base_agent.py:156-170) on a float32 scalar: the subtraction stays float32
+// ... and so do the comparisons: numpy (NEP 50) converts the Python float np.pi to float32 before comparing it with a
+// float32 scalar, so a heading of exactly float32(-pi) = -3.1415927 - below -pi as a double, and what an ego on the exit
+// straight (table heading -pi) is observed with - is NOT wrapped (tests/golden/reference_random.npz, case 6)
 MPC_HD float normalize_angle_f32(float a) {
-    const float two_pi = (float)(2.0 * kPi);
-    while ((double)a > kPi) a = f32add(a, -two_pi);
-    while ((double)a < -kPi) a = f32add(a, two_pi);
+    const float two_pi = (float)(2.0 * kPi), pi_f = (float)kPi;
+    while (a > pi_f) a = f32add(a, -two_pi);
+    while (a < -pi_f) a = f32add(a, two_pi);
     return a;
 }
 
@@ -460,8 +478,8 @@ MPC_HD bool replays_memory(const EnvState &st) { return st.collision_memory > 0 
 // step = speed * dt * [cos h, sin h], positions accumulate).
 // ag_xy (2 x 31 floats) and cand (kMaxCross points) are the caller's work space: LDS on the device, where a dynamically
 // indexed local array would be scratch memory.
-MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt, P2 &pt_out, float *ag_xy,
-                          P2 *cand) {
+// predict_future_positions (agents/pure_mpc.py:529-550) for the observation row o: 31 float32 points into ag_xy
+MPC_HD void agent_path(const float *o, double dt, float *ag_xy) {
     const float sp = speed_f32(o[3], o[4]);
     const float sdt = f32mul(sp, (float)dt);
     const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
@@ -474,6 +492,11 @@ MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable 
         ag_xy[2 * m] = ax;
         ag_xy[2 * m + 1] = ay;
     }
+}
+
+MPC_HD int detect_vehicle(const float *o, const P2 *ego, int ne, const RefTable &R, double dt, P2 &pt_out, float *ag_xy,
+                          P2 *cand) {
+    agent_path(o, dt, ag_xy);
     const AgentPath ag{ag_xy, kPredHorizon + 1};
     // candidate loop of agents/pure_mpc.py:635-654: the first intersection point whose ego / agent sample indices differ
     // by less than TIME_THRESHOLD decides (with 31 samples that is every point except the pairing 0 / 30)

@@ -50,7 +50,8 @@ _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
-            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step"]
+            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths"]
+ABI_VERSION = 4          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
 MAX_OTHERS = 16
 _lib = None
 
@@ -62,6 +63,8 @@ def load_library(path: str | None = None):
         return _lib
     if path is None and os.environ.get("MPC_EXPERIMENT_LIB"):
         path = os.environ["MPC_EXPERIMENT_LIB"]     # development aid: an experimental build of the same ABI (tools/)
+        import sys
+        print(f"[mpc engine] MPC_EXPERIMENT_LIB: loading {path} instead of the in-tree library", file=sys.stderr)
     if path is None:
         path = _build.LIB_PATH
         if _build.is_stale():
@@ -82,6 +85,8 @@ def load_library(path: str | None = None):
     lib = ctypes.CDLL(path)
     vp, dp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
     lib.mpc_version.restype = ctypes.c_int
+    if lib.mpc_version() != ABI_VERSION:        # whichever path the library came from: argument lists below are ABI-specific
+        raise EngineError(f"{path} reports ABI {lib.mpc_version()}, this binding is written for ABI {ABI_VERSION}")
     lib.mpc_last_error.restype = ctypes.c_char_p
     lib.mpc_default_config.argtypes = [ctypes.POINTER(_Config)]
     lib.mpc_default_config.restype = None
@@ -123,6 +128,10 @@ def load_library(path: str | None = None):
     lib.mpc_synth_env_step.restype = ctypes.c_int
     lib.mpc_get_last_inputs.argtypes = [vp, ctypes.c_int32, dp, ip, dp, vp, dp, ip]
     lib.mpc_get_last_inputs.restype = ctypes.c_int
+    lib.mpc_set_diagnostics.argtypes = [vp, ctypes.c_int32]
+    lib.mpc_set_diagnostics.restype = ctypes.c_int
+    lib.mpc_get_last_paths.argtypes = [vp, ctypes.c_int32, dp, ip, vp]
+    lib.mpc_get_last_paths.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -434,6 +443,19 @@ class MPCEngine:
         rc = self._lib.mpc_get_last_inputs(self._h, B, _ptr(o["state"]), _ptr(o["ego_index"]), _ptr(o["vref"]),
                                            _ptr(o["is_collide"]), _ptr(o["others"]), _ptr(o["nveh"]))
         self._check(rc, "mpc_get_last_inputs")
+        return o
+
+    def set_diagnostics(self, on=True):
+        """Keep the detector's polylines of every following predict_batch (`last_paths`); parity tests only."""
+        self._check(self._lib.mpc_set_diagnostics(self._h, 1 if on else 0), "mpc_set_diagnostics")
+
+    def last_paths(self, B, vehicles_count):
+        """Polylines of the last predict_batch: ego_path[B, 31, 2], ego_len[B] (0 where the environment replayed its
+        collision memory), agent_paths[B, V, 31, 2] float32."""
+        V = max(int(vehicles_count) - 1, 1)
+        o = dict(ego_path=np.zeros((B, 31, 2)), ego_len=np.zeros(B, np.int32), agent_paths=np.zeros((B, V, 31, 2), np.float32))
+        rc = self._lib.mpc_get_last_paths(self._h, B, _ptr(o["ego_path"]), _ptr(o["ego_len"]), _ptr(o["agent_paths"]))
+        self._check(rc, "mpc_get_last_paths")
         return o
 
     def close(self):

@@ -36,6 +36,33 @@ extern "C" int preamble_batch(int B, const float *obs, int rows, const double *r
     return 0;
 }
 
+// the same with the detector left as the records say (MPC_FLAG_DETECTED: `advance` = 0): ego index and speed profile only
+extern "C" int preamble_batch_adv(int B, const float *obs, int rows, const double *ref_table, int M, int N, double dt,
+                                  const double *ref_speed, int32_t *env, double *state, int32_t *ego_index, double *vref,
+                                  uint8_t *is_collide, double *others, int32_t *nveh, int advance) {
+    std::vector<double> t((size_t)M * (mpc::REF_COLS + 1));
+    for (int i = 0; i < M; ++i) {
+        t[(size_t)i * mpc::REF_COLS + mpc::R_X] = ref_table[i * 4 + 0];
+        t[(size_t)i * mpc::REF_COLS + mpc::R_Y] = ref_table[i * 4 + 1];
+        t[(size_t)i * mpc::REF_COLS + mpc::R_H] = ref_table[i * 4 + 3];
+        t[(size_t)M * mpc::REF_COLS + i] = ref_table[i * 4 + 2];
+    }
+    const mpc::pre::RefTable R{t.data(), M};
+    const int V = rows - 1 > 0 ? rows - 1 : 1;
+    auto *st = reinterpret_cast<mpc::pre::EnvState *>(env);
+    for (int b = 0; b < B; ++b) {
+        double *oth = others + (size_t)b * V * 4;
+        for (int j = 0; j < V * 4; ++j) oth[j] = 0.0;
+        mpc::pre::preamble_env(obs + (size_t)b * rows * mpc::pre::kObsCols, rows, R, N, dt,
+                               ref_speed ? ref_speed + b : nullptr, st[b], state + (size_t)b * 4, ego_index[b],
+                               vref + (size_t)b * (N + 1), is_collide[b], oth, nveh[b], advance != 0);
+    }
+    return 0;
+}
+
+// predict_future_positions for one observation row: out [31][2] float32
+extern "C" void preamble_agent_path(const float *row, double dt, float *out) { mpc::pre::agent_path(row, dt, out); }
+
 // single pieces, for the golden vectors of the reference
 extern "C" int preamble_ego_future(const double *ref_table, int M, float px, float py, float speed, double vref,
                                    double dt, double *out /*[31][2]*/) {

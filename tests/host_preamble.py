@@ -54,12 +54,10 @@ def _seg_intersections(p, q, a, b, eps=1e-12):
     return [(lo, p + lo * r), (hi, p + hi * r)]
 
 
-def path_crossings(ego_path, agent_path, max_candidates=4):
-    """Intersection points of two polylines as the candidate list the reference builds from shapely's result
-    (agents/pure_mpc.py:615-633): every transversal crossing, and for a collinear overlap the middle vertex of the
-    overlapping stretch.  ORDER: along the ego's direction of travel - GEOS returns the members of a Multi* geometry in
-    the iteration order of a hash map of its overlay graph, which cannot be reproduced; a straight agent path meets the
-    ego path more than once only when it cuts the arc twice."""
+def path_pieces(ego_path, agent_path, max_pieces=4):
+    """The intersection of the two polylines as a list of pieces along the ego's direction of travel: ("point", p) for a
+    transversal crossing, ("line", [p0, p1, ...]) for a collinear overlap with every node of the overlapping stretch (its
+    ends on each ego segment it covers and the agent's own vertices inside it), de-duplicated and ordered along the ego."""
     ego = np.asarray(ego_path, dtype=np.float64)
     ag = np.asarray(agent_path, dtype=np.float64)
     out = []
@@ -67,17 +65,25 @@ def path_crossings(ego_path, agent_path, max_candidates=4):
         return out
     a, b = ag[0], ag[-1]                   # constant-velocity prediction: the agent polyline is one straight segment
     i = 0
-    while i < len(ego) - 1 and len(out) < max_candidates:
+    while i < len(ego) - 1 and len(out) < max_pieces:
         hits = _seg_intersections(ego[i], ego[i + 1], a, b)
         if not hits:
             i += 1
             continue
         if len(hits) == 1:
             pt = np.asarray(hits[0][1], dtype=np.float64)
+            same = lambda q: abs(q[0] - pt[0]) <= 1e-12 + 1e-5 * abs(pt[0]) and abs(q[1] - pt[1]) <= 1e-12 + 1e-5 * abs(pt[1])
             # a crossing exactly at an ego vertex is found by both segments that share it
-            if not out or not (abs(out[-1][0] - pt[0]) <= 1e-12 + 1e-5 * abs(pt[0]) and
-                               abs(out[-1][1] - pt[1]) <= 1e-12 + 1e-5 * abs(pt[1])):
-                out.append(pt)
+            dup = bool(out) and out[-1][0] == "point" and same(out[-1][1])
+            # the intersection is a point SET: where the ego joins or leaves the other path's line at a vertex, the segment
+            # before / behind the collinear stretch touches the line in the stretch's end point, which is part of that piece
+            if not dup and out and out[-1][0] == "line" and same(out[-1][1][-1]):
+                dup = True
+            if not dup and i + 2 < len(ego):
+                nxt = _seg_intersections(ego[i + 1], ego[i + 2], a, b)
+                dup = len(nxt) == 2 and same(nxt[0][1])
+            if not dup:
+                out.append(("point", pt))
             i += 1
             continue
         # collinear overlap starting on this ego segment: collect the overlapping stretch over following segments
@@ -101,9 +107,18 @@ def path_crossings(ego_path, agent_path, max_candidates=4):
         for _, pt in keyed:
             if not uniq or not np.allclose(uniq[-1], pt, atol=1e-12):
                 uniq.append(pt)
-        out.append(np.array(uniq[len(uniq) // 2], dtype=np.float64))
+        out.append(("line", [np.array(u, dtype=np.float64) for u in uniq]))
         i = j                               # go on behind the overlap
     return out
+
+
+def path_crossings(ego_path, agent_path, max_candidates=4):
+    """Intersection points of two polylines as the candidate list the reference builds from shapely's result
+    (agents/pure_mpc.py:615-633): every transversal crossing, and for a collinear overlap the middle vertex of the
+    overlapping stretch (`coords[len(coords) // 2]`).  ORDER: along the ego's direction of travel - GEOS returns the
+    members of a Multi* geometry in the iteration order of a hash map of its overlay graph, which cannot be reproduced; a
+    straight agent path meets the ego path more than once only when it cuts the arc twice."""
+    return [p if kind == "point" else p[len(p) // 2] for kind, p in path_pieces(ego_path, agent_path, max_candidates)]
 
 
 def first_path_crossing(ego_path, agent_path):

@@ -1,0 +1,347 @@
+"""Everything the REFERENCE's own Python statements produced in this container (tests/golden/make_golden.py round 4:
+reference_random.npz, reference_sequences.npz, reference_distance_cost.npz; what stands in for the absent casadi / shapely
+and what that leaves unpinned: tests/golden/standins.py) against
+  * the numpy mirror of the preamble (tests/host_preamble.py),
+  * the device preamble compiled for the host (csrc/mpc_preamble.hpp through tests/cpu_preamble_harness.cpp),
+  * the oracle's restatement of the NLP (oracle/nlp_spec.py, oracle/nlp_batch.py).
+CPU only; tests/test_reference_vectors_gpu.py replays the same fixtures through the C ABI on the GPU."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import ref_fixtures as rf
+from test_host import CFG, Env, FakeEngine
+from test_preamble_cpu import DevicePreamble, load_pre
+
+
+@pytest.fixture(scope="module")
+def rnd():
+    return rf.load("reference_random.npz")
+
+
+@pytest.fixture(scope="module")
+def seq():
+    return rf.load("reference_sequences.npz")
+
+
+@pytest.fixture(scope="module")
+def pre():
+    lib = load_pre()
+    lib.preamble_batch_adv.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 8 + [ctypes.c_int]
+    lib.preamble_agent_path.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+    lib.preamble_agent_path.restype = None
+    return lib
+
+
+@pytest.fixture()
+def mirror():
+    from host_preamble import HostPreambleAgent
+    return HostPreambleAgent(Env(), dict(CFG), engine=FakeEngine())
+
+
+def test_fixture_sizes(rnd, seq):
+    """>= 500 cases per function of the reference."""
+    assert len(rnd["parse_ego"]) >= 500 and len(rnd["normalize_out"]) >= 500 and len(rnd["ego_future_len"]) >= 500
+    assert len(rnd["agent_future_out"]) >= 500 and len(rnd["update_ref_speed_out"]) >= 500
+    T, E = seq["seq_obs"].shape[:2]
+    assert T * E >= 1500 and seq["seq_is_collide"].sum() > 300 and (seq["seq_is_collide"] == 0).sum() > 300
+    assert seq["seq_reset"][1:].sum() >= 5                        # episode boundaries inside the sequences
+    assert len(seq["nlp_f"]) >= 1000
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# numpy mirror
+# ---------------------------------------------------------------------------------------------------------------
+def test_mirror_parse_and_normalize(mirror, rnd):
+    for b, obs in enumerate(rnd["parse_obs"]):
+        mirror._parse_obs(obs)
+        e = mirror.ego_vehicle
+        got = np.array([e.position[0], e.position[1], e.heading, e.speed, mirror.observed_vehicles_count], np.float64)
+        assert np.array_equal(got, rnd["parse_ego"][b])
+        oth = np.zeros((9, 4))
+        for j, v in enumerate(mirror.agent_vehicles):
+            oth[j] = (v.position[0], v.position[1], v.speed, v.heading)
+        assert np.array_equal(oth, rnd["parse_others"][b])
+    assert np.array_equal([mirror.normalize_angle(a) for a in rnd["normalize_in"]], rnd["normalize_out"])
+    got32 = [float(mirror.normalize_angle(np.float32(a))) for a in rnd["normalize32_in"]]
+    assert np.array_equal(got32, rnd["normalize32_out"])
+
+
+def test_mirror_predictors(mirror, rnd):
+    for obs, vref, want, n in zip(rnd["ego_future_obs"], rnd["ego_future_vref"], rnd["ego_future_out"],
+                                  rnd["ego_future_len"]):
+        mirror._parse_obs(obs)
+        e = mirror.ego_vehicle
+        fut = mirror.predict_ego_future_positions(e.position, e.speed, e.heading, e.max_acceleration, 0.1, 30, vref)
+        assert len(fut) == n
+        assert np.array_equal(np.asarray([np.asarray(q, np.float64) for q in fut]), want[:n])
+    for obs, want in zip(rnd["agent_future_obs"], rnd["agent_future_out"]):
+        mirror._parse_obs(obs)
+        v = mirror.agent_vehicles[0]
+        fut = mirror.predict_future_positions(np.array(v.position), v.speed, v.heading, 0.1, 30)
+        assert np.array_equal(np.asarray(fut, np.float64), want)
+
+
+def test_mirror_update_reference_states(mirror, rnd):
+    from host_preamble import _EnvState
+    tr = mirror.reference_trajectory
+    for b in range(len(rnd["update_ref_is_collide"])):
+        mirror._parse_obs(rnd["update_ref_obs"][b])
+        st = _EnvState()
+        nc, nm = int(rnd["update_ref_n_conf"][b]), int(rnd["update_ref_n_mem"][b])
+        st.is_collide = bool(rnd["update_ref_is_collide"][b])
+        st.conflict_index = [None if c < 0 else int(c) for c in rnd["update_ref_conflict"][b, :nc]]
+        st.collision_memory = int(rnd["update_ref_mem"][b])
+        st.memorized_conflict_indices = None if not rnd["update_ref_has_mem"][b] else \
+            [None if c < 0 else int(c) for c in rnd["update_ref_memorized"][b, :nm]]
+        lv = int(rnd["update_ref_last_valid"][b])
+        st.last_valid_stop_point = None if lv < 0 else tr[lv]
+        st.ego_index = mirror._nearest_ref_index(mirror.ego_vehicle.position)
+        assert st.ego_index == rnd["update_ref_ego_index"][b]
+        rl = rnd["update_ref_rl"][b]
+        ref = mirror.update_reference_states(0, None if np.isnan(rl) else np.array([[rl]]), st, mirror.ego_vehicle.speed)
+        assert np.array_equal(ref[:, 2], rnd["update_ref_speed_out"][b]), b
+        stop = -1 if st.stop_point is None else int(np.argmin(np.linalg.norm(tr - st.stop_point, axis=1)))
+        assert stop == rnd["update_ref_stop_out"][b], b
+
+
+def _replay_sequences(seq, step, reset):
+    """Feeds the recorded observation sequences to `step(t, envs, obs, ref_speed or None)` group by group and compares what
+    it returns with what the reference's predict() computed; `reset(group, ids)` at episode boundaries."""
+    N = 20
+    T = seq["seq_obs"].shape[0]
+    for gi, envs in enumerate(rf.sequence_groups(seq)):
+        if envs.size == 0:
+            continue
+        for t in range(T):
+            ids = np.nonzero(seq["seq_reset"][t, envs])[0]
+            if t > 0 and ids.size:
+                reset(gi, ids)
+            rs = seq["seq_ref_speed"][t, envs]
+            got = step(gi, t, envs, np.ascontiguousarray(seq["seq_obs"][t, envs]), None if np.isnan(rs[0]) else rs)
+            want_vref = rf.window(seq["seq_speed_col"][t, envs], seq["seq_ego_index"][t, envs], N)
+            tag = (gi, t)
+            assert np.array_equal(got["state"], seq["seq_state"][t, envs]), tag
+            assert np.array_equal(got["nveh"], seq["seq_nveh"][t, envs]), tag
+            assert np.array_equal(got["ego_index"], seq["seq_ego_index"][t, envs]), tag
+            assert np.array_equal(got["is_collide"], seq["seq_is_collide"][t, envs]), tag
+            assert np.array_equal(got["collision_memory"], seq["seq_collision_memory"][t, envs]), tag
+            assert np.array_equal(got["vref"], want_vref), tag
+            assert np.array_equal(got["stop_index"], seq["seq_stop_index"][t, envs]), tag
+            assert np.array_equal(got["conflict_index"][:, :9], seq["seq_conflict_index"][t, envs]), tag
+            assert np.array_equal(got["conflict_points"][:, :9], seq["seq_conflict_points"][t, envs], equal_nan=True), tag
+            for i in range(envs.size):
+                nv = got["nveh"][i]
+                assert np.array_equal(got["others"][i, :nv], seq["seq_others"][t, envs[i], :nv]), tag
+
+
+def test_mirror_state_machine_on_reference_sequences(seq):
+    """The mirror's `_check_collision` / `update_reference_states` against the reference's, step by step, over closed-loop
+    episodes (both read the same geometry: the mirror's segment arithmetic is what serves LineString.intersection there)."""
+    from host_preamble import HostPreambleAgent
+    agents = {}
+
+    def step(gi, t, envs, obs, rs):
+        ag = agents.setdefault(gi, HostPreambleAgent(Env(), dict(CFG), engine=FakeEngine()))
+        ag.predict_batch_host(obs, None, None if rs is None else rs[:, None])
+        inp, B = ag.last_inputs, len(envs)
+        out = dict(state=inp["state"], ego_index=inp["ego_index"], is_collide=inp["is_collide"], vref=inp["vref"],
+                   nveh=np.array([int((o[:, 0] == 1).sum()) - 1 for o in obs], np.int32),
+                   collision_memory=np.array([s.collision_memory for s in ag._states[:B]], np.int32),
+                   conflict_index=np.full((B, 9), -1, np.int32), conflict_points=np.full((B, 9, 2), np.nan),
+                   stop_index=np.full(B, -1, np.int32), others=np.zeros((B, 9, 4)))
+        for i, s in enumerate(ag._states[:B]):
+            for j, c in enumerate(s.conflict_index):
+                out["conflict_index"][i, j] = -1 if c is None else c
+            for j, c in enumerate(s.conflict_points):
+                if c is not None:
+                    out["conflict_points"][i, j] = c
+            if s.stop_point is not None:
+                out["stop_index"][i] = int(np.argmin(np.linalg.norm(ag.reference_trajectory - s.stop_point, axis=1)))
+            e, others = ag._vehicles_from_obs(obs[i])
+            for j, v in enumerate(others):
+                out["others"][i, j] = (v.position[0], v.position[1], v.speed, v.heading)
+        return out
+
+    def reset(gi, ids):
+        for i in ids:
+            agents[gi]._states[int(i)] = type(agents[gi]._states[0])()
+    _replay_sequences(seq, step, reset)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the device preamble, compiled for the host
+# ---------------------------------------------------------------------------------------------------------------
+def test_device_code_parse_and_predictors(pre, rnd, ref_table):
+    dev = DevicePreamble(pre, ref_table)
+    got = dev(rnd["parse_obs"])
+    assert np.array_equal(got["state"], rnd["parse_ego"][:, :4])
+    assert np.array_equal(got["nveh"], rnd["parse_ego"][:, 4].astype(np.int32))
+    for b in range(len(got["nveh"])):
+        nv = got["nveh"][b]
+        assert np.array_equal(got["others"][b, :nv], rnd["parse_others"][b, :nv])
+    ref = np.ascontiguousarray(ref_table)
+    for obs, vref, want, n in zip(rnd["ego_future_obs"], rnd["ego_future_vref"], rnd["ego_future_out"],
+                                  rnd["ego_future_len"]):
+        sp = np.sqrt(obs[0, 3] * obs[0, 3] + obs[0, 4] * obs[0, 4])
+        out = np.full((31, 2), np.nan)
+        k = pre.preamble_ego_future(ref.ctypes.data, ref.shape[0], obs[0, 1], obs[0, 2], sp, float(vref), 0.1, out.ctypes.data)
+        assert k == n and np.array_equal(out[:k], want[:k])
+    check_agent_paths(rnd, lambda b, row: _host_agent_path(pre, row))
+
+
+def _host_agent_path(pre, row):
+    row = np.ascontiguousarray(row)
+    out = np.zeros((31, 2), np.float32)
+    pre.preamble_agent_path(row.ctypes.data, 0.1, out.ctypes.data)
+    return out
+
+
+def check_agent_paths(rnd, path_of):
+    """predict_future_positions (agents/pure_mpc.py:529-550) is float32 arithmetic on the float32 observation, INCLUDING
+    np.cos / np.sin of the float32 heading - numpy's SIMD float32 kernels, which are not correctly rounded (and whose
+    dispatch depends on the CPU the reference runs on).  The device rounds the double-precision value to float32.  On the
+    lane axes (what the intersection's straight lanes give) the two agree and the paths are bit-identical; elsewhere the
+    step vector may differ in its last float32 bit: <= 3e-6 m over the 30 steps.  Documented deviation, bounded here."""
+    axes = np.array([0.0, np.pi / 2, np.pi, -np.pi / 2], np.float32)
+    exact = off = 0
+    for b, (obs, want) in enumerate(zip(rnd["agent_future_obs"], rnd["agent_future_out"])):
+        got = np.asarray(path_of(b, obs[1]), np.float64)
+        if obs[1, 5] in axes:
+            assert np.array_equal(got, want), b
+            exact += 1
+        else:
+            assert np.abs(got - want).max() <= 3e-6, b
+            off += 1
+    assert exact >= 200 and off >= 200
+
+
+def test_device_code_update_reference_states(pre, rnd, ref_table):
+    """The device's speed-profile rewrite from detector records set like the reference agent's attributes
+    (MPC_FLAG_DETECTED path: the records are not advanced)."""
+    n = len(rnd["update_ref_is_collide"])
+    rec = rf.update_ref_records(rnd)
+    env = np.ascontiguousarray(rec.view(np.int32).reshape(n, -1))
+    obs = np.ascontiguousarray(rnd["update_ref_obs"])
+    rl = rnd["update_ref_rl"]
+    ref = np.ascontiguousarray(ref_table)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for has_rl in (False, True):
+        sel = np.nonzero(~np.isnan(rl) if has_rl else np.isnan(rl))[0]
+        B = sel.size
+        o = np.ascontiguousarray(obs[sel])
+        e = np.ascontiguousarray(env[sel])
+        rs = np.ascontiguousarray(rl[sel]) if has_rl else None
+        out = dict(state=np.zeros((B, 4)), ego=np.zeros(B, np.int32), vref=np.zeros((B, 21)), col=np.zeros(B, np.uint8),
+                   oth=np.zeros((B, 9, 4)), nveh=np.zeros(B, np.int32))
+        rc = pre.preamble_batch_adv(B, p(o), 10, p(ref), 85, 20, 0.1, None if rs is None else p(rs), p(e), p(out["state"]),
+                                    p(out["ego"]), p(out["vref"]), p(out["col"]), p(out["oth"]), p(out["nveh"]), 0)
+        assert rc == 0
+        assert np.array_equal(out["ego"], rnd["update_ref_ego_index"][sel])
+        assert np.array_equal(out["vref"], rf.window(rnd["update_ref_speed_out"][sel], out["ego"], 20))
+        after = e.view(rf.ENV_DTYPE).reshape(B)
+        assert np.array_equal(after["stop_index1"] - 1, rnd["update_ref_stop_out"][sel])
+        assert np.array_equal(after["last_valid_stop1"] - 1, rnd["update_ref_last_valid_out"][sel])
+        assert np.array_equal(out["col"], rnd["update_ref_is_collide"][sel])
+
+
+def test_device_code_state_machine_on_reference_sequences(pre, seq, ref_table):
+    devs = {}
+
+    def step(gi, t, envs, obs, rs):
+        dev = devs.setdefault(gi, DevicePreamble(pre, ref_table))
+        o = dev(obs, rs)
+        B = len(envs)
+        rec = dev.env[:B].view(rf.ENV_DTYPE).reshape(B)
+        nc = rec["n_conflict"]
+        ci = np.where(np.arange(16)[None, :] < nc[:, None], rec["conflict"], -1)
+        cp = np.where((ci >= 0)[:, :, None], rec["conflict_pt"], np.nan)
+        return dict(state=o["state"], nveh=o["nveh"], ego_index=o["ego_index"], is_collide=o["is_collide"], vref=o["vref"],
+                    collision_memory=rec["collision_memory"].copy(), conflict_index=ci, conflict_points=cp,
+                    stop_index=rec["stop_index1"] - 1, others=o["others"])
+
+    def reset(gi, ids):
+        devs[gi].env[ids] = 0
+    _replay_sequences(seq, step, reset)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the NLP itself: the reference's own objective / constraint / bound / initial-guess statements, evaluated numerically
+# ---------------------------------------------------------------------------------------------------------------
+def test_oracle_nlp_equals_the_references_statements(seq, ref_table):
+    """agents/pure_mpc.py:128-283 executed with a numeric stand-in for casadi (values in, values out): f(z), g(z) at the
+    cold start, at the oracle's solution and at random points of 400 closed-loop steps (default and RL weights incl.
+    negative ones, with and without a predicted collision, with the RL speed override), lbx / ubx / lbg / ubg / x0, and
+    the solver options the reference passes."""
+    import nlp_batch as nb
+    import nlp_spec as ns
+    assert int(seq["seq_ipopt_max_iter"]) == 1000 and float(seq["seq_ipopt_tol"]) == 1e-6       # agents/pure_mpc.py:294-295
+    t, e = seq["nlp_t"], seq["nlp_e"]
+    n = len(t)
+    w = seq["seq_weights"][e].copy()
+    w[np.isnan(w[:, 0])] = 1.0
+    tab = np.broadcast_to(ref_table, (n, 85, 4)).copy()
+    tab[:, :, 2] = seq["seq_speed_col"][t, e]
+    ego = seq["seq_ego_index"][t, e]
+    col = seq["seq_is_collide"][t, e]
+    state = seq["seq_state"][t, e]
+    assert (w < 0).any() and col.any() and (~col.astype(bool)).any()
+    worst_f = worst_g = 0.0
+    for i in range(n):
+        p = ns.Problem.build(20, 0.1, state[i], int(ego[i]), tab[i], w[i], bool(col[i]))
+        X, U = ns.unpack(p, seq["nlp_z"][i])
+        f, g = ns.cost(p, X, U), ns.constraints(p, X, U).ravel()
+        worst_f = max(worst_f, abs(f - seq["nlp_f"][i]) / max(1.0, abs(f)))
+        worst_g = max(worst_g, float(np.abs(g - seq["nlp_g"][i]).max()))
+    assert worst_f <= 1e-14 and worst_g == 0.0, (worst_f, worst_g)
+    # bounds, cold start, equality right-hand sides
+    p = ns.Problem.build(20, 0.1, seq["seq_state"][0, 0], int(seq["seq_ego_index"][0, 0]), ref_table, np.ones(3), False)
+    lo, hi = ns.bounds(p)
+    assert np.array_equal(lo, seq["seq_lbx"]) and np.array_equal(hi, seq["seq_ubx"])
+    assert not seq["seq_lbg"].any() and not seq["seq_ubg"].any() and len(seq["seq_lbg"]) == 84
+    X0, U0 = ns.initial_guess(p)
+    assert np.array_equal(ns.pack(X0, U0), seq["seq_x0"])
+    # the batched restatement (what certifies the GPU's solutions) on the same points
+    vref = rf.window(seq["seq_speed_col"][t, e], ego, 20)
+    pb = nb.Batch.build(ref_table, state, ego, w, col, vref=vref)
+    Xb = seq["nlp_z"][:, :84].reshape(n, 21, 4)
+    Ub = seq["nlp_z"][:, 84:].reshape(n, 20, 2)
+    fb = nb.cost(pb, Xb, Ub)
+    cb = nb.constraints(pb, Xb, Ub).reshape(n, -1)
+    assert np.max(np.abs(fb - seq["nlp_f"]) / np.maximum(1.0, np.abs(fb))) <= 1e-13
+    assert np.max(np.abs(cb - seq["nlp_g"])) <= 1e-12
+
+
+def test_oracle_distance_cost_equals_the_archived_agents(ref_table):
+    """the distance term of agents/archive/pure_mpc.py:189-206, evaluated by the archived agent's own
+    statements.  The reference advances the other vehicles in float32 (their observation's dtype, base_agent.py:172-174);
+    oracle and engine place vehicle j at stage k at p_j + k speed_j dt (cos h_j, sin h_j) in double: positions within
+    2e-5 m, the cost within 2e-4 relative where a node sits inside d < 1 m (1000 / d^2 is steep there) and 5e-5 elsewhere
+    - a documented deviation, bounded here."""
+    import nlp_spec as ns
+    d = rf.load("reference_distance_cost.npz")
+    assert len(d["distance_cost"]) >= 500
+    rel = np.zeros(len(d["distance_cost"]))
+    near = np.zeros(len(rel), bool)
+    for b in range(len(rel)):
+        o = d["obs"][b]
+        nv = int((o[:, 0] == 1).sum()) - 1
+        oth = np.zeros((nv, 4))
+        for j in range(nv):
+            r = o[j + 1]
+            oth[j] = (r[1], r[2], np.sqrt(r[3] * r[3] + r[4] * r[4]), r[5])
+        p = ns.Problem.build(20, 0.1, np.zeros(4), 0, ref_table, np.ones(3), False, collision_cost=True, others=oth)
+        X, _ = ns.unpack(p, d["z"][b])
+        J = 0.0
+        for k in range(20):
+            dd = np.linalg.norm(X[k, :2][None, :] - p.other_positions(k), axis=1)
+            J += np.sum(np.where(dd < 1.0, 1000.0, 100.0) / (dd + 1e-6) ** 2)
+            near[b] |= bool((dd < 1.0).any())
+        rel[b] = abs(J - d["distance_cost"][b]) / max(1.0, abs(J))
+    assert near.sum() >= 100
+    assert rel[near].max() <= 2e-4 and rel[~near].max() <= 5e-5, (rel[near].max(), rel[~near].max())
+    # state, control and input-difference components of the archived agent are the live agent's statements with other
+    # constants; its collision component is commented out there (:204-208) and reads 0
+    assert not d["components"][:, 5].any()
