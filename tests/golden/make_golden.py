@@ -601,6 +601,102 @@ def ltv_reference_vectors():
     print("wrote ltv_reference_numpy.npz", {k: v.shape for k, v in out.items()})
 
 
+def ltv_reference_random_vectors(n=512):
+    """Round 4: >= 500 randomised cases for each numpy-only helper of the reference's iterative-linear agent
+    (agents/pure_mpc_linear.py: calc_nearest_index_in_direction :38-60, linear_model_matrix :62-82, predict_motion
+    :84-110), the per-stage models along nominal rollouts (what _linear_mpc_control linearises about, :222-228), and the
+    agent's own `_solve` / `_linear_mpc_control` statements (:153-257) evaluated numerically at given (x, u) with the cvxpy
+    stand-in of tests/golden/standins.py: objective value, equality residuals, inequality slacks."""
+    import contextlib
+    import io
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, HERE)
+    import standins
+    standins.install()
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from agents import pure_mpc_linear as RL
+    from mpc_rl_for_avs_amd import synth
+    from mpc_rl_for_avs_amd.reference_path import reference_states
+    ref = reference_states()
+    rng = np.random.default_rng(4321)
+    out = {}
+    # nearest index: parsed-observation positions, ties, far-away points
+    inp = synth.solver_inputs(n, 2, seed=19)
+    pos = inp["state"][:, :2].astype(np.float32).astype(np.float64)
+    pos[::17] += rng.uniform(-40.0, 40.0, (len(pos[::17]), 2))
+    pos[:3] = [[2.0, 30.5], [-20.5, float(ref[84, 1])], [2.0, 9.5]]           # exact ties between two path points
+    out["nearest_in"] = pos
+    out["nearest_out"] = np.array([RL.calc_nearest_index_in_direction(p[0], p[1], ref[:, 0], ref[:, 1], 0) for p in pos])
+    # linear model at random operating points
+    vb, yb = rng.uniform(0.0, 12.0, n), rng.uniform(-3.6, 3.6, n)
+    AB = [RL.linear_model_matrix(v, y, 0.0, 0.1, 2.5) for v, y in zip(vb, yb)]
+    assert not any(c.any() for _, _, c in AB)
+    out.update(linmodel_in=np.stack([vb, yb], axis=1), linmodel_A=np.stack([a for a, _, _ in AB]),
+               linmodel_B=np.stack([b for _, b, _ in AB]))
+    # nominal rollouts and the stage models along them
+    T = 20
+    x0 = np.stack([rng.uniform(-35.0, 5.0, n), rng.uniform(-5.0, 50.0, n), rng.uniform(0.0, 11.0, n),
+                   rng.uniform(-3.14, 3.14, n)], axis=1)
+    x0 = x0.astype(np.float32).astype(np.float64)               # what a parsed observation can hold
+    oa = rng.uniform(-5.0, 2.0, (n, T)) * np.where(np.arange(n) % 3 == 0, 3.0, 1.0)[:, None]
+    od = rng.uniform(-0.52, 0.52, (n, T))
+    oa[::8], od[::8] = 0.0, 0.0                                   # first calls: zero profile
+    xbar = np.stack([RL.predict_motion(x0[i], oa[i], od[i], 0.1, 2.5).T for i in range(n)])       # [n, T+1, 4]
+    out.update(nominal_x0=x0, nominal_oa=oa, nominal_od=od, nominal_xbar=xbar)
+    ns = 128
+    out["stage_A"] = np.stack([[RL.linear_model_matrix(xbar[i, t, 2], xbar[i, t, 3], 0.0, 0.1, 2.5)[0] for t in range(T)]
+                               for i in range(ns)])
+    out["stage_B"] = np.stack([[RL.linear_model_matrix(xbar[i, t, 2], xbar[i, t, 3], 0.0, 0.1, 2.5)[1] for t in range(T)]
+                               for i in range(ns)])
+    # the agent's own QP statements at given points
+    ag = RL.IterativeLinearMPC_Agent(_RefEnv, dict(horizon=T, render=False))
+    nq = 256
+    q_obs = synth.make_obs_batch(nq, 0, seed=77)
+    q_u = rng.uniform([-6.0, -0.6], [3.0, 0.6], (nq, T, 2))
+    q_x = np.zeros((nq, T + 1, 4))
+    q_cost, q_eq, q_le, q_xref, q_target = np.zeros(nq), [], [], np.zeros((nq, T + 1, 4)), np.zeros(nq, np.int32)
+    q_oa, q_od = oa[:nq].copy(), od[:nq].copy()
+    for i in range(nq):
+        ag._parse_obs(q_obs[i])
+        first = i % 8 == 0
+        ag.oa, ag.od = (None, None) if first else (q_oa[i].copy(), q_od[i].copy())
+        e = ag.ego_vehicle
+        xs = np.array([e.position[0], e.position[1], e.speed, e.heading], dtype=float)
+        xb = RL.predict_motion(xs, np.zeros(T) if first else q_oa[i], np.zeros(T) if first else q_od[i], 0.1, 2.5)
+        x = np.zeros((4, T + 1))
+        x[:, 0] = xs
+        for t in range(T):                                          # a point ON the linear dynamics: residuals vanish
+            A, B, C = RL.linear_model_matrix(xb[2, t], xb[3, t], 0.0, 0.1, 2.5)
+            x[:, t + 1] = A @ x[:, t] + B @ q_u[i, t] + C
+        if i % 5 == 4:
+            x[:, 1:] += rng.normal(0.0, 0.3, (4, T))                # ... and some off them
+        standins.POINT["cvx"] = [x.copy(), q_u[i].T.copy()]
+        standins.CAPTURED.clear()
+        got = {}
+        orig = ag._linear_mpc_control
+
+        def spy(xref, xbar_, x0_):
+            got["xref"], got["xbar"] = np.array(xref), np.array(xbar_)
+            return orig(xref, xbar_, x0_)
+        ag._linear_mpc_control = spy
+        with contextlib.redirect_stdout(io.StringIO()):
+            act = ag._solve()
+        ag._linear_mpc_control = orig
+        assert act.acceleration == 0.0 and act.steer == 0.0                      # the reference's "solver failed" exit
+        assert np.array_equal(got["xbar"], xb)
+        c = standins.CAPTURED
+        q_x[i], q_cost[i], q_xref[i], q_target[i] = x.T, c["cvx_cost"], got["xref"].T, ag.target_ind
+        q_eq.append(c["cvx_eq"])
+        q_le.append(c["cvx_le"])
+        if first:
+            q_oa[i], q_od[i] = 0.0, 0.0
+    out.update(qp_obs=q_obs, qp_oa=q_oa, qp_od=q_od, qp_x=q_x, qp_u=q_u, qp_cost=q_cost, qp_eq=np.array(q_eq),
+               qp_le=np.array(q_le), qp_xref=q_xref, qp_target=q_target)
+    np.savez_compressed(os.path.join(HERE, "ltv_reference_random.npz"), **out)
+    print("wrote ltv_reference_random.npz", {k: v.shape for k, v in out.items()})
+
+
 def ltv_oracle_vectors():
     import ltv_oracle as L
     from scipy.optimize import minimize
@@ -660,6 +756,7 @@ if __name__ == "__main__":
         reference_random_vectors()
         reference_sequences()
         reference_distance_cost()
+        ltv_reference_random_vectors()
         sys.exit(0)
     if "--oracle-only" not in sys.argv:      # the reference's own numpy code (needs /root/reference)
         reference_vectors()
@@ -667,6 +764,7 @@ if __name__ == "__main__":
         reference_random_vectors()
         reference_sequences()
         reference_distance_cost()
+        ltv_reference_random_vectors()
     if "--reference-only" not in sys.argv:
         oracle_vectors()
         ltv_oracle_vectors()

@@ -205,6 +205,85 @@ class LineString:
         return _Multi("GeometryCollection", geoms)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# cvxpy: the same idea as the casadi stand-in - a NUMERIC evaluator.  Variable((r, c)) holds the values the generator put
+# into POINT["cvx"] (in creation order); quad_form / abs / the operators evaluate with numpy; `==`, `<=`, `>=` return records
+# of the residual (equalities) or slack (inequalities, >= 0 when satisfied); Problem(...).solve() stores the objective value
+# and those records in CAPTURED and reports a status that makes the reference take its "solver failed" exit
+# (agents/pure_mpc_linear.py:260-262) - nothing is solved.  Pins: the QP of _linear_mpc_control (:205-257) at the points
+# evaluated.  Does not pin: ECOS.
+class CvxExpr:
+    __array_ufunc__ = None
+    __array_priority__ = 1000
+
+    def __init__(self, a):
+        self.a = np.asarray(a, dtype=np.float64)
+
+    @staticmethod
+    def v(o):
+        return o.a if isinstance(o, CvxExpr) else np.asarray(o, dtype=np.float64)
+
+    def __getitem__(self, idx):
+        return CvxExpr(self.a[idx])
+
+    def __add__(self, o):
+        return CvxExpr(self.a + CvxExpr.v(o))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return CvxExpr(self.a - CvxExpr.v(o))
+
+    def __rsub__(self, o):
+        return CvxExpr(CvxExpr.v(o) - self.a)
+
+    def __mul__(self, o):
+        return CvxExpr(self.a * CvxExpr.v(o))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return CvxExpr(-self.a)
+
+    def __matmul__(self, o):
+        return CvxExpr(self.a @ CvxExpr.v(o))
+
+    def __rmatmul__(self, o):
+        return CvxExpr(CvxExpr.v(o) @ self.a)
+
+    def __eq__(self, o):
+        return ("eq", np.ravel(self.a - CvxExpr.v(o)).copy())
+
+    def __le__(self, o):
+        return ("le", np.ravel(CvxExpr.v(o) - self.a).copy())
+
+    def __ge__(self, o):
+        return ("le", np.ravel(self.a - CvxExpr.v(o)).copy())
+
+    __hash__ = None
+
+
+class _CvxVariable(CvxExpr):
+    def __init__(self, shape):
+        vals = POINT["cvx"].pop(0)
+        assert vals.shape == tuple(shape), (vals.shape, shape)
+        super().__init__(vals.copy())
+        self.value = None
+
+
+class _CvxProblem:
+    def __init__(self, objective, constraints):
+        self.objective, self.constraints, self.status = objective, constraints, "not_solved"
+
+    def solve(self, **kw):
+        CAPTURED["cvx_cost"] = float(np.ravel(CvxExpr.v(self.objective))[0])
+        CAPTURED["cvx_eq"] = np.concatenate([r for k, r in self.constraints if k == "eq"])
+        CAPTURED["cvx_le"] = np.concatenate([r for k, r in self.constraints if k == "le"])
+        CAPTURED["cvx_solver"] = kw.get("solver")
+        self.status = "stand-in: nothing solved"
+        return None
+
+
 def install():
     """Put the stand-ins into sys.modules (only names that are really absent are replaced)."""
     for name in ("gymnasium", "casadi", "shapely", "shapely.errors", "matplotlib", "matplotlib.pyplot", "cvxpy"):
@@ -225,3 +304,10 @@ def install():
     ca.vertcat, ca.reshape, ca.if_else, ca.norm_2 = _vertcat, _reshape, _if_else, _norm_2
     ca.Function, ca.nlpsol = _Function, _Solver
     ca.pi, ca.inf = float(np.pi), float("inf")
+    cp = sys.modules["cvxpy"]
+    cp.Variable = _CvxVariable
+    cp.quad_form = lambda x, Q: CvxExpr(CvxExpr.v(x) @ np.asarray(Q, np.float64) @ CvxExpr.v(x))
+    cp.abs = lambda x: CvxExpr(np.abs(CvxExpr.v(x)))
+    cp.Minimize = lambda c: c
+    cp.Problem = _CvxProblem
+    cp.ECOS, cp.OPTIMAL, cp.OPTIMAL_INACCURATE = "ECOS", "optimal", "optimal_inaccurate"

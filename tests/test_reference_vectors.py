@@ -345,3 +345,56 @@ def test_oracle_distance_cost_equals_the_archived_agents(ref_table):
     # state, control and input-difference components of the archived agent are the live agent's statements with other
     # constants; its collision component is commented out there (:204-208) and reads 0
     assert not d["components"][:, 5].any()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# iterative-linear agent (agents/pure_mpc_linear.py)
+# ---------------------------------------------------------------------------------------------------------------
+def ltv_reference_slacks(u, x, dt=0.1):
+    """The inequality slacks in the order the reference appends its constraints (agents/pure_mpc_linear.py:232-255)."""
+    import ltv_oracle as L
+    T = u.shape[0]
+    s = [L.MAX_DSTEER * dt - abs(u[t + 1, 1] - u[t, 1]) for t in range(T - 1)]
+    for t in range(T):
+        s += [L.MAX_ACCEL - u[t, 0], u[t, 0] - L.MAX_DECEL, L.MAX_STEER - abs(u[t, 1])]
+    for t in range(T + 1):
+        s += [x[t, 2], L.MAX_SPEED - x[t, 2]]
+    return np.array(s)
+
+
+def test_ltv_oracle_equals_the_references_helpers_and_qp(ref_table):
+    import ltv_oracle as L
+    d = rf.load("ltv_reference_random.npz")
+    assert min(len(d["nearest_out"]), len(d["linmodel_A"]), len(d["nominal_xbar"])) >= 500 and len(d["qp_cost"]) >= 250
+    assert np.array_equal(L.nearest_index(d["nearest_in"][:, 0], d["nearest_in"][:, 1], ref_table), d["nearest_out"])
+    A, B = L.linear_model(d["linmodel_in"][:, 0], d["linmodel_in"][:, 1], 0.1)
+    assert np.array_equal(A, d["linmodel_A"]) and np.array_equal(B, d["linmodel_B"])
+    xbar = L.nominal_rollout(d["nominal_x0"], d["nominal_oa"], d["nominal_od"], 0.1)
+    assert np.abs(xbar - d["nominal_xbar"]).max() <= 1e-12          # math.cos / np.cos: last-bit differences at most
+    ns = len(d["stage_A"])
+    A, B = L.linear_model(d["nominal_xbar"][:ns, :20, 2], d["nominal_xbar"][:ns, :20, 3], 0.1)
+    assert np.array_equal(A, d["stage_A"]) and np.array_equal(B, d["stage_B"])
+    # the QP: objective and constraints of _linear_mpc_control, evaluated by the reference's own cvxpy statements
+    n_on = 0
+    for i in range(len(d["qp_cost"])):
+        o = d["qp_obs"][i, 0]
+        x0 = np.array([o[1], o[2], np.sqrt(o[3] * o[3] + o[4] * o[4]), o[5]], dtype=np.float64)   # make_obs_batch: |heading| <= pi
+        assert np.array_equal(x0, d["qp_x"][i, 0])
+        tgt = L.nearest_index(x0[:1], x0[1:2], ref_table)
+        assert tgt[0] == d["qp_target"][i]
+        assert np.array_equal(L.reference_window(ref_table, tgt, 20)[0], d["qp_xref"][i])
+        xb = L.nominal_rollout(x0[None], d["qp_oa"][i][None], d["qp_od"][i][None], 0.1)[0]
+        u, x = d["qp_u"][i], d["qp_x"][i]
+        on = np.abs(d["qp_eq"][i]).max() <= 1e-9                    # the point satisfies the reference's equalities
+        if on:
+            n_on += 1
+            assert np.abs(L.simulate_linear(x0, u, xb, 0.1) - x).max() <= 1e-9
+            f = L.objective_loops(u, x0, d["qp_xref"][i], xb, 0.1)
+            assert abs(f - d["qp_cost"][i]) <= 1e-10 * max(1.0, abs(f))
+            want = ltv_reference_slacks(u, L.simulate_linear(x0, u, xb, 0.1))
+            assert np.abs(want - d["qp_le"][i]).max() <= 1e-9
+            c = L.constraint_loops(u, x0, xb, 0.1)                  # the oracle's own row order: same feasible set
+            assert (c.min() >= 0) == (d["qp_le"][i].min() >= 0) or abs(c.min()) < 1e-9
+        else:
+            assert np.abs(ltv_reference_slacks(u, x) - d["qp_le"][i]).max() <= 1e-12
+    assert n_on >= 150
