@@ -249,14 +249,22 @@ def main():
     elapsed = time.perf_counter() - t0
     dist_info = None
     if use_dist:
-        assert gathered.shape == (world * BATCH, 2) and gathered_st.shape == (world * BATCH,)
+        if tuple(gathered.shape) != (world * BATCH, 2) or tuple(gathered_st.shape) != (world * BATCH,):
+            raise SystemExit(f"bench.py: rank {rank}: gathered actions {tuple(gathered.shape)} / status {tuple(gathered_st.shape)}, "
+                             f"expected ({world * BATCH}, 2) / ({world * BATCH},) for {world} ranks")
         lo = rank * BATCH
         last = outs_s[(a.steps - 1) % n_str]
+        # rank -> physical device: every rank must drive its own GPU (a 1-rank rehearsal has nothing to compare)
+        ids = sharding.rank_devices(dev)
+        try:
+            n_distinct = sharding.assert_distinct_devices(ids)
+        except RuntimeError as e:
+            raise SystemExit(f"bench.py: {e}")
         dist_info = {"backend": dist.get_backend(), "world_size": world, "gathered_actions_shape": list(gathered.shape),
                      "gathered_status_shape": list(gathered_st.shape),
                      "own_block_equals_local": bool(torch.equal(gathered[lo:lo + BATCH], last["u0"]) and
                                                     torch.equal(gathered_st[lo:lo + BATCH], last["status"])),
-                     "bytes_per_rank_per_step": BATCH * 24}
+                     "bytes_per_rank_per_step": BATCH * 24, "rank_devices": ids, "distinct_devices": n_distinct}
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -391,7 +399,7 @@ def side_measurements(a, eng, args, inp, out, dev):
     the iterative-linear QP.  Medians of event-timed repetitions."""
     import numpy as np
     import torch
-    from mpc_rl_for_avs_amd import engine
+    from mpc_rl_for_avs_amd import engine, synth
     res = {}
 
     def timed(fn, reps=7):
@@ -423,6 +431,70 @@ def side_measurements(a, eng, args, inp, out, dev):
                      "iters_p99": float(np.percentile(it2, 99)), "iters_max": int(it2.max())}
         e2.close()
     res["solver_settings_sweep"] = caps
+    # the headline over seeds 0-2 (the batch time is that of its slowest instance: it moves with the draw)
+    per_seed = []
+    for sd in (0, 1, 2):
+        inp_s = synth.solver_inputs(BATCH, V, seed=sd, N=HORIZON)
+        t_ = lambda x, dt_: torch.as_tensor(np.ascontiguousarray(x), dtype=dt_, device=dev)
+        a_s = dict(state=t_(inp_s["state"], torch.float64), ego_index=t_(inp_s["ego_index"], torch.int32),
+                   weights=t_(inp_s["weights"], torch.float64), is_collide=t_(inp_s["is_collide"], torch.uint8),
+                   vref=t_(inp_s["vref"], torch.float64), others=t_(inp_s["others"], torch.float64), collision_cost=True)
+        o_s = eng.solve_batch_torch(**a_s, sync=True)
+        ms = timed(lambda: eng.solve_batch_torch(**a_s, out=o_s), reps=9)
+        st_s, it_s = o_s["status"].cpu().numpy(), o_s["iters"].cpu().numpy()
+        per_seed.append({"seed": sd, "ms": ms, "converged_frac": float(conv_mask(st_s).mean()), "iters_max": int(it_s.max()),
+                         "value": BATCH * float(conv_mask(st_s).mean()) / (ms * 1e-3)})
+    mss = sorted(r["ms"] for r in per_seed)
+    res["headline_over_seeds"] = {"per_seed": per_seed, "ms_min": mss[0], "ms_median": mss[1], "ms_max": mss[2],
+                                  "value_min": min(r["value"] for r in per_seed), "value_median": sorted(r["value"] for r in per_seed)[1],
+                                  "value_max": max(r["value"] for r in per_seed), "unit": "solves/s",
+                                  "note": "config 3 at cap 100, median of 9 event-timed launches per seed; `value` above is seed 0"}
+    # BASELINE configs[1]: batch=1024, horizon 20, 4 other vehicles, the LIVE objective (agents/pure_mpc.py:204-212: others
+    # matter only through the detector), one GPU
+    inp2 = synth.solver_inputs(1024, 4, seed=0, N=HORIZON)
+    t_ = lambda x, dt_: torch.as_tensor(np.ascontiguousarray(x), dtype=dt_, device=dev)
+    a2 = dict(state=t_(inp2["state"], torch.float64), ego_index=t_(inp2["ego_index"], torch.int32),
+              weights=t_(inp2["weights"], torch.float64), is_collide=t_(inp2["is_collide"], torch.uint8),
+              vref=t_(inp2["vref"], torch.float64), others=None, collision_cost=False)
+    o2 = eng.solve_batch_torch(**a2, sync=True)
+    ms = timed(lambda: eng.solve_batch_torch(**a2, out=o2), reps=15)
+    st2, it2 = o2["status"].cpu().numpy(), o2["iters"].cpu().numpy()
+    res["config2"] = {"workload": "BASELINE configs[1]: batch=1024 pure_mpc horizon=20, 4 other vehicles, live objective, cold "
+                                  f"start, tol 1e-8, max_iter {MAX_ITER}", "ms": ms, "value": 1024 * float(conv_mask(st2).mean()) / (ms * 1e-3),
+                      "unit": "solves/s", "converged_frac": float(conv_mask(st2).mean()), "iters_mean": float(it2.mean()),
+                      "iters_max": int(it2.max())}
+    # BASELINE configs[3]: 256 parallel intersection environments, MPC-in-the-loop rollout (policy -> clip -> mpc_predict_batch
+    # -> environment step -> buffer row; agents/ppo_mpc.py:385-469), v0 = the RL action is the reference speed
+    from mpc_rl_for_avs_amd import rollout
+    torch.manual_seed(1234)
+    pol = rollout.ActorCritic(1).to(dev)
+    e4 = engine.MPCEngine(horizon=HORIZON, max_iter=MAX_ITER, device=dev.index)
+    env4 = rollout.SyntheticIntersectionEnv(256, device=dev, seed=0, n_others=4)
+    col4 = rollout.BatchedCollector(env4, pol, e4, version="v0", algorithm="ppo", n_steps=64, collision_cost=False, seed=0)
+    col4.collect_rollouts()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    st4 = col4.collect_rollouts()
+    torch.cuda.synchronize()
+    dt4 = time.perf_counter() - t1
+    s4 = col4.last_mpc["status"].cpu().numpy()
+    res["config4"] = {"workload": "BASELINE configs[3]: ppo_mpc 256 parallel intersection envs (synthetic stand-in for highway-env), "
+                                  "MPC-in-the-loop rollout of 64 steps, 4 other vehicles, v0, untrained seeded policy, hipGraph step",
+                      "value": 256 * 64 / dt4, "unit": "env-steps/s", "ms_per_step": dt4 / 64 * 1e3,
+                      "converged_frac_last_step": float(conv_mask(s4).mean()), "episodes": st4["episodes"],
+                      "mpc_unconverged_in_rollout": int(st4.get("mpc_unconverged", -1))}
+    e4.close()
+    # BASELINE configs[0] / the reference's own caller shape (main/run_pure_mpc.py:27): ONE environment, predict() per step,
+    # closed loop on the synthetic environment; wall time of the call as Python sees it (H2D of the observation, preamble and
+    # solve kernels, D2H of the action, read-back of the detector record)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import run_pure_mpc
+    outcome, log, lat_ms = run_pure_mpc.run(steps=150, n_others=1, seed=0, verbose=False)
+    res["predict_b1"] = {"workload": "BASELINE configs[0]: single ego, horizon 20, 1 other vehicle, closed loop (tools/run_pure_mpc.py), "
+                                     "PureMPC_Agent.predict() per step", "ms_median": float(np.median(lat_ms)),
+                         "ms_p95": float(np.percentile(lat_ms, 95)), "steps": len(log), "outcome": outcome,
+                         "converged_frac": float(np.mean([r[6] in (0, 5) for r in log])), "unit": "ms per predict() call",
+                         "calls_per_s": 1e3 / float(np.median(lat_ms))}
     # batches in flight: the straggler tail of one batch overlaps with the bulk of the next ones (same kernel, same inputs,
     # identical outputs) - what a serving loop with several independent environment groups would run
     n_fl = 6
@@ -456,7 +528,6 @@ def side_measurements(a, eng, args, inp, out, dev):
     res["pcie_inclusive"] = {"ms": ms, "value": BATCH / (ms * 1e-3), "unit": "solves/s",
                              "note": "mpc_solve_batch with host pointers, wall time of the synchronous call"}
     # observation-level call (device preamble + solve, per-environment detector state): fresh handle, first step of an episode
-    from mpc_rl_for_avs_amd import synth
     obs = torch.as_tensor(synth.make_obs_batch(BATCH, V, seed=0), device=dev)
     w = args["weights"]
     e3 = engine.MPCEngine(horizon=HORIZON, max_iter=MAX_ITER, device=dev.index)

@@ -284,7 +284,7 @@ class MPCEngine:
         return dict(act=act, status=status, iters=iters)
 
     def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False,
-                            warm_start=False):
+                            warm_start=False, throughput=False):
         """Zero-copy variant on torch device tensors (obs float32 [B, R, 8], weights float64 [B, 3], ref_speed float64
         [B] or None), enqueued on torch's current stream.  Returns dict(act, status, iters) of device tensors."""
         import torch
@@ -303,7 +303,7 @@ class MPCEngine:
                        status=torch.empty(B, dtype=torch.int32, device=dev),
                        iters=torch.empty(B, dtype=torch.int32, device=dev))
         flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC) | \
-            (FLAG_WARM_START if warm_start else 0)
+            (FLAG_WARM_START if warm_start else 0) | (FLAG_THROUGHPUT if throughput else 0)   # several groups in flight
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = self._lib.mpc_predict_batch(self._h, B, p(obs), rows, p(weights), p(ref_speed), flags, p(out["act"]),

@@ -83,8 +83,24 @@ class PureMPC_Agent:
 
     weight_components = ["speed", "control", "input_diff"]   # agents/pure_mpc.py:15-22
 
+    # the solver options the reference passes to IPOPT (agents/pure_mpc.py:291-296; read back from its own `opts` dict by
+    # tests/golden/make_golden.py: reference_sequences.npz seq_ipopt_max_iter / seq_ipopt_tol)
+    REFERENCE_MAX_ITER = 1000
+    REFERENCE_TOL = 1e-6
+
     def __init__(self, env, cfg: dict, engine: MPCEngine | None = None, collision_cost: bool = False,
-                 device: int = 0, max_iter: int = 100, tol: float = 1e-8, warm_start: bool = False) -> None:
+                 device: int = 0, max_iter: int = 100, tol: float = 1e-8, warm_start: bool = False,
+                 reference_settings: bool = False, stall_window: int = 0) -> None:
+        """reference_settings=True: `ipopt.max_iter 1000`, `ipopt.tol 1e-6` as in agents/pure_mpc.py:294-295 instead of the
+        engine's defaults (100 iterations, tol 1e-8 - a tighter tolerance under a latency budget: a batched call lasts as
+        long as its slowest instance, and an instance at the cap returns its last iterate like the reference's failed
+        solve does, :303-305).  stall_window (not an IPOPT option, off by default, include/mpc_mi355x.h): ends solves whose
+        KKT error has stopped halving, which is what keeps a max_iter-1000 batch from waiting for the one instance in a
+        thousand that never converges."""
+        if reference_settings:
+            max_iter, tol = PureMPC_Agent.REFERENCE_MAX_ITER, PureMPC_Agent.REFERENCE_TOL
+        self.solver_settings = dict(max_iter=int(max_iter), tol=float(tol), stall_window=int(stall_window),
+                                    reference_settings=bool(reference_settings))
         # agents/base_agent.py:28-49
         self.env = env.unwrapped if hasattr(env, "unwrapped") else env
         self.env_config = self.env.config
@@ -108,7 +124,7 @@ class PureMPC_Agent:
         self.collision_cost = bool(collision_cost)
         self.warm_start = bool(warm_start)       # not in the reference, which always starts cold
         self._engine = engine if engine is not None else MPCEngine(
-            horizon=self.horizon, dt=self.dt, max_iter=max_iter, tol=tol,
+            horizon=self.horizon, dt=self.dt, max_iter=max_iter, tol=tol, stall_window=stall_window,
             w_distance=float(self.config.get("weight_distance", 10.0)),
             w_collision=float(self.config.get("weight_collision", 1.0)), device=device,
             ref_table=self.global_reference_states)

@@ -58,6 +58,10 @@ class SyntheticIntersectionEnv:
         assert 0 <= n_others <= VEHICLES_COUNT - 1
         self.num_envs, self.K, self.dt = int(num_envs), int(n_others), float(dt)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            # an indexed device, resolved once: the fused step hands the ordinal to hipSetDevice, and "cuda" without an index
+            # means the CURRENT device (torch.cuda.set_device(local_rank) under torchrun), not device 0
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.spawn_probability = float(spawn_probability)
         if backend not in ("auto", "hip", "torch"):
             raise ValueError("backend must be auto|hip|torch")
@@ -96,7 +100,7 @@ class SyntheticIntersectionEnv:
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         rc = self._lib.mpc_synth_env_step(
-            self.device.index or 0, self.num_envs, self.K, self.dt, self.spawn_probability, self.seed, self.env_offset,
+            self.device.index, self.num_envs, self.K, self.dt, self.spawn_probability, self.seed, self.env_offset,
             p(self.ref_xy), self.M, p(action), p(self.ego), p(self.opos), p(self.ospeed), p(self.ohead), p(self.oactive),
             p(self.t), p(self.rng_counter), p(o["obs"]), p(o["terminal_obs"]), p(o["reward"]), p(o["done"]),
             p(o["truncated"]), p(o["crashed"]), p(o["arrived"]), 1 if reset_all else 0, stream)
@@ -403,7 +407,7 @@ class BatchedCollector:
                  n_steps: int = 64, gamma: float = 0.99, gae_lambda: float = 0.95,
                  default_weights=(1.0, 1.0, 1.0), collision_cost: bool = False, reset_mpc_on_done: bool = False,
                  gather_actions: bool = False, seed: int = 0, warm_start: bool = False,
-                 use_graph: bool | None = None):
+                 use_graph: bool | None = None, throughput: bool = False):
         if version not in ("v0", "v1") or algorithm not in ("ppo", "a2c"):
             raise ValueError("version must be v0|v1 and algorithm ppo|a2c")
         if version == "v1" and policy.action_dim < 3:
@@ -412,6 +416,9 @@ class BatchedCollector:
         self.version, self.algorithm = version, algorithm
         self.collision_cost, self.reset_mpc_on_done, self.gather_actions = collision_cost, reset_mpc_on_done, gather_actions
         self.warm_start = bool(warm_start)
+        # several collectors stepping on their own streams (PipelinedCollector): MPC_FLAG_THROUGHPUT, the build of the solve
+        # kernel for four resident waves per SIMD whatever this group's batch size (include/mpc_mi355x.h)
+        self._mpc_kw = dict(throughput=True) if throughput else {}
         dev = env.device
         B = env.num_envs
         self.buffer = RolloutBuffer(n_steps, B, policy.action_dim, dev, gamma, gae_lambda, keep_terminal=algorithm == "ppo")
@@ -466,7 +473,7 @@ class BatchedCollector:
         actions, values, log_probs = self.policy.act(obs, generator=self.gen)
         weights, ref_speed = self.mpc_inputs(actions)
         self._mpc_out = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
-                                                        warm_start=self.warm_start, out=self._mpc_out)
+                                                        warm_start=self.warm_start, out=self._mpc_out, **self._mpc_kw)
         self.last_mpc = self._mpc_out
         mpc_action = self.last_mpc["act"]
         if self.gather_actions:
@@ -501,8 +508,20 @@ class BatchedCollector:
         writes across steps lives at a fixed address (environment state, last observation, buffer, counters); the buffer
         row comes from a device-side counter; both random generators are registered with the graph."""
         dev = self.env.device
+        env, B = self.env, self.env.num_envs
         if hasattr(self.engine, "reserve_envs"):     # the handle's per-environment buffers must not grow inside the capture
-            self.engine.reserve_envs(self.env.num_envs)
+            self.engine.reserve_envs(B)
+        # The warm-up and capture steps below really step the environment and the detector.  Everything they touch is
+        # snapshotted here and put back afterwards, so that building the collector changes nothing the caller can see:
+        # episodes, random streams (both generators, the fused environment's counters), the observation, and the engine's
+        # detector records - including records a caller restored with mpc_set_env_state before building the collector
+        # (resume).  A graph collector and an eager one with the same seeds therefore produce the same rollouts
+        # (tests/test_predict_gpu.py::test_graph_and_eager_collectors_produce_the_same_rollout).
+        names = [n for n in ("ego", "opos", "ospeed", "ohead", "oactive", "t", "rng_counter") if hasattr(env, n)]
+        snap = {n: getattr(env, n).clone() for n in names}
+        snap_obs, snap_starts = self._last_obs.clone(), self._last_episode_starts.clone()
+        gen_states = [self.gen.get_state(), env.gen.get_state()]
+        records = self.engine.save_env_state(B) if hasattr(self.engine, "save_env_state") else None
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -516,13 +535,16 @@ class BatchedCollector:
         with torch.cuda.graph(g, stream=side):
             self._rollout_step(device_pos=True)
         self._graph = g
+        torch.cuda.synchronize(dev)
         self.buffer.reset()
-        # the warm-up steps must leave no trace: fresh episodes, fresh detector records and warm-start memory in the engine
-        # (an eager collector starts from exactly this state)
-        if hasattr(self.engine, "reset_env_state"):
-            self.engine.reset_env_state()
-        self._last_obs.copy_(self.env.reset())
-        self._last_episode_starts.fill_(1.0)
+        for n in names:                               # in place: the graph replays against these addresses
+            getattr(env, n).copy_(snap[n])
+        self._last_obs.copy_(snap_obs)
+        self._last_episode_starts.copy_(snap_starts)
+        self.gen.set_state(gen_states[0])
+        env.gen.set_state(gen_states[1])
+        if records is not None:
+            self.engine.load_env_state(records)       # also forgets the warm-start memory the warm-up steps left
         self._roll["counts"].zero_()
         self._roll["dones"].zero_()
 

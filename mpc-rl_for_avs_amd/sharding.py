@@ -55,3 +55,35 @@ def all_gather_ragged(local_u0, total: int, group=None):
         parts.append(full[r * width: r * width + (hi - lo)])
     del rank
     return torch.cat(parts, dim=0)
+
+
+def rank_devices(device, group=None):
+    """Which physical device every rank of the job drives: one dict per rank (rank, local_rank, device, pci, uuid, key),
+    gathered with one object collective at start-up.  `key` identifies the hardware - PCI bus id + UUID of a GPU, which
+    HIP_VISIBLE_DEVICES cannot alias; host name + process id for a CPU rank of the gloo tests."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    device = torch.device(device)
+    me = {"rank": dist.get_rank(group), "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": str(device)}
+    if device.type == "cuda":
+        prop = torch.cuda.get_device_properties(device)
+        me["pci"] = (f"{getattr(prop, 'pci_domain_id', 0):04x}:{getattr(prop, 'pci_bus_id', -1):02x}:"
+                     f"{getattr(prop, 'pci_device_id', -1):02x}")
+        me["uuid"] = str(getattr(prop, "uuid", ""))
+        me["key"] = f"{socket.gethostname()}/{me['pci']}/{me['uuid']}"
+    else:
+        me["pci"], me["uuid"] = None, None
+        me["key"] = f"{socket.gethostname()}/cpu/{os.getpid()}"
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, me, group=group)
+    return out
+
+
+def assert_distinct_devices(ids):
+    """One process per GPU: two ranks on one device would halve what a scaling run measures without failing."""
+    keys = {d["key"] for d in ids}
+    if len(keys) != len(ids):
+        raise RuntimeError(f"{len(ids)} ranks drive {len(keys)} distinct devices: {ids}")
+    return len(keys)

@@ -162,3 +162,49 @@ def converged(status):
 def rel_u0_err(got, want):
     """max-norm error of the returned action relative to max(1, |u0_ref|_inf)  (BASELINE.md accuracy metric)."""
     return np.abs(got - want).max(axis=1) / np.maximum(1.0, np.abs(want).max(axis=1))
+
+
+def unexplained_disagreements(oracle, ref_table, inp, cc, got, want, tol=1e-4, tries=48, **oracle_kw):
+    """The exact gate of the engine-vs-oracle comparisons: instances both sides call converged whose first control differs
+    by more than `tol` and for which that is NOT explained.  Explained means all of
+      (i)  both points are KKT points of the reference NLP by the solver-independent certificate (oracle/kkt_batch.py) -
+           two local minimisers of a non-convex programme, and
+      (ii) the instance is last-bit chaotic for the ORACLE ITSELF: moving the ego state by one or two units in the last
+           place makes the oracle's own answer jump by more than `tol` in at least one of `tries` draws - no two
+           implementations of any algorithm can be expected to agree on such an instance.
+    Kernel and oracle are different programmes for the same algorithm (matrix-core 4x4x4 products, DPP reductions,
+    compiler-contracted multiply-adds, hardware reciprocals on one side; dense loops and libm on the other), so their
+    iterates differ from the first iteration on in the last bits; what the tests require is that this NEVER shows in the
+    action unless (i) and (ii) hold.  Returns the list of unexplained instance indices (the tests assert it is empty)."""
+    import kkt_batch as kb
+    import nlp_batch as nb
+    both = converged(got["status"]) & converged(want["status"])
+    err = rel_u0_err(got["u0"], want["u0"])
+    far = np.nonzero(both & (err > tol))[0]
+    bad = []
+    for b in far:
+        one = {k: (None if inp.get(k) is None else np.ascontiguousarray(inp[k][b:b + 1]))
+               for k in ("state", "ego_index", "weights", "is_collide", "vref", "others")}
+        p = nb.Batch.build(ref_table, one["state"], one["ego_index"], one["weights"], one["is_collide"], vref=one["vref"],
+                           others=one["others"] if cc else None, collision_cost=cc, N=got["U"].shape[1])
+        eps = 1e-8 / kb.objective_scale(p)
+        ok = True
+        for sol in (got, want):
+            c = kb.certify(p, sol["X"][b:b + 1], sol["U"][b:b + 1], eps_c=eps)
+            ok = ok and c["stationarity"].max() <= 1e-8 and c["feasibility"].max() <= 1e-10
+        chaotic = False
+        rng = np.random.default_rng(1000 + int(b))
+        for _ in range(tries if ok else 0):
+            d = rng.integers(-2, 3, one["state"].shape)
+            st = one["state"].copy()
+            for _k in range(2):
+                st = np.where(d > _k, np.nextafter(st, np.inf), np.where(d < -_k, np.nextafter(st, -np.inf), st))
+            r = oracle.solve_batch(ref_table, st, one["ego_index"], one["weights"], one["is_collide"], vref=one["vref"],
+                                   others=one["others"] if cc else None, collision_cost=cc, xy_bounds=False,
+                                   N=got["U"].shape[1], **oracle_kw)
+            if converged(r["status"])[0] and rel_u0_err(r["u0"], want["u0"][b:b + 1])[0] > tol:
+                chaotic = True
+                break
+        if not (ok and chaotic):
+            bad.append(int(b))
+    return bad

@@ -14,11 +14,16 @@ driving mpc-rl_for_avs_amd/rollout.SyntheticIntersectionEnv):
          untrained policy, clipped to [-1, 1] like agents/ppo_mpc.py:399-407)
   c4mpc  the same environments driven by the MPC alone (no RL override): the speeds / crossings of a trained agent
   c4cc   c4mpc with the collision-cost term on
+  c4v1   the v1 INPUT DOMAIN (round 4): the same environments with the RL action = the three cost weights, clipped to
+         [-1, 1] as PPO's Box(-1, 1) action space makes them (agents/ppo_mpc.py:399-407, 416-420) - i.e. NEGATIVE cost weights
+         half of the time: drawn uniformly from [-1, 1]^3 per environment and step, every fifth environment all-negative
 Every step's problem data (state, ego_index, vref, weights, is_collide, others) is one instance.  A seeded subsample
 keeps the file small.  Stored per scenario: the problem data, `u0/U/X/status/iters/kkt` of the independent solver, and
 `oracle_u0/oracle_status/oracle_iters` of oracle/mpc_oracle.c (tol 1e-8) for the classification in
 tools/parity_vs_ipopt.py.  status of the independent solver: 0 converged, 1 iteration limit, 2 inertia correction
-failed, 5 step below alpha_min (IPOPT would enter its restoration phase, which is not restated).
+failed, 5 restoration failed, 6 restoration converged to a point of local infeasibility (round 4: IPOPT's restoration
+phase IS restated, oracle/ipopt_restated.py; until round 3 status 5 meant "would enter restoration").  Also stored:
+`n_resto`, the number of restoration phases the solve went through.
 """
 import os
 import sys
@@ -45,7 +50,7 @@ from host_preamble import HostPreambleAgent  # noqa: E402
 REF = reference_states(0.1)
 CFG = dict(horizon=20, render=False, ttc_threshold=3, weight_speed=1, weight_control=1, weight_input_diff=1,
            speed_override=0, weight_distance=10.0, weight_collision=1.0)
-KEEP = {"c1": 160, "c1cc": 160, "c4": 160, "c4mpc": 160, "c4cc": 160}
+KEEP = {"c1": 160, "c1cc": 160, "c4": 160, "c4mpc": 160, "c4cc": 160, "c4v1": 160}
 
 
 class Env:
@@ -71,6 +76,7 @@ def record(n_env, n_others, steps, cc, mode, seed):
     agent = HostPreambleAgent(Env, dict(CFG), engine=OracleEngine(), collision_cost=cc)
     pol = rollout.ActorCritic(1)
     gen = torch.Generator().manual_seed(seed)
+    wrng = np.random.default_rng(1000 + seed)
     obs = env.reset()
     rows = []
     for _ in range(steps):
@@ -80,7 +86,11 @@ def record(n_env, n_others, steps, cc, mode, seed):
             with torch.no_grad():
                 a, _, _ = pol(obs, generator=gen)
             rs = torch.clamp(a, -1.0, 1.0)[:, :1].to(torch.float64).numpy()
-        act = agent.predict_batch_host(o, None, rs)
+        w = None
+        if mode == "v1":
+            w = wrng.uniform(-1.0, 1.0, (n_env, 3))
+            w[::5] = -np.abs(w[::5])
+        act = agent.predict_batch_host(o, w, rs)
         inp = agent.last_inputs
         oth = np.zeros((n_env, n_others, 4))
         oth[:, :, :2] = 1e6                       # absent vehicles are parked far away, as the host mirror does
@@ -109,6 +119,8 @@ def scenario(name):
         return record(48, 4, 16, False, "mpc", seed=8)
     if name == "c4cc":
         return record(48, 4, 16, True, "mpc", seed=9)
+    if name == "c4v1":
+        return record(48, 4, 16, False, "v1", seed=10)
     raise KeyError(name)
 
 
@@ -123,7 +135,7 @@ def _one(args):
     p = nb.Batch.build(REF, d["state"][b:b + 1], d["ego_index"][b:b + 1], d["weights"][b:b + 1], d["is_collide"][b:b + 1],
                        vref=d["vref"][b:b + 1], others=d["others"][b:b + 1], collision_cost=cc)
     r = ipr.solve(p, tol=1e-6, max_iter=1000, sf_min=1e-2)          # the reference's settings, pure_mpc.py:294-295
-    return r["U"], r["X"], r["status"], r["iters"], r["kkt"]
+    return r["U"], r["X"], r["status"], r["iters"], r["kkt"], r["n_resto"]
 
 
 def main():
@@ -146,6 +158,7 @@ def main():
         out[f"{name}_status"] = np.array([np.ravel(r[2])[0] for r in res], dtype=np.int32)
         out[f"{name}_iters"] = np.array([np.ravel(r[3])[0] for r in res], dtype=np.int32)
         out[f"{name}_kkt"] = np.array([np.ravel(r[4])[0] for r in res])
+        out[f"{name}_n_resto"] = np.array([int(r[5]) for r in res], dtype=np.int32)
         out[f"{name}_oracle_u0"] = orc["u0"]
         out[f"{name}_oracle_status"] = orc["status"]
         out[f"{name}_oracle_iters"] = orc["iters"]
@@ -153,7 +166,7 @@ def main():
         ok = (st == 0) & ((orc["status"] == 0) | (orc["status"] == 5))
         err = np.abs(orc["u0"] - out[f"{name}_u0"]).max(axis=1) / np.maximum(1.0, np.abs(out[f"{name}_u0"]).max(axis=1))
         print(f"{name}: {len(rows)} recorded, {len(sel)} kept; independent solver status histogram "
-              f"{np.bincount(st, minlength=6).tolist()}, iterations mean {out[f'{name}_iters'].mean():.1f} max "
+              f"{np.bincount(st, minlength=7).tolist()}, went through restoration {int((out[f'{name}_n_resto'] > 0).sum())}, iterations mean {out[f'{name}_iters'].mean():.1f} max "
               f"{out[f'{name}_iters'].max()}; oracle status {np.bincount(orc['status'], minlength=6).tolist()}; both converged "
               f"{int(ok.sum())}, of those within 1e-4: {int((err[ok] <= 1e-4).sum())}, max {err[ok].max():.2e}", flush=True)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "closed_loop_ipopt.npz"), **out)

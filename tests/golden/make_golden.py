@@ -736,7 +736,8 @@ def oracle_vectors():
     for name, V, cc, seed in (("cfg2", 4, False, 101), ("cfg3", 8, True, 202)):
         inp = synth.solver_inputs(32, V, seed=seed)
         sol = oracle_lib.solve_batch(ref, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
-                                     vref=inp["vref"], others=inp["others"], collision_cost=cc, max_iter=100)
+                                     vref=inp["vref"], others=inp["others"], collision_cost=cc, max_iter=100,
+                                     xy_bounds=False)       # what the engine solves (the |x|, |y| <= 500 bounds never bind)
         p = nb.Batch.build(ref, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
                            others=inp["others"], collision_cost=cc)
         cert = kb.certify(p, sol["X"], sol["U"])

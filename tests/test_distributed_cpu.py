@@ -28,6 +28,14 @@ def _worker(rank, world, port, total, q):
                                  inp["weights"][lo:hi], inp["is_collide"][lo:hi], vref=inp["vref"][lo:hi],
                                  max_iter=60, nthreads=1)
     full = sharding.all_gather_ragged(torch.from_numpy(out["u0"]), total)
+    ids = sharding.rank_devices("cpu")                    # what bench.py reports as distributed.rank_devices
+    assert sharding.assert_distinct_devices(ids) == world
+    assert [d["rank"] for d in ids] == list(range(world)) and all(set(d) >= {"rank", "local_rank", "device", "pci", "uuid", "key"} for d in ids)
+    try:
+        sharding.assert_distinct_devices([ids[0], ids[0]])
+        raise AssertionError("two ranks on one device must be refused")
+    except RuntimeError:
+        pass
     q.put((rank, full.numpy()))
     dist.barrier()
     dist.destroy_process_group()

@@ -82,7 +82,7 @@ def test_golden_solutions_reproduce(oracle, ref_table):
     for name, cc in (("cfg2", False), ("cfg3", True)):
         out = _solve(oracle, ref_table, state=g[f"{name}_state"], ego_index=g[f"{name}_ego_index"],
                      weights=g[f"{name}_weights"], is_collide=g[f"{name}_is_collide"], vref=g[f"{name}_vref"],
-                     others=g[f"{name}_others"], collision_cost=cc, max_iter=100)
+                     others=g[f"{name}_others"], collision_cost=cc, max_iter=100, xy_bounds=False)
         ok = g[f"{name}_status"] == 0
         assert np.array_equal(out["status"] == 0, ok)
         assert rel_u0_err(out["u0"], g[f"{name}_u0"])[ok].max() < 1e-9

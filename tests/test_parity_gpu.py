@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, converged, rel_u0_err
+from conftest import GOLDEN, converged, rel_u0_err, unexplained_disagreements
 
 pytestmark = pytest.mark.gpu
 
@@ -42,14 +42,15 @@ def test_engine_matches_oracle(eng, oracle, ref_table, B, V, cc, seed):
     want = _oracle(oracle, ref_table, inp, cc)
     got = _gpu(eng, inp, cc)
     both = converged(got["status"]) & converged(want["status"])
-    # measured (round 3, all three builds of the kernel): 99.2 - 100 % converge within 100 iterations, statuses equal on
-    # >= 99.8 %, iteration counts equal on >= 99.6 %, and of the 2638 instances of the four cases at most ONE is beyond 1e-4
-    # (an instance whose iterates are chaotic in the last bit ends in another minimiser when the compiler contracts one
-    # multiply-add differently than the oracle's libm build; which instance it is changes from build to build)
+    # measured (rounds 3 and 4, all three builds of the kernel): 99.2 - 100 % converge within 100 iterations, statuses equal
+    # on >= 99.8 %, iteration counts equal on >= 99.6 %.  The action gate is EXACT: no instance beyond 1e-4 unless it is
+    # proven to be two certified minimisers of an instance on which the oracle itself is last-bit chaotic
+    # (conftest.unexplained_disagreements; round 4 measured 0 such instances in 18 432 on three seeds,
+    # profiles/r04_bitcompare.txt)
     assert both.mean() >= 0.99
     assert (got["status"] == want["status"]).mean() >= 0.995
     err = rel_u0_err(got["u0"], want["u0"])[both]
-    assert (err > TOL).sum() <= 1, f"{(err > TOL).sum()} of {both.sum()} instances beyond {TOL}"
+    assert unexplained_disagreements(oracle, ref_table, inp, cc, got, want, TOL, max_iter=100) == []
     assert np.percentile(err, 99) < 1e-8
     assert (got["iters"] == want["iters"])[both].mean() > 0.99
     # full trajectories of the agreeing instances
@@ -89,22 +90,14 @@ def test_golden_fixtures(eng):
     for name, cc in (("cfg2", False), ("cfg3", True)):
         inp = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
         got = _gpu(eng, inp, cc)
-        ok = (g[f"{name}_status"] == 0) & (got["status"] == 0)
-        assert ok.sum() >= 0.9 * (g[f"{name}_status"] == 0).sum()
-        # the fixture is the oracle WITH the |x|, |y| <= 500 bounds of the reference (never active, but their barrier terms
-        # move the iterates in the last digits): an instance whose path is chaotic in the last bit may end in another
-        # minimiser than the engine, which drops those bounds - at most 2 of the 32, and then a certified KKT point
+        assert np.array_equal(got["status"], g[f"{name}_status"]), name        # all 32, incl. the one status-5 instance
+        ok = converged(g[f"{name}_status"])
+        assert ok.sum() >= 31
+        # the fixture is the oracle solving what the engine solves (xy_bounds=False: the never-active |x|, |y| <= 500 bounds
+        # of agents/pure_mpc.py:272-274 carry no barrier terms, tests/test_oracle.py::test_xy_bounds_never_matter): every one
+        # of the 32 instances per configuration to 1e-6
         err = rel_u0_err(got["u0"], g[f"{name}_u0"])
-        far = np.nonzero(ok & (err >= 1e-6))[0]
-        assert far.size <= 2, (name, far, err[far])
-        if far.size:
-            import kkt_batch as kb
-            import nlp_batch as nb
-            from mpc_rl_for_avs_amd.reference_path import reference_states
-            p = nb.Batch.build(reference_states(), inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"],
-                               vref=inp["vref"], others=inp["others"], collision_cost=cc).take(far)
-            cert = kb.certify(p, got["X"][far], got["U"][far], eps_c=1e-8 / kb.objective_scale(p))
-            assert cert["stationarity"].max() <= 1e-8 and cert["feasibility"].max() <= 1e-10
+        assert err[ok].max() < 1e-6, (name, np.nonzero(ok & (err >= 1e-6))[0], err[ok].max())
 
 
 def test_known_answers(eng):
@@ -305,9 +298,8 @@ def _certified_full_batch(eng, oracle, ref_table, B, V, cc):
     assert (got["status"] == want["status"]).mean() >= 0.995
     both = conv & converged(want["status"])
     err = rel_u0_err(got["u0"], want["u0"])[both]
-    # measured: 0 of 4081 beyond 1e-4 (worst 2.1e-9); one instance landing in another minimum through a last-bit
-    # difference is the most this admits
-    assert (err > TOL).sum() <= 1, f"{(err > TOL).sum()} of {both.sum()} beyond {TOL}"
+    # measured: 0 of 4081 beyond 1e-4 (worst 2.1e-9); exact gate, see test_engine_matches_oracle
+    assert unexplained_disagreements(oracle, ref_table, inp, cc, got, want, TOL, max_iter=100) == []
     assert np.percentile(err, 99) < 1e-8 and np.percentile(err, 99.9) < 1e-6
     assert (got["iters"] == want["iters"])[both].mean() > 0.99
     p = nb.Batch.build(ref_table, inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
@@ -429,7 +421,7 @@ def test_stall_window_on_the_gpu(oracle, ref_table):
     assert (got["status"] == want["status"]).mean() >= 0.998 and converged(got["status"]).mean() >= 0.996
     assert 3 <= (got["status"] == 4).sum() <= 30
     both = converged(got["status"]) & converged(want["status"])
-    assert (rel_u0_err(got["u0"], want["u0"])[both] > TOL).sum() <= 1
+    assert unexplained_disagreements(oracle, ref_table, inp, True, got, want, TOL, max_iter=1000, stall_window=64) == []
     e.close()
 
 

@@ -59,7 +59,7 @@ def main():
             engs.append(e_g)
             cols.append(rollout.BatchedCollector(env, pol, e_g, version=a.version, algorithm=a.algorithm, n_steps=a.steps,
                                                  collision_cost=False, gather_actions=use_dist and G == 1,
-                                                 seed=g, use_graph=a.graph and not use_dist))
+                                                 seed=g, use_graph=a.graph and not use_dist, throughput=G > 1))
         col = cols[0] if G == 1 else rollout.PipelinedCollector(cols)
         col.collect_rollouts()                                   # warm-up (allocations, first launches)
         events = []
