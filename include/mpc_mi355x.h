@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 4
+#define MPC_ABI_VERSION 5
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -259,6 +259,34 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
                        double *ospeed, double *ohead, uint8_t *oactive, int32_t *t, int64_t *rng_counter, float *obs,
                        float *terminal_obs, float *reward, uint8_t *done, uint8_t *truncated, uint8_t *crashed,
                        uint8_t *arrived, int32_t reset_all, void *stream);
+
+/*
+ * Rollout glue for the same configurations (csrc/mpc_rollout_glue.hpp): what a step of the reference's collect_rollouts does
+ * besides the MPC call and env.step, as two launches instead of ~40 torch kernels.  Device pointers, enqueue only.
+ *
+ * mpc_policy_act: the SB3 MlpPolicy-shaped actor-critic of PPO_MPC / A2C_MPC (agents/ppo_mpc.py:390-394; 80 -> H -> H tanh
+ * twice, Gaussian head) for B observations obs [B][80] f32: both towers as one 80 -> 2H -> 2H -> (A + 1) network with the
+ * weights laid out as w1 [80][2H], b1 [2H], w2 [2H][2H] (block diagonal), b2 [2H], wh [2H][A + 1], bh [A + 1], std [A] =
+ * exp(log_std), c0 [1] = sum(log_std) + A / 2 log(2 pi); noise [B][A] standard normal draws of the caller's generator.
+ * Outputs: actions [B][A] = mean + std * noise, values [B], log_probs [B], and the MPC's inputs as the reference maps the
+ * action: version_v1 == 0 -> mpc_ref_speed [B] f64 = action 0 (agents/ppo_mpc.py:410-414), else mpc_weights [B][3] f64 =
+ * actions 0..2 (:416-420); clip != 0 clips to the Box(-1, 1) action space first (PPO, :399-407; A2C does not, a2c_mpc.py:138-144).
+ *
+ * mpc_rollout_record: row pos_dev[0] of the rollout buffer row [T][B][cols] = [obs 80 | action A | reward | episode_start |
+ * value | log_prob | (terminal_obs 80 | truncated)] (rollout_buffer.add, agents/ppo_mpc.py:462-469) and of mpc_actions_buf
+ * [T][B][2]; last_obs <- new_obs, last_starts <- done; counts [4] += finished / crashed / arrived episodes and solves whose
+ * status is not converged; dones_out <- done; pos_dev[0] += 1 (ticket: one zero-initialised int32 of scratch).
+ */
+int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float *obs, const float *w1, const float *b1,
+                   const float *w2, const float *b2, const float *wh, const float *bh, const float *std_, const float *c0,
+                   const float *noise, int32_t version_v1, int32_t clip, float *actions, float *values, float *log_probs,
+                   double *mpc_weights, double *mpc_ref_speed, void *stream);
+int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
+                       double *mpc_actions_buf, int64_t *pos_dev, int32_t *ticket, float *last_obs, float *last_starts,
+                       const float *actions, const float *values, const float *log_probs, const double *mpc_act,
+                       const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
+                       const float *terminal_obs, const uint8_t *truncated, const uint8_t *crashed, const uint8_t *arrived,
+                       int64_t *counts, uint8_t *dones_out, void *stream);
 
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
  * collision-cost term (V = 0: term off) in a batch of B (the builds for batches that leave LDS to spare keep 12 more

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpc_mi355x.so")
 _SOURCES = [os.path.join(_HERE, "csrc", "mpc_engine.hip")]
 _DEPS = _SOURCES + [os.path.join(_HERE, "csrc", f) for f in ("mpc_core.hpp", "mpc_wave.hpp", "mpc_ltv.hpp",
-                                                              "mpc_preamble.hpp", "mpc_wave_dev.hpp", "mpc_synth_env.hpp")] + \
+                                                              "mpc_preamble.hpp", "mpc_preamble_wave.hpp", "mpc_wave_dev.hpp", "mpc_synth_env.hpp", "mpc_rollout_glue.hpp")] + \
     [os.path.join(os.path.dirname(_HERE), "include", "mpc_mi355x.h")]
 
 

@@ -4,7 +4,7 @@
 //   mpc_solve_wave_kernel   one wave per MPC instance (mpc_wave.hpp + mpc_wave_dev.hpp): stage-parallel phases,
 //                           Riccati stage on the FP64 matrix cores, all line-search step lengths at once;
 //                           per-instance state (46-54 doubles per stage + trial areas, 14 KB at N = 20) in LDS
-//   mpc_preamble_kernel     observation -> problem data (mpc_preamble.hpp), 16 lanes per environment
+//   mpc_preamble_kernel     observation -> problem data (mpc_preamble_wave.hpp), one wave per environment
 //   mpc_env_reset_kernel    episode boundaries of the per-environment detector state
 // Host side: argument checks, staging of host-pointer calls through one device buffer on the caller's stream,
 // per-handle device state (reference table, environment records, preamble outputs).
@@ -24,7 +24,9 @@
 #include "mpc_wave.hpp"
 #include "mpc_wave_dev.hpp"
 #include "mpc_preamble.hpp"
+#include "mpc_preamble_wave.hpp"
 #include "mpc_synth_env.hpp"
+#include "mpc_rollout_glue.hpp"
 
 namespace {
 
@@ -262,109 +264,29 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_ltv_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// observation -> problem data (mpc_preamble.hpp).  16 lanes per environment, 4 environments per wave: lane 0
-// parses, predicts the ego polyline into LDS and runs the detector state machine / speed profile; lane j tests other
-// vehicle j against that polyline (the part that scales with the number of vehicles).
+// observation -> problem data: ONE wave per environment (mpc_preamble_wave.hpp says which lanes do what).  Workgroup = one
+// wave, grid = B, 21 KB of LDS (predicted paths, running arc lengths, crossing candidates), nothing in scratch.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kPreGroup = mpc::pre::kMaxOthers;         // lanes per environment
-constexpr int kPreEnvs = kBlock / kPreGroup;            // environments per workgroup
-
-__global__ __launch_bounds__(kBlock) void mpc_preamble_kernel(
+__global__ __launch_bounds__(kBlock, 2) void mpc_preamble_kernel(
     int B, const float *__restrict__ obs, int rows, const double *__restrict__ ref5, int M, int N, double dt,
     const double *__restrict__ ref_speed, mpc::pre::EnvState *__restrict__ env, double *__restrict__ state,
     int32_t *__restrict__ ego_index, double *__restrict__ vref, uint8_t *__restrict__ is_collide,
     double *__restrict__ others, int Vslots, int32_t *__restrict__ nveh, int advance, double *__restrict__ dbg_ego,
     int32_t *__restrict__ dbg_len, float *__restrict__ dbg_agents) {
     namespace pre = mpc::pre;
-    __shared__ pre::P2 s_ego[kPreEnvs][pre::kPredHorizon + 1];
-    __shared__ int s_ne[kPreEnvs];
-    __shared__ int32_t s_conf[kPreEnvs][pre::kMaxOthers];
-    __shared__ pre::P2 s_cpt[kPreEnvs][pre::kMaxOthers];
-    __shared__ float s_ag[kBlock][2 * (pre::kPredHorizon + 1)];    // each lane's vehicle path (31 float32 points)
-    __shared__ pre::P2 s_cand[kBlock][pre::kMaxCross];             // ... and its crossing candidates
-    // the reference table (85 rows x 6 doubles = 4 KB) is walked point by point several times per environment (nearest
-    // point, arc length): from LDS, not through the vector memory path
-    constexpr int kTabDoubles = 128 * (mpc::REF_COLS + 1);
-    __shared__ double s_tab[kTabDoubles];
-    __shared__ double s_nd[kBlock];
-    __shared__ int s_ni[kBlock];
-    const int g = threadIdx.x / kPreGroup, l = threadIdx.x % kPreGroup;
-    const int bq = blockIdx.x * kPreEnvs + g;
-    const bool live = bq < B;
-    const int b = live ? bq : B - 1;                    // surplus groups read the last environment, write nothing
-    const bool staged = M * (mpc::REF_COLS + 1) <= kTabDoubles;
-    if (staged) {
-        for (int i = threadIdx.x; i < M * (mpc::REF_COLS + 1); i += kBlock) s_tab[i] = ref5[i];
-        __syncthreads();
-    }
-    const pre::RefTable R{staged ? (const double *)s_tab : ref5, M};
-    const float *ob = obs + (size_t)b * rows * pre::kObsCols;
-    const pre::Parsed p = pre::parse_obs(ob, rows);
-    // nearest reference point of the ego (first minimum, agents/pure_mpc.py:106-109, 567-570): the 16 lanes of the
-    // environment take every 16th point, lane 0 picks the first minimum of the 16 partial results; it serves the
-    // predicted path, the reference speed and the ego index alike
-    {
-        double bd = INFINITY;
-        int bi = 0;      // like RefTable::nearest: index 0 when no distance compares smaller (NaN / inf positions, M < 16)
-        for (int i = l; i < M; i += kPreGroup) {
-            const double d = pre::dist2d(R.x(i), R.y(i), (double)p.ex, (double)p.ey);
-            if (d < bd) {
-                bd = d;
-                bi = i;
-            }
-        }
-        s_nd[threadIdx.x] = bd;
-        s_ni[threadIdx.x] = bi;
-    }
-    __syncthreads();
-    int e0 = 0;
-    {
-        double bd = s_nd[g * kPreGroup];
-        e0 = s_ni[g * kPreGroup];
-        for (int q = 1; q < kPreGroup; ++q) {
-            const double d = s_nd[g * kPreGroup + q];
-            const int i = s_ni[g * kPreGroup + q];
-            if (d < bd || (d == bd && i < e0)) {
-                bd = d;
-                e0 = i;
-            }
-        }
-    }
-    // surplus groups (live == false) only keep the barriers company: no detector work on possibly changing state
-    const bool replay = !live || !advance || (env[b].collision_memory > 0 && env[b].has_memorized);
-    if (!replay && l == 0) s_ne[g] = pre::ego_future(R, p.ex, p.ey, p.ev, R.v(e0), dt, s_ego[g], e0);
-    __syncthreads();
-    if (!replay) {
-        pre::P2 cp{0.0, 0.0};
-        s_conf[g][l] = l < p.observed ? pre::detect_vehicle(ob + (l + 1) * pre::kObsCols, s_ego[g], s_ne[g], R, dt, cp, s_ag[threadIdx.x], s_cand[threadIdx.x]) : -1;
-        s_cpt[g][l] = cp;
-    }
-    __syncthreads();
-    // diagnostics (mpc_set_diagnostics): the polylines the detector worked on, for the parity tests against the
-    // reference's predict_ego_future_positions / predict_future_positions
-    if (dbg_len && live) {
-        const int ne = replay ? 0 : s_ne[g];
-        if (l == 0) dbg_len[b] = ne;
-        for (int m = l; m < ne; m += kPreGroup) {
-            dbg_ego[((size_t)b * (pre::kPredHorizon + 1) + m) * 2 + 0] = s_ego[g][m].x;
-            dbg_ego[((size_t)b * (pre::kPredHorizon + 1) + m) * 2 + 1] = s_ego[g][m].y;
-        }
-        if (!replay && l < p.observed && l < Vslots)
-            for (int m = 0; m < 2 * (pre::kPredHorizon + 1); ++m)
-                dbg_agents[((size_t)b * Vslots + l) * 2 * (pre::kPredHorizon + 1) + m] = s_ag[threadIdx.x][m];
-    }
-    if (l != 0 || !live) return;
-    pre::EnvState &st = env[b];      // in place: a local copy of the 672-byte record is 672 bytes of scratch per lane
-    double *oth = others + (size_t)b * Vslots * 4;
-    pre::write_vehicles(ob, p, state + (size_t)b * 4, oth);
-    for (int j = p.observed; j < Vslots; ++j) oth[j * 4 + 0] = oth[j * 4 + 1] = oth[j * 4 + 2] = oth[j * 4 + 3] = 0.0;
-    int32_t e = 0;
-    uint8_t c = 0;
-    pre::finish_env(p, R, N, ref_speed ? ref_speed + b : nullptr, s_conf[g], s_cpt[g], st, e, vref + (size_t)b * (N + 1), c,
-                    advance != 0, e0);
-    ego_index[b] = e;
-    is_collide[b] = c;
-    nveh[b] = p.observed;
+    __shared__ double s_words[pre::preamble_wave_lds_doubles()];
+    __shared__ int32_t s_conf[pre::kMaxOthers];
+    __shared__ pre::P2 s_cpt[pre::kMaxOthers];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    WaveCtx<0, 3> ctx((mpc::wave::lds_double_t *)s_words, ref5, 0, M);
+    const pre::RefTable R{ref5, M};
+    constexpr size_t P = pre::kPredHorizon + 1;
+    const pre::PreDiag diag{dbg_len ? dbg_ego + (size_t)b * P * 2 : nullptr, dbg_len ? dbg_len + b : nullptr,
+                            dbg_len ? dbg_agents + (size_t)b * Vslots * P * 2 : nullptr, Vslots};
+    pre::preamble_env_wave(ctx, obs + (size_t)b * rows * pre::kObsCols, rows, R, N, dt, ref_speed ? ref_speed + b : nullptr,
+                           env[b], state + (size_t)b * 4, ego_index[b], vref + (size_t)b * (N + 1), is_collide[b],
+                           others + (size_t)b * Vslots * 4, Vslots, nveh[b], advance != 0, s_conf, s_cpt, diag);
 }
 
 __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, const uint8_t *__restrict__ mask,
@@ -421,6 +343,56 @@ __global__ __launch_bounds__(64) void mpc_synth_env_kernel(
     truncated[b] = so.truncated;
     crashed[b] = so.crashed;
     arrived[b] = so.arrived;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rollout glue (mpc_rollout_glue.hpp): the policy forward + sample + MPC inputs, and the buffer row / carry-over /
+// counters of a step.  One workgroup per environment.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(mpc::glue::kMaxHidden2) void mpc_policy_act_kernel(
+    int B, int A, int H2, const float *__restrict__ obs, mpc::glue::PolicyWeights W, const float *__restrict__ noise,
+    int version_v1, int clip, float *__restrict__ actions, float *__restrict__ values, float *__restrict__ log_probs,
+    double *__restrict__ mpc_weights, double *__restrict__ mpc_ref_speed) {
+    namespace glue = mpc::glue;
+    __shared__ float s_x[glue::kObsDim];
+    __shared__ float s_h1[glue::kMaxHidden2], s_h2[glue::kMaxHidden2];
+    __shared__ float s_head[glue::kMaxAction + 1];
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (b >= B) return;
+    if (j < glue::kObsDim) s_x[j] = obs[(size_t)b * glue::kObsDim + j];
+    __syncthreads();
+    if (j < H2) s_h1[j] = glue::layer1_unit(W, H2, s_x, j);
+    __syncthreads();
+    if (j < H2) s_h2[j] = glue::layer2_unit(W, H2, s_h1, j);
+    __syncthreads();
+    if (j <= A) s_head[j] = glue::head_unit(W, H2, A, s_h2, j);
+    __syncthreads();
+    if (j == 0)
+        glue::finish_action(W, A, s_head, noise + (size_t)b * A, version_v1, clip, nullptr, actions + (size_t)b * A, values + b,
+                            log_probs + b, mpc_weights ? mpc_weights + (size_t)b * 3 : nullptr,
+                            mpc_ref_speed ? mpc_ref_speed + b : nullptr);
+}
+
+__global__ __launch_bounds__(128) void mpc_rollout_record_kernel(mpc::glue::RecordArgs R, long long *__restrict__ pos_dev,
+                                                                 int32_t *__restrict__ ticket,
+                                                                 unsigned long long *__restrict__ counts) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (b >= R.B) return;
+    const long long pos = *pos_dev;
+    const int bits = mpc::glue::record_thread(R, pos, b, j);
+    if (bits & 1) atomicAdd(counts + 0, 1ull);
+    if (bits & 2) atomicAdd(counts + 1, 1ull);
+    if (bits & 4) atomicAdd(counts + 2, 1ull);
+    if (bits & 8) atomicAdd(counts + 3, 1ull);
+    // the last workgroup to finish advances the buffer position (every workgroup has read it by then)
+    __syncthreads();
+    if (j == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1) == R.B - 1) {
+            *ticket = 0;
+            *pos_dev = pos + 1;
+        }
+    }
 }
 
 }  // namespace
@@ -899,7 +871,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         h->diag_V = (int)Vs;
         HIP_TRY(hipMemsetAsync(h->d_diag, 0, off, stream));
     }
-    hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)((B + kPreEnvs - 1) / kPreEnvs)), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL(mpc_preamble_kernel, dim3((unsigned)B), dim3(kBlock), 0, stream,
                        (int)B, d_obs, rows, h->d_ref, h->M, N, h->cfg.dt, d_rs, h->d_env, h->p_state, h->p_ego,
                        h->p_vref, h->p_coll, h->p_others, V > 0 ? V : 1, h->p_nveh, detected ? 0 : 1,
                        h->diag ? h->g_ego : nullptr, h->diag ? h->g_len : nullptr, h->diag ? h->g_agents : nullptr);
@@ -1213,6 +1185,51 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
                        (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
                        ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
                        (int)reset_all);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float *obs, const float *w1, const float *b1,
+                   const float *w2, const float *b2, const float *wh, const float *bh, const float *std_, const float *c0,
+                   const float *noise, int32_t version_v1, int32_t clip, float *actions, float *values, float *log_probs,
+                   double *mpc_weights, double *mpc_ref_speed, void *stream_) {
+    if (B < 0 || A < 1 || A > mpc::glue::kMaxAction || H2 < 2 || H2 > mpc::glue::kMaxHidden2 || (H2 & 1))
+        return fail(MPC_ERR_INVALID_ARG, "mpc_policy_act: bad size (action_dim 1..8, 2 x hidden <= 256)");
+    if (!obs || !w1 || !b1 || !w2 || !b2 || !wh || !bh || !std_ || !c0 || !noise || !actions || !values || !log_probs)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_policy_act: null pointer");
+    if (version_v1 ? (!mpc_weights || A < 3) : !mpc_ref_speed)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_policy_act: v1 needs mpc_weights and >= 3 action components, v0 needs mpc_ref_speed");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(device));
+    const mpc::glue::PolicyWeights W{w1, b1, w2, b2, wh, bh, std_, c0};
+    const int threads = H2 > mpc::glue::kObsDim ? H2 : mpc::glue::kObsDim;
+    hipLaunchKernelGGL(mpc_policy_act_kernel, dim3((unsigned)B), dim3((unsigned)((threads + 63) / 64 * 64)), 0,
+                       reinterpret_cast<hipStream_t>(stream_), (int)B, (int)A, (int)H2, obs, W, noise, (int)version_v1, (int)clip,
+                       actions, values, log_probs, version_v1 ? mpc_weights : nullptr, version_v1 ? nullptr : mpc_ref_speed);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
+                       double *mpc_actions_buf, int64_t *pos_dev, int32_t *ticket, float *last_obs, float *last_starts,
+                       const float *actions, const float *values, const float *log_probs, const double *mpc_act,
+                       const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
+                       const float *terminal_obs, const uint8_t *truncated, const uint8_t *crashed, const uint8_t *arrived,
+                       int64_t *counts, uint8_t *dones_out, void *stream_) {
+    constexpr int O = mpc::glue::kObsDim;
+    if (B < 0 || A < 1 || A > mpc::glue::kMaxAction || cols != O + A + 4 + (keep_terminal ? O + 1 : 0))
+        return fail(MPC_ERR_INVALID_ARG, "mpc_rollout_record: bad size / row layout");
+    if (!row || !mpc_actions_buf || !pos_dev || !ticket || !last_obs || !last_starts || !actions || !values || !log_probs ||
+        !mpc_act || !mpc_status || !new_obs || !reward || !done || !crashed || !arrived || !counts || !dones_out ||
+        (keep_terminal && (!terminal_obs || !truncated)))
+        return fail(MPC_ERR_INVALID_ARG, "mpc_rollout_record: null pointer");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(device));
+    const mpc::glue::RecordArgs R{(int)B, (int)A, (int)cols, (int)keep_terminal, row, mpc_actions_buf, last_obs, last_starts, actions,
+                                 values, log_probs, mpc_act, mpc_status, new_obs, reward, done, terminal_obs, truncated, crashed,
+                                 arrived, dones_out};
+    hipLaunchKernelGGL(mpc_rollout_record_kernel, dim3((unsigned)B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream_), R,
+                       reinterpret_cast<long long *>(pos_dev), ticket, reinterpret_cast<unsigned long long *>(counts));
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }

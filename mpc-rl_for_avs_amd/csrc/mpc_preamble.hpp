@@ -263,26 +263,47 @@ struct AgentPath {
 // stop at the middle.  (Until round 3 the list was materialised and insertion-sorted in 1.5 KB of scratch per lane.)
 constexpr int kMaxCross = 4;
 
+// views of the data the crossing code walks over: plain arrays (the one-thread-per-environment form and the host harness) or
+// LDS words of the wave-cooperative kernel (mpc_preamble_wave.hpp)
+struct EgoPtr {
+    const P2 *p;
+    MPC_HD P2 at(int i) const { return p[i]; }
+};
+struct CandPtr {            // where the candidates go (indexed dynamically: LDS on the device, never a local array)
+    P2 *p;
+    MPC_HD void put(int q, P2 v) const { p[q] = v; }
+    MPC_HD P2 get(int q) const { return p[q]; }
+};
+struct NoNodes {            // far ends of a collinear stretch on the ego segments it covers: recomputed on demand ...
+    static constexpr bool kCached = false;
+    MPC_HD void put(int, P2) const {}
+    MPC_HD P2 get(int) const { return P2{0.0, 0.0}; }
+};
+
+template <class EGO, class AG, class NODES>
 struct OverlapWalk {
-    const P2 *ego;
+    const EGO *ego;
+    const NODES *nodes;   // ... or kept by the extent scan (the wave kernel: 2 x 30 words of LDS per vehicle)
     int i, jend;          // ego segments i .. jend - 1 overlap the agent's line
     P2 a, b;
-    AgentPath ag;
+    const AG *ag;
     double klo, khi, sx, sy, ss, dx, dy;
     bool asc;             // agent vertices by ascending index are ascending along the ego's direction
+    P2 e_i;               // ego->at(i)
     // ego-derived node q: 0, 1 = the ends of the overlap on segment i; q >= 2 = the far end on segment i + q - 1
     MPC_HD P2 ego_node(int q) const {
+        if (NODES::kCached) return nodes->get(q);
         Hit h[2];
         if (q < 2) {
-            seg_intersections(ego[i], ego[i + 1], a, b, h);
+            seg_intersections(ego->at(i), ego->at(i + 1), a, b, h);
             return q == 0 ? h[0].p : h[1].p;
         }
-        seg_intersections(ego[i + q - 1], ego[i + q], a, b, h);
+        seg_intersections(ego->at(i + q - 1), ego->at(i + q), a, b, h);
         return h[1].p;
     }
-    MPC_HD double key(P2 p) const { return f64add(f64mul(p.x - ego[i].x, dx), f64mul(p.y - ego[i].y, dy)); }
+    MPC_HD double key(P2 p) const { return f64add(f64mul(p.x - e_i.x, dx), f64mul(p.y - e_i.y, dy)); }
     MPC_HD bool agent_inside(int m) const {
-        const P2 v = ag.at(m);
+        const P2 v = ag->at(m);
         const double kv = f64add(f64mul(v.x - a.x, sx), f64mul(v.y - a.y, sy));
         return ss > 0 && klo <= kv && kv <= khi;
     }
@@ -293,14 +314,15 @@ struct OverlapWalk {
     // walks the merged, de-duplicated list; returns its length, and in `out` its element number `want` (if want >= 0)
     MPC_HD int walk(int want, P2 &out) const {
         const int ne_nodes = 2 + (jend - (i + 1));
+        const int na = ag->n;
         int qe = 0;                                   // next ego-derived node
-        int ma = asc ? 0 : ag.n - 1;                  // next agent vertex (index), skipping those outside the overlap
+        int ma = asc ? 0 : na - 1;                    // next agent vertex (index), skipping those outside the overlap
         const int mstep = asc ? 1 : -1;
-        while (ma >= 0 && ma < ag.n && !agent_inside(ma)) ma += mstep;
+        while (ma >= 0 && ma < na && !agent_inside(ma)) ma += mstep;
         int nu = 0;
         P2 last{0.0, 0.0};
         for (;;) {
-            const bool he = qe < ne_nodes, ha = ma >= 0 && ma < ag.n;
+            const bool he = qe < ne_nodes, ha = ma >= 0 && ma < na;
             if (!he && !ha) break;
             P2 pe{0.0, 0.0}, pa{0.0, 0.0};
             double ke = 0.0, ka = 0.0;
@@ -309,7 +331,7 @@ struct OverlapWalk {
                 ke = key(pe);
             }
             if (ha) {
-                pa = ag.at(ma);
+                pa = ag->at(ma);
                 ka = key(pa);
             }
             const bool take_e = he && (!ha || !before(ka, pa, ke, pe));
@@ -318,7 +340,7 @@ struct OverlapWalk {
                 ++qe;
             } else {
                 ma += mstep;
-                while (ma >= 0 && ma < ag.n && !agent_inside(ma)) ma += mstep;
+                while (ma >= 0 && ma < na && !agent_inside(ma)) ma += mstep;
             }
             if (nu == 0 || !close2(last, p)) {
                 if (nu == want) out = p;
@@ -330,7 +352,10 @@ struct OverlapWalk {
     }
 };
 
-MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, int maxc) {
+// `hits`: bit i set = ego segment i meets the agent's line at all (the wave kernel tests all (vehicle, segment) pairs in
+// parallel first and the serial part below then visits only those); ~0 = test every segment here.
+template <class EGO, class AG, class CAND, class NODES>
+MPC_HD int path_crossings_t(const EGO &ego, int ne, const AG &ag, const CAND &out, int maxc, unsigned hits, const NODES &nodes) {
     const int na = ag.n;
     if (ne < 2 || na < 2) return 0;
     const P2 a = ag.at(0), b = ag.at(na - 1);
@@ -338,38 +363,44 @@ MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, i
     bool last_is_point = false;      // what out[nc - 1] came from
     P2 line_end{0.0, 0.0};           // far end of the last collinear stretch
     for (int i = 0; i < ne - 1 && nc < maxc; ++i) {
+        if (!((hits >> i) & 1u)) continue;
         Hit h[2];
-        const int nh = seg_intersections(ego[i], ego[i + 1], a, b, h);
+        const int nh = seg_intersections(ego.at(i), ego.at(i + 1), a, b, h);
         if (nh == 0) continue;
         if (nh == 1) {
             // a crossing exactly at an ego vertex is found by both segments that share it
-            bool dup = nc > 0 && last_is_point && close2(out[nc - 1], h[0].p);
+            bool dup = nc > 0 && last_is_point && close2(out.get(nc - 1), h[0].p);
             // the intersection is a point SET: where the ego joins or leaves the other path's line at a vertex, the segment
             // before / behind the collinear stretch touches the line in the stretch's end point, which is part of that piece
             if (!dup && nc > 0 && !last_is_point && close2(line_end, h[0].p)) dup = true;
             if (!dup && i + 2 < ne) {
                 Hit h2[2];
-                dup = seg_intersections(ego[i + 1], ego[i + 2], a, b, h2) == 2 && close2(h2[0].p, h[0].p);
+                dup = seg_intersections(ego.at(i + 1), ego.at(i + 2), a, b, h2) == 2 && close2(h2[0].p, h[0].p);
             }
             if (!dup) {
-                out[nc++] = h[0].p;
+                out.put(nc++, h[0].p);
                 last_is_point = true;
             }
             continue;
         }
         // collinear overlap starting on ego segment i: it goes on over the following segments that overlap too
-        OverlapWalk w;
-        w.ego = ego;
+        OverlapWalk<EGO, AG, NODES> w;
+        w.ego = &ego;
+        w.nodes = &nodes;
         w.i = i;
         w.a = a;
         w.b = b;
-        w.ag = ag;
+        w.ag = &ag;
+        w.e_i = ego.at(i);
+        nodes.put(0, h[0].p);
+        nodes.put(1, h[1].p);
         int j = i + 1;
         P2 pl = h[1].p;
         for (; j < ne - 1; ++j) {
             Hit h2[2];
-            if (seg_intersections(ego[j], ego[j + 1], a, b, h2) != 2) break;
+            if (seg_intersections(ego.at(j), ego.at(j + 1), a, b, h2) != 2) break;
             pl = h2[1].p;
+            nodes.put(j - i + 1, pl);
         }
         w.jend = j;
         w.sx = b.x - a.x;
@@ -380,18 +411,22 @@ MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, i
         const double k1 = f64add(f64mul(pl.x - a.x, w.sx), f64mul(pl.y - a.y, w.sy));
         w.klo = fmin(k0, k1) - 1e-12;
         w.khi = fmax(k0, k1) + 1e-12;
-        w.dx = ego[i + 1].x - ego[i].x;
-        w.dy = ego[i + 1].y - ego[i].y;
+        const P2 e1 = ego.at(i + 1);
+        w.dx = e1.x - w.e_i.x;
+        w.dy = e1.y - w.e_i.y;
         w.asc = f64add(f64mul(w.sx, w.dx), f64mul(w.sy, w.dy)) >= 0.0;
         P2 mid{0.0, 0.0}, dummy{0.0, 0.0};
         const int nu = w.walk(-1, dummy);
         w.walk(nu / 2, mid);
-        out[nc++] = mid;
+        out.put(nc++, mid);
         last_is_point = false;
         line_end = pl;
         i = j - 1;      // go on behind the overlap
     }
     return nc;
+}
+MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, int maxc) {
+    return path_crossings_t(EgoPtr{ego}, ne, ag, CandPtr{out}, maxc, ~0u, NoNodes{});
 }
 // the first candidate (the only one in all but double-crossing scenes)
 MPC_HD bool first_crossing(const P2 *ego, int ne, const AgentPath &ag, P2 &out) {
@@ -631,15 +666,19 @@ MPC_HD void preamble_env(const float *obs, int rows, const RefTable &R, int N, d
     int32_t conflict[kMaxOthers];
     P2 cpt[kMaxOthers];
     const int e0 = R.nearest((double)p.ex, (double)p.ey);
+    // An ego standing on the LAST reference point has a predicted path of one point (agents/pure_mpc.py:476-478): LineString
+    // of a single point raises, _check_collision prints a warning and returns with the detector state untouched (:582-587)
+    bool degenerate = false;
     if (advance && !replays_memory(st)) {
         P2 ego[kPredHorizon + 1];
         const int ne = ego_future(R, p.ex, p.ey, p.ev, R.v(e0), dt, ego, e0);
+        degenerate = ne < 2;
         float ag_xy[2 * (kPredHorizon + 1)];
         P2 cand[kMaxCross];
-        for (int j = 0; j < p.observed; ++j)
+        for (int j = 0; j < p.observed && !degenerate; ++j)
             conflict[j] = detect_vehicle(obs + (j + 1) * kObsCols, ego, ne, R, dt, cpt[j], ag_xy, cand);
     }
-    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out, advance, e0);
+    finish_env(p, R, N, ref_speed, conflict, cpt, st, ego_index_out, vref, collide_out, advance && !degenerate, e0);
 }
 
 }  // namespace pre

@@ -1,0 +1,403 @@
+// mpc_preamble_wave.hpp - the observation preamble of mpc_preamble.hpp (a2 parse, a4 detector, a5 speed profile, a6 problem
+// data; reference agents/base_agent.py:81-116, agents/pure_mpc.py:459-724) spread over the 64 lanes of ONE wave per
+// environment.  Same arithmetic, statement for statement, as the one-thread form `preamble_env` (which stays the host
+// harness's reference and the specification of every rounding): what changes is who computes what.
+//
+//   nearest reference point of the ego     64 lanes x M / 64 points, two wave reductions (value, then first index)
+//   ego speed ramp / travelled distance    30 dependent steps of float32 / float64 additions, wave-uniform (they ARE serial)
+//   arc length along the route             segment lengths by 128 lanes' worth of loads at once, then one uniform running sum
+//                                          that stops where the 3 s look-ahead ends (np.cumsum order: sequential by definition)
+//   the 30 predicted ego points            lane k = prediction step k: binary search in the running sums + interpolation
+//   vehicle paths (30 float32 additions)   lane j = vehicle j
+//   path x path crossing tests             all (vehicle, ego segment) pairs at once, 2 vehicles x 32 segments per pass; the
+//                                          hit masks (wave ballots) tell the serial candidate logic which segments to visit
+//   candidate logic (agents/pure_mpc.py:615-633: points, collinear stretches, order)   lane j, only on segments with a hit
+//   candidate test (:635-654: nearest sample of either path, nearest reference point)  the whole wave per candidate
+//   state machine, speed profile (:558-563, 661-724)                                   lane 0, unchanged code (finish_env)
+//
+// Until round 3 the kernel ran 4 environments per wave with lane 0 of each 16-lane group doing the ego path, the state
+// machine and the speed profile alone: 76 us per call at 256 environments, 303 us when every environment runs the full
+// detection (profiles/r03_rollout_kernel_stats.csv), 256 VGPRs.  profiles/r04_rollout_kernel_stats.csv has this one.
+//
+// CTX: the wave interface of mpc_wave.hpp (phase / ld / st / wave_min / ballot / wave_bcast): WaveOpsT on the device
+// (mpc_wave_dev.hpp), HostCtx in tests/host_wave_ctx.hpp, where tests/cpu_preamble_harness.cpp runs this file on the CPU
+// against `preamble_env`, the numpy mirror and the reference-generated fixtures.
+#pragma once
+
+#include "mpc_preamble.hpp"
+#include "mpc_wave.hpp"
+
+namespace mpc {
+namespace pre {
+
+constexpr int kWin = 128;      // reference points the arc-length walk stages at once (the table has 85)
+// LDS words (doubles) of one environment
+enum : int {
+    PL_EGO = 0,                                   // 31 x (x, y)   predicted ego polyline
+    PL_CD = PL_EGO + 2 * (kPredHorizon + 1),      // 31            travelled distance after step k (k = 1 .. 30)
+    PL_SEG = PL_CD + kPredHorizon + 1,            // kWin          lengths of the route segments behind the start point
+    PL_CUM = PL_SEG + kWin,                       // kWin + 1      their running sums (np.cumsum)
+    PL_AG = PL_CUM + kWin + 1,                    // 16 x 31 x (x, y)   vehicle paths (float32 values)
+    PL_NODE = PL_AG + kMaxOthers * 2 * (kPredHorizon + 1),   // 16 x 31 x (x, y)   nodes of a collinear stretch (per vehicle)
+    PL_CAND = PL_NODE + kMaxOthers * 2 * (kPredHorizon + 1), // 16 x 4 x (x, y)    crossing candidates
+    PL_SIZE = PL_CAND + kMaxOthers * kMaxCross * 2
+};
+constexpr int preamble_wave_lds_doubles() { return PL_SIZE; }
+
+template <class CTX>
+struct LdsPts {             // n points (x, y) at consecutive LDS words
+    const CTX *c;
+    int base, n;
+    MPC_HD P2 at(int i) const { return P2{c->ld(base + 2 * i), c->ld(base + 2 * i + 1)}; }
+};
+template <class CTX>
+struct LdsSink {
+    static constexpr bool kCached = true;
+    CTX *c;
+    int base;
+    MPC_HD void put(int q, P2 v) const {
+        c->st(base + 2 * q, v.x);
+        c->st(base + 2 * q + 1, v.y);
+    }
+    MPC_HD P2 get(int q) const { return P2{c->ld(base + 2 * q), c->ld(base + 2 * q + 1)}; }
+};
+
+// wave minimum of a per-lane value that is still needed afterwards (the host model of the reductions works in place)
+template <class CTX>
+MPC_HD double wmin(CTX &ctx, const wave::PerLane<double> &p) {
+    wave::PerLane<double> t = p;
+    return ctx.wave_min(t);
+}
+MPC_HD int popc64(unsigned long long v) { return __builtin_popcountll(v); }
+MPC_HD int ctz64(unsigned long long v) { return __builtin_ctzll(v); }
+
+// what the diagnostics export wants to see (mpc_get_last_paths); nullptr = off
+struct PreDiag {
+    double *ego;      // [31][2]
+    int32_t *len;     // [1]
+    float *agents;    // [Vslots][31][2]
+    int vslots;
+};
+
+// The preamble of ONE environment by one wave.  conf / cpt: 16 words each of workgroup memory for the detection results.
+template <class CTX>
+MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTable &R, int N, double dt, const double *ref_speed,
+                              EnvState &st, double *state, int32_t &ego_index_out, double *vref, uint8_t &collide_out,
+                              double *others, int vslots, int32_t &nveh_out, bool advance, int32_t *conf, P2 *cpt,
+                              const PreDiag &diag) {
+    using wave::PerLane;
+    const int M = R.M;
+    const Parsed p = parse_obs(obs, rows);                        // wave-uniform
+    const double ex = (double)p.ex, ey = (double)p.ey;
+
+    // ---- nearest reference point of the ego (first minimum; agents/pure_mpc.py:106-109, 567-570, 471-474)
+    PerLane<double> bd, bi;
+    ctx.phase([&](int lane) {
+        double d0 = INFINITY;
+        int i0 = 0;                                               // like RefTable::nearest: 0 when nothing compares smaller
+        for (int i = lane; i < M; i += wave::kLanes) {
+            const double d = dist2d(R.x(i), R.y(i), ex, ey);
+            if (d < d0) {
+                d0 = d;
+                i0 = i;
+            }
+        }
+        bd.at(lane) = d0;
+        bi.at(lane) = (double)i0;
+    });
+    const double dmin = wmin(ctx, bd);
+    ctx.phase([&](int lane) { bi.at(lane) = bd.at(lane) == dmin ? bi.at(lane) : 1e9; });
+    int e0 = (int)wmin(ctx, bi);
+    e0 = (e0 < 0 || e0 >= M) ? 0 : e0;
+
+    const bool replay = !advance || replays_memory(st);
+    int ne = 0;
+    bool degenerate = false;      // the ego's predicted path has a single point (it stands on the last reference point):
+                                  // LineString() of one point raises, _check_collision returns early (agents/pure_mpc.py:582-587)
+    if (!replay) {
+        const int npts = M - e0;
+        if (npts < 2) {
+            ne = 1;
+            degenerate = true;
+            ctx.phase([&](int lane) {
+                if (lane == 0) {
+                    ctx.st(PL_EGO, ex);
+                    ctx.st(PL_EGO + 1, ey);
+                }
+            });
+        } else {
+            // ---- speed ramp and travelled distance, agents/pure_mpc.py:489-499: float32 until the ramp reaches the float64
+            //      reference speed (see ego_future); wave-uniform, every lane keeps the same values
+            const double reference_speed = R.v(e0);
+            bool s32 = true, d32 = true;
+            float cs_f = p.ev, cd_f = 0.0f;
+            double cs_d = 0.0, cd_d = 0.0;
+            const float acc_dt_f = (float)(3.5 * dt);
+            const float dt_f = (float)dt;
+            double cd_last = 0.0;
+#pragma unroll 1
+            for (int step = 0; step < kPredHorizon; ++step) {
+                const double cs_now = s32 ? (double)cs_f : cs_d;
+                if (cs_now < reference_speed) {
+                    if (s32) {
+                        const float t = f32add(cs_f, acc_dt_f);
+                        if (reference_speed < (double)t) {
+                            s32 = false;
+                            cs_d = reference_speed;
+                        } else {
+                            cs_f = t;
+                        }
+                    } else {
+                        const double t = f64add(cs_d, 3.5 * dt);
+                        cs_d = reference_speed < t ? reference_speed : t;
+                    }
+                } else {
+                    s32 = false;
+                    cs_d = reference_speed;
+                }
+                if (s32) {
+                    const float inc = f32mul(cs_f, dt_f);
+                    if (d32) cd_f = f32add(cd_f, inc);
+                    else cd_d = f64add(cd_d, (double)inc);
+                } else {
+                    const double inc = f64mul(cs_d, dt);
+                    if (d32) {
+                        cd_d = f64add((double)cd_f, inc);
+                        d32 = false;
+                    } else {
+                        cd_d = f64add(cd_d, inc);
+                    }
+                }
+                cd_last = d32 ? (double)cd_f : cd_d;
+                ctx.st(PL_CD + step + 1, cd_last);                 // every lane stores the same value
+            }
+            // ---- route segments behind the start point, kWin at a time; running sums in np.cumsum's order
+            const int nseg = npts - 1 < kWin ? npts - 1 : kWin;
+            ctx.phase([&](int lane) {
+                for (int i = lane; i < nseg; i += wave::kLanes)
+                    ctx.st(PL_SEG + i, dist2d(R.x(e0 + i + 1), R.y(e0 + i + 1), R.x(e0 + i), R.y(e0 + i)));
+            });
+            int ncum = 1;
+            {
+                double cum = 0.0;
+                ctx.st(PL_CUM, 0.0);
+#pragma unroll 1
+                for (int i = 1; i <= nseg; ++i) {
+                    cum = f64add(cum, ctx.ld(PL_SEG + i - 1));
+                    ctx.st(PL_CUM + i, cum);
+                    ncum = i + 1;
+                    if (!(cum < cd_last)) break;                   // the look-ahead ends here: nothing beyond is searched
+                }
+            }
+            ctx.phase([&](int) {});
+            // ---- the 30 predicted points: lane k = step k (agents/pure_mpc.py:501-521)
+            PerLane<int> inside;
+            ctx.phase([&](int lane) {
+                int ok = 0;
+                if (lane >= 1 && lane <= kPredHorizon) {
+                    const double cd = ctx.ld(PL_CD + lane);
+                    int idx;
+                    double prev = 0.0, cum = 0.0;
+                    if (!(ctx.ld(PL_CUM + ncum - 1) < cd)) {
+                        // np.searchsorted(cumulative, cd): first index with cumulative >= cd
+                        int lo = 0, hi = ncum - 1;
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (ctx.ld(PL_CUM + mid) < cd) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        idx = lo;
+                        cum = ctx.ld(PL_CUM + idx);
+                        prev = idx > 0 ? ctx.ld(PL_CUM + idx - 1) : 0.0;
+                    } else {
+                        // beyond what was summed up (the staged window was too short, or the route ends): go on from there
+                        idx = ncum - 1;
+                        cum = ctx.ld(PL_CUM + idx);
+                        prev = idx > 0 ? ctx.ld(PL_CUM + idx - 1) : 0.0;
+                        while (idx < npts && cum < cd) {
+                            ++idx;
+                            if (idx < npts) {
+                                prev = cum;
+                                cum = f64add(cum, dist2d(R.x(e0 + idx), R.y(e0 + idx), R.x(e0 + idx - 1), R.y(e0 + idx - 1)));
+                            }
+                        }
+                    }
+                    if (idx < npts) {
+                        ok = 1;
+                        P2 q;
+                        if (idx == 0) {
+                            q = P2{R.x(e0), R.y(e0)};
+                        } else {
+                            double alpha = (cum != prev) ? f64sub(cd, prev) / f64sub(cum, prev) : 1.0;
+                            alpha = alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+                            const double ax = R.x(e0 + idx - 1), ay = R.y(e0 + idx - 1);
+                            q = P2{f64add(ax, f64mul(alpha, f64sub(R.x(e0 + idx), ax))),
+                                   f64add(ay, f64mul(alpha, f64sub(R.y(e0 + idx), ay)))};
+                        }
+                        ctx.st(PL_EGO + 2 * lane, q.x);
+                        ctx.st(PL_EGO + 2 * lane + 1, q.y);
+                    }
+                } else if (lane == 0) {
+                    ctx.st(PL_EGO, ex);
+                    ctx.st(PL_EGO + 1, ey);
+                }
+                inside.at(lane) = ok;
+            });
+            // the loop of :501 ends at the first step beyond the route: the travelled distance never decreases, so the steps
+            // that stay inside are a prefix
+            ne = 1 + popc64(ctx.ballot(inside));
+            if (ne <= 1) {                                         // agents/pure_mpc.py:524-526
+                ne = kPredHorizon;
+                ctx.phase([&](int lane) {
+                    if (lane < kPredHorizon) {
+                        ctx.st(PL_EGO + 2 * lane, ex);
+                        ctx.st(PL_EGO + 2 * lane + 1, ey);
+                    }
+                });
+            }
+        }
+    }
+
+    // ---- the other vehicles
+    const int V = p.observed;
+    if (!replay && !degenerate) {
+        // constant-velocity paths, agents/pure_mpc.py:529-550: lane j = vehicle j
+        ctx.phase([&](int lane) {
+            if (lane < V) {
+                const float *o = obs + (lane + 1) * kObsCols;
+                const float sp = speed_f32(o[3], o[4]);
+                const float sdt = f32mul(sp, (float)dt);
+                const float stx = f32mul(sdt, (float)cos((double)o[5])), sty = f32mul(sdt, (float)sin((double)o[5]));
+                float ax = o[1], ay = o[2];
+                const int b = PL_AG + lane * 2 * (kPredHorizon + 1);
+                ctx.st(b, (double)ax);
+                ctx.st(b + 1, (double)ay);
+                for (int m = 1; m <= kPredHorizon; ++m) {
+                    ax = f32add(ax, stx);
+                    ay = f32add(ay, sty);
+                    ctx.st(b + 2 * m, (double)ax);
+                    ctx.st(b + 2 * m + 1, (double)ay);
+                }
+                conf[lane] = -1;
+                cpt[lane] = P2{0.0, 0.0};
+            }
+        });
+        // which ego segments meet which vehicle's line at all: 2 vehicles x 32 segment slots per pass
+        const LdsPts<CTX> ego{&ctx, PL_EGO, ne};
+        PerLane<int> hits, hit;
+        ctx.phase([&](int lane) { hits.at(lane) = 0; });
+        for (int r = 0; 2 * r < V; ++r) {
+            ctx.phase([&](int lane) {
+                const int i = lane & 31, j = 2 * r + (lane >> 5);
+                int h1 = 0;
+                if (j < V && i < ne - 1) {
+                    const LdsPts<CTX> ag{&ctx, PL_AG + j * 2 * (kPredHorizon + 1), kPredHorizon + 1};
+                    Hit h[2];
+                    h1 = seg_intersections(ego.at(i), ego.at(i + 1), ag.at(0), ag.at(kPredHorizon), h) > 0 ? 1 : 0;
+                }
+                hit.at(lane) = h1;
+            });
+            const unsigned long long bm = ctx.ballot(hit);
+            ctx.phase([&](int lane) {
+                if ((lane >> 1) == r && lane < V) hits.at(lane) = (int)(unsigned)((lane & 1) ? (bm >> 32) : (bm & 0xffffffffull));
+            });
+        }
+        // candidates (agents/pure_mpc.py:615-633), lane j = vehicle j, only the segments with a hit are visited
+        PerLane<int> ncand;
+        ctx.phase([&](int lane) {
+            int nc = 0;
+            if (lane < V && hits.at(lane) != 0) {
+                const LdsPts<CTX> ag{&ctx, PL_AG + lane * 2 * (kPredHorizon + 1), kPredHorizon + 1};
+                const LdsSink<CTX> cand{&ctx, PL_CAND + lane * 2 * kMaxCross};
+                const LdsSink<CTX> nodes{&ctx, PL_NODE + lane * 2 * (kPredHorizon + 1)};
+                nc = path_crossings_t(ego, ne, ag, cand, kMaxCross, (unsigned)hits.at(lane), nodes);
+            }
+            ncand.at(lane) = nc;
+        });
+        // candidate loop of agents/pure_mpc.py:635-654, the whole wave per candidate: nearest sample of the ego's path (lanes
+        // 0..30) and of the vehicle's (lanes 32..62); the first candidate whose sample indices differ by less than
+        // TIME_THRESHOLD decides, and its nearest reference point is the conflict index
+        unsigned long long todo = ctx.ballot(ncand);
+        while (todo) {
+            const int j = ctz64(todo);
+            todo &= todo - 1;
+            const int nc = ctx.wave_bcast(ncand, j);
+            for (int q = 0; q < nc; ++q) {
+                const P2 pt{ctx.ld(PL_CAND + j * 2 * kMaxCross + 2 * q), ctx.ld(PL_CAND + j * 2 * kMaxCross + 2 * q + 1)};
+                PerLane<double> de, da, ie, ia;
+                ctx.phase([&](int lane) {
+                    double d1 = INFINITY, d2 = INFINITY;
+                    if (lane < ne && lane <= kPredHorizon) d1 = dist2d(ctx.ld(PL_EGO + 2 * lane), ctx.ld(PL_EGO + 2 * lane + 1), pt.x, pt.y);
+                    if (lane >= 32 && lane - 32 <= kPredHorizon) {
+                        const int m = lane - 32, b = PL_AG + j * 2 * (kPredHorizon + 1);
+                        d2 = dist2d(ctx.ld(b + 2 * m), ctx.ld(b + 2 * m + 1), pt.x, pt.y);
+                    }
+                    de.at(lane) = d1;
+                    da.at(lane) = d2;
+                });
+                const double me = wmin(ctx, de), ma = wmin(ctx, da);
+                ctx.phase([&](int lane) {
+                    ie.at(lane) = (lane <= kPredHorizon && de.at(lane) == me) ? (double)lane : 1e9;
+                    ia.at(lane) = (lane >= 32 && da.at(lane) == ma) ? (double)(lane - 32) : 1e9;
+                });
+                const int ego_time = (int)wmin(ctx, ie), agent_time = (int)wmin(ctx, ia);
+                int dtm = ego_time - agent_time;
+                dtm = dtm < 0 ? -dtm : dtm;
+                if (dtm < kTimeThreshold) {
+                    PerLane<double> rd, ri;
+                    ctx.phase([&](int lane) {
+                        double d0 = INFINITY;
+                        int i0 = 0;
+                        for (int i = lane; i < M; i += wave::kLanes) {
+                            const double d = dist2d(R.x(i), R.y(i), pt.x, pt.y);
+                            if (d < d0) {
+                                d0 = d;
+                                i0 = i;
+                            }
+                        }
+                        rd.at(lane) = d0;
+                        ri.at(lane) = (double)i0;
+                    });
+                    const double mr = wmin(ctx, rd);
+                    ctx.phase([&](int lane) { ri.at(lane) = rd.at(lane) == mr ? ri.at(lane) : 1e9; });
+                    int ci = (int)wmin(ctx, ri);
+                    ci = (ci < 0 || ci >= M) ? 0 : ci;
+                    ctx.phase([&](int lane) {
+                        if (lane == 0) {
+                            conf[j] = ci;
+                            cpt[j] = pt;
+                        }
+                    });
+                    break;
+                }
+            }
+        }
+    }
+
+    // ---- diagnostics export (mpc_get_last_paths)
+    if (diag.len) {
+        const int nexp = replay ? 0 : ne;
+        ctx.phase([&](int lane) {
+            if (lane == 0) diag.len[0] = nexp;
+            if (lane < nexp) {
+                diag.ego[2 * lane] = ctx.ld(PL_EGO + 2 * lane);
+                diag.ego[2 * lane + 1] = ctx.ld(PL_EGO + 2 * lane + 1);
+            }
+            if (!replay && !degenerate && lane < V && lane < diag.vslots)
+                for (int m = 0; m < 2 * (kPredHorizon + 1); ++m)
+                    diag.agents[lane * 2 * (kPredHorizon + 1) + m] = (float)ctx.ld(PL_AG + lane * 2 * (kPredHorizon + 1) + m);
+        });
+    }
+
+    // ---- problem data that comes straight from the observation, state machine, ego index, speed profile: lane 0
+    ctx.phase([&](int lane) {
+        if (lane != 0) return;
+        write_vehicles(obs, p, state, others);
+        for (int j = p.observed; j < vslots; ++j) others[j * 4 + 0] = others[j * 4 + 1] = others[j * 4 + 2] = others[j * 4 + 3] = 0.0;
+        nveh_out = p.observed;
+        finish_env(p, R, N, ref_speed, conf, cpt, st, ego_index_out, vref, collide_out, advance && !degenerate, e0);
+    });
+}
+
+}  // namespace pre
+}  // namespace mpc

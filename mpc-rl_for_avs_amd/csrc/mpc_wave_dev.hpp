@@ -137,6 +137,8 @@ struct WaveOpsT {
     __device__ __forceinline__ int wave_bcast(PerLane<int> &p, int lane) const {
         return __builtin_amdgcn_readlane(p.v, lane);
     }
+    // bit l = lane l's value is non-zero
+    __device__ __forceinline__ unsigned long long ballot(PerLane<int> &p) const { return __ballot(p.v != 0); }
     // wave reductions: DPP inside the 16-lane rows, then the four row results (read with v_readlane) are combined
     // as (r0 op r1) op (r2 op r3) identically in every lane
     template <class OP>

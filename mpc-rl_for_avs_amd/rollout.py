@@ -407,7 +407,7 @@ class BatchedCollector:
                  n_steps: int = 64, gamma: float = 0.99, gae_lambda: float = 0.95,
                  default_weights=(1.0, 1.0, 1.0), collision_cost: bool = False, reset_mpc_on_done: bool = False,
                  gather_actions: bool = False, seed: int = 0, warm_start: bool = False,
-                 use_graph: bool | None = None, throughput: bool = False):
+                 use_graph: bool | None = None, throughput: bool = False, fused_glue: bool | None = None):
         if version not in ("v0", "v1") or algorithm not in ("ppo", "a2c"):
             raise ValueError("version must be v0|v1 and algorithm ppo|a2c")
         if version == "v1" and policy.action_dim < 3:
@@ -438,18 +438,42 @@ class BatchedCollector:
         self._mpc_out = None
         self.gathered_actions = None
         self.gathered_status = None
+        # fused_glue (None = whenever possible: fused HIP environment, SB3-shaped policy, real engine): policy forward + sample
+        # + MPC inputs in ONE launch (mpc_policy_act) and buffer row + carry-over + counters in one (mpc_rollout_record)
+        # instead of ~40 torch kernels - csrc/mpc_rollout_glue.hpp
+        can_fuse = (dev.type == "cuda" and getattr(env, "backend", "") == "hip" and isinstance(policy, ActorCritic) and
+                    hasattr(engine, "predict_batch_torch") and hasattr(engine, "_lib") and
+                    policy.pi[0].in_features == VEHICLES_COUNT * 8 and 2 * policy.pi[0].out_features <= 256 and
+                    policy.action_dim <= 8 and policy.log_std.dtype == torch.float32)
+        if fused_glue and not can_fuse:
+            raise ValueError("fused_glue needs the fused HIP environment, an ActorCritic policy (80 inputs, hidden <= 128) and the real engine")
+        self.fused_glue = can_fuse if fused_glue is None else bool(fused_glue)
+        if self.fused_glue:
+            A = policy.action_dim
+            z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device=dev)
+            self._fg = dict(act=z(B, A), val=z(B), logp=z(B), w=z(B, 3, dt=torch.float64), rs=z(B, dt=torch.float64),
+                            ticket=z(1, dt=torch.int32))
         # None = the default path: on a GPU with the real engine a step (policy -> MPC -> environment -> buffer row) is
         # captured once as a hipGraph and replayed; eager on the CPU, with stand-in engines, and when the actions are
         # all-gathered (the collective stays outside the graph)
         if use_graph is None:
-            use_graph = (dev.type == "cuda" and hasattr(engine, "reserve_envs") and hasattr(engine, "predict_batch_torch")
-                         and not gather_actions)
+            use_graph = dev.type == "cuda" and hasattr(engine, "reserve_envs") and hasattr(engine, "predict_batch_torch")
         self.use_graph = bool(use_graph)
         self._graph = None
+        self.graph_fallback_reason = None
         if self.use_graph:
-            if gather_actions:
-                raise ValueError("use_graph and gather_actions are not combined (the collective stays outside the graph)")
-            self._capture()
+            if not gather_actions:
+                self._capture()
+            else:
+                # sharded runs (config 5): the RCCL all-gather of actions + status is captured INSIDE the graph, so they keep
+                # the one-launch step.  Should this RCCL / torch build refuse to capture a collective, the collector steps
+                # eagerly and says why (graph_fallback_reason) instead of failing the run.
+                try:
+                    self._capture()
+                except Exception as e:      # noqa: BLE001 - whatever the capture raised is the reason reported
+                    torch.cuda.synchronize(dev)
+                    self._graph, self.use_graph = None, False
+                    self.graph_fallback_reason = f"{type(e).__name__}: {e}"
 
     def mpc_inputs(self, actions):
         """RL action -> (weights[B,3] float64, ref_speed[B] float64 or None) as the reference maps them."""
@@ -468,7 +492,56 @@ class BatchedCollector:
         self._roll["counts"].zero_()
 
     @torch.no_grad()
+    def _rollout_step_fused(self):
+        """The same step with the two glue kernels: identical random draws (the policy's noise comes from the same generator
+        call as ActorCritic.act), identical data flow; the float32 sums of the three small matrix products are accumulated in
+        index order instead of hipBLASLt's (tests/test_predict_gpu.py::test_fused_glue_step_equals_the_torch_step)."""
+        import ctypes
+        lib, env, pol, buf, fg = self.engine._lib, self.env, self.policy, self.buffer, self._fg
+        f, A, B = pol._fz, pol.action_dim, env.num_envs
+        H2 = f["b1"].numel()
+        dev = env.device
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        obs = self._last_obs
+        noise = torch.randn((B, A), generator=self.gen, device=dev, dtype=torch.float32)
+        v1 = self.version == "v1"
+        rc = lib.mpc_policy_act(dev.index, B, A, H2, p(obs), p(f["w1"]), p(f["b1"]), p(f["w2"]), p(f["b2"]), p(f["wh"]),
+                                p(f["bh"]), p(f["std"]), p(f["c0"]), p(noise), 1 if v1 else 0, 1 if self.algorithm == "ppo" else 0,
+                                p(fg["act"]), p(fg["val"]), p(fg["logp"]), p(fg["w"]) if v1 else None, None if v1 else p(fg["rs"]),
+                                stream)
+        if rc != 0:
+            raise RuntimeError(f"mpc_policy_act failed ({rc}): {lib.mpc_last_error().decode()}")
+        weights, ref_speed = (fg["w"], None) if v1 else (self.default_weights, fg["rs"])
+        self._mpc_out = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
+                                                        warm_start=self.warm_start, out=self._mpc_out, **self._mpc_kw)
+        self.last_mpc = self._mpc_out
+        mpc_action = self.last_mpc["act"]
+        if self.gather_actions:
+            from . import sharding
+            self.gathered_actions, self.gathered_status = sharding.all_gather_results(mpc_action, self.last_mpc["status"])
+        env.step(mpc_action)
+        o = env._out
+        if self.reset_mpc_on_done:
+            self.engine.reset_env_mask_torch(o["done"])
+        elif self.warm_start:
+            self.engine.reset_env_mask_torch(o["done"], warm_only=True)
+        keep = buf.terminal_obs is not None
+        rc = lib.mpc_rollout_record(dev.index, B, A, buf._cols, 1 if keep else 0, p(buf._row), p(buf.mpc_actions), p(buf.pos_dev),
+                                    p(fg["ticket"]), p(self._last_obs), p(self._last_episode_starts), p(fg["act"]), p(fg["val"]),
+                                    p(fg["logp"]), p(mpc_action), p(self.last_mpc["status"]), p(o["obs"]), p(o["reward"]),
+                                    p(o["done"]), p(o["terminal_obs"]) if keep else None, p(o["truncated"]) if keep else None,
+                                    p(o["crashed"]), p(o["arrived"]), p(self._roll["counts"]), p(self._roll["dones"]), stream)
+        if rc != 0:
+            raise RuntimeError(f"mpc_rollout_record failed ({rc}): {lib.mpc_last_error().decode()}")
+
+    @torch.no_grad()
     def _rollout_step(self, device_pos: bool = False):
+        if self.fused_glue:
+            self._rollout_step_fused()
+            if not device_pos:
+                self.buffer.pos += 1
+            return
         obs = self._last_obs
         actions, values, log_probs = self.policy.act(obs, generator=self.gen)
         weights, ref_speed = self.mpc_inputs(actions)

@@ -355,8 +355,10 @@ def _ipm(P, z, zL, zU, lam, mu, tol, max_iter, trace=False, exit_test=None, allo
             counters["resto_iters"] += r["iters"]
             if r["status"] != 7:
                 # the restoration problem was solved (or gave up) without reaching a point the filter accepts
+                # (IPOPT: RESTORATION_FAILED / LOCALLY_INFEASIBLE / "restoration converged to a feasible point that is
+                # unacceptable to the filter" - all of them failure exits of nlpsol; the iterate the caller gets, and the
+                # reference then ACTS on (agents/pure_mpc.py:303-311), is the regular method's last one, x_R)
                 status = 6 if r["status"] == 0 else (1 if r["status"] == 1 else 5)
-                z = r["z"][:n] if r["status"] == 0 else z
                 break
             x_new = r["z"][:n]
             dxr = x_new - zR

@@ -244,6 +244,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * below 1e-3).  Without it instances on the nonconvex side of the heading wrap crawl with 1/64-steps for the whole
      * iteration budget. */
     const double REG_MIN = 1e-3, REG_FACTOR = 4.0, REG_MAX = 1e6;
+    /* the multiple of the identity the last inertia correction ended with (0: none yet in this solve).  Until round 3 every
+     * correction climbed 1e-8, 1e-6, ... x 100 from scratch: with NEGATIVE cost weights (the v1 input domain: the RL action
+     * clipped to [-1, 1], agents/ppo_mpc.py:407-417) the control block needs ~1e-2 in every iteration, the ladder ended at 1
+     * - five wasted sweeps per iteration and steps a hundred times shorter than the curvature warrants: 121 iterations on
+     * average where IPOPT's rule takes 45 (tests/golden/closed_loop_ipopt.npz, scenario c4v1). */
+    double dw_last = 0.0;
     /* a rollout that would take theta or v of the next node out of its bounds gets the one control that decides it
      * (delta resp. a) pulled back so that the node keeps PROJ_KEEP of its slack: the Newton direction of a single
      * shooting method knows the state bounds only to first order, and without this every trial of an instance that
@@ -621,8 +627,13 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 ++nmod;
                 if (!gn) {
                     gn = 1;
+                } else if (dw_last == 0.0) {
+                    /* first inertia correction of this solve (IPOPT's algorithm IC: delta_w^0 = 1e-4, then x 100) */
+                    delta_w = (delta_w < 1e-4) ? 1e-4 : 100.0 * delta_w;
                 } else {
-                    delta_w = (delta_w == 0.0) ? 1e-8 : 100.0 * delta_w;
+                    /* later ones start at a third of the value that worked last and grow by 8 (kappa_w^- = 1/3,
+                     * kappa_w^+ = 8): the term stays within an order of magnitude of the curvature it has to cover */
+                    delta_w = (delta_w < dw_last / 3.0) ? dw_last / 3.0 : 8.0 * delta_w;
                 }
                 if (delta_w > 1e40) break;
             }
@@ -631,6 +642,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             status = 2;
             break;
         }
+        if (delta_w > reg) dw_last = delta_w; /* the ladder was needed: remember where it ended */
 
         /* ---------------- linear forward sweep: full primal-dual Newton step, step-length limits -------- */
         const double tau = fmax(0.99, 1.0 - mu);

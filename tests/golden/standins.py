@@ -188,6 +188,8 @@ class _Multi(_Geom):
 class LineString:
     def __init__(self, coords):
         self.pts = np.asarray([np.asarray(c, dtype=np.float64) for c in coords])
+        if len(self.pts) == 1:      # shapely 2.0: "point array must contain 0 or >1 elements" (what :582-587 catches)
+            raise sys.modules["shapely.errors"].GEOSException("IllegalArgumentException: point array must contain 0 or >1 elements")
 
     def intersection(self, other):
         from host_preamble import path_pieces          # tests/ is on the generator's sys.path

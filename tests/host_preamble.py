@@ -372,6 +372,10 @@ class HostPreambleAgent:
             max_acceleration=ego.max_acceleration, dt=self.dt, prediction_horizon=PREDICTION_HORIZON,
             reference_speed=self.global_reference_states[st.ego_index, 2])
         ego_arr = np.asarray([np.asarray(p, dtype=np.float64) for p in ego_future])
+        if len(ego_arr) < 2:
+            # the ego stands on the last reference point: LineString of ONE point raises GEOSException, the reference prints a
+            # warning and returns with the detector state as it was (agents/pure_mpc.py:582-587)
+            return
         st.conflict_points, st.conflict_index = [], []
         collide = []
         for veh in agents:

@@ -100,6 +100,11 @@ struct HostCtx {
         hi = p.v[32] + p.v[48];
     }
     int wave_bcast(mpc::wave::PerLane<int> &p, int lane) const { return p.v[lane]; }
+    unsigned long long ballot(mpc::wave::PerLane<int> &p) const {
+        unsigned long long m = 0;
+        for (int l = 0; l < mpc::wave::kLanes; ++l) m |= (unsigned long long)(p.v[l] != 0) << l;
+        return m;
+    }
     void wave_max_ratio(mpc::wave::PerLane<double> &pn, mpc::wave::PerLane<double> &pd, double &rn, double &rd) const {
         for (int step = 0; step < 4; ++step) {
             double nn[mpc::wave::kLanes], nd[mpc::wave::kLanes];

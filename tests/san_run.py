@@ -72,4 +72,24 @@ for K in (0, 1, 4, 9):
     he.reset()
     for _ in range(220):
         he.step(np.stack([rng.uniform(-6, 6, 33), rng.uniform(-0.1, 0.1, 33)], axis=1))
-print(f"sanitized run ok: {n} wave solves, LTV, preamble and environment harnesses clean")
+# the wave-per-environment form of the preamble (mpc_preamble_wave.hpp): every LDS word bounds-checked by HostCtx
+for rows in (1, 2, 10, 17):
+    dp = tp.DevicePreamble(lib, ref, wave=True)
+    for t in range(4):
+        obs = np.zeros((5, rows, 8), np.float32)
+        full = synth.make_obs_batch(5, min(rows - 1, 9), seed=40 * rows + t)
+        obs[:, :min(rows, 10)] = full[:, :min(rows, 10)]
+        if rows > 10:
+            obs[:, 10:] = full[:, 1:rows - 9]
+        o = dp(obs)
+        assert o["state"].shape == (5, 4)
+# rollout glue (mpc_rollout_glue.hpp): policy forward / sample / MPC inputs and the buffer row
+import torch  # noqa: E402
+import glue_host  # noqa: E402
+from mpc_rl_for_avs_amd import rollout  # noqa: E402
+for A, version in ((1, "v0"), (3, "v1"), (8, "v1")):
+    pol = rollout.ActorCritic(A)
+    g = glue_host.policy_act(pol, np.random.default_rng(A).normal(size=(7, 10, 8)).astype(np.float32),
+                             np.zeros((7, A), np.float32), version, True)
+    assert np.isfinite(g["actions"]).all()
+print(f"sanitized run ok: {n} wave solves, LTV, preamble (both forms), environment and rollout-glue harnesses clean")

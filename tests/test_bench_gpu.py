@@ -80,3 +80,6 @@ def test_config5_shape_rollout_over_rccl():
     assert g["backend"] == "nccl" and g["gathered_actions_shape"] == [2048, 2] and g["gathered_status_shape"] == [2048]
     assert g["own_block_equals_local"] is True
     assert d["env_steps_per_s"] > 1e5 and d["converged_frac"] > 0.99
+    # the RCCL gather is captured INSIDE the step's hipGraph: sharded runs keep the one-launch step
+    assert d["graph"] is True and d["graph_fallback_reason"] is None, d["graph_fallback_reason"]
+    assert d["fused_glue"] is True

@@ -425,55 +425,62 @@ def test_stall_window_on_the_gpu(oracle, ref_table):
     e.close()
 
 
-# scenario -> (both converged, of those within 1e-4) measured with the engine's algorithm on the CPU
-# (profiles/r03_parity_vs_ipopt.txt, tools/parity_vs_ipopt.py); the GPU must reproduce the agreement, not approach it
-CLOSED_LOOP_AGREEMENT = {"c1": (117, 113), "c1cc": (117, 110), "c4": (160, 160), "c4mpc": (159, 155), "c4cc": (152, 149)}
-
-
 def test_closed_loop_fixtures_vs_independent_solver(ref_table):
     """tests/golden/closed_loop_ipopt.npz: problem data recorded from closed-loop runs (BASELINE config 1 and the
-    config-4 rollout, collision cost off / on, RL speed override / none; generator tests/golden/make_closed_loop.py)
-    solved by oracle/ipopt_restated.py at the REFERENCE's settings (tol 1e-6, max_iter 1000, agents/pure_mpc.py:294-295).
-    The engine at its reference-like settings (max_iter 1000) must return the same action to 1e-4 on exactly the set
-    the analysis in profiles/r03_parity_vs_ipopt.txt found (97.2 % overall; 100 % under the RL speed override), and
-    where it does not its own point must be a certified KKT point (a different local minimiser: the 20 cases are
-    classified one by one in that file - end of the route with the reference window clamped, spawn transients with the
-    heading off the path and steering almost free, one stop profile)."""
+    config-4 rollout, collision cost off / on, RL speed override / none, and the v1 input domain: cost weights from
+    [-1, 1]^3; generator tests/golden/make_closed_loop.py) solved by oracle/ipopt_restated.py - IPOPT's algorithm incl. its
+    restoration phase - at the REFERENCE's settings (tol 1e-6, max_iter 1000, agents/pure_mpc.py:294-295).
+    The engine at max_iter 1000 must reproduce, instance by instance, the classification the CPU analysis made with the
+    same algorithm (profiles/r04_parity_vs_ipopt.txt; tests/test_oracle.py pins its counts): the same statuses, the same
+    actions to 1e-6 where converged, hence the same set of instances within 1e-4 of the proxy; and every converged
+    answer that differs from the proxy's must be a certified KKT point (another local minimiser of a non-convex NLP)."""
     import kkt_batch as kb
     import nlp_batch as nb
     from mpc_rl_for_avs_amd import engine
+    from test_oracle import CLOSED_LOOP_COUNTS
     g = np.load(os.path.join(GOLDEN, "closed_loop_ipopt.npz"))
     e = engine.MPCEngine(horizon=20, max_iter=1000)
     tot_both = tot_agree = 0
-    for name, (n_both, n_agree) in CLOSED_LOOP_AGREEMENT.items():
+    for name, (n_proxy, n_eng, n_both, n_agree) in CLOSED_LOOP_COUNTS.items():
         cc = name.endswith("cc")
         d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
         got = e.solve_batch(d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"], others=d["others"],
                             collision_cost=cc)
-        # the device against the CPU run of the same algorithm that the analysis used (c1 holds two stalled solves; at most
-        # one instance whose iterates are chaotic in the last bit may end differently on the device)
-        assert (got["status"] == g[f"{name}_oracle_status"]).sum() >= 159, (name, np.bincount(got["status"], minlength=6))
         assert (got["status"] == 2).sum() == 0, name      # the slack floor (kMinSlack) removed the NaN sweeps
-        assert converged(got["status"]).mean() >= 0.98
+        # the device against the CPU run of the same algorithm: converged on the same instances, same actions there
         ok = converged(got["status"])
+        assert np.array_equal(ok, converged(g[f"{name}_oracle_status"])), (name, np.bincount(got["status"], minlength=6))
+        assert int(ok.sum()) == n_eng
         assert rel_u0_err(got["u0"], g[f"{name}_oracle_u0"])[ok].max() < 1e-6, name
-        both = (g[f"{name}_status"] == 0) & converged(got["status"])
+        both = (g[f"{name}_status"] == 0) & ok
         err = rel_u0_err(got["u0"], g[f"{name}_u0"])
         agree = both & (err <= TOL)
-        # exactly the counts of the CPU analysis (tests/test_oracle.py pins those), minus at most the one instance above
-        assert n_both - 1 <= int(both.sum()) <= n_both and n_agree - 1 <= int(agree.sum()) <= n_agree, (name, both.sum(), agree.sum())
-        assert int(both.sum()) - int(agree.sum()) <= n_both - n_agree
-        assert np.median(err[agree]) < 1e-7          # the proxy stops at tol 1e-6
+        assert (int(both.sum()), int(agree.sum())) == (n_both, n_agree), (name, both.sum(), agree.sum())
+        assert np.median(err[agree]) < 1e-6          # the proxy stops at tol 1e-6
         other = np.nonzero(both & ~agree)[0]
         if other.size:
             p = nb.Batch.build(ref_table, d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"],
                                others=d["others"], collision_cost=cc).take(other)
             mine = kb.certify(p, got["X"][other], got["U"][other])
             assert mine["stationarity"].max() <= 1e-8 and mine["feasibility"].max() <= 1e-10, name
-        tot_both += int(both.sum())
-        tot_agree += int(agree.sum())
-    assert tot_agree / tot_both >= 0.97
+        if name != "c4v1":
+            tot_both += int(both.sum())
+            tot_agree += int(agree.sum())
+    assert tot_agree / tot_both >= 0.97              # scenarios with non-negative weights: 747 of 766
     e.close()
+    # the three instances the engine's algorithm does not finish at tol 1e-8 while the proxy converges at its 1e-6: at the
+    # reference's own tolerance the engine converges on them and returns the proxy's action
+    e6 = engine.MPCEngine(horizon=20, max_iter=1000, tol=1e-6)
+    n_hard = 0
+    for name in ("c1", "c4v1"):
+        hard = np.nonzero((g[f"{name}_status"] == 0) & ~converged(g[f"{name}_oracle_status"]))[0]
+        d = {k: g[f"{name}_{k}"][hard] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
+        got = e6.solve_batch(d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"], others=d["others"])
+        assert converged(got["status"]).all() and got["iters"].max() <= 40
+        assert rel_u0_err(got["u0"], g[f"{name}_u0"][hard]).max() < 1e-5
+        n_hard += hard.size
+    assert n_hard == 3
+    e6.close()
 
 
 def test_config4_rollout_256_envs_against_oracle(oracle, ref_table):

@@ -21,7 +21,7 @@ def load_pre():
     import conftest
     out = os.path.join(conftest.BUILD_DIR, "libcpu_preamble.so")
     src = os.path.join(ROOT, "tests", "cpu_preamble_harness.cpp")
-    deps = [src] + [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_preamble.hpp")]
+    deps = [src, os.path.join(ROOT, "tests", "host_wave_ctx.hpp")] + [os.path.join(ROOT, "mpc-rl_for_avs_amd", "csrc", f) for f in ("mpc_core.hpp", "mpc_preamble.hpp", "mpc_preamble_wave.hpp", "mpc_wave.hpp")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.run(["g++"] + conftest.HOST_CXXFLAGS + ["-o", out, src], check=True)
@@ -31,16 +31,22 @@ def load_pre():
                                         ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
     lib.preamble_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 8
+    lib.preamble_wave_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_double] + [ctypes.c_void_p] * 8 + [ctypes.c_int] + \
+        [ctypes.c_void_p] * 3
     return lib
 
 
 class DevicePreamble:
     """The harness as a stateful object: same call pattern as mpc_predict_batch up to the solve."""
 
-    def __init__(self, lib, ref, N=20, dt=0.1):
-        self.lib, self.ref, self.N, self.dt = lib, np.ascontiguousarray(ref, np.float64), N, dt
+    def __init__(self, lib, ref, N=20, dt=0.1, wave=False):
+        """wave=False: the one-thread-per-environment form (mpc_preamble.hpp: preamble_env); wave=True: the form the HIP
+        kernel runs, one wave per environment (mpc_preamble_wave.hpp), its 64 lanes emulated by loops."""
+        self.lib, self.ref, self.N, self.dt, self.wave = lib, np.ascontiguousarray(ref, np.float64), N, dt, wave
         self.words = lib.preamble_env_state_ints()
         self.env = np.zeros((0, self.words), np.int32)
+        self.paths = None
 
     def __call__(self, obs, ref_speed=None):
         B, rows = obs.shape[:2]
@@ -52,9 +58,16 @@ class DevicePreamble:
         obs = np.ascontiguousarray(obs, np.float32)
         rs = None if ref_speed is None else np.ascontiguousarray(ref_speed, np.float64).reshape(B)
         p = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-        rc = self.lib.preamble_batch(B, p(obs), rows, p(self.ref), self.ref.shape[0], self.N, self.dt, p(rs),
-                                     p(self.env), p(o["state"]), p(o["ego_index"]), p(o["vref"]), p(o["is_collide"]),
-                                     p(o["others"]), p(o["nveh"]))
+        if self.wave:
+            self.paths = dict(ego_path=np.zeros((B, 31, 2)), ego_len=np.zeros(B, np.int32), agent_paths=np.zeros((B, V, 31, 2), np.float32))
+            rc = self.lib.preamble_wave_batch(B, p(obs), rows, p(self.ref), self.ref.shape[0], self.N, self.dt, p(rs),
+                                              p(self.env), p(o["state"]), p(o["ego_index"]), p(o["vref"]), p(o["is_collide"]),
+                                              p(o["others"]), p(o["nveh"]), 1, p(self.paths["ego_path"]),
+                                              p(self.paths["ego_len"]), p(self.paths["agent_paths"]))
+        else:
+            rc = self.lib.preamble_batch(B, p(obs), rows, p(self.ref), self.ref.shape[0], self.N, self.dt, p(rs),
+                                         p(self.env), p(o["state"]), p(o["ego_index"]), p(o["vref"]), p(o["is_collide"]),
+                                         p(o["others"]), p(o["nveh"]))
         assert rc == 0
         o["memory"] = self.env[:B, 0].copy()
         o["conflict"] = self.env[:B, 8:24].copy()
@@ -124,12 +137,13 @@ def test_stop_profile_matches_reference_golden(pre, ref_table):
         assert np.array_equal(got["vref"][0], want[idx])
 
 
+@pytest.mark.parametrize("wave", [False, True])
 @pytest.mark.parametrize("V", [0, 3, 9])
-def test_preamble_sequence_matches_host_mirror(pre, ref_table, V):
+def test_preamble_sequence_matches_host_mirror(pre, ref_table, V, wave):
     from mpc_rl_for_avs_amd import synth
     from host_preamble import HostPreambleAgent as PureMPC_Agent
     agent = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
-    dev = DevicePreamble(pre, ref_table)
+    dev = DevicePreamble(pre, ref_table, wave=wave)
     B, T = 96, 14
     rng = np.random.default_rng(5 + V)
     n_coll = 0
@@ -165,11 +179,12 @@ def test_preamble_sequence_matches_host_mirror(pre, ref_table, V):
         assert n_coll > B                                    # the detector actually fired
 
 
-def test_preamble_collinear_and_degenerate_cases(pre, ref_table):
+@pytest.mark.parametrize("wave", [False, True])
+def test_preamble_collinear_and_degenerate_cases(pre, ref_table, wave):
     """Same-lane traffic (collinear overlap of the two paths), a stopped ego, the end of the path."""
     from host_preamble import HostPreambleAgent as PureMPC_Agent
     agent = PureMPC_Agent(Env(), dict(CFG), engine=FakeEngine())
-    dev = DevicePreamble(pre, ref_table)
+    dev = DevicePreamble(pre, ref_table, wave=wave)
     obs = np.zeros((6, 10, 8), np.float32)
     obs[:, 0, 0] = 1
     ego = [(2.0, 45.0, 0.0, -8.0, -np.pi / 2), (2.0, 30.0, 0.0, 0.0, -np.pi / 2), (-36.2, -2.2, -9.0, 0.0, np.pi),

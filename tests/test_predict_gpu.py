@@ -460,3 +460,54 @@ def test_graph_and_eager_collectors_produce_the_same_rollout():
     assert np.array_equal(eng2.save_env_state(B), recs)
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("version,algorithm", [("v0", "ppo"), ("v1", "ppo"), ("v0", "a2c")])
+def test_fused_glue_step_equals_the_torch_step(version, algorithm):
+    """mpc_policy_act + mpc_rollout_record (csrc/mpc_rollout_glue.hpp) against the torch ops they replace: same seeds, same
+    random draws, the same rollout - up to the summation order of three float32 matrix products."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, rollout
+    dev = torch.device("cuda", 0)
+    B, T = 96, 6
+    out = []
+    for fused in (True, False):
+        torch.manual_seed(11)
+        pol = rollout.ActorCritic(3 if version == "v1" else 1).to(dev)
+        with torch.no_grad():
+            pol.log_std.fill_(-1.0)
+        eng = engine.MPCEngine(horizon=20, max_iter=100)
+        env = rollout.SyntheticIntersectionEnv(B, device=dev, seed=9, n_others=4)
+        col = rollout.BatchedCollector(env, pol, eng, version=version, algorithm=algorithm, n_steps=T, seed=4,
+                                       use_graph=False, fused_glue=fused)
+        assert col.fused_glue == fused
+        stats = col.collect_rollouts()
+        b = col.buffer
+        out.append(dict(stats=stats, obs=b.obs.clone(), actions=b.actions.clone(), values=b.values.clone(),
+                        logp=b.log_probs.clone(), rewards=b.rewards.clone(), starts=b.episode_starts.clone(),
+                        mpc=b.mpc_actions.clone(), adv=b.advantages.clone(), last=col._last_obs.clone(),
+                        term=None if b.terminal_obs is None else b.terminal_obs.clone(),
+                        trunc=None if b.truncated is None else b.truncated.clone()))
+        eng.close()
+    f, t = out
+    # step 0: the same observation on both sides - the policy's outputs agree to float32 summation order, the MPC's actions
+    # to what a 1e-7 change of its inputs does
+    assert torch.equal(f["obs"][0], t["obs"][0]) and torch.equal(f["starts"][0], t["starts"][0])
+    assert torch.allclose(f["actions"][0], t["actions"][0], atol=2e-5) and torch.allclose(f["values"][0], t["values"][0], atol=2e-5)
+    assert torch.allclose(f["logp"][0], t["logp"][0], atol=1e-4)
+    d0 = (f["mpc"][0] - t["mpc"][0]).abs().amax(dim=-1)
+    assert d0.quantile(0.9) < 1e-4
+    assert torch.allclose(f["rewards"][0], t["rewards"][0], atol=1e-2) or version == "v1"
+    # later steps: the same rollout as long as no solve lands in another minimum (v1 hands the MPC negative cost weights:
+    # non-convex problems, where a 1e-7 change of an input may do that) - required of most environments, not of all
+    same = (f["obs"] - t["obs"]).abs().amax(dim=(2, 3)) < 1e-3                # [T, B]
+    assert same.float().mean() > (0.6 if version == "v1" else 0.97), same.float().mean()
+    da = (f["actions"] - t["actions"]).abs().amax(dim=-1)
+    assert da[same].max() < 1e-3
+    assert torch.equal(f["starts"][same], t["starts"][same])
+    if version == "v0":
+        assert f["stats"]["episodes"] == t["stats"]["episodes"] and f["stats"]["crashed"] == t["stats"]["crashed"]
+        assert abs(f["stats"]["mpc_unconverged"] - t["stats"]["mpc_unconverged"]) <= 3
+    if f["term"] is not None:
+        assert torch.equal(f["trunc"][same], t["trunc"][same])
+    assert torch.isfinite(f["adv"]).all() and torch.isfinite(t["adv"]).all()

@@ -174,8 +174,9 @@ def test_mirror_state_machine_on_reference_sequences(seq):
 # ---------------------------------------------------------------------------------------------------------------
 # the device preamble, compiled for the host
 # ---------------------------------------------------------------------------------------------------------------
-def test_device_code_parse_and_predictors(pre, rnd, ref_table):
-    dev = DevicePreamble(pre, ref_table)
+@pytest.mark.parametrize("wave", [False, True])
+def test_device_code_parse_and_predictors(pre, rnd, ref_table, wave):
+    dev = DevicePreamble(pre, ref_table, wave=wave)
     got = dev(rnd["parse_obs"])
     assert np.array_equal(got["state"], rnd["parse_ego"][:, :4])
     assert np.array_equal(got["nveh"], rnd["parse_ego"][:, 4].astype(np.int32))
@@ -190,6 +191,22 @@ def test_device_code_parse_and_predictors(pre, rnd, ref_table):
         k = pre.preamble_ego_future(ref.ctypes.data, ref.shape[0], obs[0, 1], obs[0, 2], sp, float(vref), 0.1, out.ctypes.data)
         assert k == n and np.array_equal(out[:k], want[:k])
     check_agent_paths(rnd, lambda b, row: _host_agent_path(pre, row))
+    if wave:
+        # the wave form's own polylines (what mpc_get_last_paths exports on the GPU)
+        vref = rnd["ego_future_vref"]
+        for v in np.unique(vref):
+            sel = np.nonzero(vref == v)[0]
+            tab = ref_table.copy()
+            tab[:, 2] = v
+            d2 = DevicePreamble(pre, tab, wave=True)
+            d2(rnd["ego_future_obs"][sel])
+            assert np.array_equal(d2.paths["ego_len"], rnd["ego_future_len"][sel]), v
+            for i, b in enumerate(sel):
+                k = d2.paths["ego_len"][i]
+                assert np.array_equal(d2.paths["ego_path"][i, :k], rnd["ego_future_out"][b, :k]), (v, b)
+        d3 = DevicePreamble(pre, ref_table, wave=True)
+        d3(rnd["agent_future_obs"])
+        check_agent_paths(rnd, lambda b, row: d3.paths["agent_paths"][b, 0])
 
 
 def _host_agent_path(pre, row):
@@ -247,11 +264,12 @@ def test_device_code_update_reference_states(pre, rnd, ref_table):
         assert np.array_equal(out["col"], rnd["update_ref_is_collide"][sel])
 
 
-def test_device_code_state_machine_on_reference_sequences(pre, seq, ref_table):
+@pytest.mark.parametrize("wave", [False, True])
+def test_device_code_state_machine_on_reference_sequences(pre, seq, ref_table, wave):
     devs = {}
 
     def step(gi, t, envs, obs, rs):
-        dev = devs.setdefault(gi, DevicePreamble(pre, ref_table))
+        dev = devs.setdefault(gi, DevicePreamble(pre, ref_table, wave=wave))
         o = dev(obs, rs)
         B = len(envs)
         rec = dev.env[:B].view(rf.ENV_DTYPE).reshape(B)

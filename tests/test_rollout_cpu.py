@@ -176,3 +176,68 @@ def test_fused_rollout_forward_is_the_policy():
         with torch.no_grad():                         # an optimiser step later the fused copy must follow
             for p in pol.parameters():
                 p.add_(0.05 * torch.randn_like(p))
+
+
+@pytest.mark.parametrize("A,version,clip", [(1, "v0", True), (3, "v1", True), (4, "v1", False), (2, "v0", False)])
+def test_rollout_glue_code_is_the_policy_and_the_buffer_row(A, version, clip):
+    """csrc/mpc_rollout_glue.hpp (what mpc_policy_act / mpc_rollout_record run per thread), compiled for the host, against the
+    torch ops it replaces: ActorCritic.act + BatchedCollector.mpc_inputs, and RolloutBuffer.add with the collector's
+    carry-over and counters."""
+    import ctypes
+    import glue_host
+    torch.manual_seed(A)
+    pol = rollout.ActorCritic(A)
+    with torch.no_grad():
+        pol.log_std.copy_(torch.linspace(-0.5, 0.3, A))
+    B = 53
+    obs = torch.randn(B, 10, 8)
+    noise = torch.randn(B, A)
+    got = glue_host.policy_act(pol, obs.numpy(), noise.numpy(), version, clip)
+
+    class Gen:                                   # hands act() the same noise
+        pass
+    orig = torch.randn
+    try:
+        torch.randn = lambda *a, **k: noise.clone()
+        actions, values, logp = pol.act(obs)
+    finally:
+        torch.randn = orig
+    assert np.allclose(got["actions"], actions.numpy(), atol=2e-6) and np.allclose(got["values"], values.numpy(), atol=2e-6)
+    assert np.allclose(got["log_probs"], logp.numpy(), atol=2e-5)
+    c = torch.clamp(actions, -1, 1) if clip else actions
+    if version == "v0":
+        assert np.allclose(got["ref_speed"], c[:, 0].double().numpy(), atol=2e-6) and np.isnan(got["weights"]).all()
+    else:
+        assert np.allclose(got["weights"], c[:, :3].double().numpy(), atol=2e-6) and np.isnan(got["ref_speed"]).all()
+    # ---- the buffer row
+    lib = glue_host.load()
+    for keep in (True, False):
+        T = 3
+        buf = rollout.RolloutBuffer(T, B, A, "cpu", keep_terminal=keep)
+        mine = rollout.RolloutBuffer(T, B, A, "cpu", keep_terminal=keep)
+        last_obs, starts = torch.randn(B, 10, 8), (torch.rand(B) < 0.3).float()
+        my_obs, my_starts = last_obs.clone(), starts.clone()
+        counts = np.zeros(4, np.int64)
+        want_counts = np.zeros(4, np.int64)
+        pos = np.zeros(1, np.int64)
+        p = lambda t: ctypes.c_void_p(t.data_ptr()) if isinstance(t, torch.Tensor) else ctypes.c_void_p(t.ctypes.data)
+        for t in range(T):
+            act, val, lp = torch.randn(B, A), torch.randn(B), torch.randn(B)
+            mpc_act, status = torch.randn(B, 2, dtype=torch.float64), torch.randint(0, 6, (B,), dtype=torch.int32)
+            new_obs, reward, term = torch.randn(B, 10, 8), torch.randn(B), torch.randn(B, 10, 8)
+            done, trunc = (torch.rand(B) < 0.3), (torch.rand(B) < 0.2)
+            crashed, arrived = done & (torch.rand(B) < 0.5), done & (torch.rand(B) < 0.5)
+            u8 = lambda b: b.to(torch.uint8).contiguous()
+            dones_out = torch.zeros(B, dtype=torch.uint8)
+            d8, t8, c8, a8 = u8(done), u8(trunc), u8(crashed), u8(arrived)
+            rc = lib.glue_rollout_record(B, A, mine._cols, 1 if keep else 0, p(mine._row), p(mine.mpc_actions), p(pos), p(my_obs),
+                                         p(my_starts), p(act), p(val), p(lp), p(mpc_act), p(status), p(new_obs), p(reward), p(d8),
+                                         p(term) if keep else None, p(t8) if keep else None, p(c8), p(a8), p(counts), p(dones_out))
+            assert rc == 0 and pos[0] == t + 1
+            kw = dict(terminal_obs=term, truncated=trunc) if keep else {}
+            buf.add(last_obs, act, reward, starts, val, lp, mpc_act, **kw)
+            last_obs, starts = new_obs.clone(), done.float()
+            want_counts += np.array([int(done.sum()), int(crashed.sum()), int(arrived.sum()), int(((status != 0) & (status != 5)).sum())])
+            assert torch.equal(dones_out.bool(), done)
+        assert torch.equal(mine._row, buf._row) and torch.equal(mine.mpc_actions, buf.mpc_actions)
+        assert torch.equal(my_obs, last_obs) and torch.equal(my_starts, starts) and np.array_equal(counts, want_counts)

@@ -29,6 +29,8 @@ def main():
                          "captured hipGraph, which is the collector's default on a GPU")
     ap.add_argument("--env-backend", default="auto", choices=("auto", "hip", "torch"),
                     help="fused HIP environment step (default on a GPU) or the vectorised torch ops")
+    ap.add_argument("--max-iter", type=int, default=100, help="solver iteration cap (the reference: 1000)")
+    ap.add_argument("--tol", type=float, default=1e-8, help="solver tolerance (the reference: 1e-6)")
     ap.add_argument("--groups", type=int, default=1,
                     help="split this rank's environments into G groups stepped on G HIP streams (PipelinedCollector)")
     a = ap.parse_args()
@@ -53,13 +55,13 @@ def main():
         engs, cols = [], []
         for g in range(G):
             glo, ghi = sharding.shard_range(B, g, G)
-            e_g = engine.MPCEngine(horizon=20, max_iter=100, device=local)
+            e_g = engine.MPCEngine(horizon=20, max_iter=a.max_iter, tol=a.tol, device=local)
             env = rollout.SyntheticIntersectionEnv(ghi - glo, device=dev, seed=rank * 97 + g, n_others=a.others,
                                                    backend=a.env_backend, env_offset=lo + glo)
             engs.append(e_g)
             cols.append(rollout.BatchedCollector(env, pol, e_g, version=a.version, algorithm=a.algorithm, n_steps=a.steps,
                                                  collision_cost=False, gather_actions=use_dist and G == 1,
-                                                 seed=g, use_graph=a.graph and not use_dist, throughput=G > 1))
+                                                 seed=g, use_graph=a.graph, throughput=G > 1))
         col = cols[0] if G == 1 else rollout.PipelinedCollector(cols)
         col.collect_rollouts()                                   # warm-up (allocations, first launches)
         events = []
@@ -74,7 +76,7 @@ def main():
                 return out
             return call
 
-        graph = a.graph and not use_dist                         # the all-gather stays outside a graph
+        graph = all(c._graph is not None for c in cols)          # sharded runs capture the RCCL gather inside the graph
         if not graph:                                            # a replayed graph does not pass through Python
             for e_g in engs:
                 e_g.predict_batch_torch = timed(e_g.predict_batch_torch)
@@ -103,11 +105,12 @@ def main():
         st = torch.cat([c.last_mpc["status"] for c in cols]).cpu().numpy()
         if rank == 0:
             print(json.dumps(dict(config=f"{total} envs on {world} GPU(s), {a.others} other vehicles, {a.version}/{a.algorithm}, "
-                                         f"horizon 20" + (f", {G} groups on {G} streams" if G > 1 else "") + (", hipGraph step" if graph else ", eager step") + f", {cols[0].env.backend} environment",
-                              envs=total, n_gpus=world, distributed=dist_info, groups=G, graph=bool(graph), env_backend=cols[0].env.backend,
+                                         f"horizon 20, max_iter {a.max_iter}, tol {a.tol:g}" + (f", {G} groups on {G} streams" if G > 1 else "") + (", hipGraph step" if graph else ", eager step") + f", {cols[0].env.backend} environment",
+                              envs=total, n_gpus=world, distributed=dist_info, graph_fallback_reason=cols[0].graph_fallback_reason, fused_glue=cols[0].fused_glue, groups=G, graph=bool(graph), env_backend=cols[0].env.backend,
                               steps_per_env=a.steps, env_steps_per_s=total * a.steps / dt, ms_per_step=dt / a.steps * 1e3,
                               mpc_ms_per_step=(dm / a.steps * 1e3) if events else None, episodes=stats["episodes"], crashed=stats["crashed"],
-                              arrived=stats["arrived"], converged_frac=float(((st == 0) | (st == 5)).mean()))), flush=True)
+                              arrived=stats["arrived"], converged_frac=float(((st == 0) | (st == 5)).mean()),
+                              converged_frac_rollout=1.0 - stats["mpc_unconverged"] / float(total * a.steps) * world)), flush=True)
         for e_g in engs:
             e_g.close()
     if use_dist:

@@ -80,15 +80,44 @@ def study(name, d, cc, ip, pool, out):
     err = rel(orc["u0"], ip["u0"])
     agree = both & (err <= 1e-4)
     bad = np.nonzero(both & (err > 1e-4))[0]
-    out(f"{name}: {B} instances; independent solver converged {int((ip['status'] == 0).sum())} (restoration "
-        f"{int((ip['status'] == 5).sum())}, iteration limit {int((ip['status'] == 1).sum())}); engine algorithm converged "
-        f"{int(conv(orc['status']).sum())}; both {int(both.sum())}; u0 within 1e-4: {int(agree.sum())} = "
+    pfail = ip["status"] != 0                      # IPOPT's failure exits: the reference acts on the last iterate
+    efail = (ip["status"] == 0) & ~conv(orc["status"])
+    n_resto = int((ip["n_resto"] > 0).sum()) if "n_resto" in ip else -1
+    out(f"{name}: {B} instances; independent solver converged {int((ip['status'] == 0).sum())} ({n_resto} of all went through "
+        f"its restoration phase; failure exits: iteration limit {int((ip['status'] == 1).sum())}, restoration failed "
+        f"{int((ip['status'] == 5).sum())}, restoration ended at a point of local infeasibility {int((ip['status'] == 6).sum())}); "
+        f"engine algorithm converged {int(conv(orc['status']).sum())}; both {int(both.sum())}; u0 within 1e-4: {int(agree.sum())} = "
         f"{agree.sum() / max(both.sum(), 1):.4f}; median rel. error of the agreeing {np.median(err[agree]):.1e}")
+    cls = dict(n=B, agree=int(agree.sum()), two_minima=0, unexplained=0, proxy_fails=int(pfail.sum()), engine_fails=int(efail.sum()))
+    if pfail.any():
+        idx = np.nonzero(pfail)[0]
+        e_conv = conv(orc["status"][idx])
+        th0 = np.abs(np.abs(d["state"][idx, 2]) - np.pi) < 2e-7
+        out(f"    proxy fails on {idx.size}: engine converged on {int(e_conv.sum())} of them; theta_0 within 2e-7 of the heading "
+            f"bound (outside the relaxed bound by float32 rounding) in {int(th0.sum())}; |u0(engine) - u0(proxy's last iterate)| "
+            f"median {np.median(err[idx]):.2e}, within 1e-4 in {int((err[idx] <= 1e-4).sum())}")
+    if efail.any():
+        idx = np.nonzero(efail)[0]
+        # the engine's algorithm ran at tol 1e-8 above; the proxy (like the reference) stops at 1e-6: the same instances at
+        # the reference's tolerance (PureMPC_Agent(reference_settings=True))
+        o6 = oracle_lib.solve_batch(REF, d["state"][idx], d["ego_index"][idx], d["weights"][idx], d["is_collide"][idx],
+                                    vref=d["vref"][idx], others=d["others"][idx], collision_cost=cc, max_iter=1000,
+                                    xy_bounds=False, nthreads=8, tol=1e-6)
+        e6 = rel(o6["u0"], ip["u0"][idx])
+        cls["engine_fails_at_reference_tol"] = int((~conv(o6["status"])).sum())
+        out(f"    engine (tol 1e-8) fails where the proxy (tol 1e-6) converges on {idx.size}: engine statuses "
+            f"{orc['status'][idx].tolist()}, iterations {orc['iters'][idx].tolist()}, proxy iterations "
+            f"{np.asarray(ip.get('iters', np.zeros(B, int)))[idx].tolist()}.  The engine's algorithm at the reference's tol 1e-6: "
+            f"statuses {o6['status'].tolist()}, iterations {o6['iters'].tolist()}, |du0| to the proxy {[float(f'{v:.1e}') for v in e6]}")
     if not bad.size:
-        return dict(both=int(both.sum()), agree=int(agree.sum()), lower=0, higher=0, both_fixed=0)
+        return dict(both=int(both.sum()), agree=int(agree.sum()), lower=0, higher=0, both_fixed=0, cls=cls)
     Ji, Jo = nb.cost(p, ip["X"], ip["U"]), nb.cost(p, orc["X"], orc["U"])
     ci = kb.certify(p.take(bad), ip["X"][bad], ip["U"][bad])
     co = kb.certify(p.take(bad), orc["X"][bad], orc["U"][bad])
+    # the proxy stops at tol 1e-6 (scaled): its point is a KKT point to that accuracy, the engine's to 1e-8
+    certified = (co["stationarity"] <= 1e-6) & (ci["stationarity"] <= 1e-3) & (co["feasibility"] <= 1e-8) & (ci["feasibility"] <= 1e-5)
+    cls["two_minima"] = int(certified.sum())
+    cls["unexplained"] = int((~certified).sum())
     # each solver started at the other's answer
     warm = oracle_lib.solve_batch(REF, d["state"][bad], d["ego_index"][bad], d["weights"][bad], d["is_collide"][bad],
                                   vref=d["vref"][bad], others=d["others"][bad], collision_cost=cc, max_iter=1000,
@@ -109,7 +138,7 @@ def study(name, d, cc, ip, pool, out):
             f"{'stays' if stay_i else 'leaves'}  [{classify(d, b)}]")
     out(f"    => {bad.size} disagreements: engine's objective lower in {lower}, proxy's lower in {higher}; in {fixed} both "
         f"answers are fixed points of both solvers (two local minimisers, the cold start decides)")
-    return dict(both=int(both.sum()), agree=int(agree.sum()), lower=int(lower), higher=int(higher), both_fixed=int(fixed))
+    return dict(both=int(both.sum()), agree=int(agree.sum()), lower=int(lower), higher=int(higher), both_fixed=int(fixed), cls=cls)
 
 
 def main():
@@ -125,22 +154,36 @@ def main():
         out("\n## (a) closed-loop fixtures, tests/golden/closed_loop_ipopt.npz")
         g = np.load(os.path.join(ROOT, "tests", "golden", "closed_loop_ipopt.npz"))
         tot = dict(both=0, agree=0, lower=0, higher=0, both_fixed=0)
-        for name in ("c1", "c1cc", "c4", "c4mpc", "c4cc"):
+        table = []
+        for name in ("c1", "c1cc", "c4", "c4mpc", "c4cc", "c4v1"):
             d = {k: g[f"{name}_{k}"] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
-            ip = {k: g[f"{name}_{k}"] for k in ("u0", "U", "X", "status")}
+            ip = {k: g[f"{name}_{k}"] for k in ("u0", "U", "X", "status", "iters", "n_resto")}
             r = study(name, d, name.endswith("cc"), ip, pool, out)
+            table.append((name, r["cls"]))
+            if name == "c4v1":
+                neg = (d["weights"] < 0).any(axis=1)
+                out(f"    (v1 input domain: {int(neg.sum())} of {len(neg)} instances have a negative cost weight, "
+                    f"{int((d['weights'] < 0).all(axis=1).sum())} all three)")
+                continue                                     # non-convex by construction: kept out of the convex-domain total
             for k in tot:
                 tot[k] += r[k]
-        out(f"closed loop, all scenarios: {tot['agree']} of {tot['both']} actions within 1e-4 = {tot['agree'] / tot['both']:.4f}; "
-            f"of the {tot['both'] - tot['agree']} others the engine's objective is lower in {tot['lower']}, the proxy's in "
-            f"{tot['higher']}; {tot['both_fixed']} are pairs of local minimisers confirmed by both solvers")
+        out(f"closed loop, scenarios with non-negative weights: {tot['agree']} of {tot['both']} actions within 1e-4 = "
+            f"{tot['agree'] / tot['both']:.4f}; of the {tot['both'] - tot['agree']} others the engine's objective is lower in "
+            f"{tot['lower']}, the proxy's in {tot['higher']}; {tot['both_fixed']} are pairs of local minimisers confirmed by both solvers")
+        out("\n### every fixture instance in exactly one class (none dropped)")
+        out("scenario | instances | agree (<= 1e-4) | two certified minima | unexplained | proxy fails (IPOPT failure exit) | engine fails, proxy converges")
+        for name, c in table:
+            assert c["agree"] + c["two_minima"] + c["unexplained"] + c["proxy_fails"] + c["engine_fails"] == c["n"], (name, c)
+            out(f"{name} | {c['n']} | {c['agree']} | {c['two_minima']} | {c['unexplained']} | {c['proxy_fails']} | {c['engine_fails']}")
+        s_ = {k: sum(c[k] for _, c in table) for k in ("n", "agree", "two_minima", "unexplained", "proxy_fails", "engine_fails")}
+        out(f"all | {s_['n']} | {s_['agree']} | {s_['two_minima']} | {s_['unexplained']} | {s_['proxy_fails']} | {s_['engine_fails']}")
 
         out("\n## (c) synthetic fixtures of round 2, tests/golden/independent_solutions.npz (proxy at tol 1e-8)")
         g2 = np.load(os.path.join(ROOT, "tests", "golden", "independent_solutions.npz"))
         for name, V, cc in (("c2", 4, False), ("c3", 8, True)):
             inp = synth.solver_inputs(160, V, seed=0)
             d = {k: inp[k] for k in ("state", "ego_index", "vref", "weights", "is_collide", "others")}
-            ip = {k: g2[f"{name}_{k}"] for k in ("u0", "U", "X", "status")}
+            ip = {k: g2[f"{name}_{k}"] for k in ("u0", "U", "X", "status", "iters")}
             study(f"synthetic {name}", d, cc, ip, pool, out)
 
         out("\n## (b) config 3 instances the engine ends with status 5 (converged on the d = 1 discontinuity)")
@@ -163,12 +206,12 @@ def main():
         dmin = lambda XX: np.sqrt((XX[:, :, None, 0] - ox) ** 2 + (XX[:, :, None, 1] - oy) ** 2)[:, 1:N].min(axis=(1, 2))
         dm_i, dm_o = dmin(X), dmin(orc["X"][k5])
         out(f"{k5.size} of 4096 instances (seed 0).  The proxy from its cold start: converged (status 0) {int((st == 0).sum())}, "
-            f"step below alpha_min where IPOPT would enter restoration (5) {int((st == 5).sum())}, iteration limit 1000 (1) "
+            f"restoration failed (5) {int((st == 5).sum())}, restoration ended locally infeasible (6) {int((st == 6).sum())}, iteration limit 1000 (1) "
             f"{int((st == 1).sum())}, inertia correction failed (2) {int((st == 2).sum())}; iterations median {np.median(it):.0f} "
             f"max {it.max()}")
         out(f"  engine's answers hold a vehicle at d = {np.median(dm_o):.6f} (median of the minimum distance over the horizon, "
             f"min {dm_o.min():.6f} max {dm_o.max():.6f})")
-        for code, label in ((0, "converged"), (5, "restoration"), (1, "iteration limit")):
+        for code, label in ((0, "converged"), (5, "restoration failed"), (6, "locally infeasible"), (1, "iteration limit")):
             sel = st == code
             if sel.any():
                 out(f"  proxy {label}: {int(sel.sum())}; its final iterate's minimum distance: median {np.median(dm_i[sel]):.4f} "
