@@ -38,6 +38,7 @@ struct PolicyWeights {           // device pointers, float32, the layout of Acto
 // hidden unit j of layer 1 / 2 for one environment (x: 80 inputs; h1: 2H values)
 MPC_HD float layer1_unit(const PolicyWeights &W, int H2, const float *x, int j) {
     float s = W.b1[j];
+#pragma unroll 16      // the weight loads do not depend on the sum: sixteen of them in flight per thread
     for (int i = 0; i < kObsDim; ++i) s = fmaf(x[i], W.w1[i * H2 + j], s);
     return tanhf(s);
 }
@@ -45,6 +46,7 @@ MPC_HD float layer2_unit(const PolicyWeights &W, int H2, const float *h1, int j)
     // block diagonal: unit j of the policy tower (j < H) reads h1[0 .. H), of the value tower h1[H .. 2H)
     const int H = H2 / 2, lo = j < H ? 0 : H;
     float s = W.b2[j];
+#pragma unroll 16
     for (int i = lo; i < lo + H; ++i) s = fmaf(h1[i], W.w2[i * H2 + j], s);
     return tanhf(s);
 }
@@ -52,6 +54,7 @@ MPC_HD float layer2_unit(const PolicyWeights &W, int H2, const float *h1, int j)
 MPC_HD float head_unit(const PolicyWeights &W, int H2, int A, const float *h2, int o) {
     const int H = H2 / 2, lo = o < A ? 0 : H;
     float s = W.bh[o];
+#pragma unroll 16
     for (int i = lo; i < lo + H; ++i) s = fmaf(h2[i], W.wh[i * (A + 1) + o], s);
     return s;
 }

@@ -3,7 +3,7 @@
 # usage: tools/collect_profiles.sh [tag]     default tag r03
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r03}
+TAG=${1:-r04}
 S=gpurun_out/${TAG}s
 P=profiles
 cp "$(ls -t $S/stats/*/*_kernel_stats.csv | head -1)" $P/${TAG}_bench_kernel_stats.csv

@@ -3,7 +3,7 @@
 # the summaries from gpurun_out/ into profiles/).  usage: tools/profile_session.sh [tag]     default tag r03
 # Every rocprofv3 command has the program itself after `--`; PMC passes are their own runs (tools/pmc_run.sh).
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${TAG}s
 mkdir -p $O
