@@ -912,12 +912,13 @@ struct Solver {
         double mu = P.mu_init;
         int iter = 0, nfail = 0;
         double reg = 0.0;
-        // the multiple of the identity the last inertia correction ended with (0: none yet in this solve); IPOPT's algorithm
-        // IC: the first correction starts at 1e-4 and grows by 100, later ones start at a third of the last value and grow by
-        // 8.  With negative cost weights (the v1 input domain) the control block needs ~1e-2 in EVERY iteration: climbing
-        // 1e-8, 1e-6, ... from scratch (until round 3) ended at 1 - five wasted sweeps per iteration and steps a hundred times
-        // shorter than the curvature warrants (121 iterations on average where this rule takes 40, scenario c4v1)
-        double dw_last = 0.0;
+        // dw_last = the multiple of the identity the last inertia correction ended with (0: none yet in this solve); IPOPT's
+        // algorithm IC: the first correction starts at 1e-4 and grows by 100, later ones start at a third of the last value and
+        // grow by 8.  With negative cost weights (the v1 input domain) the control block needs ~1e-2 in EVERY iteration:
+        // climbing 1e-8, 1e-6, ... from scratch (until round 3) ended at 1 - five wasted sweeps per iteration and steps a
+        // hundred times shorter than the curvature warrants (121 iterations on average where this rule takes 40, scenario
+        // c4v1).  Kept in the LDS table and read only when a correction is needed: no register across the iterations.
+        sc(SC_SPARE + 3, 0.0);
         // progress guard (mpc_config.stall_window, off by default): the iteration at which the KKT error last fell below
         // half of its value at the previous such mark
         int i_mark = 0;
@@ -1307,6 +1308,52 @@ struct Solver {
                         // (one combined test, evaluated without short-circuit branches: the common case - positive definite -
                         // then passes a single branch on the sweep's critical path instead of three)
                         bool pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
+                        // ---- the rest of the stage is computed BEFORE the definiteness test is acted on: W = adj(Huu) H(u, .), the
+                        //      reciprocal of the determinant, the gains and the Schur complement go into registers of their own (Pn, pn;
+                        //      H and h stay intact), and the test's branch sits behind them.  Between the matrix-core products that form
+                        //      the control block and the reciprocal of its determinant - on the serial path of all 20 stages - it kept the
+                        //      compiler from interleaving what follows it with what precedes it: a wave alone on its SIMD ran 33.7 us per
+                        //      iteration with the branch there, 29.9 without any test (profiles/r04_spec_sweep.txt).  A stage that fails
+                        //      (one iteration in six has such a stage) falls back as before - Gauss-Newton terms of this stage alone - and
+                        //      computes its tail again.
+                        PerLane<double> G, nHA, W, kfB, Pn, pn;
+                        double idet, i00, i01, i11, kf0, kf1;
+                        auto stage_tail = [&]() {
+                            // ---- W = adj(Huu) H(u, .) (adjugate embedded in a 4x4 block: the reciprocal of the determinant is
+                            //      computed while the matrix core works and scales the other operand afterwards);
+                            //      P = H - H(., u) W / det;  p = h + H(., u) kf
+                            // (selects between wave-uniform doubles by lane position are written as 0/1 weights: the compiler
+                            // turns `cond ? scalar_a : scalar_b` on scalar-register doubles into a branch cascade)
+                            c.lanes([&](int lane_) {
+                                const int lane = c.opaque(lane_);     // weights recomputed per stage, not kept in registers
+                                const int hi = lane >> 4, lo = lane & 3;
+                                const double w22 = (hi == 2 && lo == 2) ? 1.0 : 0.0, w33 = (hi == 3 && lo == 3) ? 1.0 : 0.0;
+                                const double wof = ((hi == 2 && lo == 3) || (hi == 3 && lo == 2)) ? 1.0 : 0.0;
+                                G.at(lane_) = w22 * hc + w33 * ha - wof * hb;
+                                W.at(lane_) = 0.0;
+                            });
+                            c.mfma(G, HB, W);
+                            idet = frcp(det);
+                            i00 = hc * idet;
+                            i01 = -hb * idet;
+                            i11 = ha * idet;
+                            kf0 = -(i00 * hu0 + i01 * hu1);
+                            kf1 = -(i01 * hu0 + i11 * hu1);
+                            c.lanes([&](int lane_) {
+                                const int lane = c.opaque(lane_);
+                                const int hi = lane >> 4, col0 = (lane & 7) == 0;      // column 0 of the block: J = 0, lo = 0
+                                nHA.at(lane_) = -idet * HA.at(lane_);
+                                const double w2 = (col0 && hi == 2) ? 1.0 : 0.0, w3 = (col0 && hi == 3) ? 1.0 : 0.0;
+                                kfB.at(lane_) = w2 * kf0 + w3 * kf1;
+                            });
+                            c.lanes([&](int lane) {
+                                Pn.at(lane) = Hm.at(lane);
+                                pn.at(lane) = hv.at(lane);
+                            });
+                            c.mfma(nHA, W, Pn);      // Pn <- H - H(., u) Huu^-1 H(u, .)   (H itself stays: the fallback needs it)
+                            c.mfma(HA, kfB, pn);     // pn <- h + H(., u) kf
+                        };
+                        stage_tail();
                         if (!pd && !gn) {
                             // not positive definite with the exact Hessian: this stage alone falls back to its
                             // Gauss-Newton terms (constraint curvature off, radial part of the collision potential) -
@@ -1361,44 +1408,18 @@ struct Solver {
                             hc = c.lane_get(Hm, 63);
                             det = ha * hc - hb * hb;
                             pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
+                            if (pd) stage_tail();
                         }
                         if (!pd) {
                             ok = false;
                             break;
                         }
                         c.tick(T_RIC_2X2);
-                        // ---- W = adj(Huu) H(u, .) (adjugate embedded in a 4x4 block: the reciprocal of the determinant is
-                        //      computed while the matrix core works and scales the other operand afterwards);
-                        //      P = H - H(., u) W / det;  p = h + H(., u) kf
-                        PerLane<double> G, nHA, W, kfB;
-                        // (selects between wave-uniform doubles by lane position are written as 0/1 weights: the compiler
-                        // turns `cond ? scalar_a : scalar_b` on scalar-register doubles into a branch cascade)
-                        c.lanes([&](int lane_) {
-                            const int lane = c.opaque(lane_);     // weights recomputed per stage, not kept in registers
-                            const int hi = lane >> 4, lo = lane & 3;
-                            const double w22 = (hi == 2 && lo == 2) ? 1.0 : 0.0, w33 = (hi == 3 && lo == 3) ? 1.0 : 0.0;
-                            const double wof = ((hi == 2 && lo == 3) || (hi == 3 && lo == 2)) ? 1.0 : 0.0;
-                            G.at(lane_) = w22 * hc + w33 * ha - wof * hb;
-                            W.at(lane_) = 0.0;
-                        });
-                        c.mfma(G, HB, W);
-                        const double idet = frcp(det);
-                        const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
-                        const double kf0 = -(i00 * hu0 + i01 * hu1), kf1 = -(i01 * hu0 + i11 * hu1);
                         dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
-                        c.lanes([&](int lane_) {
-                            const int lane = c.opaque(lane_);
-                            const int hi = lane >> 4, col0 = (lane & 7) == 0;      // column 0 of the block: J = 0, lo = 0
-                            nHA.at(lane_) = -idet * HA.at(lane_);
-                            const double w2 = (col0 && hi == 2) ? 1.0 : 0.0, w3 = (col0 && hi == 3) ? 1.0 : 0.0;
-                            kfB.at(lane_) = w2 * kf0 + w3 * kf1;
-                        });
-                        c.mfma(nHA, W, Hm);      // Hm <- H - H(., u) Huu^-1 H(u, .)
-                        c.mfma(HA, kfB, hv);     // hv <- h + H(., u) kf
                         c.lanes([&](int lane) {
                             const int r = m_row.at(lane), cl = m_col.at(lane);
-                            Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) : 0.0;
-                            pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) : 0.0;
+                            Pd.at(lane) = (r < 6 && cl < 6) ? Pn.at(lane) : 0.0;
+                            pvd.at(lane) = (r < 6 && cl == 0) ? pn.at(lane) : 0.0;
                             const int ks = m_kx.at(lane);
                             if (ks >= 0) S(k, ks, -idet * W.at(lane));
                             if (lane == 0) {
@@ -1415,11 +1436,14 @@ struct Solver {
                 if (!ok) {
                     if (!gn) {
                         gn = true;
-                    } else if (dw_last == 0.0) {
-                        delta_w = (delta_w < 1e-4) ? c.fresh(1e-4) : c.fresh(100.0) * delta_w;
                     } else {
-                        const double third = dw_last / 3.0;
-                        delta_w = (delta_w < third) ? third : c.fresh(8.0) * delta_w;
+                        const double dw_last = c.uni(sc(SC_SPARE + 3));
+                        if (dw_last == 0.0) {
+                            delta_w = (delta_w < 1e-4) ? c.fresh(1e-4) : c.fresh(100.0) * delta_w;
+                        } else {
+                            const double third = c.fresh(1.0 / 3.0) * dw_last;
+                            delta_w = (delta_w < third) ? third : c.fresh(8.0) * delta_w;
+                        }
                     }
                     if (delta_w > 1e40) break;
                 }
@@ -1428,7 +1452,7 @@ struct Solver {
                 status_out = 2;
                 break;
             }
-            if (delta_w > reg) dw_last = delta_w;   // the ladder was needed: remember where it ended
+            if (delta_w > reg) sc(SC_SPARE + 3, delta_w);   // the ladder was needed: remember where it ended
 
             c.tick(T_RIC_INIT);
             const double tau = c.uni(fmax2(0.99, 1.0 - mu));

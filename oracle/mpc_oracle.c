@@ -633,7 +633,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 } else {
                     /* later ones start at a third of the value that worked last and grow by 8 (kappa_w^- = 1/3,
                      * kappa_w^+ = 8): the term stays within an order of magnitude of the curvature it has to cover */
-                    delta_w = (delta_w < dw_last / 3.0) ? dw_last / 3.0 : 8.0 * delta_w;
+                    const double third = (1.0 / 3.0) * dw_last;
+                    delta_w = (delta_w < third) ? third : 8.0 * delta_w;
                 }
                 if (delta_w > 1e40) break;
             }
