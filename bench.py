@@ -489,7 +489,9 @@ def side_measurements(a, eng, args, inp, out, dev):
     # solve kernels, D2H of the action, read-back of the detector record)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import run_pure_mpc
-    outcome, log, lat_ms = run_pure_mpc.run(steps=150, n_others=1, seed=0, verbose=False)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the agent prints the reference's "NOTICE: Not found solution" (agents/
+        outcome, log, lat_ms = run_pure_mpc.run(steps=150, n_others=1, seed=0, verbose=False)   # pure_mpc.py:303-305): stdout carries ONE JSON line
     res["predict_b1"] = {"workload": "BASELINE configs[0]: single ego, horizon 20, 1 other vehicle, closed loop (tools/run_pure_mpc.py), "
                                      "PureMPC_Agent.predict() per step", "ms_median": float(np.median(lat_ms)),
                          "ms_p95": float(np.percentile(lat_ms, 95)), "steps": len(log), "outcome": outcome,

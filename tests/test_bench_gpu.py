@@ -83,3 +83,22 @@ def test_config5_shape_rollout_over_rccl():
     # the RCCL gather is captured INSIDE the step's hipGraph: sharded runs keep the one-launch step
     assert d["graph"] is True and d["graph_fallback_reason"] is None, d["graph_fallback_reason"]
     assert d["fused_glue"] is True
+
+
+def test_default_line_is_the_only_stdout_and_carries_every_single_gpu_config():
+    """The line the driver records (no --no-side, CPU baseline on): nothing else on stdout, `roofline` and `cpu_baseline`
+    present, and the driver-visible side objects for the other BASELINE configurations one GPU can produce: config 2
+    (B = 1024, V = 4, live objective), config 4 (256-environment rollout), B = 1 predict() latency, the headline over
+    seeds 0-2 and the reference's solver settings."""
+    d = _line([sys.executable, "bench.py", "--steps", "5", "--warmup", "2"], only_line=True)
+    _check(d, 5)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 1e3 and d["cpu_baseline"]["cores"] >= 1
+    assert d["roofline"]["kernel_ms"] > 0 and d["parity"]["n_certified"] == d["parity"]["n_converged"]
+    s = d["headline_over_seeds"]
+    assert [r["seed"] for r in s["per_seed"]] == [0, 1, 2] and s["ms_min"] <= s["ms_median"] <= s["ms_max"] < 20.0
+    c2, c4, b1 = d["config2"], d["config4"], d["predict_b1"]
+    assert "batch=1024" in c2["workload"] and c2["converged_frac"] > 0.99 and 0.3 < c2["ms"] < 5.0
+    assert "256 parallel" in c4["workload"] and c4["unit"] == "env-steps/s" and c4["value"] > 1e5
+    assert b1["steps"] >= 50 and 0.1 < b1["ms_median"] < 5.0 and b1["converged_frac"] > 0.9
+    ref = d["solver_settings_sweep"]["max_iter 1000, tol 1e-6 (reference)"]
+    assert ref["converged_frac"] > 0.995 and ref["iters_max"] <= 1000
