@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 5
+#define MPC_ABI_VERSION 6
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -262,7 +262,7 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
 
 /*
  * Rollout glue for the same configurations (csrc/mpc_rollout_glue.hpp): what a step of the reference's collect_rollouts does
- * besides the MPC call and env.step, as two launches instead of ~40 torch kernels.  Device pointers, enqueue only.
+ * besides the MPC call and env.step, as two launches per step instead of ~40 torch kernels, and one at the rollout's end.  Device pointers, enqueue only.
  *
  * mpc_policy_act: the SB3 MlpPolicy-shaped actor-critic of PPO_MPC / A2C_MPC (agents/ppo_mpc.py:390-394; 80 -> H -> H tanh
  * twice, Gaussian head) for B observations obs [B][80] f32: both towers as one 80 -> 2H -> 2H -> (A + 1) network with the
@@ -276,6 +276,14 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
  * value | log_prob | (terminal_obs 80 | truncated)] (rollout_buffer.add, agents/ppo_mpc.py:462-469) and of mpc_actions_buf
  * [T][B][2]; last_obs <- new_obs, last_starts <- done; counts [4] += finished / crashed / arrived episodes and solves whose
  * status is not converged; dones_out <- done; pos_dev[0] += 1 (ticket: one zero-initialised int32 of scratch).
+ *
+ * mpc_rollout_finish: the end of a rollout of T steps (1 <= T <= 8192) over the same buffer (agents/ppo_mpc.py:471-476
+ * `rollout_buffer.compute_returns_and_advantage`, stable-baselines3's arithmetic in float32, operation by operation): if
+ * keep_terminal and terminal_values [T][B] (V of every step's terminal observation) is given, the reward column becomes
+ * reward + gamma * terminal_values * truncated first (the PPO agents' truncation bootstrap, :451-461); then, with
+ * last_values [B] = V(observation after the last step) and dones [B] = the last step ended an episode, per environment
+ *   delta_t = r_t + gamma V_{t+1} (1 - start_{t+1}) - V_t,  A_t = delta_t + gamma lambda (1 - start_{t+1}) A_{t+1}
+ * backwards from t = T - 1 (V_T = last_values, start_T = dones); advantages [T][B] = A, returns [T][B] = A + V.
  */
 int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float *obs, const float *w1, const float *b1,
                    const float *w2, const float *b2, const float *wh, const float *bh, const float *std_, const float *c0,
@@ -287,6 +295,9 @@ int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32
                        const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
                        const float *terminal_obs, const uint8_t *truncated, const uint8_t *crashed, const uint8_t *arrived,
                        int64_t *counts, uint8_t *dones_out, void *stream);
+int mpc_rollout_finish(int32_t device, int32_t T, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
+                       const float *last_values, const uint8_t *dones, const float *terminal_values, double gamma,
+                       double gae_lambda, float *advantages, float *returns, void *stream);
 
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
  * collision-cost term (V = 0: term off) in a batch of B (the builds for batches that leave LDS to spare keep 12 more

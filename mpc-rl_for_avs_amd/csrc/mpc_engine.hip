@@ -395,6 +395,25 @@ __global__ __launch_bounds__(128) void mpc_rollout_record_kernel(mpc::glue::Reco
     }
 }
 
+// end of a rollout (mpc_rollout_glue.hpp: truncation bootstrap + GAE): one workgroup per environment; thread t computes the
+// terms of step t (strided over T), thread 0 runs the reversed recurrence over the LDS copies, all threads store
+__global__ __launch_bounds__(256) void mpc_rollout_finish_kernel(mpc::glue::GaeArgs g) {
+    extern __shared__ float gae_lds[];           // [T] delta -> advantage, [T] coefficient
+    const int b = blockIdx.x;
+    float *delta = gae_lds, *coef = gae_lds + g.T;
+    for (int t = threadIdx.x; t < g.T; t += blockDim.x) mpc::glue::gae_terms(g, b, t, delta + t, coef + t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float gae = 0.0f;
+        for (int t = g.T - 1; t >= 0; --t) {
+            gae = mpc::glue::gae_step(delta[t], coef[t], gae);
+            delta[t] = gae;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < g.T; t += blockDim.x) mpc::glue::gae_store(g, b, t, delta[t]);
+}
+
 }  // namespace
 
 struct mpc_handle {
@@ -1230,6 +1249,24 @@ int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32
                                  arrived, dones_out};
     hipLaunchKernelGGL(mpc_rollout_record_kernel, dim3((unsigned)B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream_), R,
                        reinterpret_cast<long long *>(pos_dev), ticket, reinterpret_cast<unsigned long long *>(counts));
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_rollout_finish(int32_t device, int32_t T, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
+                       const float *last_values, const uint8_t *dones, const float *terminal_values, double gamma,
+                       double gae_lambda, float *advantages, float *returns, void *stream_) {
+    constexpr int O = mpc::glue::kObsDim;
+    if (T < 1 || T > 8192 || B < 0 || A < 1 || A > mpc::glue::kMaxAction || cols != O + A + 4 + (keep_terminal ? O + 1 : 0))
+        return fail(MPC_ERR_INVALID_ARG, "mpc_rollout_finish: bad size / row layout (1 <= T <= 8192)");
+    if (!row || !last_values || !dones || !advantages || !returns)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_rollout_finish: null pointer");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(device));
+    const mpc::glue::GaeArgs g{(int)T, (int)B, (int)A, (int)cols, (int)keep_terminal, row, last_values, dones, terminal_values,
+                              (float)gamma, (float)(gamma * gae_lambda), advantages, returns};
+    hipLaunchKernelGGL(mpc_rollout_finish_kernel, dim3((unsigned)B), dim3(256), (size_t)T * 2 * sizeof(float),
+                       reinterpret_cast<hipStream_t>(stream_), g);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }

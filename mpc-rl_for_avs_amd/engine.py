@@ -50,8 +50,8 @@ _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
-            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record"]
-ABI_VERSION = 5          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
+            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record", "mpc_rollout_finish"]
+ABI_VERSION = 6          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
 MAX_OTHERS = 16
 _lib = None
 
@@ -136,6 +136,8 @@ def load_library(path: str | None = None):
     lib.mpc_policy_act.restype = ctypes.c_int
     lib.mpc_rollout_record.argtypes = [ctypes.c_int32] * 5 + [vp] * 21
     lib.mpc_rollout_record.restype = ctypes.c_int
+    lib.mpc_rollout_finish.argtypes = [ctypes.c_int32] * 6 + [vp] * 4 + [ctypes.c_double] * 2 + [vp] * 3
+    lib.mpc_rollout_finish.restype = ctypes.c_int
     _lib = lib
     return lib
 

@@ -11,12 +11,15 @@ Restates reference agents/pure_mpc_linear.py:
   QP (cost, dynamics, bounds)       :205-257 _linear_mpc_control
   failure -> action (0, 0), profile kept   :193-196, 261-263
 The reference hands the QP to cvxpy -> ECOS (:259), neither of which exists offline, and has no
-test or recorded output for this path: PARITY UNPINNED.  What pins this file instead: the reference's own numpy
-helpers (linear_model_matrix, predict_motion, calc_nearest_index_in_direction) imported from /root/reference by
-tests/golden/make_golden.py -> tests/golden/ltv_reference_numpy.npz; an independent objective/constraint evaluator
-written as plain loops over the cvxpy statements (`objective_loops`, `constraint_loops`) driving scipy SLSQP; and
-KKT certificates of the returned solutions (tests/test_ltv_oracle.py).  The QP is strictly convex in the controls
-(R > 0), so its minimiser is unique and any correct solver returns the same controls up to its tolerance.
+test or recorded output for this path.  What pins this file: the reference's own numpy helpers (linear_model_matrix,
+predict_motion, calc_nearest_index_in_direction) imported from /root/reference by tests/golden/make_golden.py ->
+tests/golden/ltv_reference_numpy.npz; since round 4 the reference's own QP STATEMENTS (`_linear_mpc_control`,
+:205-257) executed with a numeric cvxpy stand-in (tests/golden/standins.py) -> tests/golden/ltv_reference_random.npz:
+objective to 1e-10, constraint slacks to 1e-9 (tests/test_reference_vectors.py::test_ltv_oracle_equals_the_references_
+helpers_and_qp).  The SOLVER (ECOS) is PARITY UNPINNED by the reference; instead: an independent objective/constraint
+evaluator written as plain loops over the cvxpy statements (`objective_loops`, `constraint_loops`) driving scipy
+SLSQP, and KKT certificates of the returned solutions (tests/test_ltv_oracle.py).  The QP is strictly convex in the
+controls (R > 0), so its minimiser is unique and any correct solver returns the same controls up to its tolerance.
 
 Solver: the states are eliminated through the (linear) dynamics and the dense QP in the 2T controls is solved by an
 infeasible-start primal-dual interior-point method with Mehrotra's predictor-corrector (one common step length) -

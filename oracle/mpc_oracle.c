@@ -2,13 +2,15 @@
  *
  * Not shipped and never on the product path: only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load this library (as the checker / the
- * reported CPU baseline).  PARITY UNPINNED by the reference's own tests: the
- * reference (SaeedRahmani/MPC-RL_for_AVs) has no tests or golden vectors and its
- * solver stack (casadi 3.6.6 -> IPOPT/MUMPS, agents/pure_mpc.py:285-300) is not
- * installed here.  This file restates the *problem* of PureMPC_Agent._solve
- * exactly and solves it to a tighter tolerance (1e-8) than the reference's IPOPT
- * call (tol 1e-6); its answers are pinned by the independent KKT certifier in
- * oracle/nlp_spec.py and by oracle/scipy_crosscheck.py.
+ * reported CPU baseline).  The reference (SaeedRahmani/MPC-RL_for_AVs) has no tests or
+ * golden vectors and its solver stack (casadi 3.6.6 -> IPOPT/MUMPS,
+ * agents/pure_mpc.py:285-300) is not installed here.  The PROBLEM this file restates is
+ * pinned by the reference's own statements executed numerically (tests/golden/
+ * reference_sequences.npz via oracle/nlp_spec.py, tests/test_reference_vectors.py); the
+ * SOLVER is PARITY UNPINNED by the reference: this file solves to a tighter tolerance
+ * (1e-8) than the reference's IPOPT call (tol 1e-6) and its answers are pinned by the
+ * independent KKT certifier (oracle/kkt_batch.py), by oracle/ipopt_restated.py (IPOPT's
+ * published algorithm incl. restoration phase) and by oracle/scipy_crosscheck.py.
  *
  * Problem restated (all citations relative to /root/reference):
  *   variables   X[k]=(x,y,theta,v) k=0..N, U[k]=(a,delta) k=0..N-1      agents/pure_mpc.py:88-93,260

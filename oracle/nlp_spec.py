@@ -6,11 +6,18 @@ This module restates, in plain numpy float64, the nonlinear programme that
 `PureMPC_Agent._solve` builds with CasADi (reference `agents/pure_mpc.py:80-318`)
 and provides an *independent KKT certifier* for candidate solutions.  The
 reference's arithmetic lives in casadi==3.6.6 / IPOPT, which is not installed in
-this image, so the reference has no runnable oracle and no
-golden vectors of its own: PARITY UNPINNED by the reference's tests.  The pins
-created here are (1) KKT certificates of the identical NLP, (2) agreement with
-an independent scipy solver (oracle/scipy_crosscheck.py), (3) analytic
-known-answer tests, (4) golden vectors of the numpy-only pieces of the reference.
+this image, and the reference has no tests or golden
+vectors of its own.  What pins this file (round 4): the reference's OWN objective,
+constraint, bound and initial-guess statements (agents/pure_mpc.py:128-283) were
+executed with a numeric stand-in for casadi's SX (tests/golden/standins.py: it holds
+values, the reference's code does the arithmetic) at 1200 points of 400 closed-loop
+steps -> tests/golden/reference_sequences.npz; `objective`, `constraints`, the bounds
+and the cold start of this module equal them to 2e-16 relative in f and exactly in g
+(tests/test_reference_vectors.py::test_oracle_nlp_equals_the_references_statements).
+The SOLVER (IPOPT) remains PARITY UNPINNED by the reference: solutions are pinned by
+(1) KKT certificates of this NLP, (2) an independent restatement of IPOPT's published
+algorithm (oracle/ipopt_restated.py) and scipy (oracle/scipy_crosscheck.py),
+(3) analytic known-answer tests.
 
 Decision variables follow the reference layout (`pure_mpc.py:260`):
     X[k] = (x, y, theta, v), k = 0..N      U[k] = (a, delta), k = 0..N-1

@@ -1,5 +1,5 @@
 // Host build of mpc-rl_for_avs_amd/csrc/mpc_rollout_glue.hpp for tests only (-m "not gpu"): the per-thread code of the two
-// rollout-glue kernels (mpc_policy_act, mpc_rollout_record) looped over environments and threads on the CPU, against
+// rollout-glue kernels (mpc_policy_act, mpc_rollout_record, mpc_rollout_finish) looped over environments and threads on the CPU, against
 // ActorCritic.act / RolloutBuffer.add in tests/test_rollout_cpu.py (and under the sanitizers).  Never loaded by the product.
 #include <cmath>
 #include <cstdint>
@@ -40,5 +40,24 @@ extern "C" int glue_rollout_record(int B, int A, int cols, int keep_terminal, fl
             for (int q = 0; q < 4; ++q) counts[q] += (bits >> q) & 1;
         }
     *pos_dev = pos + 1;
+    return 0;
+}
+
+extern "C" int glue_rollout_finish(int T, int B, int A, int cols, int keep_terminal, float *row, const float *last_values,
+                                   const uint8_t *dones, const float *terminal_values, double gamma, double gae_lambda,
+                                   float *advantages, float *returns) {
+    namespace glue = mpc::glue;
+    const glue::GaeArgs g{T, B, A, cols, keep_terminal, row, last_values, dones, terminal_values, (float)gamma,
+                          (float)(gamma * gae_lambda), advantages, returns};
+    std::vector<float> delta((size_t)T), coef((size_t)T);
+    for (int b = 0; b < B; ++b) {
+        for (int t = 0; t < T; ++t) glue::gae_terms(g, b, t, &delta[(size_t)t], &coef[(size_t)t]);   // the kernel: thread t
+        float gae = 0.0f;
+        for (int t = T - 1; t >= 0; --t) {                                                          // the kernel: thread 0
+            gae = glue::gae_step(delta[(size_t)t], coef[(size_t)t], gae);
+            delta[(size_t)t] = gae;
+        }
+        for (int t = 0; t < T; ++t) glue::gae_store(g, b, t, delta[(size_t)t]);
+    }
     return 0;
 }

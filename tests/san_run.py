@@ -92,4 +92,14 @@ for A, version in ((1, "v0"), (3, "v1"), (8, "v1")):
     g = glue_host.policy_act(pol, np.random.default_rng(A).normal(size=(7, 10, 8)).astype(np.float32),
                              np.zeros((7, A), np.float32), version, True)
     assert np.isfinite(g["actions"]).all()
+import ctypes  # noqa: E402
+for keep in (True, False):            # end of a rollout: truncation bootstrap + GAE over a buffer of odd sizes
+    T, B, A = 9, 5, 3
+    buf = rollout.RolloutBuffer(T, B, A, "cpu", keep_terminal=keep)
+    buf._row.copy_(torch.randn(buf._row.shape))
+    lv, d8, tv = torch.randn(B), torch.zeros(B, dtype=torch.uint8), torch.randn(T, B)
+    q = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert glue_host.load().glue_rollout_finish(T, B, A, buf._cols, 1 if keep else 0, q(buf._row), q(lv), q(d8),
+                                                q(tv) if keep else None, 0.99, 0.95, q(buf.advantages), q(buf.returns)) == 0
+    assert torch.isfinite(buf.advantages).all()
 print(f"sanitized run ok: {n} wave solves, LTV, preamble (both forms), environment and rollout-glue harnesses clean")

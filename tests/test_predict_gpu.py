@@ -511,3 +511,39 @@ def test_fused_glue_step_equals_the_torch_step(version, algorithm):
     if f["term"] is not None:
         assert torch.equal(f["trunc"][same], t["trunc"][same])
     assert torch.isfinite(f["adv"]).all() and torch.isfinite(t["adv"]).all()
+
+
+@pytest.mark.parametrize("algorithm", ["ppo", "a2c"])
+def test_rollout_finish_on_the_gpu_is_the_torch_gae_bit_for_bit(algorithm):
+    """mpc_rollout_finish (truncation bootstrap + generalised advantage estimation in one launch) against the torch form of
+    the same float32 arithmetic (RolloutBuffer.bootstrap_truncated + compute_returns_and_advantage) on the buffer a real
+    rollout left behind - same buffer, same value estimates: advantages, returns and bootstrapped rewards identical."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, rollout
+    dev = torch.device("cuda", 0)
+    B, T = 160, 48
+    torch.manual_seed(3)
+    pol = rollout.ActorCritic(1).to(dev)
+    eng = engine.MPCEngine(horizon=20, max_iter=60)
+    env = rollout.SyntheticIntersectionEnv(B, device=dev, seed=2, n_others=4)
+    col = rollout.BatchedCollector(env, pol, eng, algorithm=algorithm, n_steps=T, seed=1, fused_glue=True)
+    col._begin_rollout()
+    for _ in range(T):
+        col._step()
+    buf = col.buffer
+    if buf.truncated is not None:                  # 48 steps truncate nothing by themselves: mark some
+        buf.truncated.copy_((torch.rand(T, B, device=dev) < 0.1).float())
+    before = buf._row.clone()
+    col._finish_rollout()                          # the kernel
+    got = dict(row=buf._row.clone(), adv=buf.advantages.clone(), ret=buf.returns.clone())
+    buf._row.copy_(before)
+    with torch.no_grad():
+        last_values = pol.predict_values(col._last_obs)
+        buf.bootstrap_truncated(pol.predict_values)
+        buf.compute_returns_and_advantage(last_values, col._roll["dones"])
+    assert torch.equal(got["row"], buf._row)
+    assert torch.equal(got["adv"], buf.advantages) and torch.equal(got["ret"], buf.returns)
+    if algorithm == "ppo":
+        assert not torch.equal(before, buf._row)   # the bootstrap did change rewards
+    assert got["adv"].abs().max() > 0
+    eng.close()

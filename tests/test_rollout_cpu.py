@@ -241,3 +241,34 @@ def test_rollout_glue_code_is_the_policy_and_the_buffer_row(A, version, clip):
             assert torch.equal(dones_out.bool(), done)
         assert torch.equal(mine._row, buf._row) and torch.equal(mine.mpc_actions, buf.mpc_actions)
         assert torch.equal(my_obs, last_obs) and torch.equal(my_starts, starts) and np.array_equal(counts, want_counts)
+
+
+@pytest.mark.parametrize("keep", [True, False])
+def test_rollout_finish_code_is_the_buffers_gae_bit_for_bit(keep):
+    """csrc/mpc_rollout_glue.hpp::gae_* (what mpc_rollout_finish runs), compiled for the host, against the torch form of the
+    same arithmetic (RolloutBuffer.bootstrap_truncated + compute_returns_and_advantage = stable-baselines3's, which the
+    reference calls at agents/ppo_mpc.py:471-476): float32 operation by operation, so the comparison is exact."""
+    import ctypes
+    import glue_host
+    lib = glue_host.load()
+    g = torch.Generator().manual_seed(5)
+    for T, B, A, gamma, lam in ((64, 37, 1, 0.99, 0.95), (7, 5, 3, 0.9, 1.0), (1, 4, 1, 0.99, 0.95), (300, 3, 3, 0.999, 0.9)):
+        ref = rollout.RolloutBuffer(T, B, A, "cpu", gamma=gamma, gae_lambda=lam, keep_terminal=keep)
+        ref._row.copy_(torch.randn(ref._row.shape, generator=g))
+        ref.episode_starts.copy_((torch.rand(T, B, generator=g) < 0.1).float())
+        if keep:
+            ref.truncated.copy_((torch.rand(T, B, generator=g) < 0.05).float())
+        mine = rollout.RolloutBuffer(T, B, A, "cpu", gamma=gamma, gae_lambda=lam, keep_terminal=keep)
+        mine._row.copy_(ref._row)
+        last_values = torch.randn(B, generator=g)
+        dones = torch.rand(B, generator=g) < 0.3
+        tv = torch.randn(T, B, generator=g)
+        ref.bootstrap_truncated(lambda o: tv.reshape(-1))
+        ref.compute_returns_and_advantage(last_values, dones)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        d8 = dones.to(torch.uint8)
+        rc = lib.glue_rollout_finish(T, B, A, mine._cols, 1 if keep else 0, p(mine._row), p(last_values), p(d8),
+                                     p(tv) if keep else None, gamma, lam, p(mine.advantages), p(mine.returns))
+        assert rc == 0
+        assert torch.equal(mine._row, ref._row)                     # the bootstrapped rewards, nothing else touched
+        assert torch.equal(mine.advantages, ref.advantages) and torch.equal(mine.returns, ref.returns)

@@ -7,14 +7,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import oracle_lib
 from mpc_rl_for_avs_amd import engine, synth
 from mpc_rl_for_avs_amd.reference_path import reference_states
+from conftest import unexplained_disagreements
 
 ref = reference_states()
 eng = engine.MPCEngine(horizon=20, max_iter=100)
 worst = 0.0
+n_all = n_far = n_unexplained = 0
 for seed in range(1, 7):
     for V, cc in ((1, False), (4, False), (4, True), (9, True)):
         inp = synth.solver_inputs(2048, V, seed=seed)
@@ -27,10 +30,14 @@ for seed in range(1, 7):
         err = np.abs(got["u0"] - want["u0"]).max(axis=1) / np.maximum(1.0, np.abs(want["u0"]).max(axis=1))
         bad = int((err[both] > 1e-4).sum())
         worst = max(worst, float(np.percentile(err[both], 99)))
+        # the tests' exact gate on the ones beyond 1e-4: both KKT-certified AND the oracle itself jumps under 1 - 2 ulp
+        unexplained = unexplained_disagreements(oracle_lib, ref, inp, cc, got, want, max_iter=100) if bad else []
+        n_all += int(both.sum()); n_far += bad; n_unexplained += len(unexplained)
         print(f"seed {seed} V={V} cc={int(cc)}: both converged {both.mean():.4f}, status equal {(got['status'] == want['status']).mean():.4f}, "
-              f"iterations equal {(got['iters'] == want['iters'])[both].mean():.4f}, beyond 1e-4: {bad}, p99 err {np.percentile(err[both], 99):.2e}, "
+              f"iterations equal {(got['iters'] == want['iters'])[both].mean():.4f}, beyond 1e-4: {bad} (unexplained {len(unexplained)}), p99 err {np.percentile(err[both], 99):.2e}, "
               f"gpu status {np.bincount(got['status'], minlength=6)}, finite {np.isfinite(got['u0']).all()}", flush=True)
-print("worst p99", worst)
+print(f"worst p99 {worst}; {n_all} instances converged on both sides, {n_far} beyond 1e-4, {n_unexplained} of them unexplained "
+      f"(tests/conftest.py::unexplained_disagreements)")
 
 # ---- the iterative-linear agent's QP: first call and two re-linearised rounds per seed
 sys.path.insert(0, os.path.join(ROOT, "tests"))
