@@ -299,6 +299,20 @@ int mpc_rollout_finish(int32_t device, int32_t T, int32_t B, int32_t A, int32_t 
                        const float *last_values, const uint8_t *dones, const float *terminal_values, double gamma,
                        double gae_lambda, float *advantages, float *returns, void *stream);
 
+/*
+ * Diagnostics: the NLP's functions at GIVEN points, evaluated by the solve kernel's own code (csrc/mpc_wave.hpp:
+ * Solver::evaluate - stage_terms / track / dist, which judge every line-search trial, and the model step of the rollouts),
+ * so that f(z) and g(z) computed by the reference's statements (agents/pure_mpc.py:128-283; tests/golden/
+ * reference_sequences.npz) pin the device directly and not only through solutions.  Host pointers, synchronous.
+ * Problem data as for mpc_solve_batch (the ego state is X[b][0]); X [B][N+1][4], U [B][N][2] the point;
+ * f [B] <- the objective, unscaled, terms of k = 0 .. N-1 (:128-212; with MPC_FLAG_COLLISION_COST plus the terms of
+ * agents/archive/pure_mpc.py:189-206); x_next [B][N][4] <- the model's successor of (X[k], U[k]) (:220-257): the reference's
+ * dynamics constraint is X[k+1] - x_next[k] = 0.
+ */
+int mpc_eval_nlp(mpc_handle *h, int32_t B, const int32_t *ego_index, const double *vref, const double *weights,
+                 const uint8_t *is_collide, const double *others, int32_t V, uint32_t flags, const double *X, const double *U,
+                 double *f, double *x_next);
+
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
  * collision-cost term (V = 0: term off) in a batch of B (the builds for batches that leave LDS to spare keep 12 more
  * words per stage: 12.1 instead of 10.2 KB at horizon 20 with 8 vehicles).  The engine keeps no per-instance solver

@@ -90,24 +90,13 @@ struct WaveCtx : mpc::wave::WaveOpsT<RELAX> {
     }
 };
 
-template <bool CC, int NC, int OCC, int RELAX>
-__global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
-    mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
-    const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
-    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
-    const int32_t *__restrict__ nveh, double w_collision, const double *u_init, int u_shift, uint8_t *u_valid,
-    double *__restrict__ u0_out, double *U_out, double *__restrict__ X_out, int32_t *__restrict__ status_out,
-    int32_t *__restrict__ iters_out) {
-    extern __shared__ double smem[];
-    const int N = NC > 0 ? NC : P.N;
-    const int b = blockIdx.x;
-    if (b >= B) return;                          // grid = B workgroups of one wave
-    if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
-    const int lane = threadIdx.x;
-    constexpr int SL = mpc::wave::stage_slots(CC, (RELAX & 8) != 0);
-    WaveCtx<NC, RELAX> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
+// inputs of instance b -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j, advanced per stage by
+// speed x dt along the heading: agents/archive/pure_mpc.py:190-191)
+template <bool CC, class CTX>
+__device__ __forceinline__ void stage_problem(CTX &ctx, const mpc::SolveParams &P, int b, int lane, int N, int SL,
+                                              const double *__restrict__ ref5, int M, const double *__restrict__ vref,
+                                              const double *__restrict__ others, int Vin) {
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
-    // inputs -> LDS: reference speeds (lane k = stage k) and other vehicles (lane j = vehicle j)
     for (int node = lane; node <= N; node += kBlock) {
         double rv;
         if (vref) {
@@ -128,6 +117,25 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
         ctx.st(OTH + lane * 4 + 2, sp * cos(hh));
         ctx.st(OTH + lane * 4 + 3, sp * sin(hh));
     }
+}
+
+template <bool CC, int NC, int OCC, int RELAX>
+__global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
+    mpc::SolveParams P, int B, const double *__restrict__ ref5, int M, const double *__restrict__ state,
+    const int32_t *__restrict__ ego_index, const double *__restrict__ vref, const double *__restrict__ weights,
+    const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
+    const int32_t *__restrict__ nveh, double w_collision, const double *u_init, int u_shift, uint8_t *u_valid,
+    double *__restrict__ u0_out, double *U_out, double *__restrict__ X_out, int32_t *__restrict__ status_out,
+    int32_t *__restrict__ iters_out) {
+    extern __shared__ double smem[];
+    const int N = NC > 0 ? NC : P.N;
+    const int b = blockIdx.x;
+    if (b >= B) return;                          // grid = B workgroups of one wave
+    if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
+    const int lane = threadIdx.x;
+    constexpr int SL = mpc::wave::stage_slots(CC, (RELAX & 8) != 0);
+    WaveCtx<NC, RELAX> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
+    stage_problem<CC>(ctx, P, b, lane, N, SL, ref5, M, vref, others, Vin);
     __syncthreads();
     double x0[4];
 #pragma unroll
@@ -168,6 +176,40 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
         if (status_out) status_out[b] = status;
         if (iters_out) iters_out[b] = iters;
     }
+}
+
+// diagnostics (mpc_eval_nlp): the NLP's objective and model step at given points, through Solver::evaluate() of the build
+// for runtime horizons (the same class template as every solve kernel); one wave per point
+template <bool CC>
+__global__ __launch_bounds__(kBlock) void mpc_eval_kernel(mpc::SolveParams P, int B, const double *__restrict__ ref5, int M,
+                                                          const int32_t *__restrict__ ego_index, const double *__restrict__ vref,
+                                                          const double *__restrict__ weights, const uint8_t *__restrict__ is_collide,
+                                                          const double *__restrict__ others, int Vin, double w_collision,
+                                                          const double *__restrict__ X, const double *__restrict__ U,
+                                                          double *__restrict__ f_out, double *__restrict__ xnext_out) {
+    extern __shared__ double smem[];
+    const int N = P.N, b = blockIdx.x, lane = threadIdx.x;
+    if (b >= B) return;
+    constexpr int SL = mpc::wave::stage_slots(CC, false);
+    WaveCtx<0, 0> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
+    stage_problem<CC>(ctx, P, b, lane, N, SL, ref5, M, vref, others, Vin);
+    for (int node = lane; node <= N; node += kBlock) {
+        for (int i = 0; i < 4; ++i) ctx.st(node * SL + mpc::wave::W_X + i, X[((size_t)b * (N + 1) + node) * 4 + i]);
+        if (node < N)
+            for (int i = 0; i < 2; ++i) ctx.st(node * SL + mpc::wave::W_U + i, U[((size_t)b * N + node) * 2 + i]);
+    }
+    __syncthreads();
+    double x0[4];
+    for (int i = 0; i < 4; ++i) x0[i] = X[(size_t)b * (N + 1) * 4 + i];
+    const bool collide = is_collide[b] != 0;
+    const double ws_ = collide ? 100.0 : weights[(size_t)b * 3 + 0];
+    const double wcoll = (CC && collide) ? 3000.0 * w_collision : 0.0;
+    mpc::wave::Solver<CC, WaveCtx<0, 0>> solver(P, ctx, x0, ws_, weights[(size_t)b * 3 + 1], weights[(size_t)b * 3 + 2], wcoll);
+    mpc::wave::PerLane<double> xn[4];
+    const double f = solver.evaluate(xn);
+    if (lane == 0) f_out[b] = f;
+    if (lane < N)
+        for (int i = 0; i < 4; ++i) xnext_out[((size_t)b * N + lane) * 4 + i] = xn[i].at(lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -501,14 +543,9 @@ int ensure_stage(mpc_handle *h, size_t bytes) {
 
 // Launch of the solve kernel for B instances whose data already sits in device memory (shared by mpc_solve_batch and
 // mpc_predict_batch).  d_nveh: vehicles present per instance or nullptr (= V for all).
-int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, hipStream_t stream, const double *d_state,
-                   const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
-                   const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
-                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
-    const int N = h->cfg.horizon;
-    const int Vuse = cc ? V : 0;
+mpc::SolveParams solve_params(const mpc_handle *h, int Vuse) {
     mpc::SolveParams P;
-    P.N = N;
+    P.N = h->cfg.horizon;
     P.V = Vuse;
     P.max_iter = h->cfg.max_iter;
     P.dt = h->cfg.dt;
@@ -516,6 +553,16 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, 
     P.mu_init = 0.1;
     P.w_distance = h->cfg.w_distance;
     P.stall_window = h->cfg.stall_window;
+    return P;
+}
+
+int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, hipStream_t stream, const double *d_state,
+                   const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
+                   const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
+                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
+    const int N = h->cfg.horizon;
+    const int Vuse = cc ? V : 0;
+    const mpc::SolveParams P = solve_params(h, Vuse);
 
     static_assert(MPC_MAX_HORIZON <= mpc::wave::kMaxHorizon, "lane k = stage k needs the horizon to fit a wave");
     const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
@@ -1268,6 +1315,56 @@ int mpc_rollout_finish(int32_t device, int32_t T, int32_t B, int32_t A, int32_t 
     hipLaunchKernelGGL(mpc_rollout_finish_kernel, dim3((unsigned)B), dim3(256), (size_t)T * 2 * sizeof(float),
                        reinterpret_cast<hipStream_t>(stream_), g);
     HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_eval_nlp(mpc_handle *h, int32_t B, const int32_t *ego_index, const double *vref, const double *weights,
+                 const uint8_t *is_collide, const double *others, int32_t V, uint32_t flags, const double *X, const double *U,
+                 double *f, double *x_next) {
+    if (!h) return fail(MPC_ERR_INVALID_ARG, "mpc_eval_nlp: null handle");
+    if (B < 0 || !ego_index || !weights || !is_collide || !X || !U || !f || !x_next)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_eval_nlp: null required pointer or negative batch");
+    if (V < 0 || V > MPC_MAX_OTHERS) return fail(MPC_ERR_INVALID_ARG, "mpc_eval_nlp: V out of range");
+    const bool cc = (flags & MPC_FLAG_COLLISION_COST) != 0;
+    if (flags & ~(uint32_t)MPC_FLAG_COLLISION_COST) return fail(MPC_ERR_INVALID_ARG, "mpc_eval_nlp: only MPC_FLAG_COLLISION_COST (host pointers, synchronous)");
+    if (cc && V > 0 && !others) return fail(MPC_ERR_INVALID_ARG, "mpc_eval_nlp: collision cost needs `others`");
+    if (!h->d_ref) return fail(MPC_ERR_NO_REFERENCE, "mpc_eval_nlp: call mpc_set_reference first");
+    if (B == 0) return MPC_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int N = h->cfg.horizon;
+    const size_t N1 = (size_t)N + 1;
+    size_t off = 0;
+    auto seg = [&](size_t bytes) { return carve(off, bytes); };
+    const size_t o_ego = seg((size_t)B * 4), o_w = seg((size_t)B * 3 * 8), o_c = seg((size_t)B);
+    const size_t o_vref = vref ? seg((size_t)B * N1 * 8) : 0, o_oth = (cc && V > 0) ? seg((size_t)B * V * 4 * 8) : 0;
+    const size_t o_X = seg((size_t)B * N1 * 4 * 8), o_U = seg((size_t)B * N * 2 * 8), o_f = seg((size_t)B * 8);
+    const size_t o_xn = seg((size_t)B * N * 4 * 8);
+    if (int rc = ensure_stage(h, off)) return rc;
+    char *sb = static_cast<char *>(h->d_stage);
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipMemcpyAsync(sb + o_ego, ego_index, (size_t)B * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sb + o_w, weights, (size_t)B * 3 * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sb + o_c, is_collide, (size_t)B, hipMemcpyHostToDevice, stream));
+    if (vref) HIP_TRY(hipMemcpyAsync(sb + o_vref, vref, (size_t)B * N1 * 8, hipMemcpyHostToDevice, stream));
+    if (cc && V > 0) HIP_TRY(hipMemcpyAsync(sb + o_oth, others, (size_t)B * V * 4 * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sb + o_X, X, (size_t)B * N1 * 4 * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(sb + o_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
+    mpc::SolveParams P = solve_params(h, cc ? V : 0);
+    const size_t lds = (size_t)mpc::wave::lds_doubles(cc, N, P.V, false) * sizeof(double);
+    auto D = [&](size_t o) { return reinterpret_cast<double *>(sb + o); };
+    if (cc)
+        hipLaunchKernelGGL(mpc_eval_kernel<true>, dim3((unsigned)B), dim3(kBlock), lds, stream, P, (int)B, h->d_ref, h->M,
+                           reinterpret_cast<int32_t *>(sb + o_ego), vref ? D(o_vref) : nullptr, D(o_w),
+                           reinterpret_cast<uint8_t *>(sb + o_c), V > 0 ? D(o_oth) : nullptr, (int)V, h->cfg.w_collision, D(o_X),
+                           D(o_U), D(o_f), D(o_xn));
+    else
+        hipLaunchKernelGGL(mpc_eval_kernel<false>, dim3((unsigned)B), dim3(kBlock), lds, stream, P, (int)B, h->d_ref, h->M,
+                           reinterpret_cast<int32_t *>(sb + o_ego), vref ? D(o_vref) : nullptr, D(o_w),
+                           reinterpret_cast<uint8_t *>(sb + o_c), nullptr, 0, h->cfg.w_collision, D(o_X), D(o_U), D(o_f), D(o_xn));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(f, sb + o_f, (size_t)B * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(x_next, sb + o_xn, (size_t)B * N * 4 * 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return MPC_OK;
 }
 

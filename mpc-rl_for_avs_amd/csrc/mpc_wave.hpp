@@ -531,6 +531,55 @@ struct Solver {
         return true;
     }
 
+    // the table of constants in LDS that every part of the solver reads bounds and function coefficients from
+    MPC_HD void init_tables() {
+        sc(SC_SPARE + 0, 0.0);   // the constants F is made of besides the linearisation values (fetched by address)
+        sc(SC_SPARE + 1, 1.0);
+        sc(SC_SPARE + 2, dt);
+        for (int i = 0; i < kTrigWords; ++i) sc(SC_TRIG + i, trig_coef(i));
+        for (int i = 0; i < kLogWords; ++i) sc(SC_LOG + i, log_coef(i));
+        sc(SC_K + K_SF, 1.0);            // until the objective scale is known (solve())
+        for (int i = 0; i < 2; ++i) {
+            sc(SC_BND + 0 + 2 * i, xlo_r(i));
+            sc(SC_BND + 1 + 2 * i, xhi_r(i));
+            sc(SC_BND + 4 + 2 * i, ulo_r(i));
+            sc(SC_BND + 5 + 2 * i, uhi_r(i));
+        }
+    }
+
+    // ---- diagnostics (mpc_eval_nlp): the NLP's functions at a GIVEN point z = (X, U), through the code the solver itself
+    // runs - so that the reference's own f(z), g(z) (tests/golden/reference_sequences.npz: agents/pure_mpc.py:128-283 executed
+    // numerically) pin the device's objective and model directly, not through a solution.  The caller has stored the point in
+    // trajectory buffer 0 (X[k] at W_X, U[k] at W_U), the reference speeds and the other vehicles as for solve().  Returns the
+    // UNSCALED objective: stage_terms() - what every line-search trial is judged by - for the control costs and the nodes
+    // 1 .. N-1, plus the node-0 term, a constant of the solve that the solver never needs (same track() / dist()).
+    // xn[i] of lane k = component i of the model's successor of (X[k], U[k]) with the formulas of rollout_init(); the
+    // reference's dynamics constraint (:220-257) is X[k+1] - xn[k] = 0.
+    MPC_HD double evaluate(PerLane<double> (&xn)[4]) {
+        init_tables();
+        any_wall = 0;
+        c.phase([&](int lane) {
+            red_a.at(lane) = 0.0;
+            for (int i = 0; i < 4; ++i) xn[i].at(lane) = 0.0;
+            if (lane >= N) return;
+            double J, bar;
+            stage_terms(0, 0, lane, J, bar);
+            const double x_0 = S(lane, W_X + 0), x_1 = S(lane, W_X + 1), x_2 = S(lane, W_X + 2), x_3 = S(lane, W_X + 3);
+            if (lane == 0) {
+                J += SF() * track(0, x_0, x_1, x_2, x_3, (double *)nullptr);
+                if (CC) J += SF() * (dist(0, x_0, x_1, (double *)nullptr) + WCOLL() * x_3 * x_3);
+            }
+            red_a.at(lane) = J;
+            double Sn, Cn, sb, cb_;
+            dyn_eval(trig(), x_2, S(lane, W_U + 1), Sn, Cn, sb, cb_);
+            xn[0].at(lane) = x_0 + dt * (x_3 * Cn);
+            xn[1].at(lane) = x_1 + dt * (x_3 * Sn);
+            xn[2].at(lane) = x_2 + dt * (x_3 * kInvWheelbase * sb);
+            xn[3].at(lane) = x_3 + dt * S(lane, W_U + 0);
+        });
+        return c.wave_sum(red_a);
+    }
+
     // ---- line search on the barrier objective (Armijo, kTrials step lengths alpha_t = a_pr 4^-t, first passing wins).
     // Trial controls u_k = ucur_k + alpha kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1}), clamped to the
     // fraction-to-the-boundary box.  All step lengths are integrated at once - lane t runs the serial dynamics for
@@ -839,18 +888,7 @@ struct Solver {
         iters_out = 0;
         cur_out = 0;
         kkt_out = INFINITY;
-        sc(SC_SPARE + 0, 0.0);   // the constants F is made of besides the linearisation values (fetched by address)
-        sc(SC_SPARE + 1, 1.0);
-        sc(SC_SPARE + 2, dt);
-        for (int i = 0; i < kTrigWords; ++i) sc(SC_TRIG + i, trig_coef(i));
-        for (int i = 0; i < kLogWords; ++i) sc(SC_LOG + i, log_coef(i));
-        sc(SC_K + K_SF, 1.0);            // until the objective scale is known (below)
-        for (int i = 0; i < 2; ++i) {
-            sc(SC_BND + 0 + 2 * i, xlo_r(i));
-            sc(SC_BND + 1 + 2 * i, xhi_r(i));
-            sc(SC_BND + 4 + 2 * i, ulo_r(i));
-            sc(SC_BND + 5 + 2 * i, uhi_r(i));
-        }
+        init_tables();
         // cold start of the reference (agents/pure_mpc.py:240-246: controls 0), multipliers 1
         c.phase([&](int lane) {
             if (lane >= N) return;

@@ -50,7 +50,7 @@ _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
-            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record", "mpc_rollout_finish"]
+            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record", "mpc_rollout_finish", "mpc_eval_nlp"]
 ABI_VERSION = 6          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
 MAX_OTHERS = 16
 _lib = None
@@ -138,6 +138,8 @@ def load_library(path: str | None = None):
     lib.mpc_rollout_record.restype = ctypes.c_int
     lib.mpc_rollout_finish.argtypes = [ctypes.c_int32] * 6 + [vp] * 4 + [ctypes.c_double] * 2 + [vp] * 3
     lib.mpc_rollout_finish.restype = ctypes.c_int
+    lib.mpc_eval_nlp.argtypes = [vp, ctypes.c_int32] + [vp] * 5 + [ctypes.c_int32, ctypes.c_uint32] + [vp] * 4
+    lib.mpc_eval_nlp.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -316,6 +318,32 @@ class MPCEngine:
                                          p(out["status"]), p(out["iters"]), stream)
         self._check(rc, "mpc_predict_batch")
         return out
+
+    def eval_nlp(self, ego_index, weights, is_collide, X, U, vref=None, others=None, collision_cost=False):
+        """Diagnostics (mpc_eval_nlp): objective f [B] and model successors x_next [B, N, 4] of the points (X [B, N+1, 4],
+        U [B, N, 2]) as the solve kernel's own code evaluates them."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        B, N = U.shape[0], self.horizon
+        if X.shape != (B, N + 1, 4) or U.shape != (B, N, 2):
+            raise ValueError(f"X must be [B, {N + 1}, 4] and U [B, {N}, 2], got {X.shape} and {U.shape}")
+        ego = np.ascontiguousarray(ego_index, dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        c = np.ascontiguousarray(is_collide, dtype=np.uint8)
+        if ego.shape != (B,) or w.shape != (B, 3) or c.shape != (B,):
+            raise ValueError("ego_index [B], weights [B, 3], is_collide [B] expected")
+        vr = None if vref is None else np.ascontiguousarray(vref, dtype=np.float64)
+        if vr is not None and vr.shape != (B, N + 1):
+            raise ValueError(f"vref must be [B, {N + 1}]")
+        oth = None if others is None else np.ascontiguousarray(others, dtype=np.float64)
+        if oth is not None and (oth.ndim != 3 or oth.shape[0] != B or oth.shape[2] != 4):
+            raise ValueError("others must be [B, V, 4]")
+        V = 0 if oth is None else oth.shape[1]
+        f, xn = np.empty(B), np.empty((B, N, 4))
+        rc = self._lib.mpc_eval_nlp(self._h, B, _ptr(ego), _ptr(vr), _ptr(w), _ptr(c), _ptr(oth), V,
+                                    FLAG_COLLISION_COST if collision_cost else 0, _ptr(X), _ptr(U), _ptr(f), _ptr(xn))
+        self._check(rc, "mpc_eval_nlp")
+        return f, xn
 
     # ------------------------------------------------------------------ iterative-linear MPC (pure_mpc_linear.py)
     def ltv_solve_batch(self, state, U, want_traj=False):

@@ -208,3 +208,30 @@ def unexplained_disagreements(oracle, ref_table, inp, cc, got, want, tol=1e-4, t
         if not (ok and chaotic):
             bad.append(int(b))
     return bad
+
+
+def host_eval_nlp(ref, ego_index, weights, is_collide, X, U, vref=None, others=None, collision_cost=False, w_distance=1.0,
+                  w_collision=1.0, dt=0.1):
+    """Solver::evaluate() of csrc/mpc_wave.hpp compiled for the host (what mpc_eval_nlp runs on the device): the kernel
+    source's own objective and model step at given points.  Returns (f [B], x_next [B, N, 4])."""
+    import ctypes
+    _host_solver("libcpu_wave.so", "cpu_wave_harness.cpp", "wave_solve_batch")   # builds tests/_build/libcpu_wave.so when stale
+    lib = ctypes.CDLL(os.path.join(BUILD_DIR, "libcpu_wave.so"))
+    vp = ctypes.c_void_p
+    lib.wave_eval_batch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, ctypes.c_int, vp, vp, vp, vp, vp,
+                                    ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.c_double, vp, vp, vp, vp]
+    X = np.ascontiguousarray(X, np.float64)
+    U = np.ascontiguousarray(U, np.float64)
+    B, N = U.shape[0], U.shape[1]
+    ref = np.ascontiguousarray(ref, np.float64)
+    ego = np.ascontiguousarray(ego_index, np.int32)
+    w = np.ascontiguousarray(weights, np.float64)
+    c = np.ascontiguousarray(is_collide, np.uint8)
+    vr = None if vref is None else np.ascontiguousarray(vref, np.float64)
+    oth = None if others is None else np.ascontiguousarray(others, np.float64)
+    f, xn = np.zeros(B), np.zeros((B, N, 4))
+    P = lambda a: None if a is None else vp(a.ctypes.data)
+    rc = lib.wave_eval_batch(B, N, dt, P(ref), ref.shape[0], P(ego), P(vr), P(w), P(c), P(oth), 0 if oth is None else oth.shape[1],
+                             1 if collision_cost else 0, w_distance, w_collision, P(X), P(U), P(f), P(xn))
+    assert rc == 0
+    return f, xn

@@ -121,3 +121,67 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     }
     return 0;
 }
+
+// mpc_eval_nlp on the host: Solver::evaluate() at given points z = (X [B][N+1][4], U [B][N][2]) -> f [B], x_next [B][N][4]
+extern "C" int wave_eval_batch(int B, int N, double dt, const double *ref_table, int M, const int32_t *ego_index,
+                               const double *vref, const double *weights, const uint8_t *is_collide, const double *others, int V,
+                               uint32_t flags, double w_distance, double w_collision, const double *X, const double *U, double *f,
+                               double *x_next) {
+    if (N > mpc::wave::kMaxHorizon) return -1;
+    const int cc = (flags & 1u) ? 1 : 0;
+    const int Vuse = cc ? V : 0;
+    std::vector<double> table((size_t)M * mpc::REF_COLS);
+    for (int i = 0; i < M; ++i) {
+        table[i * mpc::REF_COLS + mpc::R_X] = ref_table[i * 4 + 0];
+        table[i * mpc::REF_COLS + mpc::R_Y] = ref_table[i * 4 + 1];
+        table[i * mpc::REF_COLS + mpc::R_H] = ref_table[i * 4 + 3];
+        table[i * mpc::REF_COLS + mpc::R_SIN] = std::sin(ref_table[i * 4 + 3]);
+        table[i * mpc::REF_COLS + mpc::R_COS] = std::cos(ref_table[i * 4 + 3]);
+    }
+    mpc::SolveParams P;
+    P.N = N; P.V = Vuse; P.max_iter = 0; P.dt = dt; P.tol = 1e-8; P.mu_init = 0.1;
+    P.w_distance = w_distance;
+    const int SL = mpc::wave::stage_slots(cc, true);
+    const int nd = mpc::wave::lds_doubles(cc, N, Vuse, true);
+    for (int b = 0; b < B; ++b) {
+        std::vector<double> L((size_t)nd, NAN);
+        HostCtx ctx{};
+        ctx.L = L.data();
+        ctx.table = table.data();
+        ctx.e0 = ego_index[b];
+        ctx.M = M;
+        ctx.nwords = nd;
+        for (int k = 0; k <= N; ++k) {
+            int idx = ego_index[b] + k;
+            idx = idx > M - 1 ? M - 1 : idx;
+            idx = idx < 0 ? 0 : idx;
+            L[k * SL + mpc::wave::W_RV] = vref ? vref[(size_t)b * (N + 1) + k] : ref_table[idx * 4 + 2];
+            for (int i = 0; i < 4; ++i) L[k * SL + mpc::wave::W_X + i] = X[((size_t)b * (N + 1) + k) * 4 + i];
+            if (k < N)
+                for (int i = 0; i < 2; ++i) L[k * SL + mpc::wave::W_U + i] = U[((size_t)b * N + k) * 2 + i];
+        }
+        const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
+        for (int j = 0; j < Vuse; ++j) {
+            const double *ov = others + ((size_t)b * V + j) * 4;
+            L[OTH + j * 4 + 0] = ov[0];
+            L[OTH + j * 4 + 1] = ov[1];
+            L[OTH + j * 4 + 2] = ov[2] * dt * std::cos(ov[3]);
+            L[OTH + j * 4 + 3] = ov[2] * dt * std::sin(ov[3]);
+        }
+        const bool collide = is_collide[b] != 0;
+        const double ws_ = collide ? 100.0 : weights[3 * b + 0];
+        const double wcoll = (cc && collide) ? 3000.0 * w_collision : 0.0;
+        mpc::wave::PerLane<double> xn[4];
+        const double *x0 = X + (size_t)b * (N + 1) * 4;
+        if (cc) {
+            mpc::wave::Solver<true, HostCtx> s(P, ctx, x0, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll);
+            f[b] = s.evaluate(xn);
+        } else {
+            mpc::wave::Solver<false, HostCtx> s(P, ctx, x0, ws_, weights[3 * b + 1], weights[3 * b + 2], wcoll);
+            f[b] = s.evaluate(xn);
+        }
+        for (int k = 0; k < N; ++k)
+            for (int i = 0; i < 4; ++i) x_next[((size_t)b * N + k) * 4 + i] = xn[i].at(k);
+    }
+    return 0;
+}

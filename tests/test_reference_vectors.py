@@ -332,6 +332,90 @@ def test_oracle_nlp_equals_the_references_statements(seq, ref_table):
     assert np.max(np.abs(cb - seq["nlp_g"])) <= 1e-12
 
 
+def nlp_points(seq, ref_table):
+    """The 1200 points of reference_sequences.npz as problem data + (X, U) + the reference's f, g."""
+    t, e = seq["nlp_t"], seq["nlp_e"]
+    w = seq["seq_weights"][e].copy()
+    w[np.isnan(w[:, 0])] = 1.0
+    ego = seq["seq_ego_index"][t, e]
+    n = len(t)
+    return dict(ego=ego, weights=w, collide=seq["seq_is_collide"][t, e], vref=rf.window(seq["seq_speed_col"][t, e], ego, 20),
+                state=seq["seq_state"][t, e], X=seq["nlp_z"][:, :84].reshape(n, 21, 4), U=seq["nlp_z"][:, 84:].reshape(n, 20, 2),
+                f=seq["nlp_f"], g=seq["nlp_g"].reshape(n, 21, 4))
+
+
+def check_nlp_functions(evaluate, seq, ref_table):
+    """`evaluate(ego, weights, collide, X, U, vref=...) -> (f, x_next)` of the kernel source against the reference's own
+    f(z) and g(z): the objective to 1e-13 relative (the sum over the stages is a DPP reduction tree on the device, a loop in
+    casadi), the dynamics rows X[k+1] - x_next[k] to 5e-14 (lean sine / cosine: 1.3e-15 absolute, times speed x dt; one
+    rounding of a position of ~50 m)."""
+    p = nlp_points(seq, ref_table)
+    f, xn = evaluate(p["ego"], p["weights"], p["collide"], p["X"], p["U"], vref=p["vref"])
+    assert (p["weights"] < 0).any() and p["collide"].any() and len(f) >= 1200
+    rel = np.abs(f - p["f"]) / np.maximum(1.0, np.abs(p["f"]))
+    assert rel.max() <= 1e-13, rel.max()
+    g = p["X"][:, 1:] - xn
+    assert np.abs(g - p["g"][:, 1:]).max() <= 5e-14, np.abs(g - p["g"][:, 1:]).max()
+    assert np.array_equal(p["X"][:, 0] - p["state"], p["g"][:, 0])          # the row X[0] - state, for completeness
+    return float(rel.max()), float(np.abs(g - p["g"][:, 1:]).max())
+
+
+def test_device_code_nlp_functions_equal_the_references_statements(seq, ref_table):
+    """a7 / a9 on the kernel SOURCE (Solver::evaluate of csrc/mpc_wave.hpp = what mpc_eval_nlp runs; here compiled for the
+    host): stage_terms / track / dyn_eval - the functions every line-search trial and every rollout of the solver goes
+    through - against f(z), g(z) computed by the reference's statements."""
+    from conftest import host_eval_nlp
+    check_nlp_functions(lambda ego, w, c, X, U, vref: host_eval_nlp(ref_table, ego, w, c, X, U, vref=vref), seq, ref_table)
+
+
+def distance_cost_points():
+    d = rf.load("reference_distance_cost.npz")
+    n = len(d["distance_cost"])
+    others = np.zeros((n, 9, 4))
+    nveh = np.zeros(n, np.int32)
+    for b in range(n):
+        o = d["obs"][b]
+        nv = int((o[:, 0] == 1).sum()) - 1
+        nveh[b] = nv
+        for j in range(nv):
+            r = o[j + 1]
+            others[b, j] = (r[1], r[2], np.sqrt(r[3] * r[3] + r[4] * r[4]), r[5])
+        others[b, nv:] = (1e6, 1e6, 0.0, 0.0)       # absent vehicles far away: 100 / d^2 = 5e-11, below the tolerance
+    return d, others, nveh
+
+
+def check_distance_cost(evaluate, ref_table):
+    """a8 on the kernel source: f with the collision cost minus f without it = w_distance x the archived agent's distance
+    term (agents/archive/pure_mpc.py:189-206, executed), within deviation (iv) of DESIGN.md section 3.1 (the reference walks
+    the vehicles in float32): 2e-4 relative with a node inside d < 1 m, 5e-5 elsewhere - and equal to the oracle's
+    restatement of the same term to rounding."""
+    import nlp_spec as ns
+    d, others, nveh = distance_cost_points()
+    n = len(nveh)
+    X = d["z"][:, :84].reshape(n, 21, 4)
+    U = d["z"][:, 84:].reshape(n, 20, 2)
+    ego, w, col = np.zeros(n, np.int32), np.ones((n, 3)), np.zeros(n, np.uint8)
+    f1, _ = evaluate(ego, w, col, X, U, others=others, collision_cost=True)
+    f0, _ = evaluate(ego, w, col, X, U, others=None, collision_cost=False)
+    got = f1 - f0
+    want = d["distance_cost"]
+    dd = np.linalg.norm(X[:, :20, None, :2] - (others[:, None, :, :2] + np.arange(20)[None, :, None, None] * 0.1 *
+                                              others[:, None, :, 2:3] * np.stack([np.cos(others[..., 3]), np.sin(others[..., 3])], -1)[:, None]), axis=-1)
+    near = (dd < 1.0).any(axis=(1, 2))
+    spec = np.sum(np.where(dd < 1.0, 1000.0, 100.0) / (dd + 1e-6) ** 2, axis=(1, 2))
+    rel = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert near.sum() >= 100
+    assert rel[near].max() <= 2e-4 and rel[~near].max() <= 5e-5, (rel[near].max(), rel[~near].max())
+    # against the oracle's restatement of the same term: the difference of two objectives of size |f| carries |f| x 1e-16
+    assert (np.abs(got - spec) / np.maximum(1.0, np.maximum(np.abs(spec), np.abs(f1)))).max() <= 1e-13
+
+
+def test_device_code_distance_cost_equals_the_archived_agents(ref_table):
+    from conftest import host_eval_nlp
+    check_distance_cost(lambda ego, w, c, X, U, others, collision_cost: host_eval_nlp(
+        ref_table, ego, w, c, X, U, others=others, collision_cost=collision_cost), ref_table)
+
+
 def test_oracle_distance_cost_equals_the_archived_agents(ref_table):
     """the distance term of agents/archive/pure_mpc.py:189-206, evaluated by the archived agent's own
     statements.  The reference advances the other vehicles in float32 (their observation's dtype, base_agent.py:172-174);

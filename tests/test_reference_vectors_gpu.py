@@ -218,3 +218,26 @@ def test_ltv_helpers_on_the_device(ref_table):
     for b in np.nonzero(ok)[0][:64]:
         assert ltv_reference_slacks(U[b], X[b]).min() >= -1e-7
     e.close()
+
+
+def test_nlp_functions_on_the_device_equal_the_references_statements(seq, ref_table):
+    """a7 / a9 directly on the GPU: mpc_eval_nlp runs the solve kernel's own objective and model step (Solver::evaluate:
+    stage_terms / track / dyn_eval) at the 1200 points where the REFERENCE's statements (agents/pure_mpc.py:128-283, executed
+    with numeric casadi values) computed f(z) and g(z): objective to 1e-13 relative, dynamics rows to 5e-14."""
+    from mpc_rl_for_avs_amd import engine
+    from test_reference_vectors import check_nlp_functions
+    e = engine.MPCEngine(horizon=20)
+    worst = check_nlp_functions(lambda ego, w, c, X, U, vref: e.eval_nlp(ego, w, c, X, U, vref=vref), seq, ref_table)
+    print("device objective / dynamics against the reference's statements: rel f %.1e, abs g %.1e" % worst)
+    e.close()
+
+
+def test_distance_cost_on_the_device_equals_the_archived_agents(ref_table):
+    """a8 directly on the GPU: the collision-cost term of the kernel (dist(), MPC_FLAG_COLLISION_COST) against the archived
+    agent's own statements (agents/archive/pure_mpc.py:189-206, executed) on 512 scenes, within deviation (iv)."""
+    from mpc_rl_for_avs_amd import engine
+    from test_reference_vectors import check_distance_cost
+    e = engine.MPCEngine(horizon=20)
+    check_distance_cost(lambda ego, w, c, X, U, others, collision_cost: e.eval_nlp(ego, w, c, X, U, others=others,
+                                                                                  collision_cost=collision_cost), ref_table)
+    e.close()
