@@ -237,7 +237,7 @@ def test_distance_cost_on_the_device_equals_the_archived_agents(ref_table):
     agent's own statements (agents/archive/pure_mpc.py:189-206, executed) on 512 scenes, within deviation (iv)."""
     from mpc_rl_for_avs_amd import engine
     from test_reference_vectors import check_distance_cost
-    e = engine.MPCEngine(horizon=20)
+    e = engine.MPCEngine(horizon=20, w_distance=1.0)       # the bare term (the archived agent weighs it by 10, like the default)
     check_distance_cost(lambda ego, w, c, X, U, others, collision_cost: e.eval_nlp(ego, w, c, X, U, others=others,
                                                                                   collision_cost=collision_cost), ref_table)
     e.close()
