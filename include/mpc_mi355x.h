@@ -267,7 +267,9 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
  * mpc_policy_act: the SB3 MlpPolicy-shaped actor-critic of PPO_MPC / A2C_MPC (agents/ppo_mpc.py:390-394; 80 -> H -> H tanh
  * twice, Gaussian head) for B observations obs [B][80] f32: both towers as one 80 -> 2H -> 2H -> (A + 1) network with the
  * weights laid out as w1 [80][2H], b1 [2H], w2 [2H][2H] (block diagonal), b2 [2H], wh [2H][A + 1], bh [A + 1], std [A] =
- * exp(log_std), c0 [1] = sum(log_std) + A / 2 log(2 pi); noise [B][A] standard normal draws of the caller's generator.
+ * exp(log_std), c0 [1] = sum(log_std) + A / 2 log(2 pi); noise [B][A] the sample's standard normal draws: with noise_step
+ * == NULL read from the caller (its own generator), otherwise DRAWN here - counter-based, keyed by (noise_seed, env_offset + b,
+ * noise_step[0], component), no generator state, replayable in a hipGraph - and left in `noise`.
  * Outputs: actions [B][A] = mean + std * noise, values [B], log_probs [B], and the MPC's inputs as the reference maps the
  * action: version_v1 == 0 -> mpc_ref_speed [B] f64 = action 0 (agents/ppo_mpc.py:410-414), else mpc_weights [B][3] f64 =
  * actions 0..2 (:416-420); clip != 0 clips to the Box(-1, 1) action space first (PPO, :399-407; A2C does not, a2c_mpc.py:138-144).
@@ -275,7 +277,8 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
  * mpc_rollout_record: row pos_dev[0] of the rollout buffer row [T][B][cols] = [obs 80 | action A | reward | episode_start |
  * value | log_prob | (terminal_obs 80 | truncated)] (rollout_buffer.add, agents/ppo_mpc.py:462-469) and of mpc_actions_buf
  * [T][B][2]; last_obs <- new_obs, last_starts <- done; counts [4] += finished / crashed / arrived episodes and solves whose
- * status is not converged; dones_out <- done; pos_dev[0] += 1 (ticket: one zero-initialised int32 of scratch).
+ * status is not converged; dones_out <- done; pos_dev[0] += 1 (ticket: one zero-initialised int32 of scratch) and, if given,
+ * step_counter[0] += 1 (the policy steps taken so far: mpc_policy_act's noise_step).
  *
  * mpc_rollout_finish: the end of a rollout of T steps (1 <= T <= 8192) over the same buffer (agents/ppo_mpc.py:471-476
  * `rollout_buffer.compute_returns_and_advantage`, stable-baselines3's arithmetic in float32, operation by operation): if
@@ -287,14 +290,15 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
  */
 int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float *obs, const float *w1, const float *b1,
                    const float *w2, const float *b2, const float *wh, const float *bh, const float *std_, const float *c0,
-                   const float *noise, int32_t version_v1, int32_t clip, float *actions, float *values, float *log_probs,
-                   double *mpc_weights, double *mpc_ref_speed, void *stream);
+                   float *noise, uint64_t noise_seed, int32_t env_offset, const int64_t *noise_step, int32_t version_v1,
+                   int32_t clip, float *actions, float *values, float *log_probs, double *mpc_weights, double *mpc_ref_speed,
+                   void *stream);
 int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
                        double *mpc_actions_buf, int64_t *pos_dev, int32_t *ticket, float *last_obs, float *last_starts,
                        const float *actions, const float *values, const float *log_probs, const double *mpc_act,
                        const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
                        const float *terminal_obs, const uint8_t *truncated, const uint8_t *crashed, const uint8_t *arrived,
-                       int64_t *counts, uint8_t *dones_out, void *stream);
+                       int64_t *counts, uint8_t *dones_out, int64_t *step_counter, void *stream);
 int mpc_rollout_finish(int32_t device, int32_t T, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
                        const float *last_values, const uint8_t *dones, const float *terminal_values, double gamma,
                        double gae_lambda, float *advantages, float *returns, void *stream);

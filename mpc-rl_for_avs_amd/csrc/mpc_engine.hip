@@ -392,7 +392,8 @@ __global__ __launch_bounds__(64) void mpc_synth_env_kernel(
 // counters of a step.  One workgroup per environment.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(mpc::glue::kMaxHidden2) void mpc_policy_act_kernel(
-    int B, int A, int H2, const float *__restrict__ obs, mpc::glue::PolicyWeights W, const float *__restrict__ noise,
+    int B, int A, int H2, const float *__restrict__ obs, mpc::glue::PolicyWeights W, float *noise,
+    unsigned long long noise_seed, int env_offset, const long long *__restrict__ noise_step,
     int version_v1, int clip, float *__restrict__ actions, float *__restrict__ values, float *__restrict__ log_probs,
     double *__restrict__ mpc_weights, double *__restrict__ mpc_ref_speed) {
     namespace glue = mpc::glue;
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(mpc::glue::kMaxHidden2) void mpc_policy_act_kernel(
     const int b = blockIdx.x, j = threadIdx.x;
     if (b >= B) return;
     if (j < glue::kObsDim) s_x[j] = obs[(size_t)b * glue::kObsDim + j];
+    // the sample's noise: drawn here (and left in `noise` for the caller to see) or handed in
+    if (noise_step && j < A) noise[(size_t)b * A + j] = glue::policy_noise(noise_seed, env_offset + b, *noise_step, j);
     __syncthreads();
     if (j < H2) s_h1[j] = glue::layer1_unit(W, H2, s_x, j);
     __syncthreads();
@@ -417,7 +420,8 @@ __global__ __launch_bounds__(mpc::glue::kMaxHidden2) void mpc_policy_act_kernel(
 
 __global__ __launch_bounds__(128) void mpc_rollout_record_kernel(mpc::glue::RecordArgs R, long long *__restrict__ pos_dev,
                                                                  int32_t *__restrict__ ticket,
-                                                                 unsigned long long *__restrict__ counts) {
+                                                                 unsigned long long *__restrict__ counts,
+                                                                 long long *__restrict__ step_counter) {
     const int b = blockIdx.x, j = threadIdx.x;
     if (b >= R.B) return;
     const long long pos = *pos_dev;
@@ -433,6 +437,7 @@ __global__ __launch_bounds__(128) void mpc_rollout_record_kernel(mpc::glue::Reco
         if (atomicAdd(ticket, 1) == R.B - 1) {
             *ticket = 0;
             *pos_dev = pos + 1;
+            if (step_counter) *step_counter += 1;      // policy steps taken so far: keys the next step's noise
         }
     }
 }
@@ -1257,8 +1262,9 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
 
 int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float *obs, const float *w1, const float *b1,
                    const float *w2, const float *b2, const float *wh, const float *bh, const float *std_, const float *c0,
-                   const float *noise, int32_t version_v1, int32_t clip, float *actions, float *values, float *log_probs,
-                   double *mpc_weights, double *mpc_ref_speed, void *stream_) {
+                   float *noise, uint64_t noise_seed, int32_t env_offset, const int64_t *noise_step, int32_t version_v1,
+                   int32_t clip, float *actions, float *values, float *log_probs, double *mpc_weights, double *mpc_ref_speed,
+                   void *stream_) {
     if (B < 0 || A < 1 || A > mpc::glue::kMaxAction || H2 < 2 || H2 > mpc::glue::kMaxHidden2 || (H2 & 1))
         return fail(MPC_ERR_INVALID_ARG, "mpc_policy_act: bad size (action_dim 1..8, 2 x hidden <= 256)");
     if (!obs || !w1 || !b1 || !w2 || !b2 || !wh || !bh || !std_ || !c0 || !noise || !actions || !values || !log_probs)
@@ -1270,7 +1276,8 @@ int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float
     const mpc::glue::PolicyWeights W{w1, b1, w2, b2, wh, bh, std_, c0};
     const int threads = H2 > mpc::glue::kObsDim ? H2 : mpc::glue::kObsDim;
     hipLaunchKernelGGL(mpc_policy_act_kernel, dim3((unsigned)B), dim3((unsigned)((threads + 63) / 64 * 64)), 0,
-                       reinterpret_cast<hipStream_t>(stream_), (int)B, (int)A, (int)H2, obs, W, noise, (int)version_v1, (int)clip,
+                       reinterpret_cast<hipStream_t>(stream_), (int)B, (int)A, (int)H2, obs, W, noise, (unsigned long long)noise_seed,
+                       (int)env_offset, reinterpret_cast<const long long *>(noise_step), (int)version_v1, (int)clip,
                        actions, values, log_probs, version_v1 ? mpc_weights : nullptr, version_v1 ? nullptr : mpc_ref_speed);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
@@ -1281,7 +1288,7 @@ int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32
                        const float *actions, const float *values, const float *log_probs, const double *mpc_act,
                        const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
                        const float *terminal_obs, const uint8_t *truncated, const uint8_t *crashed, const uint8_t *arrived,
-                       int64_t *counts, uint8_t *dones_out, void *stream_) {
+                       int64_t *counts, uint8_t *dones_out, int64_t *step_counter, void *stream_) {
     constexpr int O = mpc::glue::kObsDim;
     if (B < 0 || A < 1 || A > mpc::glue::kMaxAction || cols != O + A + 4 + (keep_terminal ? O + 1 : 0))
         return fail(MPC_ERR_INVALID_ARG, "mpc_rollout_record: bad size / row layout");
@@ -1295,7 +1302,8 @@ int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32
                                  values, log_probs, mpc_act, mpc_status, new_obs, reward, done, terminal_obs, truncated, crashed,
                                  arrived, dones_out};
     hipLaunchKernelGGL(mpc_rollout_record_kernel, dim3((unsigned)B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream_), R,
-                       reinterpret_cast<long long *>(pos_dev), ticket, reinterpret_cast<unsigned long long *>(counts));
+                       reinterpret_cast<long long *>(pos_dev), ticket, reinterpret_cast<unsigned long long *>(counts),
+                       reinterpret_cast<long long *>(step_counter));
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }

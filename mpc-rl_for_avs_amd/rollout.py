@@ -288,15 +288,16 @@ class ActorCritic(torch.nn.Module):
         f["c0"].copy_(self.log_std.sum() + 0.5 * A * math.log(2.0 * math.pi))
 
     @torch.no_grad()
-    def act(self, obs, generator=None):
+    def act(self, obs, generator=None, noise=None):
         """(actions, values, log_probs) like forward(obs), through the fused weights (call refresh_fused() after every
-        change of the parameters)."""
+        change of the parameters).  noise: the sample's standard-normal draws [B, action_dim] instead of the generator's."""
         f, A = self._fz, self.action_dim
         h = torch.tanh(torch.addmm(f["b1"], obs.flatten(1), f["w1"]))
         h = torch.tanh(torch.addmm(f["b2"], h, f["w2"]))
         out = torch.addmm(f["bh"], h, f["wh"])
         mean = out[:, :A]
-        noise = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
+        if noise is None:
+            noise = torch.randn(mean.shape, generator=generator, device=mean.device, dtype=mean.dtype)
         actions = torch.addcmul(mean, noise, f["std"])
         log_probs = (noise * noise).sum(dim=1).mul_(-0.5).sub_(f["c0"])
         return actions, out[:, A], log_probs
@@ -451,8 +452,11 @@ class BatchedCollector:
         if self.fused_glue:
             A = policy.action_dim
             z = lambda *sh, dt=torch.float32: torch.zeros(sh, dtype=dt, device=dev)
+            # noise: the Gaussian sample's draws of the last step, made by the kernel itself (counter-based, keyed by seed,
+            # global environment id and `step`, the number of policy steps taken so far, which mpc_rollout_record advances)
             self._fg = dict(act=z(B, A), val=z(B), logp=z(B), w=z(B, 3, dt=torch.float64), rs=z(B, dt=torch.float64),
-                            ticket=z(1, dt=torch.int32))
+                            ticket=z(1, dt=torch.int32), noise=z(B, A), step=z(1, dt=torch.int64))
+            self._noise_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         # None = the default path: on a GPU with the real engine a step (policy -> MPC -> environment -> buffer row) is
         # captured once as a hipGraph and replayed; eager on the CPU, with stand-in engines, and when the actions are
         # all-gathered (the collective stays outside the graph)
@@ -493,9 +497,10 @@ class BatchedCollector:
 
     @torch.no_grad()
     def _rollout_step_fused(self):
-        """The same step with the two glue kernels: identical random draws (the policy's noise comes from the same generator
-        call as ActorCritic.act), identical data flow; the float32 sums of the three small matrix products are accumulated in
-        index order instead of hipBLASLt's (tests/test_predict_gpu.py::test_fused_glue_step_equals_the_torch_step)."""
+        """The same step with the two glue kernels: identical data flow; the float32 sums of the three small matrix products
+        are accumulated in index order instead of hipBLASLt's, and the Gaussian sample's noise is drawn by the kernel
+        (counter-based; left in self._fg["noise"]) instead of by torch's generator - fed the same noise, ActorCritic.act
+        returns the same actions (tests/test_predict_gpu.py::test_fused_glue_step_equals_the_torch_step)."""
         import ctypes
         lib, env, pol, buf, fg = self.engine._lib, self.env, self.policy, self.buffer, self._fg
         f, A, B = pol._fz, pol.action_dim, env.num_envs
@@ -504,12 +509,12 @@ class BatchedCollector:
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         obs = self._last_obs
-        noise = torch.randn((B, A), generator=self.gen, device=dev, dtype=torch.float32)
         v1 = self.version == "v1"
         rc = lib.mpc_policy_act(dev.index, B, A, H2, p(obs), p(f["w1"]), p(f["b1"]), p(f["w2"]), p(f["b2"]), p(f["wh"]),
-                                p(f["bh"]), p(f["std"]), p(f["c0"]), p(noise), 1 if v1 else 0, 1 if self.algorithm == "ppo" else 0,
-                                p(fg["act"]), p(fg["val"]), p(fg["logp"]), p(fg["w"]) if v1 else None, None if v1 else p(fg["rs"]),
-                                stream)
+                                p(f["bh"]), p(f["std"]), p(f["c0"]), p(fg["noise"]), self._noise_seed,
+                                int(getattr(env, "env_offset", 0)), p(fg["step"]), 1 if v1 else 0,
+                                1 if self.algorithm == "ppo" else 0, p(fg["act"]), p(fg["val"]), p(fg["logp"]),
+                                p(fg["w"]) if v1 else None, None if v1 else p(fg["rs"]), stream)
         if rc != 0:
             raise RuntimeError(f"mpc_policy_act failed ({rc}): {lib.mpc_last_error().decode()}")
         weights, ref_speed = (fg["w"], None) if v1 else (self.default_weights, fg["rs"])
@@ -531,7 +536,8 @@ class BatchedCollector:
                                     p(fg["ticket"]), p(self._last_obs), p(self._last_episode_starts), p(fg["act"]), p(fg["val"]),
                                     p(fg["logp"]), p(mpc_action), p(self.last_mpc["status"]), p(o["obs"]), p(o["reward"]),
                                     p(o["done"]), p(o["terminal_obs"]) if keep else None, p(o["truncated"]) if keep else None,
-                                    p(o["crashed"]), p(o["arrived"]), p(self._roll["counts"]), p(self._roll["dones"]), stream)
+                                    p(o["crashed"]), p(o["arrived"]), p(self._roll["counts"]), p(self._roll["dones"]),
+                                    p(fg["step"]), stream)
         if rc != 0:
             raise RuntimeError(f"mpc_rollout_record failed ({rc}): {lib.mpc_last_error().decode()}")
 
@@ -543,7 +549,10 @@ class BatchedCollector:
                 self.buffer.pos += 1
             return
         obs = self._last_obs
-        actions, values, log_probs = self.policy.act(obs, generator=self.gen)
+        # (noise_feed: a list of per-step draws to consume instead of the generator's - how the tests give this path the
+        # draws the glue kernel made)
+        feed = getattr(self, "noise_feed", None)
+        actions, values, log_probs = self.policy.act(obs, generator=self.gen, noise=feed.pop(0) if feed else None)
         weights, ref_speed = self.mpc_inputs(actions)
         self._mpc_out = self.engine.predict_batch_torch(obs, weights, ref_speed, collision_cost=self.collision_cost,
                                                         warm_start=self.warm_start, out=self._mpc_out, **self._mpc_kw)
@@ -594,6 +603,7 @@ class BatchedCollector:
         snap = {n: getattr(env, n).clone() for n in names}
         snap_obs, snap_starts = self._last_obs.clone(), self._last_episode_starts.clone()
         gen_states = [self.gen.get_state(), env.gen.get_state()]
+        snap_step = self._fg["step"].clone() if self.fused_glue else None
         records = self.engine.save_env_state(B) if hasattr(self.engine, "save_env_state") else None
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -616,6 +626,8 @@ class BatchedCollector:
         self._last_episode_starts.copy_(snap_starts)
         self.gen.set_state(gen_states[0])
         env.gen.set_state(gen_states[1])
+        if snap_step is not None:
+            self._fg["step"].copy_(snap_step)
         if records is not None:
             self.engine.load_env_state(records)       # also forgets the warm-start memory the warm-up steps left
         self._roll["counts"].zero_()
@@ -629,7 +641,6 @@ class BatchedCollector:
             self._rollout_step()
         self.num_timesteps += self.env.num_envs
 
-    @torch.no_grad()
     @torch.no_grad()
     def _finish_rollout(self):
         last_values = self.policy.predict_values(self._last_obs)

@@ -9,13 +9,16 @@
 
 extern "C" int glue_policy_act(int B, int A, int H2, const float *obs, const float *w1, const float *b1, const float *w2,
                                const float *b2, const float *wh, const float *bh, const float *std_, const float *c0,
-                               const float *noise, int version_v1, int clip, float *actions, float *values, float *log_probs,
-                               double *mpc_weights, double *mpc_ref_speed) {
+                               float *noise, uint64_t noise_seed, int env_offset, const int64_t *noise_step, int version_v1,
+                               int clip, float *actions, float *values, float *log_probs, double *mpc_weights,
+                               double *mpc_ref_speed) {
     namespace glue = mpc::glue;
     const glue::PolicyWeights W{w1, b1, w2, b2, wh, bh, std_, c0};
     std::vector<float> h1((size_t)H2), h2((size_t)H2), head((size_t)A + 1);
     for (int b = 0; b < B; ++b) {
         const float *x = obs + (size_t)b * glue::kObsDim;
+        if (noise_step)
+            for (int a = 0; a < A; ++a) noise[(size_t)b * A + a] = glue::policy_noise(noise_seed, env_offset + b, *noise_step, a);
         for (int j = 0; j < H2; ++j) h1[(size_t)j] = glue::layer1_unit(W, H2, x, j);
         for (int j = 0; j < H2; ++j) h2[(size_t)j] = glue::layer2_unit(W, H2, h1.data(), j);
         for (int o = 0; o <= A; ++o) head[(size_t)o] = glue::head_unit(W, H2, A, h2.data(), o);
@@ -30,7 +33,8 @@ extern "C" int glue_rollout_record(int B, int A, int cols, int keep_terminal, fl
                                    float *last_obs, float *last_starts, const float *actions, const float *values,
                                    const float *log_probs, const double *mpc_act, const int32_t *mpc_status, const float *new_obs,
                                    const float *reward, const uint8_t *done, const float *terminal_obs, const uint8_t *truncated,
-                                   const uint8_t *crashed, const uint8_t *arrived, int64_t *counts, uint8_t *dones_out) {
+                                   const uint8_t *crashed, const uint8_t *arrived, int64_t *counts, uint8_t *dones_out,
+                                   int64_t *step_counter) {
     const mpc::glue::RecordArgs R{B, A, cols, keep_terminal, row, mpc_actions_buf, last_obs, last_starts, actions, values, log_probs,
                                  mpc_act, mpc_status, new_obs, reward, done, terminal_obs, truncated, crashed, arrived, dones_out};
     const long long pos = *pos_dev;
@@ -40,6 +44,7 @@ extern "C" int glue_rollout_record(int B, int A, int cols, int keep_terminal, fl
             for (int q = 0; q < 4; ++q) counts[q] += (bits >> q) & 1;
         }
     *pos_dev = pos + 1;
+    if (step_counter) *step_counter += 1;
     return 0;
 }
 

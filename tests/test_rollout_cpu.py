@@ -220,6 +220,7 @@ def test_rollout_glue_code_is_the_policy_and_the_buffer_row(A, version, clip):
         counts = np.zeros(4, np.int64)
         want_counts = np.zeros(4, np.int64)
         pos = np.zeros(1, np.int64)
+        steps_total = np.full(1, 7, np.int64)          # the policy-step counter the record advances (keys the next noise)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if isinstance(t, torch.Tensor) else ctypes.c_void_p(t.ctypes.data)
         for t in range(T):
             act, val, lp = torch.randn(B, A), torch.randn(B), torch.randn(B)
@@ -232,8 +233,9 @@ def test_rollout_glue_code_is_the_policy_and_the_buffer_row(A, version, clip):
             d8, t8, c8, a8 = u8(done), u8(trunc), u8(crashed), u8(arrived)
             rc = lib.glue_rollout_record(B, A, mine._cols, 1 if keep else 0, p(mine._row), p(mine.mpc_actions), p(pos), p(my_obs),
                                          p(my_starts), p(act), p(val), p(lp), p(mpc_act), p(status), p(new_obs), p(reward), p(d8),
-                                         p(term) if keep else None, p(t8) if keep else None, p(c8), p(a8), p(counts), p(dones_out))
-            assert rc == 0 and pos[0] == t + 1
+                                         p(term) if keep else None, p(t8) if keep else None, p(c8), p(a8), p(counts), p(dones_out),
+                                         p(steps_total))
+            assert rc == 0 and pos[0] == t + 1 and steps_total[0] == 7 + t + 1
             kw = dict(terminal_obs=term, truncated=trunc) if keep else {}
             buf.add(last_obs, act, reward, starts, val, lp, mpc_act, **kw)
             last_obs, starts = new_obs.clone(), done.float()
@@ -272,3 +274,33 @@ def test_rollout_finish_code_is_the_buffers_gae_bit_for_bit(keep):
         assert rc == 0
         assert torch.equal(mine._row, ref._row)                     # the bootstrapped rewards, nothing else touched
         assert torch.equal(mine.advantages, ref.advantages) and torch.equal(mine.returns, ref.returns)
+
+
+def test_policy_noise_of_the_kernel_is_standard_normal_and_keyed_by_seed_environment_and_step():
+    """mpc_policy_act's own draws (csrc/mpc_rollout_glue.hpp::policy_noise, counter-based): N(0, 1) to sampling accuracy,
+    reproducible, and different for every (seed, environment, step, component); fed to ActorCritic.act as ITS noise they give
+    the kernel's actions."""
+    import glue_host
+    torch.manual_seed(2)
+    A, B = 3, 4096
+    pol = rollout.ActorCritic(A)
+    obs = torch.randn(B, 10, 8)
+    z = lambda: np.zeros((B, A), np.float32)
+    a = glue_host.policy_act(pol, obs.numpy(), z(), "v1", True, draw=(5, 0, 11))
+    n = a["noise"]
+    assert abs(n.mean()) < 0.03 and abs(n.std() - 1.0) < 0.03 and abs(np.mean(n ** 3)) < 0.08 and abs(np.mean(n ** 4) - 3.0) < 0.25
+    assert np.abs(np.corrcoef(n.T) - np.eye(A)).max() < 0.05 and abs(np.corrcoef(n[:-1, 0], n[1:, 0])[0, 1]) < 0.05
+    again = glue_host.policy_act(pol, obs.numpy(), z(), "v1", True, draw=(5, 0, 11))["noise"]
+    assert np.array_equal(n, again)
+    for other in ((6, 0, 11), (5, 0, 12)):                    # another seed, another step
+        m = glue_host.policy_act(pol, obs.numpy(), z(), "v1", True, draw=other)["noise"]
+        assert (m != n).mean() > 0.999
+    shifted = glue_host.policy_act(pol, obs.numpy(), z(), "v1", True, draw=(5, 100, 11))["noise"]   # a shard 100 environments on
+    assert np.array_equal(shifted[:-100], n[100:])
+    orig = torch.randn
+    try:
+        torch.randn = lambda *x, **k: torch.from_numpy(n.copy())
+        actions, values, logp = pol.act(obs)
+    finally:
+        torch.randn = orig
+    assert np.allclose(a["actions"], actions.numpy(), atol=2e-6) and np.allclose(a["log_probs"], logp.numpy(), atol=2e-5)
