@@ -59,9 +59,10 @@ extern "C" {
 
 #define MPC_FLAG_THROUGHPUT 64u     /* the caller keeps several batches in flight on different streams: launch the build of the
                                       solve kernel for four resident waves per SIMD whatever the batch size.  By default the
-                                      engine picks the build by how deep ONE batch fills the SIMDs (B <= 2 waves per SIMD: 201
-                                      registers, B <= 4: 168, else 128), which is the faster choice when batches run one at a
-                                      time and the slower one when six of them share the GPU (2.56 against 2.87 M solves/s). */
+                                      engine picks the build by how deep ONE batch fills the SIMDs (B <= 4 waves per SIMD, 4096
+                                      on an MI355X: the latency build, 218 registers, two resident waves; else the 128-register
+                                      one), which is the faster choice when batches run one at a time and the slower one when
+                                      six of them share the GPU. */
 
 /* per-instance solver status written to status[] */
 #define MPC_STATUS_CONVERGED 0

@@ -51,19 +51,16 @@ constexpr int kMaxDevices = 64;
 // of LDS at N = 20 with the collision cost and 8 vehicles, so 16 waves share a CU: all 4096 waves of a BASELINE batch
 // are resident at once and a straggler never starts late.  The runtime-horizon build would spill at 128 and stays at 3.
 constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
-// Builds of the same solver for batches that do not fill the SIMDs four deep (WaveOpsT<RELAX>, mpc_wave_dev.hpp):
-// up to two waves per SIMD (B <= 2048 on 256 CUs: BASELINE configs 2, 4, 5 and every single-environment predict) the
-// 201-register build (fresh() and opaque() both the identity: everything hoisted), 7 % less time per iteration for a wave
-// that has its SIMD to itself; up to four the 168-register build for three resident waves (opaque() the identity, constants
-// still fetched where they are used: with both relaxed it spills 9 registers - 6.6 MB of scratch writes per launch of
-// 4096 - for the same speed; the rest of a 4096 batch is dispatched as slots free, which also balances the SIMDs better
-// than four static residents: 3.9 against 4.25 ms at cap 60, profiles/r03_mid_builds.txt).
-constexpr int kWaveOccLat = 2, kWaveOccMid = 3;
-// LAT: + the linearised step fused into the rollout loop (bit 2).  Bit 3: trial bounds precomputed per line search (12
-// more LDS words per stage; same-box A/B: 2 % less time per lone-wave iteration and per config-3 batch) - not in the
-// MID build without the collision cost, which it costs a spilled register and 3 %.
+// The build for batches that do not keep the SIMDs four deep in work (WaveOpsT<RELAX>, mpc_wave_dev.hpp): occupancy 2, up to
+// 256 registers (218 used), fresh() / opaque() the identity (everything hoisted), the linearised step fused into the rollout
+// loop (bit 2) and the trial bounds precomputed per line search (bit 3: 12 more LDS words per stage): 20 % less time per
+// iteration for a wave that has its SIMD to itself.  Used up to FOUR waves per SIMD of batch depth (B <= 4096 on 256 CUs:
+// every BASELINE configuration): two are resident, the rest of a 4096 batch is dispatched as slots free, which also balances
+// the SIMDs better than static residents, and the stragglers a batch ends with run at the lone-wave rate.  (Until round 4
+// a third, 168-register build served 2048 < B <= 4096; with round 4's Riccati sweep the latency build is 3 - 6 % faster
+// there at cap 100 and level at caps 40 / 60: profiles/r04_sweep4.txt.)
+constexpr int kWaveOccLat = 2, kLatDepth = 4;
 constexpr int kRelaxLat = 7 | 8;
-constexpr int relax_mid(bool cc) { return cc ? (2 | 8) : 2; }
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
@@ -577,13 +574,11 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, 
 #define MPC_LAUNCH_W(CCV, NCV, OCCV, RLX)                                                                              \
     rc = launch_wave<CCV, NCV, OCCV, RLX>(h, P, (int)B, (int)V, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
                                           d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters)
-    // which build: by how deep the batch fills the SIMDs (see kWaveOccLat / kWaveOccMid above)
+    // which build: by how deep the batch fills the SIMDs (see kWaveOccLat above)
     const int simds = 4 * h->num_cu;
-    const int depth = throughput ? kWaveOcc
-                                 : (B <= kWaveOccLat * simds ? kWaveOccLat : (B <= kWaveOcc * simds ? kWaveOccMid : kWaveOcc));
-#define MPC_LAUNCH_N(CCV, NCV)                                                         \
-    if (depth == kWaveOccLat) MPC_LAUNCH_W(CCV, NCV, kWaveOccLat, kRelaxLat);                  \
-    else if (depth == kWaveOccMid) MPC_LAUNCH_W(CCV, NCV, kWaveOccMid, relax_mid(CCV)); \
+    const bool lat = !throughput && B <= kLatDepth * simds;
+#define MPC_LAUNCH_N(CCV, NCV)                                          \
+    if (lat) MPC_LAUNCH_W(CCV, NCV, kWaveOccLat, kRelaxLat);            \
     else MPC_LAUNCH_W(CCV, NCV, kWaveOcc, 0)
     if (cc) {
         if (N == 20) { MPC_LAUNCH_N(true, 20); }       /* BASELINE horizon */

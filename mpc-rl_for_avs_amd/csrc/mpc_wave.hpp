@@ -5,11 +5,10 @@
 //   * everything that is independent per stage (trig and linearisation of the dynamics, cost and collision-potential
 //     values and derivatives, barrier terms, complementarity, stage Hessians, dual residual, step-length ratios, dual
 //     update) runs stage-parallel, lane k = stage k, with register-level wave reductions;
-//   * the Riccati / DDP factorisation stage works on the 8x8 stage KKT block [Hxx Hxp Hxu; . Hpp Hpu; . . Huu]
-//     (state 4 + previous control 2 + control 2) held in registers in the C/D layout of v_mfma_f64_4x4x4f64 (2x2 blocks
-//     of 4x4): T = P F, H = L + F'T, W = Huu^-1 H(u,.), P' = H - H(.,u) W and the gradient recursion are nine FP64
-//     matrix-core instructions per stage; blocks move between operand positions by DPP row shifts, nothing is
-//     exchanged through LDS;
+//   * the Riccati / DDP factorisation stage (state 4 + previous control 2 + control 2) runs on the FP64 matrix cores as
+//     twelve 4x4 products per stage, every operand used where the product before it left it, the 2x2 control block as
+//     wave-uniform scalar algebra (sweep4 below; until round 4 an 8x8 block form with nine products and eight block moves
+//     per stage); nothing is exchanged through LDS;
 //   * the line search integrates all four trial step lengths at once, lane t = trial t;
 //   * the adjoint recursion is three suffix sums over the stages (A' = I + strictly triangular): wave scans;
 //   * only the true recursions (linearised step, one lane's rollout, the Riccati sweep itself) are serial.
@@ -293,12 +292,6 @@ struct Solver {
     }
 
     PerLane<double> red_a, red_b, red_c, red_w;   // per-lane operands of the wave reductions
-    // MFMA sweep (kMfmaSweep): the 8x8 stage block lives in the C/D layout of v_mfma_f64_4x4x4f64 as 2x2 blocks of
-    // 4x4: lane l = 16 hi + 4 (2 I + J) + lo holds element (row 4 I + hi, col 4 J + lo)
-    PerLane<int> m_row, m_col;                     // element of this lane
-    PerLane<int> m_fa0, m_fa1, m_fb0, m_fb1;       // where F[4K+hi][4I+lo] / F[4K+hi][4J+lo] sit in LDS (>= 0: stage slot)
-    PerLane<int> m_lslot, m_hvslot, m_hvab, m_kx;  // stage-Hessian slot, gradient slot (column-0 lanes), gain slot to store
-    PerLane<double> m_lcst;
     PerLane<int> ls_feas;                  // line search: lane t = trial t stayed inside the fraction-to-the-boundary box
     // d = 1 discontinuity of the collision cost (archive/pure_mpc.py:189-196: 100/d^2 outside, 1000/d^2 inside).  A
     // vehicle that a rejected trial took across d = 1 inwards is kept outside from then on by the constraint
@@ -306,69 +299,244 @@ struct Solver {
     // pressed against d = 1 is a constrained stationary point of the outer branch (status 5), which no smooth method
     // reaches otherwise (round 1: 3.7 % of the config-3 instances ended "stalled").  any_wall: some node has one.
     int any_wall = 0;
-    // Riccati operands of stage k that come from LDS: F(k) in the four block arrangements and the accumulator inputs
-    // L(k) (stage Hessian, C/D layout) and l(k) (stage gradient, column-0 lanes)
-    MPC_HD void load_stage_operands(int k, int AB, double rdk, PerLane<double> &FA0, PerLane<double> &FA1,
-                                    PerLane<double> &FB0, PerLane<double> &FB1, PerLane<double> &Hm, PerLane<double> &hv) {
-        c.lanes([&](int lane) {
-            const int base = k * SL;
-            const int w0 = m_fa0.at(lane), w1 = m_fa1.at(lane), w2 = m_fb0.at(lane), w3 = m_fb1.at(lane);
-            FA0.at(lane) = c.ld(w0 >= 0 ? base + w0 : -w0 - 1);
-            FA1.at(lane) = c.ld(w1 >= 0 ? base + w1 : -w1 - 1);
-            FB0.at(lane) = c.ld(w2 >= 0 ? base + w2 : -w2 - 1);
-            FB1.at(lane) = c.ld(w3 >= 0 ? base + w3 : -w3 - 1);
-            const int ls = m_lslot.at(lane);
-            const double lv = c.ld(base + (ls >= 0 ? ls : 0));
-            Hm.at(lane) = (ls >= 0 ? lv : 0.0) + m_lcst.at(lane) * rdk;
-            const int hs = m_hvslot.at(lane);
-            const double gv = c.ld(base + (hs >= 0 ? hs + (m_hvab.at(lane) ? AB : 0) : 0));
-            hv.at(lane) = hs >= 0 ? gv : 0.0;
-        });
-    }
-
     MPC_HD int f_word(int r, int c) const {
         return stage_transition_word(r, c, W_LIN, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
                                      -(SCR + SC_SPARE + 2 + 1));
     }
-    // The role tables are pure functions of the lane id.  They are recomputed at the start of every factorisation (a
-    // few dozen integer operations against ~150 k cycles of an iteration) from a lane id the compiler cannot see through,
-    // so that their 16 registers are live during the sweep only and not across the line search and the stage-parallel
-    // phases, where the kernel is short of registers.
-    MPC_HD void set_mfma_roles() {
+    // ================================================================================================================
+    // Riccati / DDP sweep on 4x4 blocks (round 4).  The stage matrix F = [A B; 0 I] has structure the 8x8 form above does
+    // not use: the next "previous control" IS the control, so with the value function of node k + 1 split as
+    //     V(x, p) = 1/2 x'Pxx x + x'Pxp p + 1/2 p'Ppp p + px'x + pp'p        (x: state 4, p: previous control 2)
+    // the stage's quadratic model is
+    //     Qxx = Lxx + A'Pxx A            Qux = Lux + (Pxx B + Pxp)'A          Quu = Luu + B'(Pxx B + Pxp) + Pxp'B + Ppp
+    //     qx  = lx + A'px                qu  = lu + B'px + pp                 Qpp = rd I, Qpu = -rd I, Qxp = 0, qp = lp
+    // and the new value function, with W = Quu^-1, kf = -W qu, Kx = -W Qux, Kp = rd W:
+    //     Pxx' = Qxx + Qux'Kx            Pxp' = rd Qux'W           Ppp' = rd I - rd^2 W         px' = qx + Qux'kf
+    //     pp'  = qp - rd kf.
+    // Everything 4-dimensional is a 4x4 matrix-core block (B, Pxp, Qux padded with zeros), everything 2-dimensional is
+    // wave-uniform scalar algebra.  ALL FOUR blocks of v_mfma_f64_4x4x4f64 compute the same product: a value held by lane
+    // 16 hi + 4 blk + lo depends on (hi, lo) only.  The redundancy is free - the instruction processes four blocks whatever
+    // they hold - and it is what removes every block move of the 8x8 form: with r[hi][lo] a register's content,
+    //     mfma(a, b, cd):  cd += a'b    (A operand lane (hi, lo) = A[row lo][k hi]; B and C/D: [hi][lo])
+    // so a product's output is directly the B operand of the next product, directly the A operand of a product with its
+    // TRANSPOSE, and a symmetric matrix is its own A operand.  Twelve products per stage, operands as they fall:
+    //     T0 = Pxx A             T1 = Pxx B + Pxp        Qxx = Lxx + A'T0        Qux = Lux + T1'A
+    //     M  = Luu + Pxp'B + B'T1  (Quu = M + Ppp)       qx = lx + A'px          qu = lu + B'px (+ pp)
+    //     Ya = -adj(Quu) Qux (= det Kx)      and with Qs = Qux / det:
+    //     Pxx' = Qxx + Qs'Ya     Pxp' = Qs'(rd adj(Quu))      px' = qx + Qs'(-adj(Quu) qu)
+    // The 8x8 form needed nine products and eight block moves (22 DPP moves + 20 copies + the masks: 52 of the stage's 165
+    // instructions; 145 now).  Measured (profiles/r04_sweep4.txt): a wave alone on its SIMD 33.2 -> 32.3 us per iteration,
+    // a straggler 39.1 -> 37.6, config 2 0.99 -> 0.95 ms, one launch of 65 536 2.70 -> 2.80 M solves/s, 231 -> 218 registers
+    // in the latency build - which with it is also the faster one for a batch of 4096 (config 3 5.19 -> 5.03 ms).
+    // ================================================================================================================
+    // LDS word of this lane's element of each operand: stage-relative (>= 0) or absolute, encoded as -(word + 1) - the
+    // constants 0, 1, dt of the table; an element that is structurally zero reads the 0 there, so no load needs a select
+    PerLane<int> r_a, r_b, r_lxx, r_lux, r_m, r_lx, r_lu, r_kx;
+    MPC_HD void set_roles4(int AB) {
         c.lanes([&](int lane_) {
             const int lane = c.opaque(lane_);
-            const int hi = lane >> 4, blk = (lane >> 2) & 3, I = blk >> 1, J = blk & 1, lo = lane & 3;
-            const int row = 4 * I + hi, col = 4 * J + lo;
-            m_row.at(lane) = row;
-            m_col.at(lane) = col;
-            m_fa0.at(lane) = f_word(0 + hi, 4 * I + lo);
-            m_fa1.at(lane) = f_word(4 + hi, 4 * I + lo);
-            m_fb0.at(lane) = f_word(0 + hi, 4 * J + lo);
-            m_fb1.at(lane) = f_word(4 + hi, 4 * J + lo);
-            const int a = row < col ? row : col, b = row < col ? col : row;
-            const int key = a * 8 + b;
-            int slot = -1;
-            slot = key == 0 * 8 + 0 ? A_L00 : slot;
-            slot = key == 0 * 8 + 1 ? A_L01 : slot;
-            slot = key == 1 * 8 + 1 ? A_L11 : slot;
-            slot = key == 2 * 8 + 2 ? A_H22 : slot;
-            slot = key == 2 * 8 + 3 ? A_H23 : slot;
-            slot = key == 3 * 8 + 3 ? A_H33 : slot;
-            slot = key == 2 * 8 + 7 ? A_WTD : slot;
-            slot = key == 3 * 8 + 7 ? A_WVD : slot;
-            slot = key == 6 * 8 + 6 ? A_H66 : slot;
-            slot = key == 7 * 8 + 7 ? A_H77 : slot;
-            const double cst = (key == 4 * 8 + 4 || key == 5 * 8 + 5) ? 1.0 : ((key == 4 * 8 + 6 || key == 5 * 8 + 7) ? -1.0 : 0.0);
-            m_lslot.at(lane) = slot;
-            m_lcst.at(lane) = cst;
-            // gradient: column-0 lanes carry element `row`
-            const int q = row;
-            m_hvslot.at(lane) = col != 0 ? -1
-                                         : (q < 4 ? A_HV0 + q : (q == 4 ? A_HV4 : (q == 5 ? A_HV5 : (q == 6 ? A_HV6 : A_HV7))));
-            m_hvab.at(lane) = (q < 4 || q == 5) ? 1 : 0;
-            // gains Kx(a, j) = -W(6 + a, j), j < 4: taken from the I = 0 copy of W
-            m_kx.at(lane_) = (I == 0 && J == 0 && hi >= 2) ? W_KX + (hi - 2) * 4 + lo : -1;
+            const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
+            const int zero = -(SCR + SC_SPARE + 0 + 1);
+            r_a.at(lane_) = f_word(hi, lo);                        // A[hi][lo]
+            r_b.at(lane_) = f_word(hi, lo < 2 ? 6 + lo : 4);       // B~[hi][lo]: columns a, delta of F, then zeros
+            const int a = hi < lo ? hi : lo, b = hi < lo ? lo : hi;
+            const int key = a * 4 + b;
+            int slot = zero;
+            slot = key == 0 * 4 + 0 ? A_L00 : slot;
+            slot = key == 0 * 4 + 1 ? A_L01 : slot;
+            slot = key == 1 * 4 + 1 ? A_L11 : slot;
+            slot = key == 2 * 4 + 2 ? A_H22 : slot;
+            slot = key == 2 * 4 + 3 ? A_H23 : slot;
+            slot = key == 3 * 4 + 3 ? A_H33 : slot;
+            r_lxx.at(lane_) = slot;
+            r_lux.at(lane_) = hi == 1 ? (lo == 2 ? A_WTD : (lo == 3 ? A_WVD : zero)) : zero;   // Lux[delta][theta], [delta][v]
+            r_m.at(lane_) = (hi == 0 && lo == 0) ? A_H66 : ((hi == 1 && lo == 1) ? A_H77 : zero);
+            r_lx.at(lane_) = lo == 0 ? AB + A_HV0 + hi : zero;                                 // in the trial buffer
+            r_lu.at(lane_) = lo == 0 ? (hi == 0 ? A_HV6 : (hi == 1 ? A_HV7 : zero)) : zero;
+            r_kx.at(lane_) = (blk == 0 && hi < 2) ? W_KX + hi * 4 + lo : -1;
         });
+    }
+
+    MPC_HD void load_stage4(int k, int AB, PerLane<double> &RA, PerLane<double> &RB, PerLane<double> &QXX, PerLane<double> &QUX,
+                            PerLane<double> &M, PerLane<double> &QX, PerLane<double> &QU, double &lp0, double &lp1) {
+        c.lanes([&](int lane) {
+            const int base = k * SL;
+            auto word = [&](int w) { return c.ld(w >= 0 ? base + w : -w - 1); };
+            RA.at(lane) = word(r_a.at(lane));
+            RB.at(lane) = word(r_b.at(lane));
+            QXX.at(lane) = word(r_lxx.at(lane));
+            QUX.at(lane) = word(r_lux.at(lane));
+            M.at(lane) = word(r_m.at(lane));
+            QX.at(lane) = word(r_lx.at(lane));
+            QU.at(lane) = word(r_lu.at(lane));
+        });
+        lp0 = S(k, A_HV4);
+        lp1 = S(k, AB + A_HV5);
+    }
+    // one backward sweep over the stages with the stage Hessians / gradients the assembly phase left in LDS; false: a stage's
+    // control block was not positive definite (also not with its Gauss-Newton terms alone)
+    MPC_HD bool sweep4(int CB, int AB, double mu, double delta_w, bool gn, double &dV1) {
+        // ---- terminal value function: barrier terms of (theta, v)_N
+        double tsig[2], tgr[2];
+        for (int i = 0; i < 2; ++i) {
+            const double xi = S(N, CB + W_X + 2 + i);
+            const double rl = frcp(xi - xlo(i)), ru = frcp(xhi(i) - xi);
+            tsig[i] = S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w;
+            tgr[i] = mu * (ru - rl);
+        }
+        PerLane<double> PXX, PXP, PX;
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque_shared(lane_);
+            const int hi = lane >> 4, lo = lane & 3;
+            PXX.at(lane_) = hi == lo ? (hi == 2 ? tsig[0] : (hi == 3 ? tsig[1] : delta_w)) : 0.0;
+            PXP.at(lane_) = 0.0;
+            PX.at(lane_) = lo == 0 ? (hi == 2 ? tgr[0] : (hi == 3 ? tgr[1] : 0.0)) : 0.0;
+        });
+        double pp00 = 0.0, pp01 = 0.0, pp11 = 0.0, ppv0 = 0.0, ppv1 = 0.0;    // Ppp, pp of the node behind the stage
+        c.tick(T_RIC_INIT);
+        const double rd_full = RD();
+#pragma unroll 1
+        for (int k = N - 1; k >= 0; --k) {
+            const double rdk = (k >= 1) ? rd_full : 0.0;
+            // ---- operands from LDS (they do not depend on the recursion; requesting them one stage ahead changes nothing:
+            //      profiles/r04_sweep4.txt, like the four attempts on the 8x8 form before)
+            PerLane<double> RA, RB, QXX, QUX, M, QX, QU, T0, T1;
+            double lp0, lp1;
+            load_stage4(k, AB, RA, RB, QXX, QUX, M, QX, QU, lp0, lp1);
+            c.lanes([&](int lane) {
+                T0.at(lane) = 0.0;
+                T1.at(lane) = PXP.at(lane);
+            });
+            c.tick(T_RIC_SCALARS);
+            // ---- the value function of node k + 1 through the stage
+            c.mfma(PXX, RA, T0);       // T0 = Pxx A
+            c.mfma(PXX, RB, T1);       // T1 = Pxx B + Pxp
+            c.mfma(PXP, RB, M);        // M  = Luu + Pxp'B ...
+            c.mfma(RA, PX, QX);        // qx = lx + A'px
+            c.mfma(RB, PX, QU);        // qu = lu + B'px        (+ pp below)
+            c.tick(T_RIC_L1);
+            c.mfma(RB, T1, M);         // ... + B'T1 = Quu - Ppp
+            c.mfma(T1, RA, QUX);       // Qux = Lux + T1'A
+            c.mfma(RA, T0, QXX);       // Qxx = Lxx + A'T0
+            c.tick(T_RIC_L2);
+            // ---- 2x2 control block (uniform): elements (0,0) (0,1) (1,1) of M sit in lanes 0 1 17 (M is symmetric up to the
+            //      rounding of the two products above), qu in lanes 0, 16; the value function's own 2x2 part joins here
+            double ha = c.lane_get(M, 0) + pp00, hb = c.lane_get(M, 1) + pp01, hc = c.lane_get(M, 17) + pp11;
+            const double hu0 = c.lane_get(QU, 0) + ppv0, hu1 = c.lane_get(QU, 16) + ppv1;
+            double det = ha * hc - hb * hb;
+            bool pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
+            // The rest of the stage is computed BEFORE the test is acted on (profiles/r04_spec_sweep.txt); Qxx, Qux, qx stay
+            // intact for the fallback.  The products are arranged so that only ONE multiplication sits between the reciprocal
+            // of the determinant and the value function of this node: Ya = -adj(Quu) Qux, rd adj(Quu) and -adj(Quu) qu need no division
+            // and run on the matrix cores while the reciprocal is refined; it then scales the other operand (Qs = Qux / det).
+            PerLane<double> NWA, RWA, Ya, QS, KFB, PXXn, PXPn, PXn;
+            double idet, i00, i01, i11, kf0, kf1;
+            auto stage_tail = [&]() {
+                const double kfa0 = hb * hu1 - hc * hu0, kfa1 = hb * hu0 - ha * hu1;      // -adj(Quu) qu = det kf
+                c.lanes([&](int lane_) {
+                    const int lane = c.opaque_shared(lane_);
+                    const int hi = lane >> 4, lo = lane & 3;
+                    const double w00 = (hi == 0 && lo == 0) ? 1.0 : 0.0, w11 = (hi == 1 && lo == 1) ? 1.0 : 0.0;
+                    const double wof = ((hi == 0 && lo == 1) || (hi == 1 && lo == 0)) ? 1.0 : 0.0;
+                    const double c1 = (hi == 1 && lo == 0) ? 1.0 : 0.0;
+                    const double nwa = wof * hb - w00 * hc - w11 * ha;      // -adj(Quu), padded
+                    NWA.at(lane_) = nwa;
+                    RWA.at(lane_) = -rdk * nwa;                             // rd adj(Quu)
+                    KFB.at(lane_) = w00 * kfa0 + c1 * kfa1;                 // det kf in column 0
+                    Ya.at(lane_) = 0.0;
+                    PXPn.at(lane_) = 0.0;
+                    PXXn.at(lane_) = QXX.at(lane_);
+                    PXn.at(lane_) = QX.at(lane_);
+                });
+                c.mfma(NWA, QUX, Ya);      // Ya = -adj(Quu) Qux   (rows 0, 1;  Kx = Ya / det)
+                idet = frcp(det);
+                c.lanes([&](int lane) { QS.at(lane) = idet * QUX.at(lane); });
+                c.mfma(QS, Ya, PXXn);      // Pxx' = Qxx + Qux'Kx
+                c.mfma(QS, RWA, PXPn);     // Pxp' = Qux'(rd W)
+                c.mfma(QS, KFB, PXn);      // px' = qx + Qux'kf
+                i00 = hc * idet;
+                i01 = -hb * idet;
+                i11 = ha * idet;
+                kf0 = kfa0 * idet;
+                kf1 = kfa1 * idet;
+            };
+            stage_tail();
+            if (!pd && !gn) {
+                // not positive definite with the exact Hessian: this stage alone falls back to its Gauss-Newton terms
+                // (constraint curvature off, radial part of the collision potential) - they are taken out of Qxx, Qux, Quu,
+                // the products with the value function stay
+                double wdd, wtt = 0.0, wtv = 0.0, wtd = 0.0, wvd = 0.0, q00 = 0.0, q01 = 0.0, q11 = 0.0;
+                {
+                    const double v = S(k, CB + W_X + 3);
+                    double Sn, Cn, sb, cb_, bp, bpp;
+                    dyn_eval(trig(), S(k, CB + W_X + 2), S(k, CB + W_U + 1), Sn, Cn, sb, cb_);
+                    beta_derivs(sb, cb_, bp, bpp);
+                    const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
+                    const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
+                    wdd = dt * v * (g * bp * bp + h * bpp) + dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
+                    if (k >= 1) {
+                        wtt = dt * v * g;
+                        wtv = dt * h;
+                        wtd = dt * v * g * bp;
+                        wvd = dt * h * bp + dt * yy2 * cb_ * bp * kInvWheelbase;
+                        if (CC) {
+                            q00 = S(k, W_QG + 0) - S(k, W_Q + 0);
+                            q01 = S(k, W_QG + 1) - S(k, W_Q + 1);
+                            q11 = S(k, W_QG + 2) - S(k, W_Q + 2);
+                            if (any_wall && S(k, W_WJ) >= 0.0) {
+                                q00 += 2.0 * S(k, W_ZW);
+                                q11 += 2.0 * S(k, W_ZW);
+                            }
+                        }
+                    }
+                }
+                c.lanes([&](int lane_) {
+                    const int lane = c.opaque_shared(lane_);
+                    const int hi = lane >> 4, lo = lane & 3;
+                    const int a = hi < lo ? hi : lo, b = hi < lo ? lo : hi;
+                    double cx = 0.0;
+                    switch (a * 4 + b) {
+                        case 0 * 4 + 0: cx = q00; break;
+                        case 0 * 4 + 1: cx = q01; break;
+                        case 1 * 4 + 1: cx = q11; break;
+                        case 2 * 4 + 2: cx = -wtt; break;
+                        case 2 * 4 + 3: cx = -wtv; break;
+                        default: break;
+                    }
+                    QXX.at(lane_) += cx;
+                    QUX.at(lane_) += hi == 1 ? (lo == 2 ? -wtd : (lo == 3 ? -wvd : 0.0)) : 0.0;
+                });
+                hc -= wdd;
+                det = ha * hc - hb * hb;
+                pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
+                if (pd) stage_tail();
+            }
+            if (!pd) return false;
+            c.tick(T_RIC_2X2);
+            dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
+            const double kp00 = rdk * i00, kp01 = rdk * i01, kp11 = rdk * i11;
+            c.lanes([&](int lane) {
+                PXX.at(lane) = PXXn.at(lane);
+                PXP.at(lane) = PXPn.at(lane);
+                PX.at(lane) = PXn.at(lane);
+                const int ks = r_kx.at(lane);
+                if (ks >= 0) S(k, ks, idet * Ya.at(lane));        // Kx = -W Qux
+                if (lane == 0) {
+                    S(k, W_KF + 0, kf0);
+                    S(k, W_KF + 1, kf1);
+                    S(k, W_KP + 0, kp00);
+                    S(k, W_KP + 1, kp01);
+                    S(k, W_KP + 2, kp11);
+                }
+            });
+            pp00 = rdk - rdk * kp00;      // Ppp' = rd I - rd^2 W
+            pp01 = -rdk * kp01;
+            pp11 = rdk - rdk * kp11;
+            ppv0 = lp0 - rdk * kf0;       // pp' = lp - rd kf
+            ppv1 = lp1 - rdk * kf1;
+            c.tick(T_RIC_L4);
+        }
+        return true;
     }
 
     // ---- cost pieces (agents/pure_mpc.py:119-214) --------------------------------------------------
@@ -1181,7 +1349,7 @@ struct Solver {
             const int AB = (cur ^ 1) * 6;   // trial buffer: hv0..3 at AB + W_X, hv5 at AB + W_U
             double dV1 = 0.0, delta_w = reg;
             bool ok = false, gn = false;
-            set_mfma_roles();
+            set_roles4(AB);
             for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
                 ok = true;
                 dV1 = 0.0;
@@ -1284,193 +1452,7 @@ struct Solver {
                     S(k, A_HV6, rc * u0 + rdk * (u0 - um0) + sgr[2]);
                     S(k, A_HV7, rc * u1 + rdk * (u1 - um1) + sgr[3]);
                 });
-                {
-                    // ---- terminal value function (barrier terms of (theta, v)_N) in the matrix-core layout
-                    double tsig[2], tgr[2];
-                    for (int i = 0; i < 2; ++i) {
-                        const double xi = S(N, CB + W_X + 2 + i);
-                        const double rl = frcp(xi - xlo(i)), ru = frcp(xhi(i) - xi);
-                        tsig[i] = S(N, W_ZXL + i) * rl + S(N, W_ZXU + i) * ru + delta_w;
-                        tgr[i] = mu * (ru - rl);
-                    }
-                    PerLane<double> Pd, pvd;
-                    c.lanes([&](int lane) {
-                        const int r = m_row.at(lane), cl = m_col.at(lane);
-                        double pe = 0.0;
-                        if (r == cl && r < 4) pe = r == 2 ? tsig[0] : (r == 3 ? tsig[1] : delta_w);
-                        Pd.at(lane) = pe;
-                        pvd.at(lane) = cl == 0 ? (r == 2 ? tgr[0] : (r == 3 ? tgr[1] : 0.0)) : 0.0;
-                    });
-                    c.tick(T_RIC_INIT);
-                    const double rd_full = RD();
-#pragma unroll 1
-                    for (int k = N - 1; k >= 0; --k) {
-                        const double rdk = (k >= 1) ? rd_full : 0.0;
-                        // operands that do not depend on the recursion: F in its four block arrangements, the stage
-                        // Hessian / gradient as accumulator inputs (prefetching them one stage ahead measured slower
-                        // four times: 45.7 -> 48.2 us per lone-wave iteration with spills, 41.1 -> 41.6 without, and in
-                        // round 3's latency build, issued behind the definiteness test with registers to spare, 32.9 -> 34.6)
-                        PerLane<double> FA0, FA1, FB0, FB1, Hm, hv;
-                        load_stage_operands(k, AB, rdk, FA0, FA1, FB0, FB1, Hm, hv);
-                        c.tick(T_RIC_SCALARS);
-                        // ---- T = P F  (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
-                        PerLane<double> PA0, PA1, T;
-                        c.template take_blocks<BM_K0_I>(PA0, Pd);
-                        c.template take_blocks<BM_K1_I>(PA1, Pd);
-                        c.lanes([&](int lane) { T.at(lane) = 0.0; });
-                        c.mfma(PA0, FB0, T);
-                        c.mfma(PA1, FB1, T);
-                        c.tick(T_RIC_L1);
-                        // ---- H = L + F' T,  h = l + F' p   (F in the C/D layout is F' as A operand)
-                        PerLane<double> TB0, TB1, pB0, pB1;
-                        c.template take_blocks<BM_K0_J>(TB0, T);
-                        c.template take_blocks<BM_K1_J>(TB1, T);
-                        c.template take_blocks<BM_K0_J>(pB0, pvd);
-                        c.template take_blocks<BM_K1_J>(pB1, pvd);
-                        c.mfma(FA0, TB0, Hm);
-                        c.mfma(FA1, TB1, Hm);
-                        c.mfma(FA0, pB0, hv);
-                        c.mfma(FA1, pB1, hv);
-                        c.tick(T_RIC_L2);
-                        // the control rows / columns of H in the block positions the Schur complement needs them; issued
-                        // before the scalar work on the 2x2 block so that the permutations overlap with it
-                        PerLane<double> HB, HA;
-                        c.template take_blocks<BM_K1_J>(HB, Hm);
-                        c.template take_blocks<BM_K1_I>(HA, Hm);
-                        // ---- 2x2 control block (uniform): elements (6,6) (6,7) (7,6) (7,7) sit in lanes 46 47 62 63,
-                        //      gradient elements 6, 7 in lanes 40, 56
-                        double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
-                               hc = c.lane_get(Hm, 63);
-                        const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
-                        double det = ha * hc - hb * hb;
-                        // (one combined test, evaluated without short-circuit branches: the common case - positive definite -
-                        // then passes a single branch on the sweep's critical path instead of three)
-                        bool pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
-                        // ---- the rest of the stage is computed BEFORE the definiteness test is acted on: W = adj(Huu) H(u, .), the
-                        //      reciprocal of the determinant, the gains and the Schur complement go into registers of their own (Pn, pn;
-                        //      H and h stay intact), and the test's branch sits behind them.  Between the matrix-core products that form
-                        //      the control block and the reciprocal of its determinant - on the serial path of all 20 stages - it kept the
-                        //      compiler from interleaving what follows it with what precedes it: a wave alone on its SIMD ran 33.7 us per
-                        //      iteration with the branch there, 29.9 without any test (profiles/r04_spec_sweep.txt).  A stage that fails
-                        //      (one iteration in six has such a stage) falls back as before - Gauss-Newton terms of this stage alone - and
-                        //      computes its tail again.
-                        PerLane<double> G, nHA, W, kfB, Pn, pn;
-                        double idet, i00, i01, i11, kf0, kf1;
-                        auto stage_tail = [&]() {
-                            // ---- W = adj(Huu) H(u, .) (adjugate embedded in a 4x4 block: the reciprocal of the determinant is
-                            //      computed while the matrix core works and scales the other operand afterwards);
-                            //      P = H - H(., u) W / det;  p = h + H(., u) kf
-                            // (selects between wave-uniform doubles by lane position are written as 0/1 weights: the compiler
-                            // turns `cond ? scalar_a : scalar_b` on scalar-register doubles into a branch cascade)
-                            c.lanes([&](int lane_) {
-                                const int lane = c.opaque(lane_);     // weights recomputed per stage, not kept in registers
-                                const int hi = lane >> 4, lo = lane & 3;
-                                const double w22 = (hi == 2 && lo == 2) ? 1.0 : 0.0, w33 = (hi == 3 && lo == 3) ? 1.0 : 0.0;
-                                const double wof = ((hi == 2 && lo == 3) || (hi == 3 && lo == 2)) ? 1.0 : 0.0;
-                                G.at(lane_) = w22 * hc + w33 * ha - wof * hb;
-                                W.at(lane_) = 0.0;
-                            });
-                            c.mfma(G, HB, W);
-                            idet = frcp(det);
-                            i00 = hc * idet;
-                            i01 = -hb * idet;
-                            i11 = ha * idet;
-                            kf0 = -(i00 * hu0 + i01 * hu1);
-                            kf1 = -(i01 * hu0 + i11 * hu1);
-                            c.lanes([&](int lane_) {
-                                const int lane = c.opaque(lane_);
-                                const int hi = lane >> 4, col0 = (lane & 7) == 0;      // column 0 of the block: J = 0, lo = 0
-                                nHA.at(lane_) = -idet * HA.at(lane_);
-                                const double w2 = (col0 && hi == 2) ? 1.0 : 0.0, w3 = (col0 && hi == 3) ? 1.0 : 0.0;
-                                kfB.at(lane_) = w2 * kf0 + w3 * kf1;
-                            });
-                            c.lanes([&](int lane) {
-                                Pn.at(lane) = Hm.at(lane);
-                                pn.at(lane) = hv.at(lane);
-                            });
-                            c.mfma(nHA, W, Pn);      // Pn <- H - H(., u) Huu^-1 H(u, .)   (H itself stays: the fallback needs it)
-                            c.mfma(HA, kfB, pn);     // pn <- h + H(., u) kf
-                        };
-                        stage_tail();
-                        if (!pd && !gn) {
-                            // not positive definite with the exact Hessian: this stage alone falls back to its
-                            // Gauss-Newton terms (constraint curvature off, radial part of the collision potential) -
-                            // they are taken out of H, the products with P stay
-                            double wdd, wtt = 0.0, wtv = 0.0, wtd = 0.0, wvd = 0.0, q00 = 0.0, q01 = 0.0, q11 = 0.0;
-                            {
-                                const double v = S(k, CB + W_X + 3);
-                                double Sn, Cn, sb, cb_, bp, bpp;
-                                dyn_eval(trig(), S(k, CB + W_X + 2), S(k, CB + W_U + 1), Sn, Cn, sb, cb_);
-                                beta_derivs(sb, cb_, bp, bpp);
-                                const double yy0 = S(k + 1, W_Y + 0), yy1 = S(k + 1, W_Y + 1), yy2 = S(k + 1, W_Y + 2);
-                                const double g = -(yy0 * Cn + yy1 * Sn), h = -(yy0 * Sn - yy1 * Cn);
-                                wdd = dt * v * (g * bp * bp + h * bpp) +
-                                      dt * yy2 * v * kInvWheelbase * (-sb * bp * bp + cb_ * bpp);
-                                if (k >= 1) {
-                                    wtt = dt * v * g;
-                                    wtv = dt * h;
-                                    wtd = dt * v * g * bp;
-                                    wvd = dt * h * bp + dt * yy2 * cb_ * bp * kInvWheelbase;
-                                    if (CC) {
-                                        q00 = S(k, W_QG + 0) - S(k, W_Q + 0);
-                                        q01 = S(k, W_QG + 1) - S(k, W_Q + 1);
-                                        q11 = S(k, W_QG + 2) - S(k, W_Q + 2);
-                                        if (any_wall && S(k, W_WJ) >= 0.0) {
-                                            q00 += 2.0 * S(k, W_ZW);
-                                            q11 += 2.0 * S(k, W_ZW);
-                                        }
-                                    }
-                                }
-                            }
-                            c.lanes([&](int lane) {
-                                const int r = m_row.at(lane), cl = m_col.at(lane);
-                                const int a = r < cl ? r : cl, b = r < cl ? cl : r;
-                                double corr = 0.0;
-                                switch (a * 8 + b) {
-                                    case 0 * 8 + 0: corr = q00; break;
-                                    case 0 * 8 + 1: corr = q01; break;
-                                    case 1 * 8 + 1: corr = q11; break;
-                                    case 2 * 8 + 2: corr = -wtt; break;
-                                    case 2 * 8 + 3: corr = -wtv; break;
-                                    case 2 * 8 + 7: corr = -wtd; break;
-                                    case 3 * 8 + 7: corr = -wvd; break;
-                                    case 7 * 8 + 7: corr = -wdd; break;
-                                    default: break;
-                                }
-                                Hm.at(lane) += corr;
-                            });
-                            c.template take_blocks<BM_K1_J>(HB, Hm);
-                            c.template take_blocks<BM_K1_I>(HA, Hm);
-                            ha = c.lane_get(Hm, 46);
-                            hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62));
-                            hc = c.lane_get(Hm, 63);
-                            det = ha * hc - hb * hb;
-                            pd = (ha > 0.0) & (hc > 0.0) & (det > c.fresh(1e-12) * ha * hc);
-                            if (pd) stage_tail();
-                        }
-                        if (!pd) {
-                            ok = false;
-                            break;
-                        }
-                        c.tick(T_RIC_2X2);
-                        dV1 += 0.5 * (kf0 * hu0 + kf1 * hu1);
-                        c.lanes([&](int lane) {
-                            const int r = m_row.at(lane), cl = m_col.at(lane);
-                            Pd.at(lane) = (r < 6 && cl < 6) ? Pn.at(lane) : 0.0;
-                            pvd.at(lane) = (r < 6 && cl == 0) ? pn.at(lane) : 0.0;
-                            const int ks = m_kx.at(lane);
-                            if (ks >= 0) S(k, ks, -idet * W.at(lane));
-                            if (lane == 0) {
-                                S(k, W_KF + 0, kf0);
-                                S(k, W_KF + 1, kf1);
-                                S(k, W_KP + 0, rdk * i00);
-                                S(k, W_KP + 1, rdk * i01);
-                                S(k, W_KP + 2, rdk * i11);
-                            }
-                        });
-                        c.tick(T_RIC_L4);
-                    }
-                }
+                ok = sweep4(CB, AB, mu, delta_w, gn, dV1);
                 if (!ok) {
                     if (!gn) {
                         gn = true;

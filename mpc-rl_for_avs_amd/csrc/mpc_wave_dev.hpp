@@ -134,6 +134,13 @@ struct WaveOpsT {
         asm volatile("" : "+v"(v));
         return v;
     }
+    // the same, relaxed only in the build that has its SIMD to itself (bit 2): the 0 / 1 weights the Riccati stage builds its
+    // operands with are recomputed per stage in the builds that share a SIMD (ten registers they do not have)
+    __device__ __forceinline__ int opaque_shared(int v) const {
+        if (RELAX & 4) return v;
+        asm volatile("" : "+v"(v));
+        return v;
+    }
     __device__ __forceinline__ int wave_bcast(PerLane<int> &p, int lane) const {
         return __builtin_amdgcn_readlane(p.v, lane);
     }

@@ -60,7 +60,7 @@ def _host_solver(libname, srcname, symbol):
     def solve(ref, inp, N=20, dt=0.1, collision_cost=False, tol=1e-8, max_iter=100, u_init=None, stall_window=0,
               split_linear=False):
         """split_linear: the code path of the builds that keep the linearised step in its own loop (default: fused into
-        the rollout loop, the 201-register build's path)."""
+        the rollout loop, the latency build's path)."""
         P = lambda a, t: None if a is None else a.ctypes.data_as(t)
         if hasattr(lib, "wave_set_stall_window"):
             lib.wave_set_stall_window(int(stall_window))

@@ -68,6 +68,7 @@ struct HostCtx {
     }
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
     int opaque(int v) const { return v; }
+    int opaque_shared(int v) const { return v; }
     double fresh(double v) const { return v; }
     void sched_fence() const {}
     double keep(double v) const { return v; }

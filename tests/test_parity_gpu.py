@@ -42,7 +42,7 @@ def test_engine_matches_oracle(eng, oracle, ref_table, B, V, cc, seed):
     want = _oracle(oracle, ref_table, inp, cc)
     got = _gpu(eng, inp, cc)
     both = converged(got["status"]) & converged(want["status"])
-    # measured (rounds 3 and 4, all three builds of the kernel): 99.2 - 100 % converge within 100 iterations, statuses equal
+    # measured (rounds 3 and 4, every build of the kernel): 99.2 - 100 % converge within 100 iterations, statuses equal
     # on >= 99.8 %, iteration counts equal on >= 99.6 %.  The action gate is EXACT: no instance beyond 1e-4 unless it is
     # proven to be two certified minimisers of an instance on which the oracle itself is last-bit chaotic
     # (conftest.unexplained_disagreements; round 4 measured 0 such instances in 18 432 on three seeds,
@@ -373,11 +373,12 @@ def test_independent_solver_fixtures(eng, ref_table):
             assert theirs["stationarity"].max() <= 1e-6       # the fixture's own points are KKT points too
 
 
-def test_three_builds_of_the_solve_kernel_agree(oracle, ref_table):
-    """The engine launches one of three builds of the same solver source by how deep the batch fills the SIMDs (229
-    registers up to two waves per SIMD, 168 up to four, 128 beyond / with MPC_FLAG_THROUGHPUT).  Same instances through
-    all three: statuses equal, actions equal to 1e-6 (a different build may contract a multiply-add differently; an
-    instance whose iterates are chaotic in the last bit may then take another path to the same point)."""
+def test_both_builds_of_the_solve_kernel_agree(oracle, ref_table):
+    """The engine launches one of two builds of the same solver source by how deep the batch fills the SIMDs (the latency
+    build - 218 registers, two resident waves per SIMD, everything hoisted - up to a batch of 4096 on 256 CUs; the
+    128-register build beyond and with MPC_FLAG_THROUGHPUT).  Same instances through both: statuses equal, actions equal to
+    1e-6 (the builds fuse loops differently and may contract a multiply-add differently; an instance whose iterates are
+    chaotic in the last bit may then take another path to the same point)."""
     import torch
     from mpc_rl_for_avs_amd import engine, synth
     dev = torch.device("cuda", 0)
@@ -391,18 +392,19 @@ def test_three_builds_of_the_solve_kernel_agree(oracle, ref_table):
                     vref=t(inp["vref"][:n], torch.float64), others=t(inp["others"][:n], torch.float64), collision_cost=True)
         o = e.solve_batch_torch(**args, sync=True, throughput=throughput)
         return {k: v.cpu().numpy() for k, v in o.items()}
-    lat = run(1024, False)           # <= 2 waves per SIMD: the latency build
-    mid = run(4096, False)           # <= 4: 168-register build
+    lat1 = run(1024, False)          # every wave alone on its SIMD
+    lat4 = run(4096, False)          # the same build, four waves per SIMD of batch depth
     bulk = run(4096, True)           # 128-register build
-    for a, b, n in ((lat, mid, 1024), (mid, bulk, 4096), (lat, bulk, 1024)):
+    assert np.array_equal(lat1["status"], lat4["status"][:1024]) and np.array_equal(lat1["u0"], lat4["u0"][:1024])
+    for a, b, n in ((lat4, bulk, 4096),):
         same = (a["status"][:n] == b["status"][:n])
         assert same.mean() >= 0.998
         ok = same & converged(a["status"][:n])
         err = rel_u0_err(a["u0"][:n], b["u0"][:n])[ok]
         assert (err <= 1e-6).mean() >= 0.999 and np.median(err) < 1e-12
     want = _oracle(oracle, ref_table, {k: v[:1024] for k, v in inp.items() if isinstance(v, np.ndarray)}, True)
-    both = converged(lat["status"]) & converged(want["status"])
-    assert (rel_u0_err(lat["u0"], want["u0"])[both] <= TOL).all()
+    both = converged(lat1["status"]) & converged(want["status"])
+    assert (rel_u0_err(lat1["u0"], want["u0"])[both] <= TOL).all()
     e.close()
 
 
