@@ -395,7 +395,7 @@ struct Solver {
         double pp00 = 0.0, pp01 = 0.0, pp11 = 0.0, ppv0 = 0.0, ppv1 = 0.0;    // Ppp, pp of the node behind the stage
         c.tick(T_RIC_INIT);
         const double rd_full = RD();
-#pragma unroll 1
+#pragma unroll 1      // (two stages per trip: no gain for a lone wave, 2 % slower batches - profiles/r04_sweep4.txt)
         for (int k = N - 1; k >= 0; --k) {
             const double rdk = (k >= 1) ? rd_full : 0.0;
             // ---- operands from LDS (they do not depend on the recursion; requesting them one stage ahead changes nothing:
