@@ -25,6 +25,7 @@ python3 tools/bench_rollout.py --envs 256 2048 8192 --steps 64 > $O/rollout.json
 python3 tools/bench_rollout.py --envs 256 2048 --steps 64 --no-graph >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 256 --steps 64 --no-graph --env-backend torch >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 >> $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 --max-iter 1000 --tol 1e-6 >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 8192 --steps 32 --groups 4 >> $O/rollout.jsonl 2>> $O/rollout.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rollout_stats -- python3 tools/bench_rollout.py --envs 256 --steps 64 --no-graph > $O/rollout_prof.json 2> $O/rollout_prof.err
 BENCH_FORCE_DIST=1 python3 bench.py --steps 10 --no-side --no-cpu-baseline > $O/bench_rccl_1rank.json 2>> $O/rollout.err
