@@ -45,6 +45,17 @@ def test_default_config_and_argument_checks():
     assert lib.mpc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert lib.mpc_solve_batch(None, 1, None, None, None, None, None, None, 0, 0, None, None, None, None, None,
                                None) == -1
+    # the entry points of round 4 refuse bad arguments before they touch a device
+    assert lib.mpc_eval_nlp(None, 1, None, None, None, None, None, 0, 0, None, None, None, None) == -1
+    buf = (ctypes.c_float * 256)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.mpc_rollout_finish(0, 0, 4, 1, 85, 0, p, p, p, None, 0.99, 0.95, p, p, None) == -1      # T = 0
+    assert b"1 <= T" in lib.mpc_last_error()
+    assert lib.mpc_rollout_finish(0, 9000, 4, 1, 85, 0, p, p, p, None, 0.99, 0.95, p, p, None) == -1   # T > 8192
+    assert lib.mpc_rollout_finish(0, 8, 4, 1, 84, 0, p, p, p, None, 0.99, 0.95, p, p, None) == -1      # row layout
+    assert lib.mpc_rollout_finish(0, 8, 4, 1, 85, 0, None, p, p, None, 0.99, 0.95, p, p, None) == -1   # null row
+    assert lib.mpc_policy_act(0, 4, 0, 128, *([p] * 10), 0, 0, None, 0, 1, p, p, p, None, p, None) == -1   # action_dim 0
+    assert lib.mpc_policy_act(0, 4, 3, 128, *([p] * 10), 0, 0, None, 1, 1, p, p, p, None, None, None) == -1  # v1 without weights out
 
 
 def test_sized_default_config_refuses_a_short_struct():

@@ -562,3 +562,19 @@ def test_rollout_finish_on_the_gpu_is_the_torch_gae_bit_for_bit(algorithm):
         assert not torch.equal(before, buf._row)   # the bootstrap did change rewards
     assert got["adv"].abs().max() > 0
     eng.close()
+    # the longest rollout the entry point takes (8192 steps: 64 KB of LDS per environment) on a synthetic buffer
+    import ctypes
+    T2, B2 = 8192, 3
+    big = rollout.RolloutBuffer(T2, B2, 1, dev, keep_terminal=False)
+    ref = rollout.RolloutBuffer(T2, B2, 1, dev, keep_terminal=False)
+    big._row.copy_(torch.randn(big._row.shape, device=dev) * 0.1)
+    big.episode_starts.copy_((torch.rand(T2, B2, device=dev) < 0.01).float())
+    ref._row.copy_(big._row)
+    lv, dn = torch.randn(B2, device=dev), torch.zeros(B2, dtype=torch.uint8, device=dev)
+    q = lambda t: ctypes.c_void_p(t.data_ptr())
+    lib = engine.load_library()
+    rc = lib.mpc_rollout_finish(0, T2, B2, 1, big._cols, 0, q(big._row), q(lv), q(dn), None, 0.99, 0.95, q(big.advantages),
+                                q(big.returns), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0, lib.mpc_last_error()
+    ref.compute_returns_and_advantage(lv, dn.bool())
+    assert torch.equal(big.advantages, ref.advantages) and torch.equal(big.returns, ref.returns)
