@@ -398,8 +398,9 @@ struct Solver {
 #pragma unroll 1      // (two stages per trip: no gain for a lone wave, 2 % slower batches - profiles/r04_sweep4.txt)
         for (int k = N - 1; k >= 0; --k) {
             const double rdk = (k >= 1) ? rd_full : 0.0;
-            // ---- operands from LDS (they do not depend on the recursion; requesting them one stage ahead changes nothing:
-            //      profiles/r04_sweep4.txt, like the four attempts on the 8x8 form before)
+            // ---- operands from LDS (they do not depend on the recursion; requesting them one stage ahead - behind this stage's
+            //      products, pinned there by scheduling fences, verified in the ISA - is 1.5 % SLOWER: profiles/r04_sweep4.txt,
+            //      like the four attempts on the 8x8 form before)
             PerLane<double> RA, RB, QXX, QUX, M, QX, QU, T0, T1;
             double lp0, lp1;
             load_stage4(k, AB, RA, RB, QXX, QUX, M, QX, QU, lp0, lp1);

@@ -11,7 +11,10 @@
 
 namespace {
 
-struct ProfCtx : mpc::wave::WaveOps {
+#ifndef PROF_RELAX
+#define PROF_RELAX 0      // 15: the latency build's configuration (everything hoisted, fused linear step, precomputed trial bounds)
+#endif
+struct ProfCtx : mpc::wave::WaveOpsT<PROF_RELAX> {
     static constexpr int kN = 20;
     static constexpr bool kFine = true;     // also attribute the parts of a rollout stage
     const double *table;
@@ -19,7 +22,7 @@ struct ProfCtx : mpc::wave::WaveOps {
     unsigned long long *acc;   // [T_COUNT] accumulators of this instance in LDS, behind the solver's words (lane 0 adds)
     unsigned long long last;
     __device__ __forceinline__ ProfCtx(mpc::wave::lds_double_t *l, const double *t, int e, int m, unsigned long long *a)
-        : mpc::wave::WaveOps{l}, table(t), e0(e), M(m), acc(a), last(0ull) {}
+        : mpc::wave::WaveOpsT<PROF_RELAX>{l}, table(t), e0(e), M(m), acc(a), last(0ull) {}
     // LDS accumulation: a tick is the counter read plus one LDS add (a global read-modify-write per tick would cost
     // hundreds of cycles and land in whichever section waits for memory next)
     __device__ __forceinline__ void tick(int s) {
@@ -45,8 +48,9 @@ __global__ __launch_bounds__(64, 2) void prof_kernel(mpc::SolveParams P, int B, 
     extern __shared__ double smem[];
     constexpr int N = 20;
     const int b = blockIdx.x, lane = threadIdx.x;
-    constexpr int SL = mpc::wave::stage_slots(CC);
-    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(smem + mpc::wave::lds_doubles(CC, N, P.V));
+    constexpr bool kPre = (PROF_RELAX & 8) != 0;
+    constexpr int SL = mpc::wave::stage_slots(CC, kPre);
+    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(smem + mpc::wave::lds_doubles(CC, N, P.V, kPre));
     if (lane < mpc::wave::T_COUNT) lacc[lane] = 0ull;
     ProfCtx ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M, lacc);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
@@ -94,7 +98,7 @@ extern "C" int wave_sections(int B, int V, int cc, int max_iter, const double *r
     P.mu_init = 0.1;
     P.stall_window = 0;
     P.w_distance = 10.0;
-    const size_t lds = (size_t)(mpc::wave::lds_doubles(cc != 0, 20, P.V) + mpc::wave::T_COUNT) * sizeof(double);
+    const size_t lds = (size_t)(mpc::wave::lds_doubles(cc != 0, 20, P.V, (PROF_RELAX & 8) != 0) + mpc::wave::T_COUNT) * sizeof(double);
     if (cc) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prof_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(prof_kernel<true>, dim3(B), dim3(64), lds, 0, P, B, ref5, M, state, ego_index, vref, weights,
