@@ -488,6 +488,53 @@ def reference_sequences():
           "collide steps", int(o["is_collide"].sum()), "of", T * E)
 
 
+def reference_predict_tail():
+    """The reference's `predict()` executed END TO END (agents/pure_mpc.py:68-78, 80-318) on closed-loop observation
+    sequences, with the solver stand-in handing back a given solution - the C oracle's of that step, flagged alternately as
+    found / not found - so that the statements BEHIND the nlpsol call run too: sol['x'] unpacked into the control sequence,
+    `last_acc`, `MPC_Action(...).numpy()`, the "NOTICE: Not found solution" print of a failed solve (the last iterate is
+    used all the same).  Pins a1 (orchestration) and a12 (result) of SURVEY section 8."""
+    import contextlib
+    import io
+    for d in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    obs, reset, rl, Xs, Us = _record_closed_loop(8, 4, 40, "v0", seed=41)
+    T, E = obs.shape[:2]
+    _, standins = _reference_agent()
+    from agents.pure_mpc import PureMPC_Agent
+    agents = [None] * E
+    act = np.zeros((T, E, 2))
+    last_acc = np.zeros((T, E))
+    notice = np.zeros((T, E), bool)
+    success = np.zeros((T, E), bool)
+    try:
+        for t in range(T):
+            for e in range(E):
+                if reset[t, e] or agents[e] is None:
+                    agents[e] = PureMPC_Agent(_RefEnv, dict(_REF_CFG))
+                ok = (t + e) % 3 != 0
+                z = np.concatenate([Xs[t, e].ravel(), Us[t, e].ravel()])
+                standins.SOLVE_HOOK[0] = lambda cap, z=z, ok=ok: (z, ok)
+                standins.POINT.clear()      # the numeric SX needs a point to evaluate the (unused) cost at: the same one
+                standins.POINT.update(x=Xs[t, e].T.copy(), u=Us[t, e].T.copy())
+                standins.CAPTURED.clear()
+                rs = None if np.isnan(rl[t, e]) else np.array([[rl[t, e]]])
+                out = io.StringIO()
+                with contextlib.redirect_stdout(out):
+                    a = agents[e].predict(obs[t, e], weights_from_RL=None, ref_speed=rs)
+                assert isinstance(a, np.ndarray) and a.shape == (2,)
+                act[t, e] = a
+                last_acc[t, e] = agents[e].last_acc
+                notice[t, e] = "NOTICE: Not found solution" in out.getvalue()
+                success[t, e] = ok
+    finally:
+        standins.SOLVE_HOOK[0] = None
+    np.savez_compressed(os.path.join(HERE, "reference_predict_tail.npz"), obs=obs, reset=reset, ref_speed=rl, X=Xs, U=Us,
+                        success=success, action=act, last_acc=last_acc, notice=notice)
+    print("wrote reference_predict_tail.npz", act.shape, "failed solves", int((~success).sum()), "notices", int(notice.sum()))
+
+
 def reference_distance_cost(n=512):
     """The "collision cost on" term.  Its only LIVE definition in the reference is the distance cost of the
     archived agent (agents/archive/pure_mpc.py:189-206: per stage and observed vehicle (d < 1 ? 1000 : 100) / (d + 1e-6)^2,
@@ -753,7 +800,11 @@ def oracle_vectors():
 
 
 if __name__ == "__main__":
+    if "--predict-tail-only" in sys.argv:
+        reference_predict_tail()
+        sys.exit(0)
     if "--round4-only" in sys.argv:
+        reference_predict_tail()
         reference_random_vectors()
         reference_sequences()
         reference_distance_cost()
@@ -765,6 +816,7 @@ if __name__ == "__main__":
         reference_random_vectors()
         reference_sequences()
         reference_distance_cost()
+        reference_predict_tail()
         ltv_reference_random_vectors()
     if "--reference-only" not in sys.argv:
         oracle_vectors()

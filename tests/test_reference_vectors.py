@@ -500,3 +500,54 @@ def test_ltv_oracle_equals_the_references_helpers_and_qp(ref_table):
         else:
             assert np.abs(ltv_reference_slacks(u, x) - d["qp_le"][i]).max() <= 1e-12
     assert n_on >= 150
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# predict() end to end, incl. the statements behind the solver call (agents/pure_mpc.py:300-318)
+# ---------------------------------------------------------------------------------------------------------------
+class _StubDevice:
+    """Stands where MPCEngine stands in the PRODUCT agent (mpc-rl_for_avs_amd/pure_mpc.py): hands back a given solution and
+    status like mpc_predict_batch would, so that what the agent does with them can be compared with what the reference's own
+    statements did with the same solution."""
+
+    def __init__(self):
+        self.next = None
+
+    def predict_batch(self, obs, w, rs, collision_cost=False, warm_start=False, detected=False):
+        u0, ok = self.next
+        return dict(act=np.asarray(u0, np.float64).reshape(1, 2).copy(), status=np.array([0 if ok else 1], np.int32),
+                    iters=np.array([7], np.int32))
+
+    def env_state(self, B):
+        return dict(is_collide=np.zeros(B, np.int32), ego_index=np.zeros(B, np.int32), collision_memory=np.zeros(B, np.int32),
+                    stop_index=np.full(B, -1, np.int32), conflict_index=np.full((B, 16), -1, np.int32),
+                    conflict_points=np.full((B, 16, 2), np.nan))
+
+
+def test_product_agent_does_with_a_solution_what_the_reference_does(capsys):
+    """the reference's predict() was executed END TO END with the solver stand-in handing back a given
+    solution (the oracle's of that step, flagged found / not found alternately): first control as the action, `last_acc`,
+    the NOTICE of a failed solve whose last iterate is used all the same (agents/pure_mpc.py:300-318).  The product agent,
+    given the same solution by a stub in the engine's place, returns the same array, keeps the same `last_acc`, prints the
+    notice on the same steps."""
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    d = rf.load("reference_predict_tail.npz")
+    T, E = d["success"].shape
+    assert T * E >= 300 and (~d["success"]).sum() >= 50
+    # the fixture itself: what the reference returned IS the first control of the solution it was handed
+    assert np.array_equal(d["action"], d["U"][:, :, 0, :]) and np.array_equal(d["last_acc"], d["U"][:, :, 0, 0])
+    assert np.array_equal(d["notice"], ~d["success"])
+    stub = _StubDevice()
+    ag = PureMPC_Agent(Env(), dict(CFG), engine=stub)
+    for t in range(T):
+        for e in range(E):
+            stub.next = (d["U"][t, e, 0], bool(d["success"][t, e]))
+            rs = None if np.isnan(d["ref_speed"][t, e]) else np.array([[d["ref_speed"][t, e]]])
+            a = ag.predict(d["obs"][t, e], ref_speed=rs)
+            out = capsys.readouterr().out
+            assert isinstance(a, np.ndarray) and a.shape == (2,) and np.array_equal(a, d["action"][t, e])
+            assert ag.last_acc == d["last_acc"][t, e]
+            assert ("NOTICE: Not found solution" in out) == bool(d["notice"][t, e])
+            m = ag.predict(d["obs"][t, e], return_numpy=False, ref_speed=rs)
+            capsys.readouterr()
+            assert (m.acceleration, m.steer) == (a[0], a[1]) and m.success == bool(d["success"][t, e])

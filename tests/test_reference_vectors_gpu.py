@@ -241,3 +241,31 @@ def test_distance_cost_on_the_device_equals_the_archived_agents(ref_table):
     check_distance_cost(lambda ego, w, c, X, U, others, collision_cost: e.eval_nlp(ego, w, c, X, U, others=others,
                                                                                   collision_cost=collision_cost), ref_table)
     e.close()
+
+
+def test_predict_end_to_end_against_the_references_predict():
+    """a1 / a12 on the device: the closed-loop observation sequences on which the REFERENCE's own predict() was executed end
+    to end (solver stand-in handing back the C oracle's solution of the step) through the product agent's predict() - parse,
+    detector with its memory, problem data, solve, result - one agent per environment, renewed at episode boundaries like
+    the reference's: the returned action equals the reference's to the solver tolerance wherever the oracle converged."""
+    from mpc_rl_for_avs_amd.pure_mpc import PureMPC_Agent
+    from test_host import CFG, Env
+    d = rf.load("reference_predict_tail.npz")
+    T, E = d["success"].shape
+    agents = [None] * E
+    worst, n = 0.0, 0
+    for t in range(T):
+        for e in range(E):
+            if d["reset"][t, e] or agents[e] is None:
+                if agents[e] is not None:
+                    agents[e]._engine.close()
+                agents[e] = PureMPC_Agent(Env(), dict(CFG), max_iter=200)
+            rs = None if np.isnan(d["ref_speed"][t, e]) else np.array([[d["ref_speed"][t, e]]])
+            m = agents[e].predict(d["obs"][t, e], return_numpy=False, ref_speed=rs)
+            if m.success:
+                err = float(np.abs(m.numpy() - d["action"][t, e]).max())
+                worst = max(worst, err)
+                n += 1
+    for a in agents:
+        a._engine.close()
+    assert n >= 0.95 * T * E and worst < 1e-6, (n, worst)
