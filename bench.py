@@ -225,7 +225,8 @@ def main():
         with torch.cuda.stream(side[i % n_str]):
             if ev is not None:
                 ev[0].record()
-            eng.solve_batch_torch(**args, out=outs_s[i % n_str])      # enqueued on torch's current stream = side[i]
+            # (several batches in flight on one handle: MPC_FLAG_THROUGHPUT, include/mpc_mi355x.h)
+            eng.solve_batch_torch(**args, out=outs_s[i % n_str], throughput=n_str > 1)      # enqueued on torch's current stream = side[i]
             if ev is not None:
                 ev[1].record()
             if use_dist:

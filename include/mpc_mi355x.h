@@ -14,7 +14,9 @@
  *   - arrays are dense row-major with the batch index slowest: state[B][4], vref[B][N+1], ...
  *   - every call returns 0 on success or a negative MPC_ERR_* code; mpc_last_error() gives the text
  *   - no exceptions cross this boundary; per-instance solver outcomes go to status[] / iters[]
- *   - a handle belongs to one (process, device); calls on one handle must not overlap
+ *   - a handle belongs to one (process, device); calls on one handle must not overlap, and neither may the work they
+ *     enqueue (MPC_FLAG_NO_SYNC) on different streams - the handle owns scratch such as the batch's launch order and the
+ *     per-environment records - with one exception: mpc_solve_batch with MPC_FLAG_THROUGHPUT, made for batches in flight
  */
 #ifndef MPC_MI355X_H
 #define MPC_MI355X_H
