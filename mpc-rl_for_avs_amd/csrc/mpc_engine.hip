@@ -178,37 +178,60 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
 }
 
 // Launch order of a batch.  The hardware starts workgroups in index order, a SIMD's issue arbiter favours its oldest wave,
-// and a batch lasts as long as its slowest instance - so the instances likely to be slow should be the first to start.  The
-// one cheap predictor this NLP offers: instances WITHOUT a predicted collision are the slow ones (w_s = 100 of a predicted
-// collision, agents/pure_mpc.py:143-147, makes the speed term dominate and the problem easy: of the config-3 instances with
-// >= 50 iterations 90 - 100 % have is_collide = 0, against 50 % of all; every exception found in five draws of 4096 was an ego
-// standing still, its speed on the bound 0).  order[] = the instances with is_collide = 0 or a speed below 0.1 m/s in their
-// original order, then the others (a stable partition): one workgroup, every thread a contiguous chunk.
-__device__ __forceinline__ bool likely_slow(const uint8_t *is_collide, const double *state, int i) {
-    return is_collide[i] == 0 || state[(size_t)i * 4 + 3] < 0.1;
+// and a batch lasts as long as its slowest instance - so the instances likely to be slow should be the first to start, and
+// there should be no more of them than the GPU holds at once (2048 waves of the latency build).  The cheap predictors this NLP
+// offers (oracle iteration counts of eight draws of 4096, profiles/r04_launch_order.txt): instances WITH a predicted collision
+// are easy (w_s = 100, agents/pure_mpc.py:143-147, makes the speed term dominate: 99th percentile 26 - 29 iterations against
+// 45 - 50 without; of the instances with >= 50 iterations 90 - 100 % have is_collide = 0) unless the ego stands still (speed on
+// its bound 0: every exception found); and with the collision cost on, an instance without a vehicle within 15 m of the ego is
+// the easy live objective in all but name (no instance with >= 70 iterations had its nearest vehicle farther away, unless it
+// stood still).  Three tiers, each in its original order (a stable partition): 0 = standing ego, or no predicted collision
+// and (collision cost off or a vehicle within kNear); 1 = the other instances without a predicted collision; 2 = the rest.
+constexpr double kOrderStanding = 0.1, kOrderNear = 15.0;
+__device__ __forceinline__ int order_tier(const uint8_t *is_collide, const double *state, const double *others, int V,
+                                          const int32_t *nveh, int i) {
+    const double *x = state + (size_t)i * 4;
+    if (x[3] < kOrderStanding) return 0;
+    if (is_collide[i] != 0) return 2;
+    if (!others || V <= 0) return 0;
+    const int nv = nveh ? min(V, max(0, nveh[i])) : V;
+    bool near = false;
+    for (int j = 0; j < nv; ++j) {
+        const double *o = others + ((size_t)i * V + j) * 4;
+        const double dx = o[0] - x[0], dy = o[1] - x[1];
+        near = near || dx * dx + dy * dy < kOrderNear * kOrderNear;
+    }
+    return near ? 0 : 1;
 }
 __global__ __launch_bounds__(1024) void mpc_order_kernel(int B, const uint8_t *__restrict__ is_collide,
-                                                         const double *__restrict__ state, int32_t *__restrict__ order) {
-    __shared__ int s_cnt[1024];
-    __shared__ int s_total;
+                                                         const double *__restrict__ state, const double *__restrict__ others,
+                                                         int V, const int32_t *__restrict__ nveh, int32_t *__restrict__ order) {
+    __shared__ int s_c0[1024], s_c1[1024];
     const int t = threadIdx.x, chunk = (B + 1023) / 1024, lo = min(B, t * chunk), hi = min(B, lo + chunk);
-    int n0 = 0;
-    for (int i = lo; i < hi; ++i) n0 += likely_slow(is_collide, state, i) ? 1 : 0;
-    s_cnt[t] = n0;
+    int n0 = 0, n1 = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int k = order_tier(is_collide, state, others, V, nveh, i);
+        n0 += k == 0;
+        n1 += k == 1;
+    }
+    s_c0[t] = n0;
+    s_c1[t] = n1;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {          // inclusive scan of the zero counts
-        const int v = t >= d ? s_cnt[t - d] : 0;
+    for (int d = 1; d < 1024; d <<= 1) {          // inclusive scans of the tier counts
+        const int v0 = t >= d ? s_c0[t - d] : 0, v1 = t >= d ? s_c1[t - d] : 0;
         __syncthreads();
-        s_cnt[t] += v;
+        s_c0[t] += v0;
+        s_c1[t] += v1;
         __syncthreads();
     }
-    if (t == 1023) s_total = s_cnt[1023];
-    __syncthreads();
-    int p0 = s_cnt[t] - n0;                       // zeros before this chunk
-    int p1 = s_total + (lo - p0);                 // ones before this chunk, behind all zeros
+    const int tot0 = s_c0[1023], tot1 = s_c1[1023];
+    const int b0 = s_c0[t] - n0, b1 = s_c1[t] - n1;     // members of tier 0 / 1 before this chunk
+    int p0 = b0, p1 = tot0 + b1, p2 = tot0 + tot1 + (lo - b0 - b1);
     for (int i = lo; i < hi; ++i) {
-        if (likely_slow(is_collide, state, i)) order[p0++] = i;
-        else order[p1++] = i;
+        const int k = order_tier(is_collide, state, others, V, nveh, i);
+        if (k == 0) order[p0++] = i;
+        else if (k == 1) order[p1++] = i;
+        else order[p2++] = i;
     }
 }
 
@@ -638,7 +661,8 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, 
     // several streams may share this handle, and the order buffer is the handle's
     const int32_t *d_order = nullptr;
     if (!throughput && B > simds && h->d_order && h->order_cap >= B) {
-        hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, h->d_order);
+        hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, cc ? d_others : nullptr,
+                           (int)Vuse, d_nveh, h->d_order);
         HIP_TRY(hipGetLastError());
         d_order = h->d_order;
     }
