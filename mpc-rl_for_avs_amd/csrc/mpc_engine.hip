@@ -205,12 +205,16 @@ __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const doubl
 }
 __global__ __launch_bounds__(1024) void mpc_order_kernel(int B, const uint8_t *__restrict__ is_collide,
                                                          const double *__restrict__ state, const double *__restrict__ others,
-                                                         int V, const int32_t *__restrict__ nveh, int32_t *__restrict__ order) {
+                                                         int V, const int32_t *__restrict__ nveh, int32_t *__restrict__ order,
+                                                         int32_t *__restrict__ tier) {
     __shared__ int s_c0[1024], s_c1[1024];
     const int t = threadIdx.x, chunk = (B + 1023) / 1024, lo = min(B, t * chunk), hi = min(B, lo + chunk);
+    // tiers first, every thread an interleaved share (neighbouring threads read neighbouring instances), kept in scratch
+    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, i);
+    __syncthreads();
     int n0 = 0, n1 = 0;
     for (int i = lo; i < hi; ++i) {
-        const int k = order_tier(is_collide, state, others, V, nveh, i);
+        const int k = tier[i];
         n0 += k == 0;
         n1 += k == 1;
     }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(1024) void mpc_order_kernel(int B, const uint8_t *_
     const int b0 = s_c0[t] - n0, b1 = s_c1[t] - n1;     // members of tier 0 / 1 before this chunk
     int p0 = b0, p1 = tot0 + b1, p2 = tot0 + tot1 + (lo - b0 - b1);
     for (int i = lo; i < hi; ++i) {
-        const int k = order_tier(is_collide, state, others, V, nveh, i);
+        const int k = tier[i];
         if (k == 0) order[p0++] = i;
         else if (k == 1) order[p1++] = i;
         else order[p2++] = i;
@@ -607,7 +611,7 @@ int ensure_order(mpc_handle *h, int B, hipStream_t stream) {
     if (h->d_order) HIP_TRY(hipFree(h->d_order));
     h->d_order = nullptr;
     h->order_cap = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * 2 * sizeof(int32_t)));   // order + tiers
     h->order_cap = cap;
     return MPC_OK;
 }
@@ -660,9 +664,10 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, 
     // launch order (mpc_order_kernel): pays as soon as waves share a SIMD.  Not with MPC_FLAG_THROUGHPUT: batches in flight on
     // several streams may share this handle, and the order buffer is the handle's
     const int32_t *d_order = nullptr;
-    if (!throughput && B > simds && h->d_order && h->order_cap >= B) {
+    // ... and while the batch is not so deep that only throughput counts (beyond 8 waves per SIMD the order changed nothing)
+    if (!throughput && B > simds && B <= 8 * simds && h->d_order && h->order_cap >= B) {
         hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, cc ? d_others : nullptr,
-                           (int)Vuse, d_nveh, h->d_order);
+                           (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap);
         HIP_TRY(hipGetLastError());
         d_order = h->d_order;
     }
