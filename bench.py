@@ -300,7 +300,7 @@ def main():
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "mpc_solve_wave_kernel<CC=true, N=20, OCC=2, RELAX=15> (the latency build, used up to four waves "
                           "per SIMD of batch depth, mpc_engine.hip: dispatch_solve; kernel_ms brackets the call, i.e. it includes "
-                          "the 7 us mpc_order_kernel in front of it)", "kernel_ms": kern_ms,
+                          "the 16 us mpc_order_kernel in front of it)", "kernel_ms": kern_ms,
                 "kernel_ms_median": float(np.median(kern)) if n_str == 1 else None,
                 "algorithmic_bytes_per_solve": ALG_BYTES_PER_SOLVE,
                 "note": "path is bound by the serial FP64 + LDS-latency chain of its slowest instance; the working set is "
