@@ -62,7 +62,7 @@ def spawn_ranks(a) -> int:
 
 
 def conv_mask(status):
-    return (status == 0) | (status == 5)
+    return (status == 0) | ((status >= 5) & (status <= 7))      # MPC_STATUS_IS_SOLVED
 
 
 def cpu_baseline(inp):

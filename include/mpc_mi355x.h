@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 6
+#define MPC_ABI_VERSION 7
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -66,6 +66,13 @@ extern "C" {
                                       one), which is the faster choice when batches run one at a time and the slower one when
                                       six of them share the GPU. */
 
+#define MPC_FLAG_STRICT_DISCONTINUITY 128u /* reference-strict reading of the d = 1 discontinuity of the collision cost
+                                      (agents/archive/pure_mpc.py:189-196): an instance that ends on it - MPC_STATUS_CONVERGED_ON_KINK
+                                      or MPC_STATUS_ACCEPTABLE_ON_KINK - is reported as MPC_STATUS_KINK_UNSOLVED, i.e. NOT solved,
+                                      with the last iterate as the result: what the reference's IPOPT reports for a point no
+                                      smooth method accepts (solver.stats()['success'] false, the last iterate is used,
+                                      agents/pure_mpc.py:303-305).  The iterates are the same with and without the flag. */
+
 /* per-instance solver status written to status[] */
 #define MPC_STATUS_CONVERGED 0
 #define MPC_STATUS_MAX_ITER 1       /* last iterate returned, like the reference (agents/pure_mpc.py:303-305) */
@@ -85,6 +92,16 @@ extern "C" {
                                          would act on that last iterate (agents/pure_mpc.py:303-305); 49 converge to a
                                          smooth minimiser on one side of the jump (26 inside d < 1, 23 outside), a
                                          different action than this status returns in 35 of them. */
+
+#define MPC_STATUS_ACCEPTABLE 6        /* IPOPT's "Solved To Acceptable Level" with IPOPT's defaults, which are live in the
+                                         reference (it sets only max_iter, tol and print options, agents/pure_mpc.py:291-296):
+                                         the scaled KKT error was at most acceptable_tol = 1e-6 in acceptable_iter = 15
+                                         consecutive iterations while mpc_config.tol is tighter.  casadi reports it as success
+                                         like "Solve Succeeded".  Never returned when tol >= 1e-6 (the reference's own tol). */
+#define MPC_STATUS_ACCEPTABLE_ON_KINK 7 /* the same with a vehicle held at the d = 1 discontinuity (see status 5) */
+#define MPC_STATUS_KINK_UNSOLVED 8     /* MPC_FLAG_STRICT_DISCONTINUITY only: would be status 5 or 7; counted as not solved */
+/* solved, as a caller should count it: status 0, 5, 6, 7 */
+#define MPC_STATUS_IS_SOLVED(st) ((st) == 0 || ((st) >= 5 && (st) <= 7))
 
 typedef struct mpc_handle mpc_handle;
 

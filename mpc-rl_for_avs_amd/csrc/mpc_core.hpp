@@ -30,6 +30,7 @@ struct SolveParams {
     double mu_init;
     double w_distance;  // weight_distance
     int stall_window;   // mpc_config.stall_window: 0 = off
+    int strict_kink;    // MPC_FLAG_STRICT_DISCONTINUITY: a solve that ends on the d = 1 discontinuity is reported unsolved
 };
 
 // single v_max_f64 / v_min_f64 on the device (a compare + two v_cndmask otherwise)

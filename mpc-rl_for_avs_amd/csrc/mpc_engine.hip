@@ -160,7 +160,9 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     __syncthreads();
     const int CB = cur * 6;
     // only a converged solve may seed the next warm start
-    if (lane == 0 && u_valid && U_out) u_valid[b] = (status == MPC_STATUS_CONVERGED || status == MPC_STATUS_CONVERGED_ON_KINK) ? 1 : 0;
+    if (P.strict_kink && (status == MPC_STATUS_CONVERGED_ON_KINK || status == MPC_STATUS_ACCEPTABLE_ON_KINK))
+        status = MPC_STATUS_KINK_UNSOLVED;      // MPC_FLAG_STRICT_DISCONTINUITY: same iterate, reported as the reference's IPOPT would
+    if (lane == 0 && u_valid && U_out) u_valid[b] = MPC_STATUS_IS_SOLVED(status) ? 1 : 0;
     if (lane < 2) u0_out[(size_t)b * 2 + lane] = ctx.ld(CB + mpc::wave::W_U + lane);
     if (U_out && lane < N) {
         U_out[((size_t)b * N + lane) * 2 + 0] = ctx.ld(lane * SL + CB + mpc::wave::W_U + 0);
@@ -640,16 +642,19 @@ mpc::SolveParams solve_params(const mpc_handle *h, int Vuse) {
     P.mu_init = 0.1;
     P.w_distance = h->cfg.w_distance;
     P.stall_window = h->cfg.stall_window;
+    P.strict_kink = 0;
     return P;
 }
 
-int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, bool throughput, hipStream_t stream, const double *d_state,
+int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, hipStream_t stream, const double *d_state,
                    const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
                    const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
                    double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
     const int N = h->cfg.horizon;
     const int Vuse = cc ? V : 0;
-    const mpc::SolveParams P = solve_params(h, Vuse);
+    mpc::SolveParams P = solve_params(h, Vuse);
+    P.strict_kink = (flags & MPC_FLAG_STRICT_DISCONTINUITY) ? 1 : 0;
+    const bool throughput = (flags & MPC_FLAG_THROUGHPUT) != 0;
 
     static_assert(MPC_MAX_HORIZON <= mpc::wave::kMaxHorizon, "lane k = stage k needs the horizon to fit a wave");
     const size_t wlds = (size_t)mpc::wave::lds_doubles(cc, N, Vuse) * sizeof(double);
@@ -866,7 +871,7 @@ int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t
     if (warm && !dev)
         HIP_TRY(hipMemcpyAsync(d_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
     if (int rc = ensure_order(h, B, stream)) return rc;
-    if (int rc = dispatch_solve(h, B, cc, V, (flags & MPC_FLAG_THROUGHPUT) != 0, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, nullptr,
+    if (int rc = dispatch_solve(h, B, cc, V, flags, stream, d_state, d_ego, d_vref, d_weights, d_coll, d_others, nullptr,
                                 warm ? d_U : nullptr, 0, nullptr, d_u0, d_U, d_X, d_status, d_iters))
         return rc;
 
@@ -1047,7 +1052,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
         return MPC_OK;
     }
     if (int rc = ensure_order(h, B, stream)) return rc;
-    if (int rc = dispatch_solve(h, B, cc, V, (flags & MPC_FLAG_THROUGHPUT) != 0, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
+    if (int rc = dispatch_solve(h, B, cc, V, flags, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
                                 h->p_others, h->p_nveh, warm ? h->d_warm : nullptr, 1, warm ? h->d_warm_valid : nullptr,
                                 d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters))
         return rc;

@@ -137,7 +137,7 @@ MPC_HD int record_thread(const RecordArgs &r, long long pos, int b, int j) {
     r.mpc_actions_buf[((size_t)pos * r.B + b) * 2 + 0] = r.mpc_act[(size_t)b * 2 + 0];
     r.mpc_actions_buf[((size_t)pos * r.B + b) * 2 + 1] = r.mpc_act[(size_t)b * 2 + 1];
     const int st = r.mpc_status[b];
-    return (r.done[b] ? 1 : 0) | (r.crashed[b] ? 2 : 0) | (r.arrived[b] ? 4 : 0) | ((st != 0 && st != 5) ? 8 : 0);
+    return (r.done[b] ? 1 : 0) | (r.crashed[b] ? 2 : 0) | (r.arrived[b] ? 4 : 0) | ((st != 0 && (st < 5 || st > 7)) ? 8 : 0);
 }
 
 // ---- end of a rollout: truncation bootstrap + GAE ---------------------------------------------------------------------

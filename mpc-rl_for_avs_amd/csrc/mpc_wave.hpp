@@ -39,6 +39,36 @@ constexpr int kTrials = 4;   // step lengths tried by the line search: a_pr * 4^
 // A rollout that would take theta or v of the next node out of its bounds gets the one control that decides it (delta
 // resp. a) pulled back so that the node keeps this fraction of its slack
 constexpr double kProjKeep = 0.1;   // (0.2 until round 3; 0.1 with kKappaEps 30 measured 5 % fewer iterations)
+// ... and kProjKeepEnd of it once the barrier parameter is at most kProjEndMu (round 5): in the end-game a slack has to
+// shrink by orders of magnitude to meet its multiplier; a projection that keeps 10 % per iteration turns the full Newton step
+// into something the Armijo test rejects (the barrier objective rises by 40 x the predicted decrease), and the solve closes
+// with 15 - 20 steps of alpha = 1/4, the error falling by exactly 0.75 per iteration (BASELINE config 2's slowest instances,
+// egos on the exit straight with the heading next to its bound: 46 -> 34 iterations)
+constexpr double kProjKeepEnd = 1e-3, kProjEndMu = 1e-6;
+// Round 5, the iteration tail (the CPU restatement under oracle/ carries the same statements):
+// (vii) a streak of iterations that needed the whole-sweep Gauss-Newton fallback is watched - every kGnWatch iterations of it
+// the scaled KKT error must have halved; if not, the next kGnSkip iterations of the streak go from the failed exact sweep
+// straight to IPOPT's inertia correction of the EXACT Hessian (delta_w ladder with memory).  The Gauss-Newton model is convex:
+// near a saddle point of the barrier problem its steps are attracted to the saddle, each accepted at full length with a
+// predicted decrease of 1e-6, and the iterate drifts off along the unstable direction by 8 % per iteration (half of round 4's
+// instances at the iteration cap); the regularised exact Hessian takes a long step along the direction of negative curvature.
+constexpr int kGnWatch = 4, kGnSkip = 4;
+// (viii) a linearised Newton step smaller than this in the states and the previous control of a stage is applied OPEN LOOP
+// there (alpha times the linearised control step) instead of through the feedback law: the feedback acts on the difference of
+// two rolled-out trajectories, which carries the rounding of positions ~50 m (7e-15); times gains of 10 - 100 where a control and
+// the state bound it decides are both active that is 5e-13 of noise in a control whose slack is 1e-9, and the dual infeasibility
+// dithers at 1e-6 - 1e-5 for the rest of the iteration budget (round 4's cap-runners with a standing ego).  The linearised step
+// is a recursion on small numbers and keeps its relative precision; the two differ by O(step^2).
+constexpr double kOpenLoopStep = 1e-9;
+// (ix) IPOPT's acceptable-level termination with IPOPT's defaults (acceptable_tol 1e-6, acceptable_iter 15): live in the
+// reference, which sets only max_iter, tol and print options (agents/pure_mpc.py:291-296).  Can only end a solve whose tol is
+// tighter than acceptable_tol - never one at the reference's tol 1e-6.  Status 6 (7 with a vehicle held at d = 1).
+constexpr double kAcceptableTol = 1e-6;
+constexpr int kAcceptableIter = 15;
+// (x) the Levenberg-Marquardt term kept across iterations stops here (1e6 until round 4): an instance that needs more than
+// the curvature scale of the scaled problem to get a step accepted crawls (alpha = 1/4 at 16 for hundreds of iterations), the
+// line-search-failure exit (status 4) ends what cannot move
+constexpr double kRegMax = 1.0;
 // the barrier parameter is lowered as soon as the error of the barrier problem is below kKappaEps * mu (IPOPT's
 // kappa_epsilon, 10 there and here until round 3)
 constexpr double kKappaEps = 30.0;
@@ -299,6 +329,9 @@ struct Solver {
     // pressed against d = 1 is a constrained stationary point of the outer branch (status 5), which no smooth method
     // reaches otherwise (round 1: 3.7 % of the config-3 instances ended "stalled").  any_wall: some node has one.
     int any_wall = 0;
+    // (viii) stages whose linearised step is below kOpenLoopStep, bit k = stage k: written by the linearised pass of the builds
+    // that run it in front of the line search (wave-uniform, scalar registers); the fused builds decide inside the rollout loop
+    unsigned long long ol_mask = 0;
     MPC_HD int f_word(int r, int c) const {
         return stage_transition_word(r, c, W_LIN, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
                                      -(SCR + SC_SPARE + 2 + 1));
@@ -762,7 +795,7 @@ struct Solver {
     // length was measured no better: 17.96 against 17.50 iterations on config 3), the trials' own state-bound tests decide
     // what is feasible.  Its result is parked in the adjoint slots (du at W_Y + 0, 1 of the stage, d theta / d v at
     // W_Y + 2, 3 of the next node; d x / d y at W_DXY when a wall needs them) by lane 0.
-    MPC_HD bool line_search(int cur, double frac, double phi0, double dV1, double mu_, double &Jn, double &barn,
+    MPC_HD bool line_search(int cur, double frac, double keep, double phi0, double dV1, double mu_, double &Jn, double &barn,
                             int &acc_out) {
         const double a_pr = 1.0;
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
@@ -776,7 +809,7 @@ struct Solver {
                 const int k = lane;
                 const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
                 const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
-                const double keep_ = c.fresh(kProjKeep), ms_ = c.fresh(kMinSlack);
+                const double keep_ = keep, ms_ = c.fresh(kMinSlack);
                 const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
                 const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
                 S(k, W_PRE + B_ULO0, alo_ + fmax2(fracu * (c0 - alo_), ms_));
@@ -807,7 +840,7 @@ struct Solver {
             // the bounds, read from the table once (theta, v, a, delta)
             const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
             const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
-            const double keep_ = c.fresh(kProjKeep), vmin_ = c.fresh(1e-6), ms_ = c.fresh(kMinSlack);
+            const double keep_ = keep, vmin_ = c.fresh(1e-6), ms_ = c.fresh(kMinSlack);
 #pragma unroll 1
             for (int k = 0; k < N; ++k) {
                 // everything the stage reads from LDS first, in one batch (one wait instead of eight: the loads do not
@@ -835,7 +868,11 @@ struct Solver {
                     a23 = S(k, W_LIN + 4); b01 = S(k, W_LIN + 5); b11 = S(k, W_LIN + 6); b21 = S(k, W_LIN + 7);
                 }
                 c.sched_fence();
+                double lin0 = 0.0, lin1 = 0.0;   // linearised control step of the stage
+                bool open_loop = false;          // (viii)
                 if (fuse_linear<CTX>::value) {
+                    open_loop = fmax2(fmax2(fmax2(fabs(ld0), fabs(ld1)), fmax2(fabs(ld2), fabs(ld3))), fmax2(fabs(ldp0), fabs(ldp1))) <
+                                c.fresh(kOpenLoopStep);
                     // linearised Newton step of stage k (same arithmetic in every lane; lane 0 stores)
                     double du0 = kf0 + k00 * ld0 + k01 * ld1 + k02 * ld2 + k03 * ld3;
                     double du1 = kf1 + k10 * ld0 + k11 * ld1 + k12 * ld2 + k13 * ld3;
@@ -847,6 +884,20 @@ struct Solver {
                     const double m3 = ld3 + dt * du0;
                     ld0 = m0; ld1 = m1; ld2 = m2; ld3 = m3;
                     ldp0 = du0; ldp1 = du1;
+                    lin0 = du0; lin1 = du1;
+#if !defined(__HIPCC__)
+                    // host model only: it runs the trial lanes one after the other, and lane 1 has overwritten the linearisation
+                    // slots (its trial area) by the time lanes 2, 3 read them - on the device the four lanes run in lockstep and
+                    // every lane's recursion is the true one.  Lanes 1..3 take lane 0's decision and step, which lane 0 has parked.
+                    if (lane == 0) {
+                        if (k == 0) ol_mask = 0;
+                        if (open_loop) ol_mask |= 1ull << k;
+                    } else {
+                        open_loop = ((ol_mask >> k) & 1ull) != 0;
+                        lin0 = S(k, W_Y + 0);
+                        lin1 = S(k, W_Y + 1);
+                    }
+#endif
                     if (lane == 0) {
                         S(k, W_Y + 0, du0);
                         S(k, W_Y + 1, du1);
@@ -858,11 +909,20 @@ struct Solver {
                         }
                     }
                 }
+                if (!fuse_linear<CTX>::value) {
+                    open_loop = ((ol_mask >> k) & 1ull) != 0;
+                    if (open_loop) {
+                        lin0 = S(k, W_Y + 0);
+                        lin1 = S(k, W_Y + 1);
+                    }
+                }
                 const double e0 = x_0 - xc0, e1 = x_1 - xc1, e2 = x_2 - xc2, e3 = x_3 - xc3;
                 double s0 = alpha * kf0 + k00 * e0 + k01 * e1 + k02 * e2 + k03 * e3;
                 double s1 = alpha * kf1 + k10 * e0 + k11 * e1 + k12 * e2 + k13 * e3;
                 s0 += kp00 * dup0 + kp01 * dup1;
                 s1 += kp01 * dup0 + kp11 * dup1;
+                s0 = open_loop ? alpha * lin0 : s0;
+                s1 = open_loop ? alpha * lin1 : s1;
                 if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
                 if (!kPre) {
                     ulo0 = alo_ + fmax2(fracu * (c0 - alo_), ms_);
@@ -1130,6 +1190,9 @@ struct Solver {
         // half of its value at the previous such mark
         int i_mark = 0;
         double e_mark = INFINITY;
+        int gn_streak = 0, gn_skip = 0;    // (vii)
+        double e_streak = INFINITY;
+        int n_acceptable = 0;              // (ix)
 
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
@@ -1330,6 +1393,13 @@ struct Solver {
                 status_out = (CC && zw_max > c.fresh(1e-6) * SF()) ? 5 : 0;
                 break;
             }
+            if (P.tol < kAcceptableTol) {
+                n_acceptable = (E0 <= c.fresh(kAcceptableTol)) ? n_acceptable + 1 : 0;
+                if (n_acceptable >= kAcceptableIter) {
+                    status_out = (CC && zw_max > c.fresh(1e-6) * SF()) ? 7 : 6;
+                    break;
+                }
+            }
             if (iter == P.max_iter) break;
             if (P.stall_window > 0) {
                 if (E0 < 0.5 * e_mark) {
@@ -1350,6 +1420,8 @@ struct Solver {
             const int AB = (cur ^ 1) * 6;   // trial buffer: hv0..3 at AB + W_X, hv5 at AB + W_U
             double dV1 = 0.0, delta_w = reg;
             bool ok = false, gn = false;
+            int nmod = 0;                      // sweeps of this iteration that failed
+            bool skipped_gn = false;           // (vii) the whole-sweep Gauss-Newton fallback was skipped in favour of the ladder
             set_roles4(AB);
             for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
                 ok = true;
@@ -1455,7 +1527,9 @@ struct Solver {
                 });
                 ok = sweep4(CB, AB, mu, delta_w, gn, dV1);
                 if (!ok) {
-                    if (!gn) {
+                    ++nmod;
+                    if (gn_skip > 0) skipped_gn = true;
+                    if (!gn && gn_skip == 0) {
                         gn = true;
                     } else {
                         const double dw_last = c.uni(sc(SC_SPARE + 3));
@@ -1474,6 +1548,19 @@ struct Solver {
                 break;
             }
             if (delta_w > reg) sc(SC_SPARE + 3, delta_w);   // the ladder was needed: remember where it ended
+            if (nmod > 0) {
+                if (gn_streak == 0) e_streak = c.uni(E0);
+                ++gn_streak;
+                if (gn_skip > 0) {
+                    --gn_skip;
+                } else if (gn_streak % kGnWatch == 0) {
+                    if (E0 > 0.5 * e_streak) gn_skip = kGnSkip;
+                    e_streak = c.uni(E0);
+                }
+            } else {
+                gn_streak = 0;
+                gn_skip = 0;
+            }
 
             c.tick(T_RIC_INIT);
             const double tau = c.uni(fmax2(0.99, 1.0 - mu));
@@ -1481,8 +1568,11 @@ struct Solver {
                 // ============ linearised Newton step (serial recursion), parked in the adjoint slots; the fused builds run
                 //              the same statements inside the rollout loop of the line search
                 double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
+                ol_mask = 0;
 #pragma unroll 1
                 for (int k = 0; k < N; ++k) {
+                    if (fmax2(fmax2(fmax2(fabs(d0), fabs(d1)), fmax2(fabs(d2), fabs(d3))), fmax2(fabs(dp0), fabs(dp1))) < c.fresh(kOpenLoopStep))
+                        ol_mask |= 1ull << k;
                     // all LDS reads of the stage in one batch (they do not depend on the recursion)
                     const double kf0 = S(k, W_KF + 0), kf1 = S(k, W_KF + 1);
                     const double k00 = S(k, W_KX + 0), k01 = S(k, W_KX + 1), k02 = S(k, W_KX + 2), k03 = S(k, W_KX + 3);
@@ -1531,7 +1621,8 @@ struct Solver {
             const int tb = cur ^ 1;
             double Jn = 0.0, barn = 0.0;
             int acc_trial = -1;
-            const bool accepted = line_search(cur, 0.5 * (1.0 - tau), phi0, dV1, mu, Jn, barn, acc_trial);
+            const double keep = c.uni(mu <= c.fresh(kProjEndMu) ? c.fresh(kProjKeepEnd) : c.fresh(kProjKeep));
+            const bool accepted = line_search(cur, 0.5 * (1.0 - tau), keep, phi0, dV1, mu, Jn, barn, acc_trial);
             const bool have_cross = CC && P.V > 0 && acc_trial != 0;
             // ============ length of the dual step (stage-parallel, from the linearised step parked by the line search)
             c.phase([&](int lane) {
@@ -1586,7 +1677,7 @@ struct Solver {
                 reg = 0.25 * reg;
                 if (reg < 1e-3) reg = 0.0;
             } else if (!accepted || acc_trial >= 2) {
-                reg = (reg == 0.0) ? 1e-3 : fmin2(4.0 * reg, 1e6);
+                reg = (reg == 0.0) ? 1e-3 : fmin2(4.0 * reg, kRegMax);
             }
             reg = c.uni(reg);
             // ============ dual update (stage-parallel)
@@ -1653,6 +1744,9 @@ struct Solver {
                 nfail = 0;
             } else if (newwall) {
                 nfail = 0;
+                if (skipped_gn) gn_skip = 0;
+            } else if (skipped_gn) {
+                gn_skip = 0;      // (vii) no acceptable step with the regularised exact Hessian: Gauss-Newton first again, no strike
             } else if (++nfail >= 3) {
                 status_out = 4;
                 ++iter;

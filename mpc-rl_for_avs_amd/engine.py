@@ -21,6 +21,7 @@ FLAG_WARM_START = 8      # not in the reference: start from given / previous con
 FLAG_DETECT_ONLY = 16    # mpc_predict_batch: _check_collision alone (advance the detector records, no solve)
 FLAG_DETECTED = 32       # mpc_predict_batch: _solve after such a call for the same observation
 FLAG_THROUGHPUT = 64     # several batches in flight: always the build for four resident waves per SIMD
+FLAG_STRICT_DISCONTINUITY = 128   # a solve that ends on the d = 1 discontinuity of the collision cost is reported unsolved (status 8)
 
 STATUS_CONVERGED = 0
 STATUS_MAX_ITER = 1
@@ -28,11 +29,14 @@ STATUS_FACTORIZATION = 2
 STATUS_INFEASIBLE_START = 3
 STATUS_STALLED = 4
 STATUS_CONVERGED_ON_KINK = 5     # include/mpc_mi355x.h
+STATUS_ACCEPTABLE = 6            # IPOPT's "Solved To Acceptable Level" (acceptable_tol 1e-6 for 15 iterations; casadi: success)
+STATUS_ACCEPTABLE_ON_KINK = 7
+STATUS_KINK_UNSOLVED = 8         # FLAG_STRICT_DISCONTINUITY: would be 5 or 7, counted as not solved
 
 
 def converged(status):
-    """Solved to tolerance (0, or 5: on the d = 1 discontinuity of the collision cost)."""
-    return (status == STATUS_CONVERGED) | (status == STATUS_CONVERGED_ON_KINK)
+    """Solved (MPC_STATUS_IS_SOLVED): 0; 5 on the d = 1 discontinuity of the collision cost; 6 / 7 IPOPT's acceptable level."""
+    return (status == STATUS_CONVERGED) | ((status >= STATUS_CONVERGED_ON_KINK) & (status <= STATUS_ACCEPTABLE_ON_KINK))
 
 
 class EngineError(RuntimeError):
@@ -51,7 +55,7 @@ _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
             "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record", "mpc_rollout_finish", "mpc_eval_nlp"]
-ABI_VERSION = 6          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
+ABI_VERSION = 7          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
 MAX_OTHERS = 16
 _lib = None
 
@@ -189,9 +193,11 @@ class MPCEngine:
 
     # ------------------------------------------------------------------ host (numpy) path
     def solve_batch(self, state, ego_index, weights, is_collide, vref=None, others=None, collision_cost=False,
-                    want_trajectories=True, u_init=None):
+                    want_trajectories=True, u_init=None, strict_discontinuity=False):
         """Solve B instances given host arrays; returns dict(u0, U, X, status, iters).
-        u_init [B, N, 2] (optional, not in the reference): initial controls instead of the cold start."""
+        u_init [B, N, 2] (optional, not in the reference): initial controls instead of the cold start.
+        strict_discontinuity (MPC_FLAG_STRICT_DISCONTINUITY): a solve that ends on the d = 1 discontinuity of the collision
+        cost is reported as not solved (status 8) with its last iterate, as the reference's IPOPT would report it."""
         N = self.horizon
         state = np.ascontiguousarray(state, dtype=np.float64)
         if state.ndim != 2 or state.shape[1] != 4:
@@ -215,7 +221,7 @@ class MPCEngine:
         X = np.empty((B, N + 1, 4)) if want_trajectories else None
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
-        flags = FLAG_COLLISION_COST if collision_cost else 0
+        flags = (FLAG_COLLISION_COST if collision_cost else 0) | (FLAG_STRICT_DISCONTINUITY if strict_discontinuity else 0)
         if u_init is not None:
             U = np.array(u_init, dtype=np.float64, order="C")       # in: initial controls, out: solution
             if U.shape != (B, N, 2):
@@ -229,7 +235,7 @@ class MPCEngine:
 
     # ------------------------------------------------------------------ device (torch) path
     def solve_batch_torch(self, state, ego_index, weights, is_collide, vref=None, others=None,
-                          collision_cost=False, out=None, sync=False, throughput=False):
+                          collision_cost=False, out=None, sync=False, throughput=False, strict_discontinuity=False):
         """Zero-copy solve on torch CUDA(=HIP) tensors, enqueued on torch's current stream.
 
         dtypes: state/weights/vref/others float64, ego_index int32, is_collide uint8; all contiguous and on
@@ -250,7 +256,8 @@ class MPCEngine:
                        iters=torch.empty(B, dtype=torch.int32, device=dev))
         V = 0 if others is None else int(others.shape[1])
         flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC) | \
-            (FLAG_THROUGHPUT if throughput else 0)     # throughput: several batches in flight (MPC_FLAG_THROUGHPUT)
+            (FLAG_THROUGHPUT if throughput else 0) | \
+            (FLAG_STRICT_DISCONTINUITY if strict_discontinuity else 0)     # throughput: several batches in flight (MPC_FLAG_THROUGHPUT)
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = self._lib.mpc_solve_batch(self._h, B, p(state), p(ego_index), p(vref), p(weights), p(is_collide),
@@ -270,7 +277,8 @@ class MPCEngine:
         rc = self._lib.mpc_predict_batch(self._h, B, _ptr(obs), rows, None, None, FLAG_DETECT_ONLY, None, None, None, None)
         self._check(rc, "mpc_predict_batch")
 
-    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False, warm_start=False, detected=False):
+    def predict_batch(self, obs, weights, ref_speed=None, collision_cost=False, warm_start=False, detected=False,
+                      strict_discontinuity=False):
         """obs[B, vehicles_count, 8] float32 -> dict(act[B, 2], status, iters): parsing, collision detector (with the
         per-environment memory kept inside the engine), speed-profile rewrite and solve, all on the device.
         warm_start (not in the reference): each environment starts from its previous solution advanced one stage.
@@ -285,14 +293,14 @@ class MPCEngine:
         status = np.empty(B, dtype=np.int32)
         iters = np.empty(B, dtype=np.int32)
         flags = (FLAG_COLLISION_COST if collision_cost else 0) | (FLAG_WARM_START if warm_start else 0) | \
-            (FLAG_DETECTED if detected else 0)
+            (FLAG_DETECTED if detected else 0) | (FLAG_STRICT_DISCONTINUITY if strict_discontinuity else 0)
         rc = self._lib.mpc_predict_batch(self._h, B, _ptr(obs), rows, _ptr(weights), _ptr(rs), flags, _ptr(act),
                                          _ptr(status), _ptr(iters), None)
         self._check(rc, "mpc_predict_batch")
         return dict(act=act, status=status, iters=iters)
 
     def predict_batch_torch(self, obs, weights, ref_speed=None, collision_cost=False, out=None, sync=False,
-                            warm_start=False, throughput=False):
+                            warm_start=False, throughput=False, strict_discontinuity=False):
         """Zero-copy variant on torch device tensors (obs float32 [B, R, 8], weights float64 [B, 3], ref_speed float64
         [B] or None), enqueued on torch's current stream.  Returns dict(act, status, iters) of device tensors."""
         import torch
@@ -311,7 +319,8 @@ class MPCEngine:
                        status=torch.empty(B, dtype=torch.int32, device=dev),
                        iters=torch.empty(B, dtype=torch.int32, device=dev))
         flags = FLAG_DEVICE_PTRS | (FLAG_COLLISION_COST if collision_cost else 0) | (0 if sync else FLAG_NO_SYNC) | \
-            (FLAG_WARM_START if warm_start else 0) | (FLAG_THROUGHPUT if throughput else 0)   # several groups in flight
+            (FLAG_WARM_START if warm_start else 0) | (FLAG_THROUGHPUT if throughput else 0) | \
+            (FLAG_STRICT_DISCONTINUITY if strict_discontinuity else 0)   # throughput: several groups in flight
         p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rc = self._lib.mpc_predict_batch(self._h, B, p(obs), rows, p(weights), p(ref_speed), flags, p(out["act"]),

@@ -28,7 +28,22 @@ implementation of an interior-point filter line-search algorithm for large-scale
     zero (constr_mult_reset_threshold 0), mu is unchanged.  A restoration that cannot reduce the infeasibility ends the
     solve (status 5, IPOPT's "Restoration Failed" / "Converged to a point of local infeasibility").
 
-Not restated: the watchdog, the acceptable-level termination and the tiny-step logic.  It shares no solver code
+  * (round 5) the ACCEPTABLE-LEVEL TERMINATION (IpOptErrorConvCheck: acceptable_tol 1e-6, acceptable_iter 15,
+    acceptable_dual_inf_tol 1e10, acceptable_constr_viol_tol 1e-2, acceptable_compl_inf_tol 1e-2, acceptable_obj_change_tol
+    1e20 - all defaults, the reference sets none of them, agents/pure_mpc.py:291-296): the 15th consecutive iterate whose
+    scaled error is at most acceptable_tol ends the solve with status 3 ("Solved To Acceptable Level", which casadi reports
+    as success like "Solve Succeeded"); an iterate acceptable in that sense also turns a restoration failure or a tiny-step
+    exit into status 3, as IPOPT's `STOP_AT_ACCEPTABLE_POINT` does.  It cannot fire when tol >= acceptable_tol (the
+    reference's tol 1e-6: the regular test is met first);
+  * (round 5) the TINY-STEP logic (IpBacktrackingLineSearch::DetectTinyStep, tiny_step_tol 10 eps, tiny_step_y_tol 1e-2): a
+    search direction with max_i |dx_i| / (1 + |x_i|) below 10 eps at an iterate with constraint violation below 1e-4 is
+    taken without a line search (full fraction-to-the-boundary step); two such iterations in a row with |d lambda|_inf <
+    tiny_step_y_tol raise the tiny-step flag, which forces the next barrier update (MonotoneMuUpdate) even if the
+    barrier problem's error test is not met, and ends the solve with status 4 ("Search Direction Becomes Too Small",
+    a failure exit of nlpsol unless the point is acceptable) when mu cannot be lowered any more.
+
+Not restated: the watchdog (measured in round 5 on the engine's own globalisation, where it bought nothing: DESIGN.md
+section 2.1).  It shares no solver code
 with oracle/mpc_oracle.c or the HIP kernel (those factorise stage by stage; this one factorises the dense 208x208 KKT
 matrix), only the NLP functions of oracle/nlp_batch.py, which tests check against finite differences and - since round 4 -
 against the reference's own objective / constraint statements evaluated numerically (tests/test_reference_vectors.py).
@@ -40,8 +55,12 @@ import numpy as np
 
 import nlp_batch as nb
 
-STATUS = {0: "converged", 1: "max_iter", 2: "inertia correction failed", 5: "restoration failed / not restated",
+STATUS = {0: "converged", 1: "max_iter", 2: "inertia correction failed", 3: "solved to acceptable level",
+          4: "search direction becomes too small (tiny step)", 5: "restoration failed / not restated",
           6: "restoration converged to a point of local infeasibility"}
+ACCEPTABLE_TOL, ACCEPTABLE_ITER = 1e-6, 15
+ACCEPTABLE_DUAL_INF, ACCEPTABLE_CONSTR_VIOL, ACCEPTABLE_COMPL_INF = 1e10, 1e-2, 1e-2
+TINY_STEP_TOL, TINY_STEP_Y_TOL = 10.0 * np.finfo(np.float64).eps, 1e-2
 RHO_RESTO, KAPPA_RESTO, BOUND_MULT_RESET = 1000.0, 0.9, 1000.0
 
 
@@ -181,6 +200,11 @@ def _ipm(P, z, zL, zU, lam, mu, tol, max_iter, trace=False, exit_test=None, allo
     filt = []
     status, it, E0 = 1, 0, np.inf
     nb_cnt = int(fl.sum() + fu.sum())
+    n_acceptable = 0                  # consecutive acceptable iterates (IpOptErrorConvCheck::acceptable_counter_)
+    is_acceptable = False
+    tiny_last = False                 # the previous iteration's direction was tiny
+    tiny_flag = False                 # IpData().tiny_step_flag(): two tiny directions in a row
+    orig = isinstance(P, _OrigNLP)    # both rules belong to the regular method, not to the restoration subproblem
 
     def slack(zz):
         return np.where(fl, zz - lo, 1.0), np.where(fu, hi - zz, 1.0)
@@ -214,13 +238,32 @@ def _ipm(P, z, zL, zU, lam, mu, tol, max_iter, trace=False, exit_test=None, allo
         if E0 <= tol:
             status = 0
             break
+        if orig:
+            # acceptable level: the scaled error and the three unscaled parts (objective scaling sf <= 1 makes the scaled
+            # dual infeasibility / complementarity the smaller ones; their bounds 1e10 / 1e-2 are met a fortiori by E0 <= 1e-6)
+            comp0 = max(np.max((sL * zL)[fl], initial=0.0), np.max((sU * zU)[fu], initial=0.0))
+            is_acceptable = (E0 <= ACCEPTABLE_TOL and np.max(np.abs(rd)) / P.sf <= ACCEPTABLE_DUAL_INF
+                             and np.max(np.abs(c)) <= ACCEPTABLE_CONSTR_VIOL and comp0 / P.sf <= ACCEPTABLE_COMPL_INF)
+            n_acceptable = n_acceptable + 1 if is_acceptable else 0
+            if n_acceptable >= ACCEPTABLE_ITER:
+                status = 3
+                break
         if it >= max_iter:
             break
         changed = False
-        while E(mu) <= kap_eps * mu and mu > tol / 10.0:
+        force = tiny_flag                 # MonotoneMuUpdate: a tiny step asks for the next barrier problem regardless
+        tiny_flag = False
+        stop_tiny = False
+        while (E(mu) <= kap_eps * mu or force) and mu > tol / 10.0:
             mu = max(tol / 10.0, min(kap_mu * mu, mu ** th_mu))
             tau = max(0.99, 1.0 - mu)
             changed = True
+            force = False
+        if force and not changed:
+            stop_tiny = True              # "Problem solved to best possible numerical accuracy": mu cannot be lowered
+        if stop_tiny:
+            status = 3 if is_acceptable else 4
+            break
         if changed:
             filt = []
 
@@ -259,6 +302,25 @@ def _ipm(P, z, zL, zU, lam, mu, tol, max_iter, trace=False, exit_test=None, allo
             dzU = np.where(fu, mu / sU - zU + zU / sU * dx, 0.0)
             a_max = min(max_step(sL, dx, fl), max_step(sU, -dx, fu))
             a_z = min(max_step(zL, dzL, fl), max_step(zU, dzU, fu))
+
+            # ---- a tiny search direction is taken as it is (DetectTinyStep)
+            tiny = bool(orig and np.max(np.abs(dx) / (1.0 + np.abs(z))) <= TINY_STEP_TOL and np.max(np.abs(c), initial=0.0) <= 1e-4)
+            if tiny:
+                if tiny_last and np.max(np.abs(dlam), initial=0.0) < TINY_STEP_Y_TOL:
+                    tiny_flag = True
+                tiny_last = True
+                z = z + a_max * dx
+                lam = lam + a_max * dlam
+                zL = zL + a_z * dzL
+                zU = zU + a_z * dzU
+                sL, sU = slack(z)
+                zL = np.where(fl, np.maximum(np.minimum(zL, KSIG * mu / sL), mu / (KSIG * sL)), 0.0)
+                zU = np.where(fu, np.maximum(np.minimum(zU, KSIG * mu / sU), mu / (KSIG * sU)), 0.0)
+                it += 1
+                if trace:
+                    print(f"{tag}it {it:3d} mu {mu:.1e} E0 {E0:.3e} tiny step taken without line search")
+                continue
+            tiny_last = False
 
             # ---- filter line search
             dphi = float(gphi @ dx)
@@ -322,6 +384,9 @@ def _ipm(P, z, zL, zU, lam, mu, tol, max_iter, trace=False, exit_test=None, allo
         if need_resto:
             if not allow_resto or not isinstance(P, _OrigNLP):
                 status = 5 if d is not None else 2
+                break
+            if is_acceptable:                # IPOPT: "Restoration phase is called at acceptable point" -> STOP_AT_ACCEPTABLE_POINT
+                status = 3
                 break
             # ---- feasibility restoration phase (sec. 3.3)
             filt.append(((1 - gam_th) * theta, phi - gam_phi * theta))

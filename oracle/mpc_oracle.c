@@ -39,6 +39,9 @@
  * next node out of its bounds gets the control that decides it pulled back (PROJ_KEEP); a vehicle that a
  * rejected trial took across the d = 1 discontinuity of the collision cost becomes a wall constraint
  * |p - o|^2 >= 1 of that node (status 5 when it ends with a multiplier); four line-search trials.
+ * Round 5 (the iteration tail): IPOPT's inertia correction on the EXACT Hessian when the
+ * Gauss-Newton fallback stagnates; Newton steps below the resolution of the feedback law applied open loop; the projection
+ * floor lowered in the end-game; IPOPT's acceptable-level termination (status 6); the Levenberg-Marquardt term capped.
  * oracle_last_work() reports the iterations / sweeps / rollouts of the last call and their flops.
  */
 #include <math.h>
@@ -227,7 +230,9 @@ static double barrier_objective(const prob_t *p, const iter_t *it, double mu) {
 /* solve one instance.
  * status: 0 converged, 1 max_iter reached, 2 factorisation failure, 3 start not strictly feasible,
  *         4 stalled (no acceptable step in three consecutive iterations),
- *         5 converged with a vehicle held at the d = 1 discontinuity of the collision cost */
+ *         5 converged with a vehicle held at the d = 1 discontinuity of the collision cost,
+ *         6 IPOPT's "solved to acceptable level" (scaled KKT error <= 1e-6 in 15 consecutive iterations while tol is tighter),
+ *         7 the same with a vehicle held at d = 1 */
 static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit, int *iters_out, double *kkt_out) {
     const int N = p->N;
     const double dt = p->dt;
@@ -245,7 +250,11 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * more backtracks (or no acceptable step) multiply it by 4 (from 1e-3), a full first trial divides it by 4 (to 0
      * below 1e-3).  Without it instances on the nonconvex side of the heading wrap crawl with 1/64-steps for the whole
      * iteration budget. */
-    const double REG_MIN = 1e-3, REG_FACTOR = 4.0, REG_MAX = 1e6;
+    /* REG_MAX: 1e6 until round 4.  An instance that needs more than the curvature scale of the scaled problem (1) to get a
+     * step accepted crawls - alpha = 1/4 with the term at 16 for hundreds of iterations on BASELINE config 3's worst
+     * instances (368 iterations to converge; IPOPT's restated algorithm gives up on the same instance after 1000) - so the
+     * term stops at 1 and the line-search-failure exit (status 4) ends what cannot move. */
+    const double REG_MIN = 1e-3, REG_FACTOR = 4.0, REG_MAX = 1.0;
     /* the multiple of the identity the last inertia correction ended with (0: none yet in this solve).  Until round 3 every
      * correction climbed 1e-8, 1e-6, ... x 100 from scratch: with NEGATIVE cost weights (the v1 input domain: the RL action
      * clipped to [-1, 1], agents/ppo_mpc.py:407-417) the control block needs ~1e-2 in every iteration, the ladder ended at 1
@@ -258,7 +267,13 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * runs along theta = -pi (the reference heading of the exit straight IS the bound, base_agent.py:146-152 vs
      * pure_mpc.py:273) is infeasible until the step is tiny (2048 instances of config 2: 66 -> 10 with 40 iterations
      * or more, none left at the cap) */
-    const double PROJ_KEEP = 0.1;
+    const double PROJ_KEEP0 = 0.1;
+    /* ... and PROJ_KEEP_END of it once the barrier parameter is at most PROJ_END_MU: in the end-game a slack has to shrink by
+     * orders of magnitude to meet its multiplier, a projection that keeps 10 % per iteration turns the full Newton step into
+     * something the Armijo test rejects (the barrier objective RISES by 40 x the predicted decrease) and the solve closes with
+     * 15 - 20 steps of alpha = 1/4, the error falling by exactly 0.75 per iteration (round 4's trace of BASELINE config 2's
+     * slowest instances, egos on the exit straight with the heading next to its bound): 46 -> 34 iterations there */
+    const double PROJ_KEEP_END = 1e-3, PROJ_END_MU = 1e-6;
     /* no trial may bring a control or a bounded state nearer to its bound than this: late in a solve tau = 1 - mu lets a
      * slack shrink by the factor mu ~ 1e-9 per iteration, two such steps take a control at -5 below one ulp of its bound -
      * slack exactly 0, 1 / slack infinite, a NaN in the sweep that no regularisation repairs (status 2; seen on the GPU
@@ -266,6 +281,31 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * become too small are corrected). */
     const double MIN_SLACK = 1e-14;
     double reg = 0.0;
+    /* (vii) IPOPT's inertia correction on the exact Hessian when the Gauss-Newton fallback stagnates.  The Gauss-Newton model
+     * is convex: near a saddle point of the barrier problem (a stationary point with an indefinite reduced Hessian) its steps
+     * are attracted to the saddle, every one is accepted at full length with a predicted decrease of 1e-6, and the iterate
+     * drifts away along the unstable direction by 8 % per iteration - half of round 4's instances at the iteration cap.  A
+     * streak of iterations that needed the whole-sweep fallback is therefore watched: every GN_WATCH iterations of it the scaled
+     * KKT error must have halved; if it has not, the next GN_SKIP iterations of the streak go from the failed exact sweep straight
+     * to the exact Hessian + delta_w I ladder (Waechter & Biegler 2006, section 3.1, with its memory dw_last), whose step along a
+     * direction of negative curvature is long.  (Always skipping the Gauss-Newton model is much worse: mean 19.8 iterations.) */
+    const int GN_WATCH = 4, GN_SKIP = 4;
+    int gn_streak = 0, gn_skip = 0;
+    double e_streak = INFINITY;
+    /* (viii) a Newton step smaller than OPEN_LOOP_STEP in the states and the previous control of a stage is applied OPEN LOOP
+     * there (alpha times the linearised control step) instead of through the feedback law.  The feedback acts on the difference
+     * of two rolled-out trajectories, which carries the rounding of positions ~50 m (7e-15); times gains of 10 - 100 where a
+     * control and the state bound it decides are both active that is 5e-13 of noise in a control whose slack is 1e-9, and the
+     * dual infeasibility dithers at 1e-6 - 1e-5 for the rest of the iteration budget (round 4's cap-runners with a standing ego).
+     * The linearised step is a recursion on small numbers and keeps its relative precision; the two differ by O(step^2). */
+    const double OPEN_LOOP_STEP = 1e-9;
+    /* (ix) IPOPT's acceptable-level termination with IPOPT's defaults (acceptable_tol 1e-6, acceptable_iter 15; the
+     * acceptable_dual_inf / constr_viol / compl_inf tolerances 1e10 / 1e-2 / 1e-2 cannot bind once the scaled error is below
+     * 1e-6, acceptable_obj_change_tol 1e20 is off): live in the reference, which sets only max_iter, tol and print options
+     * (agents/pure_mpc.py:291-296).  It can end a solve only when tol < acceptable_tol, i.e. never at the reference's tol 1e-6. */
+    const double ACCEPTABLE_TOL = 1e-6;
+    const int ACCEPTABLE_ITER = 15;
+    int n_acceptable = 0;
 
     static _Thread_local double A[NMAX][4][4], Bm[NMAX][4][2];
     static _Thread_local double lxs[NMAX + 1][4], Qs[NMAX + 1][4][4], Qgs[NMAX + 1][4][4], lus[NMAX][2], lps[NMAX][2];
@@ -480,6 +520,15 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 if (it->wj[k] >= 0 && it->zw[k] > 1e-6 * p->sf) status = 5;
             break;
         }
+        if (o->tol < ACCEPTABLE_TOL) {
+            n_acceptable = (E0 <= ACCEPTABLE_TOL) ? n_acceptable + 1 : 0;
+            if (n_acceptable >= ACCEPTABLE_ITER) {
+                status = 6;
+                for (int k = 1; k < N; ++k)
+                    if (it->wj[k] >= 0 && it->zw[k] > 1e-6 * p->sf) status = 7;
+                break;
+            }
+        }
         if (iter == o->max_iter) break;
         if (g_stall_window > 0) {
             if (E0 < 0.5 * e_mark) {
@@ -496,7 +545,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
          * (no constraint curvature, radial part of the collision potential); should that fail numerically too, a
          * multiple of the identity is added. */
         double dV1 = 0.0, delta_w = reg;
-        int nmod = 0, ok = 0, gn = 0;
+        int nmod = 0, ok = 0, gn = 0, skipped_gn = 0;
         ++t_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
             ++t_cnt_sweep;
@@ -627,7 +676,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                 /* exact Hessian not positive definite on the null space: use the convex Gauss-Newton model for this
                  * iteration; if even that is numerically singular, add a small multiple of the identity */
                 ++nmod;
-                if (!gn) {
+                if (gn_skip > 0) skipped_gn = 1;
+                if (!gn && gn_skip == 0) {
                     gn = 1;
                 } else if (dw_last == 0.0) {
                     /* first inertia correction of this solve (IPOPT's algorithm IC: delta_w^0 = 1e-4, then x 100) */
@@ -646,6 +696,19 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             break;
         }
         if (delta_w > reg) dw_last = delta_w; /* the ladder was needed: remember where it ended */
+        if (nmod > 0) {
+            if (gn_streak == 0) e_streak = E0;
+            ++gn_streak;
+            if (gn_skip > 0) {
+                --gn_skip;
+            } else if (gn_streak % GN_WATCH == 0) {
+                if (E0 > 0.5 * e_streak) gn_skip = GN_SKIP;
+                e_streak = E0;
+            }
+        } else {
+            gn_streak = 0;
+            gn_skip = 0;
+        }
 
         /* ---------------- linear forward sweep: full primal-dual Newton step, step-length limits -------- */
         const double tau = fmax(0.99, 1.0 - mu);
@@ -694,6 +757,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
         }
 
         /* ---------------- nonlinear rollout with feedback, Armijo on the barrier objective ------------- */
+        const double PROJ_KEEP = (mu <= PROJ_END_MU) ? PROJ_KEEP_END : PROJ_KEEP0;
         double phi0 = barrier_objective(p, it, mu), alpha = a_pr, phi1 = phi0;
         int accepted = 0, nls = 0;
         int cross[NMAX + 1]; /* vehicle that a rejected trial took across d = 1 inwards (smallest slack), per node */
@@ -703,11 +767,19 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             ++t_cnt_roll;
             trial = *it;
             for (int k = 0; k < N && feas; ++k) {
+                double dmax = 0.0; /* size of the linearised step that reaches this stage */
+                for (int j = 0; j < 4; ++j) dmax = fmax(dmax, fabs(dxl[k][j]));
+                if (k >= 1)
+                    for (int j = 0; j < 2; ++j) dmax = fmax(dmax, fabs(dul[k - 1][j]));
                 for (int i = 0; i < 2; ++i) {
                     double s = alpha * kf[k][i];
-                    for (int j = 0; j < 4; ++j) s += Kx[k][i][j] * (trial.x[k][j] - it->x[k][j]);
-                    if (k >= 1)
-                        for (int j = 0; j < 2; ++j) s += Kp[k][i][j] * (trial.u[k - 1][j] - it->u[k - 1][j]);
+                    if (dmax < OPEN_LOOP_STEP) {
+                        s = alpha * dul[k][i];
+                    } else {
+                        for (int j = 0; j < 4; ++j) s += Kx[k][i][j] * (trial.x[k][j] - it->x[k][j]);
+                        if (k >= 1)
+                            for (int j = 0; j < 2; ++j) s += Kp[k][i][j] * (trial.u[k - 1][j] - it->u[k - 1][j]);
+                    }
                     trial.u[k][i] = it->u[k][i] + s;
                     /* control bounds: clamp each component to the fraction-to-the-boundary box instead of
                      * shortening the whole step (saturated accelerations would otherwise jam every iteration) */
@@ -785,6 +857,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             reg = (reg == 0.0) ? REG_MIN : fmin(REG_FACTOR * reg, REG_MAX);
         }
         nfail = accepted ? 0 : nfail + 1;
+        if (!accepted && skipped_gn) {
+            /* (vii) the step of the regularised exact Hessian was not acceptable at any length: the next iteration starts with
+             * the Gauss-Newton fallback again, and this one does not count towards the line-search-failure exit */
+            gn_skip = 0;
+            --nfail;
+        }
         /* ---------------- dual step: multipliers that shrink share one fraction-to-the-boundary length, multipliers
          *                  that grow (no positivity issue) take the full Newton step ---------------- */
         for (int k = 1; k <= N; ++k)

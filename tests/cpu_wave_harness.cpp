@@ -66,6 +66,7 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     P.N = N; P.V = Vuse; P.max_iter = max_iter; P.dt = dt; P.tol = tol; P.mu_init = 0.1;
     P.w_distance = w_distance;
     P.stall_window = g_stall_window;
+    P.strict_kink = 0;
     const bool pre = !g_split;   // HostCtx (fused linear step, precomputed trial bounds) or HostCtxSplit (neither)
     const int SL = mpc::wave::stage_slots(cc, pre);
     const int nd = mpc::wave::lds_doubles(cc, N, Vuse, pre);

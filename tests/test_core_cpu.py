@@ -105,22 +105,23 @@ def test_heading_on_the_bound(cpu_core, oracle, ref_table):
 
 def test_stall_window_guard(cpu_wave, oracle, ref_table):
     """mpc_config.stall_window (off by default): a solve whose KKT error has not halved within W iterations ends with
-    status 4.  Host build of the kernel source == oracle, instances that converge quickly are untouched, and the batch no
-    longer waits for the one instance in a thousand that runs to the reference's max_iter 1000."""
+    status 4.  Host build of the kernel source == oracle, instances that converge quickly are untouched.  (Until round 4 the
+    slowest instances of this batch ran to the reference's max_iter 1000 and W = 64 was what bounded a batch; with round 5's
+    globalisation - DESIGN.md section 2 (vii) - (x) - the slowest needs 150 iterations, so the guard is exercised with W = 32.)"""
     from mpc_rl_for_avs_amd import synth
     from conftest import converged
     inp = synth.solver_inputs(4096, 8, seed=0)
-    # the slowest instances of the batch (known from profiles/r03_tail.txt) and a random handful
-    sel = np.array([3526, 1655, 550, 1611, 2211, 4075, 3123] + list(range(0, 200, 8)))
+    # the slowest instances of the batch at max_iter 1000 (tools/tail_study.py) and a random handful
+    sel = np.array([3424, 1037, 3543, 965, 1611, 2461, 1655, 3000] + list(range(0, 200, 8)))
     sub = {k: (v[sel] if v is not None else None) for k, v in inp.items() if k in ("state", "ego_index", "weights", "is_collide", "vref", "others")}
     kw = dict(collision_cost=True, max_iter=1000)
     free = oracle.solve_batch(ref_table, sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=sub["vref"],
                               others=sub["others"], xy_bounds=False, **kw)
     guard = oracle.solve_batch(ref_table, sub["state"], sub["ego_index"], sub["weights"], sub["is_collide"], vref=sub["vref"],
-                               others=sub["others"], xy_bounds=False, stall_window=64, **kw)
-    got = cpu_wave(ref_table, sub, stall_window=64, **kw)
-    assert free["iters"].max() == 1000 and guard["iters"].max() < 250
-    quick = free["iters"] <= 60
+                               others=sub["others"], xy_bounds=False, stall_window=32, **kw)
+    got = cpu_wave(ref_table, sub, stall_window=32, **kw)
+    assert 100 < free["iters"].max() <= 200 and guard["iters"].max() <= 64
+    quick = free["iters"] <= 30
     assert np.array_equal(guard["status"][quick], free["status"][quick]) and np.array_equal(guard["iters"][quick], free["iters"][quick])
     assert (guard["status"][~quick] == 4).sum() >= 3
     assert np.array_equal(got["status"], guard["status"])

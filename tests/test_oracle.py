@@ -139,8 +139,12 @@ def test_oracle_warm_start_reaches_the_same_solution_in_fewer_iterations(oracle,
 
 # scenario -> (proxy converged, engine's algorithm converged, both, of those within 1e-4); profiles/r04_parity_vs_ipopt.txt
 # classifies every other instance (two certified minima / proxy's failure exit / engine fails at tol 1e-8)
+# (round 5: the same 960 closed-loop states as round 4 - make_closed_loop.py --keep-states - with round 5's globalisation:
+# c4cc 155 -> 154 and c4v1 122 -> 121, two instances on which the regularised exact Hessian of DESIGN.md section 2 (vii) takes
+# the iterate to another certified local minimiser than the Gauss-Newton fallback did; 867 / 58 / 0 / 32 / 3 in the classes of
+# profiles/r05_parity_vs_ipopt.txt against 869 / 56 / 0 / 32 / 3)
 CLOSED_LOOP_COUNTS = {"c1": (144, 158, 142, 138), "c1cc": (146, 160, 146, 138), "c4": (160, 160, 160, 160),
-                      "c4mpc": (160, 160, 160, 156), "c4cc": (158, 160, 158, 155), "c4v1": (160, 159, 159, 122)}
+                      "c4mpc": (160, 160, 160, 156), "c4cc": (158, 160, 158, 154), "c4v1": (160, 159, 159, 121)}
 
 
 def test_closed_loop_fixtures_agreement_is_what_the_profile_says(oracle, ref_table):
@@ -158,9 +162,10 @@ def test_closed_loop_fixtures_agreement_is_what_the_profile_says(oracle, ref_tab
                                others=d["others"], collision_cost=name.endswith("cc"), max_iter=1000, xy_bounds=False)
         assert np.array_equal(o["status"], g[f"{name}_oracle_status"])
         assert rel_u0_err(o["u0"], g[f"{name}_oracle_u0"]).max() < 1e-9
-        both = (g[f"{name}_status"] == 0) & converged(o["status"])
+        ipok = (g[f"{name}_status"] == 0) | (g[f"{name}_status"] == 3)       # 3: IPOPT's "solved to acceptable level"
+        both = ipok & converged(o["status"])
         agree = both & (rel_u0_err(o["u0"], g[f"{name}_u0"]) <= 1e-4)
-        got = (int((g[f"{name}_status"] == 0).sum()), int(converged(o["status"]).sum()), int(both.sum()), int(agree.sum()))
+        got = (int(ipok.sum()), int(converged(o["status"]).sum()), int(both.sum()), int(agree.sum()))
         assert got == counts, (name, got)
     w = g["c4v1_weights"]
     assert (w < 0).any(axis=1).sum() >= 120 and (w < 0).all(axis=1).sum() >= 30      # the v1 domain incl. all-negative rows

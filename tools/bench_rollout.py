@@ -109,7 +109,7 @@ def main():
                               envs=total, n_gpus=world, distributed=dist_info, graph_fallback_reason=cols[0].graph_fallback_reason, fused_glue=cols[0].fused_glue, groups=G, graph=bool(graph), env_backend=cols[0].env.backend,
                               steps_per_env=a.steps, env_steps_per_s=total * a.steps / dt, ms_per_step=dt / a.steps * 1e3,
                               mpc_ms_per_step=(dm / a.steps * 1e3) if events else None, episodes=stats["episodes"], crashed=stats["crashed"],
-                              arrived=stats["arrived"], converged_frac=float(((st == 0) | (st == 5)).mean()),
+                              arrived=stats["arrived"], converged_frac=float(((st == 0) | ((st >= 5) & (st <= 7))).mean()),
                               converged_frac_rollout=1.0 - stats["mpc_unconverged"] / float(total * a.steps) * world)), flush=True)
         for e_g in engs:
             e_g.close()

@@ -33,7 +33,7 @@ typ = int(np.argmin(np.abs(it - np.median(it))))
 for name, i in (("typical", typ), ("straggler", strag)):
     ms, s1, i1 = run(1, 8, 1, idx=[i])
     print(f"lone wave, {name} instance {i}: {ms*1e3:.0f} us / {i1[0]} iterations = {ms*1e3/max(i1[0],1):.1f} us per iteration (status {s1[0]})")
-conv = ((st == 0) | (st == 5)).mean()
+conv = ((st == 0) | ((st >= 5) & (st <= 7))).mean()
 print(f"config 3 B=4096: {full_ms:.3f} ms -> {4096/full_ms*1e3:.0f} solves/s, converged {conv:.4f}, iters mean {it.mean():.2f} p99 {np.percentile(it,99):.0f} max {it.max()}")
 for mi in (40, 60):
     ms, s2, i2 = run(4096, 8, 1, max_iter=mi)

@@ -28,7 +28,7 @@ for cc in (False, True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     st = out["status"].cpu().numpy()
-    print(f"predict_batch B={B} V=9 cc={int(cc)}: {dt * 1e3:.2f} ms/call -> {B / dt:.0f} env-steps/s, converged {np.mean((st == 0) | (st == 5)):.4f}")
+    print(f"predict_batch B={B} V=9 cc={int(cc)}: {dt * 1e3:.2f} ms/call -> {B / dt:.0f} env-steps/s, converged {np.mean((st == 0) | ((st >= 5) & (st <= 7))):.4f}")
 # host-pointer call (PCIe-inclusive)
 o = obs.cpu().numpy()
 wn = np.ones((B, 3))

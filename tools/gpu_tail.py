@@ -35,7 +35,7 @@ print("seed max_iter tol      ms     solves/s  converged  st0    st5    st1  st2
 for seed in (0, 1, 2):
     for max_iter, tol in ((60, 1e-8), (100, 1e-8), (200, 1e-8), (1000, 1e-8), (100, 1e-6), (1000, 1e-6)):
         ms, st, it = run(seed, max_iter, tol, reps=5 if max_iter <= 200 else 3)
-        conv = (st == 0) | (st == 5)
+        conv = (st == 0) | ((st >= 5) & (st <= 7))
         c = lambda s: int((st == s).sum())
         pc = np.percentile(it, [50, 90, 99, 99.9])
         print(f"{seed:4d} {max_iter:8d} {tol:.0e} {ms:7.3f} {B / ms * 1e3:10.0f}  {conv.mean():.5f}  {c(0):5d} {c(5):5d} {c(1):5d} "
@@ -48,7 +48,7 @@ for seed in (0, 1, 2):
         cut = st_c == 1
         st_f, it_f = keep[f"s{seed}_m1000_t1e-08_status"][cut], keep[f"s{seed}_m1000_t1e-08_iters"][cut]
         print(f"     seed {seed}: {int(cut.sum())} instances at cap {cap} -> with cap 1000: "
-              f"{int(((st_f == 0) | (st_f == 5)).sum())} converge (iterations {sorted(it_f[(st_f == 0) | (st_f == 5)].tolist())}), "
+              f"{int(((st_f == 0) | ((st_f >= 5) & (st_f <= 7))).sum())} converge (iterations {sorted(it_f[(st_f == 0) | ((st_f >= 5) & (st_f <= 7))].tolist())}), "
               f"{int((st_f == 4).sum())} stall (status 4), {int((st_f == 1).sum())} still running at 1000, {int((st_f == 2).sum())} status 2")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "tail_iters.npz"), **keep)

@@ -97,6 +97,7 @@ extern "C" int wave_sections(int B, int V, int cc, int max_iter, const double *r
     P.tol = 1e-8;
     P.mu_init = 0.1;
     P.stall_window = 0;
+    P.strict_kink = 0;
     P.w_distance = 10.0;
     const size_t lds = (size_t)(mpc::wave::lds_doubles(cc != 0, 20, P.V, (PROF_RELAX & 8) != 0) + mpc::wave::T_COUNT) * sizeof(double);
     if (cc) {
