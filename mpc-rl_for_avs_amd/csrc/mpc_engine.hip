@@ -46,21 +46,18 @@ int fail(int code, const std::string &msg) {
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
 constexpr int kMaxDevices = 64;
-// Waves per SIMD the wave-cooperative kernel is compiled for.  The compile-time-horizon builds fit 128 VGPRs without
-// scratch (the constants of the solve live in an LDS table, not in registers: mpc_wave.hpp) and an instance needs 9.9 KB
-// of LDS at N = 20 with the collision cost and 8 vehicles, so 16 waves share a CU: all 4096 waves of a BASELINE batch
-// are resident at once and a straggler never starts late.  The runtime-horizon build would spill at 128 and stays at 3.
-constexpr int kWaveOcc = 4, kWaveOccGeneric = 3;
-// The build for batches that do not keep the SIMDs four deep in work (WaveOpsT<RELAX>, mpc_wave_dev.hpp): occupancy 2, up to
-// 256 registers (218 used), fresh() / opaque() the identity (everything hoisted), the linearised step fused into the rollout
-// loop (bit 2) and the trial bounds precomputed per line search (bit 3: 12 more LDS words per stage): 20 % less time per
-// iteration for a wave that has its SIMD to itself.  Used up to FOUR waves per SIMD of batch depth (B <= 4096 on 256 CUs:
-// every BASELINE configuration): two are resident, the rest of a 4096 batch is dispatched as slots free, which also balances
-// the SIMDs better than static residents, and the stragglers a batch ends with run at the lone-wave rate.  (Until round 4
-// a third, 168-register build served 2048 < B <= 4096; with round 4's Riccati sweep the latency build is 3 - 6 % faster
-// there at cap 100 and level at caps 40 / 60: profiles/r04_sweep4.txt.)
+// Waves per SIMD the wave-cooperative kernel is compiled for.  Since round 5 an instance needs 15.2 KB of LDS at N = 20 with
+// the collision cost and 8 vehicles (the F[c][i] table and the PQ table of the row-cooperative rollout, mpc_wave.hpp), i.e. 10
+// instances per CU: the throughput build is compiled for 3 waves per SIMD (168 registers, no scratch), which is what LDS
+// admits anyway.  (Rounds 2 - 4: 9.9 KB, 128 registers, 4 per SIMD.)
+constexpr int kWaveOcc = 3, kWaveOccGeneric = 3;
+// The build for batches that do not keep the SIMDs deep in work (WaveOpsT<RELAX>, mpc_wave_dev.hpp): occupancy 2, up to 256
+// registers, fresh() / opaque() the identity (everything hoisted): less time per iteration for a wave that has its SIMD to
+// itself.  Used up to FOUR waves per SIMD of batch depth (B <= 4096 on 256 CUs: every BASELINE configuration): two are
+// resident, the rest of a 4096 batch is dispatched as slots free, which also balances the SIMDs better than static residents,
+// and the stragglers a batch ends with run at the lone-wave rate.
 constexpr int kWaveOccLat = 2, kLatDepth = 4;
-constexpr int kRelaxLat = 7 | 8;
+constexpr int kRelaxLat = 7;
 
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative kernel: ONE wave64 per instance (mpc_wave.hpp); workgroup = 1 wave, grid = B
@@ -132,7 +129,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
     if (nveh) P.V = min(P.V, max(0, nveh[b]));   // vehicles actually present in this instance
     const int lane = threadIdx.x;
-    constexpr int SL = mpc::wave::stage_slots(CC, (RELAX & 8) != 0);
+    constexpr int SL = mpc::wave::stage_slots(CC);
     WaveCtx<NC, RELAX> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
     stage_problem<CC>(ctx, P, b, lane, N, SL, ref5, M, vref, others, Vin);
     __syncthreads();
@@ -253,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void mpc_eval_kernel(mpc::SolveParams P, in
     extern __shared__ double smem[];
     const int N = P.N, b = blockIdx.x, lane = threadIdx.x;
     if (b >= B) return;
-    constexpr int SL = mpc::wave::stage_slots(CC, false);
+    constexpr int SL = mpc::wave::stage_slots(CC);
     WaveCtx<0, 0> ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M);
     stage_problem<CC>(ctx, P, b, lane, N, SL, ref5, M, vref, others, Vin);
     for (int node = lane; node <= N; node += kBlock) {
@@ -582,7 +579,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
                 uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters,
                 const int32_t *d_order) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC, RELAX>;
-    const size_t lds = (size_t)mpc::wave::lds_doubles(CC, P.N, P.V, (RELAX & 8) != 0) * sizeof(double);
+    const size_t lds = (size_t)mpc::wave::lds_doubles(CC, P.N, P.V) * sizeof(double);
     // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
     // capture (hipGraph) of the launch
     static std::atomic<size_t> lds_set[kMaxDevices];      // zero-initialised; concurrent callers at worst both set it
@@ -798,10 +795,10 @@ int mpc_set_reference(mpc_handle *h, const double *ref, int32_t M) {
 
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V) {
     if (!h || B < 0 || V < 0 || V > MPC_MAX_OTHERS) return -1;
-    // the builds for batches up to kWaveOcc waves per SIMD deep keep 12 more words per stage (dispatch_solve, kPreBounds)
+    // every build of the solve kernel has the same LDS layout since round 5 (mpc_wave.hpp: lds_doubles)
     const int N = h->cfg.horizon;
-    const bool pre = (N == 20 || N == 16) && (B <= kWaveOccLat * 4 * h->num_cu || (V > 0 && B <= kWaveOcc * 4 * h->num_cu));
-    return (int64_t)mpc::wave::lds_doubles(V > 0, N, V, pre) * (int64_t)sizeof(double);
+    (void)B;
+    return (int64_t)mpc::wave::lds_doubles(V > 0, N, V) * (int64_t)sizeof(double);
 }
 
 int mpc_solve_batch(mpc_handle *h, int32_t B, const double *state, const int32_t *ego_index, const double *vref,
@@ -1457,7 +1454,7 @@ int mpc_eval_nlp(mpc_handle *h, int32_t B, const int32_t *ego_index, const doubl
     HIP_TRY(hipMemcpyAsync(sb + o_X, X, (size_t)B * N1 * 4 * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(sb + o_U, U, (size_t)B * N * 2 * 8, hipMemcpyHostToDevice, stream));
     mpc::SolveParams P = solve_params(h, cc ? V : 0);
-    const size_t lds = (size_t)mpc::wave::lds_doubles(cc, N, P.V, false) * sizeof(double);
+    const size_t lds = (size_t)mpc::wave::lds_doubles(cc, N, P.V) * sizeof(double);
     auto D = [&](size_t o) { return reinterpret_cast<double *>(sb + o); };
     if (cc)
         hipLaunchKernelGGL(mpc_eval_kernel<true>, dim3((unsigned)B), dim3(kBlock), lds, stream, P, (int)B, h->d_ref, h->M,

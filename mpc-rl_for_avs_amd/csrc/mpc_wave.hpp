@@ -84,44 +84,50 @@ constexpr double kInitPush = 1e-2;
 enum : int {
     W_X = 0,     // 4 (buffer 0; buffer 1 at +6)
     W_U = 4,     // 2
-    W_LIN = 12,  // 8  stage linearisation of the current trajectory: a02 a03 a12 a13 a23 b01 b11 b21
-    W_ZXL = 20,  // 2
-    W_ZXU = 22,  // 2
-    W_ZUL = 24,  // 2
-    W_ZUU = 26,  // 2
-    W_Y = 28,    // 4  node gradient g_k, then adjoint y_k; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
-    W_KX = 32,   // 8
-    W_KP = 40,   // 3
-    W_KF = 43,   // 2
-    W_RV = 45,   // 1
+    // stage linearisation of the current trajectory as the 4 x 4 table F[c][i] at W_LIN + 5 c + i: row i = state component
+    // (x, y, theta, v), column c = what it is multiplied with (d theta, d v, d a, d delta); a fifth entry per column is 0.
+    // In this form lane 8 + i of a rollout row reads row i with four loads at the SAME offsets from its own base (round 5:
+    // row-cooperative rollout, see rollouts()); the zeros and dt are written with the rest by the preparation phase.
+    W_LIN = 12,  // 20
+    W_ZXL = 32,  // 2
+    W_ZXU = 34,  // 2
+    W_ZUL = 36,  // 2
+    W_ZUU = 38,  // 2
+    W_Y = 40,    // 4  node gradient g_k, then adjoint y_k; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
+    // gains, TRANSPOSED since round 5 so that the two control lanes of a rollout row read their rows at the same offsets:
+    // Kx[i][j] at W_KX + 2 j + i, Kp[i][j] at W_KP + 2 j + i, kf[i] at W_KF + i - contiguous, 14 words
+    W_KX = 44,   // 8
+    W_KP = 52,   // 4
+    W_KF = 56,   // 2
+    W_RV = 58,   // 1
     // The stage stride is kept ODD: lane k of a stage-parallel phase addresses word k * stride + slot, and with 64 LDS
     // banks of 4 bytes an even number of doubles per stage puts every 4th (56 slots) or 16th (46, 54 slots) stage on the
     // same banks - measured with 56 slots: SQ_LDS_BANK_CONFLICT 17 % of the LDS cycles, against 3 % in round 1.
-    W_TE = 46,   // 4  (variant without the collision cost) states of line-search trial 2, see trial_x / trial_u
-    W_SLOTS = 51,
-    W_LX = 46,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
-    W_Q = 48,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
-    W_QG = 51,   // 3  its Gauss-Newton part
-    W_ZW = 54,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
-    W_WJ = 55,   // 1  its vehicle j (as a double), -1: none
-    W_CROSS = 56,  // 1  after the line search: vehicle a rejected trial took across d = 1 (also keeps the stride odd)
-    W_SLOTS_CC = 57
+    W_SLOTS = 59,
+    W_LX = 59,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
+    W_Q = 61,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
+    W_QG = 64,   // 3  its Gauss-Newton part
+    W_ZW = 67,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
+    W_WJ = 68,   // 1  its vehicle j (as a double), -1: none
+    W_CROSS = 69,  // 1  after the line search: vehicle a rejected trial took across d = 1
+    W_SLOTS_CC = 71   // (one spare word keeps the stride odd)
 };
+// positions in the W_LIN table of the eight values that are not structural constants, and of dt
+enum : int { LIN_A02 = 0, LIN_A12 = 1, LIN_A03 = 5, LIN_A13 = 6, LIN_A23 = 7, LIN_DT = 13, LIN_B01 = 15, LIN_B11 = 16, LIN_B21 = 17 };
 // parked values (valid between the factorisation and the next preparation phase)
 enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1 };
 // The four trial trajectories of the line search (x 4, u 2 per node, stage stride like everything else) live in slots
-// that are dead while the line search runs, so that an instance fits in 10 KB of LDS and 16 waves share a CU:
+// that are dead while the line search runs, so that an instance does not pay 24 more words per stage for them:
 //   trial 0  the spare trajectory buffer (the accepted trial ends up there)
 //   trial 1  W_LIN + 0..5          the linearisation is recomputed by the next preparation phase
-//   trial 2  x: W_Q + 2 .. W_QG + 2 (collision-cost variant: curvatures, recomputed likewise) resp. W_TE; u: W_LIN + 6, 7
-//   trial 3  W_KX + 0..5           the gains of stage k have been read by all four trials (one wave, program order) when
+//   trial 2  W_LIN + 10..15        likewise
+//   trial 3  W_KX + 0..5           the gains of stage k have been read by every lane (one wave, program order) when
 //                                  the stage's results are stored; nothing after the rollout reads gains
 // trial_x(t) is the slot of element 0, trial_u(t) the slot of element 4 minus 4: element e of node k sits at
-// k * stride + (e < 4 ? trial_x : trial_u) + e.  (The host model runs the lanes of a phase one after the other: trial 3,
-// the only one that overwrites something the others read, is the last lane.)
+// k * stride + (e < 4 ? trial_x : trial_u) + e.
 static_assert(kTrials == 4, "the trial areas below are laid out for four trials");
-MPC_HD constexpr int trial_x(bool cc, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? (cc ? W_Q + 2 : W_TE) : W_KX)); }
-MPC_HD constexpr int trial_u(bool cc, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 2 : W_KX)); }
+MPC_HD constexpr int trial_x(bool, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 10 : W_KX)); }
+MPC_HD constexpr int trial_u(bool cc, int t, int TB) { return trial_x(cc, t, TB); }
 // scratch behind the stage arrays: the three constants the F operands are made of besides the linearisation values
 enum : int {
     SC_SPARE = 0,  // 0.0, 1.0, dt
@@ -143,24 +149,22 @@ enum : int {
     A_HV5 = W_U    // + trial buffer offset
 };
 
-// CTX::kPreBounds = true (the builds for batches that leave LDS to spare: up to 12 instances per CU): the bounds a trial
-// rollout applies at stage k that do not depend on the trial - the fraction-to-the-boundary box of the two controls, the
-// projection box of theta / v of the next node and the four feasibility margins, 40 FP64 operations per stage of the
-// serial loop - are computed once per line search, stage-parallel, into kPreSlots extra words per stage (B_* below) and
-// only loaded in the loop.  Same expressions, same results.
-constexpr int kPreSlots = 12;
-enum : int { B_ULO0 = 0, B_UHI0, B_ULO1, B_UHI1, B_VLO, B_VHI, B_TLO, B_THI, B_M2LO, B_M2HI, B_M3LO, B_M3HI };
-template <class CTX, class = void>
-struct pre_bounds { static constexpr bool value = false; };
-template <class CTX>
-struct pre_bounds<CTX, decltype((void)CTX::kPreBounds)> { static constexpr bool value = CTX::kPreBounds; };
+// What a trial rollout applies at stage k that does not depend on the trial - the fraction-to-the-boundary box of the two
+// controls, the projection box of theta / v of the next node, the feasibility margins and the previous control of the current
+// iterate - is computed once per line search, stage-parallel, into kPreSlots words per stage behind the stage's own slots
+// (round 3: 12 words, only in the builds with LDS to spare; round 5: every build, laid out for the row-cooperative rollout).
+// PQ[m][j] at 4 m + j: the quadruple m of lane 2 + j of a rollout row (j = 0: theta, 1: v, 2: a, 3: delta)
+//     m = 0, 1   theta, v: feasibility margin at the lower / upper bound        a, delta: lower / upper edge of the clamp box
+//     m = 2, 3   theta: projection box of the next node; a: box that keeps v of the next node inside ITS projection box;
+//                v, delta: none (-kNoBound, +kNoBound)
+// PC[i] at 16 + i: control i of stage k - 1 of the current iterate (0 at stage 0)
+constexpr int kPreSlots = 18;
+enum : int { PQ = 0, PC = 16 };
+constexpr double kNoBound = 1e300;
 
-// (12 more words keep the stage stride odd: 57 -> 69, 51 -> 63)
-MPC_HD constexpr int stage_slots(bool cc, bool pre = false) { return (cc ? W_SLOTS_CC : W_SLOTS) + (pre ? kPreSlots : 0); }
+MPC_HD constexpr int stage_slots(bool cc) { return (cc ? W_SLOTS_CC : W_SLOTS) + kPreSlots; }
 // doubles of LDS one instance needs: stage arrays + constants + other vehicles
-MPC_HD constexpr int lds_doubles(bool cc, int N, int V, bool pre = false) {
-    return stage_slots(cc, pre) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0);
-}
+MPC_HD constexpr int lds_doubles(bool cc, int N, int V) { return stage_slots(cc) * (N + 1) + SC_SIZE + (cc ? 4 * V : 0); }
 
 // section ids for CTX::tick (cycle attribution in tools/ubench/wave_sections.hip; a no-op in the product kernel)
 enum : int {
@@ -173,14 +177,6 @@ template <class CTX, class = void>
 struct fine_ticks { static constexpr bool value = false; };
 template <class CTX>
 struct fine_ticks<CTX, decltype((void)CTX::kFine)> { static constexpr bool value = CTX::kFine; };
-
-// CTX::kFuseLinear = true: the linearised Newton step runs inside the rollout loop of the line search (two independent
-// dependency chains in one instruction stream: for a wave that is alone on its SIMD); false / absent: in its own loop in
-// front of the line search (fewer live registers: for the builds that share a SIMD).  Same arithmetic either way.
-template <class CTX, class = void>
-struct fuse_linear { static constexpr bool value = false; };
-template <class CTX>
-struct fuse_linear<CTX, decltype((void)CTX::kFuseLinear)> { static constexpr bool value = CTX::kFuseLinear; };
 
 // A value that differs per lane and lives across phases: one register per lane on the device; the host emulation,
 // which runs the lanes of a phase one after the other, keeps all 64.
@@ -290,7 +286,7 @@ struct Solver {
     MPC_HD double WCOLL() const { return c.fresh(wcoll); }
 
     MPC_HD Solver(const SolveParams &P_, CTX &c_, const double *x0_, double ws, double wc, double wd, double wcl)
-        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC, pre_bounds<CTX>::value)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
+        : P(P_), c(c_), N(CTX::kN > 0 ? CTX::kN : P_.N), SL(stage_slots(CC)), SCR(SL * (N + 1)), OTH(SCR + SC_SIZE),
           dt(P_.dt), ws_(c_.uni(ws)), wc_(c_.uni(wc)), wd_(c_.uni(wd)), wcoll(c_.uni(wcl)) {
         x0[0] = x0_[0]; x0[1] = x0_[1]; x0[2] = x0_[2]; x0[3] = x0_[3];
     }
@@ -322,19 +318,28 @@ struct Solver {
     }
 
     PerLane<double> red_a, red_b, red_c, red_w;   // per-lane operands of the wave reductions
-    PerLane<int> ls_feas;                  // line search: lane t = trial t stayed inside the fraction-to-the-boundary box
+    PerLane<int> ls_feas;                  // line search: the lanes of row t = trial t stayed inside the fraction-to-the-boundary box
     // d = 1 discontinuity of the collision cost (archive/pure_mpc.py:189-196: 100/d^2 outside, 1000/d^2 inside).  A
     // vehicle that a rejected trial took across d = 1 inwards is kept outside from then on by the constraint
     // |p_k - o_jk|^2 - 1 >= 0 of that node (one per node, multiplier W_ZW): the cost jumps upwards there, so a minimiser
     // pressed against d = 1 is a constrained stationary point of the outer branch (status 5), which no smooth method
     // reaches otherwise (round 1: 3.7 % of the config-3 instances ended "stalled").  any_wall: some node has one.
     int any_wall = 0;
-    // (viii) stages whose linearised step is below kOpenLoopStep, bit k = stage k: written by the linearised pass of the builds
-    // that run it in front of the line search (wave-uniform, scalar registers); the fused builds decide inside the rollout loop
-    unsigned long long ol_mask = 0;
     MPC_HD int f_word(int r, int c) const {
-        return stage_transition_word(r, c, W_LIN, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
-                                     -(SCR + SC_SPARE + 2 + 1));
+        // stage_transition_word() names the eight stored values lin + 0..7 = a02 a03 a12 a13 a23 b01 b11 b21; here they sit in
+        // the F[c][i] table of W_LIN
+        const int w = stage_transition_word(r, c, 0, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
+                                            -(SCR + SC_SPARE + 2 + 1));
+        int t = w;
+        t = w == 0 ? W_LIN + LIN_A02 : t;
+        t = w == 1 ? W_LIN + LIN_A03 : t;
+        t = w == 2 ? W_LIN + LIN_A12 : t;
+        t = w == 3 ? W_LIN + LIN_A13 : t;
+        t = w == 4 ? W_LIN + LIN_A23 : t;
+        t = w == 5 ? W_LIN + LIN_B01 : t;
+        t = w == 6 ? W_LIN + LIN_B11 : t;
+        t = w == 7 ? W_LIN + LIN_B21 : t;
+        return t;
     }
     // ================================================================================================================
     // Riccati / DDP sweep on 4x4 blocks (round 4).  The stage matrix F = [A B; 0 I] has structure the 8x8 form above does
@@ -386,7 +391,7 @@ struct Solver {
             r_m.at(lane_) = (hi == 0 && lo == 0) ? A_H66 : ((hi == 1 && lo == 1) ? A_H77 : zero);
             r_lx.at(lane_) = lo == 0 ? AB + A_HV0 + hi : zero;                                 // in the trial buffer
             r_lu.at(lane_) = lo == 0 ? (hi == 0 ? A_HV6 : (hi == 1 ? A_HV7 : zero)) : zero;
-            r_kx.at(lane_) = (blk == 0 && hi < 2) ? W_KX + hi * 4 + lo : -1;
+            r_kx.at(lane_) = (blk == 0 && hi < 2) ? W_KX + 2 * lo + hi : -1;      // Kx[hi][lo], transposed layout
         });
     }
 
@@ -558,9 +563,10 @@ struct Solver {
                 if (lane == 0) {
                     S(k, W_KF + 0, kf0);
                     S(k, W_KF + 1, kf1);
-                    S(k, W_KP + 0, kp00);
+                    S(k, W_KP + 0, kp00);      // Kp[i][j] at W_KP + 2 j + i (symmetric)
                     S(k, W_KP + 1, kp01);
-                    S(k, W_KP + 2, kp11);
+                    S(k, W_KP + 2, kp01);
+                    S(k, W_KP + 3, kp11);
                 }
             });
             pp00 = rdk - rdk * kp00;      // Ppp' = rd I - rd^2 W
@@ -782,240 +788,319 @@ struct Solver {
         return c.wave_sum(red_a);
     }
 
-    // ---- line search on the barrier objective (Armijo, kTrials step lengths alpha_t = a_pr 4^-t, first passing wins).
-    // Trial controls u_k = ucur_k + alpha kf_k + Kx_k (x_k - xcur_k) + Kp_k (u_{k-1} - ucur_{k-1}), clamped to the
-    // fraction-to-the-boundary box.  All step lengths are integrated at once - lane t runs the serial dynamics for
-    // alpha_t into its own trial area (t = 0: the spare trajectory buffer) - and their costs are evaluated two trials
-    // per pass (lanes 0..31 / 32..63 = stages of trial 2p / 2p + 1); the winner is copied into the spare buffer.
-    // The linearised Newton step (a 6-dimensional recursion over the stages: the dual step and the dual step length need
-    // it) runs INSIDE the rollout loop: it reads the gains the rollout loads anyway, and its dependency chain is independent
-    // of the rollout's, so the two interleave in one instruction stream instead of paying their latencies one after the
-    // other (a wave alone on its SIMD is latency-bound).  That is possible because the trial step
-    // lengths do not depend on it: they are 1, 1/4, 1/16, 1/64 (a ladder anchored at the linearised fraction-to-the-boundary
-    // length was measured no better: 17.96 against 17.50 iterations on config 3), the trials' own state-bound tests decide
-    // what is feasible.  Its result is parked in the adjoint slots (du at W_Y + 0, 1 of the stage, d theta / d v at
-    // W_Y + 2, 3 of the next node; d x / d y at W_DXY when a wall needs them) by lane 0.
+    // the serial part of the line search: all trials and the linearised step through the N stages (see line_search)
+    MPC_HD void rollouts(const int CB, const int TB, const int W_PRE, const double idt, const double frac_wall, unsigned long long &bad) {
+        PerLane<double> ZU;                                    // the rows' state, see above
+        PerLane<double> ALPHA, MNL, WDEL, WTH, ISS, ISC, FW0, FW1, FW2, W3DT, LOABS, HIABS, P0, P1, P2, P3, P4, P5;
+        PerLane<int> o_zc, o_ck, o_g, o_q, o_f, o_st, is_ctrl, is_lin, is_lin6, is_th, is_tv, big;
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque(lane_);
+            const int q = lane & 15, t = lane >> 4;
+            const bool st4 = q < 4, ct = q == 4 || q == 5, ls4 = q >= 8 && q < 12, lc = q == 12 || q == 13;
+            double alpha = 1.0;
+            for (int j = 0; j < t; ++j) alpha *= 0.25;
+            ALPHA.at(lane_) = lc ? 1.0 : alpha;                 // the linearised step is the Newton step itself
+            MNL.at(lane_) = q < 8 ? 1.0 : 0.0;                  // lanes of the nonlinear trial
+            WDEL.at(lane_) = q < 2 ? 0.5 : 0.0;                 // lanes 0, 1: sin, cos of delta / 2
+            WTH.at(lane_) = (q == 2 || q == 3) ? 0.25 : 0.0;    // lanes 2, 3: sin, cos of theta / 4
+            ISS.at(lane_) = (q & 1) ? 0.0 : 1.0;
+            ISC.at(lane_) = (q & 1) ? 1.0 : 0.0;
+            FW0.at(lane_) = q == 0 ? 1.0 : 0.0;                 // x' = x + dt v cos(theta + beta)
+            FW1.at(lane_) = q == 1 ? 1.0 : 0.0;                 // y' = y + dt v sin(theta + beta)
+            FW2.at(lane_) = q == 2 ? kInvWheelbase : 0.0;       // theta' = theta + dt v sin(beta) / L
+            W3DT.at(lane_) = q == 3 ? dt : 0.0;                 // v' = v + dt a
+            LOABS.at(lane_) = q == 2 ? xlo(0) : xlo(1);
+            HIABS.at(lane_) = q == 2 ? xhi(0) : xhi(1);
+            const int tw = SCR + SC_TRIG + ((q & 1) ? 6 : 0);   // sine lanes take the sine kernel's coefficients, cosine lanes the cosine's
+            P0.at(lane_) = c.ld(tw + 0); P1.at(lane_) = c.ld(tw + 1); P2.at(lane_) = c.ld(tw + 2);
+            P3.at(lane_) = c.ld(tw + 3); P4.at(lane_) = c.ld(tw + 4); P5.at(lane_) = c.ld(tw + 5);
+            // stage-relative LDS words of this lane (a lane whose value is never used reads a word that is always initialised)
+            o_zc.at(lane_) = st4 ? CB + W_X + q : (ct ? W_PRE + PC + (q - 4) : CB + W_X);      // what ZU is compared with
+            o_ck.at(lane_) = ct ? CB + W_U + (q - 4) : CB + W_U;                                // current control of the stage
+            o_g.at(lane_) = W_KX + ((q == 5 || q == 13) ? 1 : 0);                               // this lane's row of the gains
+            o_q.at(lane_) = W_PRE + PQ + ((q >= 2 && q < 6) ? q - 2 : 0);                       // its column of the PQ table
+            o_f.at(lane_) = W_LIN + (ls4 ? q - 8 : 4);                                          // its row of F[c][i] (i = 4: zeros)
+            // where the lane's component is stored: the trial's area, or (row 0) where the linearised step is parked
+            const int tx = t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 10 : W_KX));
+            int so = -1;
+            so = (st4 || ct) ? tx + q : so;
+            if (t == 0) {
+                so = (q == 8 || q == 9) ? ((CC && any_wall) ? W_DXY + (q - 8) : -1) : so;
+                so = (q == 10 || q == 11) ? W_Y + 2 + (q - 10) : so;
+                so = lc ? W_Y + (q - 12) : so;
+            }
+            o_st.at(lane_) = so;
+            is_ctrl.at(lane_) = (ct || lc) ? 1 : 0;
+            is_lin.at(lane_) = q >= 8 ? 1 : 0;
+            is_th.at(lane_) = q == 2 ? 1 : 0;
+            is_tv.at(lane_) = (q == 2 || q == 3) ? 1 : 0;
+            is_lin6.at(lane_) = (q >= 8 && q < 14) ? 1 : 0;
+            // (as a weighted sum: a select chain over x0[] becomes an indexed load, and an indexed load of a member puts the
+            // whole solver object into scratch memory)
+            ZU.at(lane_) = (q == 0 ? 1.0 : 0.0) * x0[0] + (q == 1 ? 1.0 : 0.0) * x0[1] + (q == 2 ? 1.0 : 0.0) * x0[2] +
+                           (q == 3 ? 1.0 : 0.0) * x0[3];
+        });
+        const double vmin_ = c.fresh(1e-6);
+        // operands of a stage, requested one stage ahead (below): a lone wave cannot hide the LDS latency at the top of a stage
+        PerLane<double> ZC, CK, G0, G1, G2, G3, G4, G5, G6, Q0, Q1, Q2, Q3, F0, F1, F2, F3;
+        auto load_gains = [&](int base) __attribute__((always_inline)) {
+            c.lanes([&](int lane) {
+                const int g = base + o_g.at(lane);
+                ZC.at(lane) = c.ld(base + o_zc.at(lane));
+                CK.at(lane) = c.ld(base + o_ck.at(lane));
+                G0.at(lane) = c.ld(g + 0); G1.at(lane) = c.ld(g + 2); G2.at(lane) = c.ld(g + 4); G3.at(lane) = c.ld(g + 6);
+                G4.at(lane) = c.ld(g + 8); G5.at(lane) = c.ld(g + 10); G6.at(lane) = c.ld(g + 12);
+            });
+        };
+        auto load_bounds = [&](int base) __attribute__((always_inline)) {
+            c.lanes([&](int lane) {
+                const int qq = base + o_q.at(lane), f = base + o_f.at(lane);
+                Q0.at(lane) = c.ld(qq + 0); Q1.at(lane) = c.ld(qq + 4); Q2.at(lane) = c.ld(qq + 8); Q3.at(lane) = c.ld(qq + 12);
+                F0.at(lane) = c.ld(f + 0); F1.at(lane) = c.ld(f + 5); F2.at(lane) = c.ld(f + 10); F3.at(lane) = c.ld(f + 15);
+            });
+        };
+#pragma unroll 1
+        for (int k = 0; k < N; ++k) {
+            const int base = k * SL;
+            load_gains(base);
+            load_bounds(base);
+            PerLane<double> E, ACC, AN, AL, T, V, TH, A, B, DTV, LOV, HIV, UN1, NX, BASE;
+            // ---- e = ZU - current iterate (the linearised lanes: ZU itself)
+            c.lanes([&](int lane) {
+                E.at(lane) = ZU.at(lane) - MNL.at(lane) * ZC.at(lane);
+                ACC.at(lane) = ALPHA.at(lane) * G6.at(lane);
+                big.at(lane) = (is_lin6.at(lane) && !(fabs(E.at(lane)) < c.fresh(kOpenLoopStep))) ? 1 : 0;
+            });
+            // (viii) a linearised step that reaches this stage below kOpenLoopStep is applied open loop (wave-uniform decision)
+            const bool open_loop = c.ballot(big) == 0;
+            // ---- what depends on theta_k, v_k only - known since the previous stage, so all of this is off the stage's critical
+            //      path (position -> feedback -> delta -> sin / cos(theta + beta) -> position): sin, cos of theta (lanes 2, 3: the
+            //      fdlibm kernels at theta / 4, two angle doublings) folded into the coefficients (A, B) of (cos beta, sin beta) in
+            //      this lane's model row - x: (cos theta, -sin theta), y: (sin theta, cos theta), theta: (0, 1 / L) - and dt v
+            c.template row_bcast<2>(TH, ZU);
+            c.template row_bcast<3>(V, ZU);
+            {
+                PerLane<double> R, SY, CY;
+                c.lanes([&](int lane) {
+                    const double r = WTH.at(lane) * TH.at(lane), z = r * r, z2 = z * z;
+                    const double pa = fma(z, P0.at(lane), P1.at(lane)), pb = fma(z, P2.at(lane), P3.at(lane)), pc = fma(z, P4.at(lane), P5.at(lane));
+                    const double p = fma(z2, fma(z2, pa, pb), pc);
+                    const double m = ISS.at(lane) * r + ISC.at(lane) * z;
+                    const double a0 = ISS.at(lane) * r + ISC.at(lane) * fma(-0.5, z, 1.0);
+                    R.at(lane) = fma(z * m, p, a0);
+                });
+                c.template row_bcast<2>(SY, R);
+                c.template row_bcast<3>(CY, R);
+                c.lanes([&](int lane) {
+                    const double sy = SY.at(lane), cy = CY.at(lane);
+                    const double s2 = 2.0 * sy * cy, c2 = fma(-2.0 * sy, sy, 1.0);     // theta / 2
+                    const double st = 2.0 * s2 * c2, ctt = fma(-2.0 * s2, s2, 1.0);
+                    A.at(lane) = FW0.at(lane) * ctt + FW1.at(lane) * st;
+                    B.at(lane) = FW1.at(lane) * ctt - FW0.at(lane) * st + FW2.at(lane);
+                    DTV.at(lane) = dt * V.at(lane);
+                    LOV.at(lane) = (Q2.at(lane) - V.at(lane)) * idt;       // lane 4: the accelerations that keep v of node k + 1 in its box
+                    HIV.at(lane) = (Q3.at(lane) - V.at(lane)) * idt;
+                });
+            }
+            // ---- feedback law of the trial (lanes 4, 5) and linearised control step (lanes 12, 13): the same gains
+            c.template row_bcast<4>(T, E);  c.lanes([&](int lane) { AN.at(lane) = ACC.at(lane) + G4.at(lane) * T.at(lane); });
+            c.template row_bcast<12>(T, E); c.lanes([&](int lane) { AL.at(lane) = ACC.at(lane) + G4.at(lane) * T.at(lane); });
+            c.template row_bcast<5>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G5.at(lane) * T.at(lane); });
+            c.template row_bcast<13>(T, E); c.lanes([&](int lane) { AL.at(lane) += G5.at(lane) * T.at(lane); });
+            c.template row_bcast<3>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G3.at(lane) * T.at(lane); });
+            c.template row_bcast<11>(T, E); c.lanes([&](int lane) { AL.at(lane) += G3.at(lane) * T.at(lane); });
+            c.template row_bcast<2>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G2.at(lane) * T.at(lane); });
+            c.template row_bcast<10>(T, E); c.lanes([&](int lane) { AL.at(lane) += G2.at(lane) * T.at(lane); });
+            c.template row_bcast<8>(T, E);  c.lanes([&](int lane) { AL.at(lane) += G0.at(lane) * T.at(lane); });
+            c.template row_bcast<9>(T, E);  c.lanes([&](int lane) { AL.at(lane) += G1.at(lane) * T.at(lane); });
+            c.template row_bcast<0>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G0.at(lane) * T.at(lane); });
+            c.template row_bcast<1>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G1.at(lane) * T.at(lane); });
+            if (open_loop) {
+                PerLane<double> T2;
+                c.template row_bcast<12>(T, AL);
+                c.template row_bcast<13>(T2, AL);
+                c.lanes([&](int lane) { AN.at(lane) = ALPHA.at(lane) * ((lane & 1) ? T2.at(lane) : T.at(lane)); });
+            }
+            if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
+            // ---- the trial's controls, clamped to the fraction-to-the-boundary box.  delta is final here (the model step waits
+            //      for it); a goes on: v of node k + 1 is decided by a_k alone and is kept inside the node's box (LOV, HIV of
+            //      lane 4; none for delta).  The linearised step takes no clamp.
+            c.lanes([&](int lane) { UN1.at(lane) = fmin2(fmax2(CK.at(lane) + AN.at(lane), Q0.at(lane)), Q1.at(lane)); });
+            c.lanes([&](int lane) {
+                const double a = fmin2(fmax2(UN1.at(lane), LOV.at(lane)), HIV.at(lane));
+                const double un = fmin2(fmax2(a, Q0.at(lane)), Q1.at(lane));
+                const double nc = is_lin.at(lane) ? AL.at(lane) : un;
+                ZU.at(lane) = is_ctrl.at(lane) ? nc : ZU.at(lane);
+            });
+            c.template row_bcast<4>(T, ZU);
+            c.lanes([&](int lane) { BASE.at(lane) = ZU.at(lane) + W3DT.at(lane) * T.at(lane); });      // v' = v + dt a; the others: ZU
+            if (fine_ticks<CTX>::value) c.tick(T_R_CLAMP);
+            // ---- model step: sin, cos of delta (lanes 0, 1: the kernels at delta / 2, one doubling), beta = atan(tan(delta) / 2) as
+            //      (cos beta, sin beta) = q (2 cos delta, sin delta), q = (3 cos^2 delta + 1)^-1/2, and every state lane its row:
+            //      x' = x + dt v q (A 2 cos delta + B sin delta).  A second pass follows a projection (below).
+            PerLane<int> pj, redo;
+            PerLane<double> KEEP, DSRC;
+            c.lanes([&](int lane) {
+                redo.at(lane) = 0;
+                DSRC.at(lane) = UN1.at(lane);
+            });
+#pragma unroll 1
+            for (int pass = 0;; ++pass) {
+                PerLane<double> D, R, SX, CX;
+                c.template row_bcast<5>(D, DSRC);
+                c.lanes([&](int lane) {
+                    const double r = WDEL.at(lane) * D.at(lane), z = r * r, z2 = z * z;
+                    const double pa = fma(z, P0.at(lane), P1.at(lane)), pb = fma(z, P2.at(lane), P3.at(lane)), pc = fma(z, P4.at(lane), P5.at(lane));
+                    const double p = fma(z2, fma(z2, pa, pb), pc);
+                    const double m = ISS.at(lane) * r + ISC.at(lane) * z;
+                    const double a0 = ISS.at(lane) * r + ISC.at(lane) * fma(-0.5, z, 1.0);
+                    R.at(lane) = fma(z * m, p, a0);
+                });
+                c.template row_bcast<0>(SX, R);
+                c.template row_bcast<1>(CX, R);
+                c.lanes([&](int lane) {
+                    const double sx = SX.at(lane), cx = CX.at(lane);
+                    const double cd = fma(-2.0 * sx, sx, 1.0), sxcx = sx * cx;       // cos delta, sin delta / 2
+                    const double qn = frsqrt(fma(3.0 * cd, cd, 1.0));
+                    const double g = 2.0 * (A.at(lane) * cd + B.at(lane) * sxcx);
+                    const double n = fma(DTV.at(lane), qn * g, BASE.at(lane));
+                    // second pass (after a projection): the rows it did not concern keep what the first pass gave them
+                    NX.at(lane) = (pass == 1 && !redo.at(lane)) ? KEEP.at(lane) : n;
+                    pj.at(lane) = (is_th.at(lane) && ((n < Q2.at(lane)) | (n > Q3.at(lane))) && V.at(lane) > vmin_) ? 1 : 0;
+                });
+                if (pass == 1 || c.ballot(pj) == 0) break;
+                // theta of node k + 1 is decided by delta_k alone (theta + dt v / L sin beta(delta)): a trial whose node leaves the
+                // box gets the delta that puts it on the edge of the box (rare; the rows it does not concern keep their delta)
+                PerLane<double> N2, TLO, THI, DLO, DHI, FL, PJF;
+                c.lanes([&](int lane) { PJF.at(lane) = pj.at(lane) ? 1.0 : 0.0; });
+                c.template row_bcast<2>(FL, PJF);
+                c.template row_bcast<2>(N2, NX);
+                c.template row_bcast<2>(TLO, Q2);
+                c.template row_bcast<2>(THI, Q3);
+                c.template row_bcast<5>(DLO, Q0);
+                c.template row_bcast<5>(DHI, Q1);
+                const TrigCoef K = trig();
+                c.lanes([&](int lane) {
+                    KEEP.at(lane) = NX.at(lane);
+                    DSRC.at(lane) = ZU.at(lane);
+                    if (FL.at(lane) == 0.0) return;
+                    const double tgt = N2.at(lane) < TLO.at(lane) ? TLO.at(lane) : THI.at(lane);
+                    const double sreq = (tgt - TH.at(lane)) * (1.0 / kInvWheelbase) * frcp(dt * V.at(lane));
+                    if (fabs(sreq) < 0.9) {
+                        const double u1 = fmin2(fmax2(atan_b(K, 2.0 * sreq * frsqrt(1.0 - sreq * sreq)), DLO.at(lane)), DHI.at(lane));
+                        if ((lane & 15) == 5) {
+                            ZU.at(lane) = u1;
+                            DSRC.at(lane) = u1;
+                            BASE.at(lane) = u1;      // a control lane's "next state" is the control itself (it is committed below)
+                        }
+                        redo.at(lane) = 1;
+                    }
+                });
+                if (fine_ticks<CTX>::value) c.tick(T_R_PROJ);
+                if (c.ballot(redo) == 0) break;
+            }
+            if (fine_ticks<CTX>::value) c.tick(T_R_DYN);
+            // ---- every lane stores its component of node / stage k (the trial's area; row 0: the parked linearised step)
+            c.lanes([&](int lane) {
+                const int so = o_st.at(lane);
+                if (so >= 0) c.st(base + so, ZU.at(lane));
+            });
+            if (fine_ticks<CTX>::value) c.tick(T_R_LDSW);
+            // ---- linearised state step d' = d + F (d theta, d v, d a, d delta) in lanes 8..11 (the other lanes' rows are zeros)
+            c.template row_bcast<10>(T, ZU); c.lanes([&](int lane) { AL.at(lane) = F0.at(lane) * T.at(lane); });
+            c.template row_bcast<11>(T, ZU); c.lanes([&](int lane) { AL.at(lane) += F1.at(lane) * T.at(lane); });
+            c.template row_bcast<12>(T, ZU); c.lanes([&](int lane) { AL.at(lane) += F2.at(lane) * T.at(lane); });
+            c.template row_bcast<13>(T, ZU); c.lanes([&](int lane) { AL.at(lane) += F3.at(lane) * T.at(lane); });
+            // ---- commit (control lanes: NX = ZU), feasibility of theta, v of node k + 1 against the fraction-to-the-boundary
+            //      margins.  A trial that leaves its box is infeasible; it is integrated to the end all the same (its lanes would
+            //      idle otherwise) and whatever it computes from here on is never looked at (bounded polynomials, rsq / rcp of
+            //      garbage give NaN at worst).
+            PerLane<int> viol;
+            c.lanes([&](int lane) {
+                const double n = NX.at(lane) + AL.at(lane);
+                ZU.at(lane) = n;
+                viol.at(lane) = (is_tv.at(lane) && ((n - LOABS.at(lane) < Q0.at(lane)) | (HIABS.at(lane) - n < Q1.at(lane)))) ? 1 : 0;
+            });
+            bad |= c.ballot(viol);
+            if (CC && any_wall && k + 1 < N) {
+                const double wjv = S(k + 1, W_WJ);
+                if (wjv >= 0.0) {
+                    PerLane<double> X0, X1;
+                    c.template row_bcast<0>(X0, ZU);
+                    c.template row_bcast<1>(X1, ZU);
+                    const double lim = frac_wall * S(k + 1, W_GW);
+                    c.lanes([&](int lane) {
+                        double nx, ny;
+                        viol.at(lane) = wall_slack(k + 1, X0.at(lane), X1.at(lane), (int)wjv, nx, ny) < lim ? 1 : 0;
+                    });
+                    bad |= c.ballot(viol);
+                }
+            }
+            if (fine_ticks<CTX>::value) c.tick(T_R_CHECK);
+        }
+        // the last node: x_N of the trials, d x_N of the linearised step
+        c.lanes([&](int lane) {
+            const int so = o_st.at(lane);
+            if (so >= 0 && (lane & 15) != 4 && (lane & 15) != 5 && (lane & 15) < 12) c.st(N * SL + so, ZU.at(lane));
+        });
+    }
+
+    // ---- line search on the barrier objective (Armijo, kTrials step lengths alpha_t = 4^-t, first passing wins).
+    // Trial controls u_k = ucur_k + alpha kf_k + Kp_k (u_{k-1} - ucur_{k-1}) + Kx_k (x_k - xcur_k), clamped to the
+    // fraction-to-the-boundary box and projected into the state bounds of the next node.
+    //
+    // ROW-COOPERATIVE ROLLOUT (round 5).  Until round 4 lane t integrated trial t on its own - four active lanes of 64, 335
+    // instructions per stage, 53 % of an iteration, and an FP64 instruction occupies the vector unit for four cycles however
+    // many lanes are active.  Now trial t owns the 16-lane DPP row t and the lanes of a row are the COMPONENTS of the stage:
+    //     q = 0..3   x, y, theta, v of the trial's node k            q = 4, 5    a, delta of the trial (stage k - 1, then stage k)
+    //     q = 8..11  linearised step d x, d y, d theta, d v          q = 12, 13  linearised control step (the same in every row)
+    // all in ONE register ZU.  What couples components is a matrix-vector product, and gfx950 has the instruction for it:
+    // v_mov_b64_dpp row_newbcast:j hands lane j of a row to all its lanes (CTX::row_bcast), so with row i of a matrix in lane i
+    //     y_i += M[i][j] * bcast_j(x)        is one broadcast + one FMA for every row of the matrix and all four trials at once.
+    // The feedback law (2 x 7), the model step (4 state rows) and the linearised recursion d' = A d + B du (4 x 4 nontrivial
+    // entries, the F[c][i] table of W_LIN) are such products; the four Horner chains of the trigonometry (sin, cos of delta / 2 and
+    // of theta / 4) run in lanes 0..3 with per-lane coefficients; bounds, margins and boxes are per-lane values loaded from the
+    // PQ table instead of per-instruction constants; every lane stores its own component with one ds_write.  The linearised
+    // Newton step (the dual step needs it) is the "fifth trial" in lanes 8..13: same gains, same instruction stream, its own
+    // broadcasts.  ~140 instructions per stage.  Same arithmetic as before except for the association of a few sums (the
+    // feedback law adds its terms in the order kf, Kp, Kx[v], Kx[theta], Kx[x], Kx[y] - what arrives last is added last).
     MPC_HD bool line_search(int cur, double frac, double keep, double phi0, double dV1, double mu_, double &Jn, double &barn,
                             int &acc_out) {
         const double a_pr = 1.0;
         const int CB = cur * 6, TB = (cur ^ 1) * 6;
         const double fracu = 2.0 * frac, idt = frcp(c.fresh(dt));
-        constexpr bool kPre = pre_bounds<CTX>::value;
-        constexpr int W_PRE = stage_slots(CC, false);
-        if (kPre) {
-            // what the trials' stages need of the current iterate and frac alone (see kPreBounds): stage-parallel, once
-            c.phase([&](int lane) {
-                if (lane >= N) return;
-                const int k = lane;
-                const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
-                const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
-                const double keep_ = keep, ms_ = c.fresh(kMinSlack);
-                const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
-                const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
-                S(k, W_PRE + B_ULO0, alo_ + fmax2(fracu * (c0 - alo_), ms_));
-                S(k, W_PRE + B_UHI0, ahi_ - fmax2(fracu * (ahi_ - c0), ms_));
-                S(k, W_PRE + B_ULO1, dlo_ + fmax2(fracu * (c1 - dlo_), ms_));
-                S(k, W_PRE + B_UHI1, dhi_ - fmax2(fracu * (dhi_ - c1), ms_));
-                S(k, W_PRE + B_VLO, vlo_ + keep_ * (o3 - vlo_));
-                S(k, W_PRE + B_VHI, vhi_ - keep_ * (vhi_ - o3));
-                S(k, W_PRE + B_TLO, tlo_ + keep_ * (o2 - tlo_));
-                S(k, W_PRE + B_THI, thi_ - keep_ * (thi_ - o2));
-                S(k, W_PRE + B_M2LO, fmax2(frac * (o2 - tlo_), ms_));
-                S(k, W_PRE + B_M2HI, fmax2(frac * (thi_ - o2), ms_));
-                S(k, W_PRE + B_M3LO, fmax2(frac * (o3 - vlo_), ms_));
-                S(k, W_PRE + B_M3HI, fmax2(frac * (vhi_ - o3), ms_));
-            });
-        }
+        constexpr int W_PRE = CC ? W_SLOTS_CC : W_SLOTS;
+        // ---- what the trials' stages need of the current iterate and frac alone: stage-parallel, once per line search
         c.phase([&](int lane) {
-            ls_feas.at(lane) = 0;
-            if (lane >= kTrials) return;
-            double alpha = a_pr;
-            for (int q = 0; q < lane; ++q) alpha *= 0.25;
-            const int bx = trial_x(CC, lane, TB), bu = trial_u(CC, lane, TB);
-            double x_0 = x0[0], x_1 = x0[1], x_2 = x0[2], x_3 = x0[3];
-            double dup0 = 0.0, dup1 = 0.0;
-            double ld0 = 0.0, ld1 = 0.0, ld2 = 0.0, ld3 = 0.0, ldp0 = 0.0, ldp1 = 0.0;   // linearised step: d x_k, d u_{k-1}
-            bool feas = true;
-            const TrigCoef K = trig();
-            // the bounds, read from the table once (theta, v, a, delta)
+            if (lane >= N) return;
+            const int k = lane;
             const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
             const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
-            const double keep_ = keep, vmin_ = c.fresh(1e-6), ms_ = c.fresh(kMinSlack);
-#pragma unroll 1
-            for (int k = 0; k < N; ++k) {
-                // everything the stage reads from LDS first, in one batch (one wait instead of eight: the loads do not
-                // depend on the recursion, the arithmetic below does)
-                const double xc0 = S(k, CB + W_X + 0), xc1 = S(k, CB + W_X + 1), xc2 = S(k, CB + W_X + 2), xc3 = S(k, CB + W_X + 3);
-                const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
-                const double kf0 = S(k, W_KF + 0), kf1 = S(k, W_KF + 1);
-                const double k00 = S(k, W_KX + 0), k01 = S(k, W_KX + 1), k02 = S(k, W_KX + 2), k03 = S(k, W_KX + 3);
-                const double k10 = S(k, W_KX + 4), k11 = S(k, W_KX + 5), k12 = S(k, W_KX + 6), k13 = S(k, W_KX + 7);
-                const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);   // zero at stage 0
-                double o2 = 0, o3 = 0, ulo0, uhi0, ulo1, uhi1, vlo, vhi, tlo, thi, m2lo, m2hi, m3lo, m3hi;
-                if (kPre) {
-                    ulo0 = S(k, W_PRE + B_ULO0); uhi0 = S(k, W_PRE + B_UHI0); ulo1 = S(k, W_PRE + B_ULO1); uhi1 = S(k, W_PRE + B_UHI1);
-                    vlo = S(k, W_PRE + B_VLO); vhi = S(k, W_PRE + B_VHI); tlo = S(k, W_PRE + B_TLO); thi = S(k, W_PRE + B_THI);
-                    m2lo = S(k, W_PRE + B_M2LO); m2hi = S(k, W_PRE + B_M2HI); m3lo = S(k, W_PRE + B_M3LO); m3hi = S(k, W_PRE + B_M3HI);
-                } else {
-                    o2 = S(k + 1, CB + W_X + 2);
-                    o3 = S(k + 1, CB + W_X + 3);
-                }
-                // the stage linearisation, for the linearised step (the trial areas of this stage overwrite these slots
-                // at the end of the stage, after they have been read)
-                double a02 = 0, a03 = 0, a12 = 0, a13 = 0, a23 = 0, b01 = 0, b11 = 0, b21 = 0;
-                if (fuse_linear<CTX>::value) {
-                    a02 = S(k, W_LIN + 0); a03 = S(k, W_LIN + 1); a12 = S(k, W_LIN + 2); a13 = S(k, W_LIN + 3);
-                    a23 = S(k, W_LIN + 4); b01 = S(k, W_LIN + 5); b11 = S(k, W_LIN + 6); b21 = S(k, W_LIN + 7);
-                }
-                c.sched_fence();
-                double lin0 = 0.0, lin1 = 0.0;   // linearised control step of the stage
-                bool open_loop = false;          // (viii)
-                if (fuse_linear<CTX>::value) {
-                    open_loop = fmax2(fmax2(fmax2(fabs(ld0), fabs(ld1)), fmax2(fabs(ld2), fabs(ld3))), fmax2(fabs(ldp0), fabs(ldp1))) <
-                                c.fresh(kOpenLoopStep);
-                    // linearised Newton step of stage k (same arithmetic in every lane; lane 0 stores)
-                    double du0 = kf0 + k00 * ld0 + k01 * ld1 + k02 * ld2 + k03 * ld3;
-                    double du1 = kf1 + k10 * ld0 + k11 * ld1 + k12 * ld2 + k13 * ld3;
-                    du0 += kp00 * ldp0 + kp01 * ldp1;
-                    du1 += kp01 * ldp0 + kp11 * ldp1;
-                    const double m0 = ld0 + a02 * ld2 + a03 * ld3 + b01 * du1;
-                    const double m1 = ld1 + a12 * ld2 + a13 * ld3 + b11 * du1;
-                    const double m2 = ld2 + a23 * ld3 + b21 * du1;
-                    const double m3 = ld3 + dt * du0;
-                    ld0 = m0; ld1 = m1; ld2 = m2; ld3 = m3;
-                    ldp0 = du0; ldp1 = du1;
-                    lin0 = du0; lin1 = du1;
-#if !defined(__HIPCC__)
-                    // host model only: it runs the trial lanes one after the other, and lane 1 has overwritten the linearisation
-                    // slots (its trial area) by the time lanes 2, 3 read them - on the device the four lanes run in lockstep and
-                    // every lane's recursion is the true one.  Lanes 1..3 take lane 0's decision and step, which lane 0 has parked.
-                    if (lane == 0) {
-                        if (k == 0) ol_mask = 0;
-                        if (open_loop) ol_mask |= 1ull << k;
-                    } else {
-                        open_loop = ((ol_mask >> k) & 1ull) != 0;
-                        lin0 = S(k, W_Y + 0);
-                        lin1 = S(k, W_Y + 1);
-                    }
-#endif
-                    if (lane == 0) {
-                        S(k, W_Y + 0, du0);
-                        S(k, W_Y + 1, du1);
-                        S(k + 1, W_Y + 2, m2);
-                        S(k + 1, W_Y + 3, m3);
-                        if (CC && any_wall) {
-                            S(k + 1, W_DXY + 0, m0);
-                            S(k + 1, W_DXY + 1, m1);
-                        }
-                    }
-                }
-                if (!fuse_linear<CTX>::value) {
-                    open_loop = ((ol_mask >> k) & 1ull) != 0;
-                    if (open_loop) {
-                        lin0 = S(k, W_Y + 0);
-                        lin1 = S(k, W_Y + 1);
-                    }
-                }
-                const double e0 = x_0 - xc0, e1 = x_1 - xc1, e2 = x_2 - xc2, e3 = x_3 - xc3;
-                double s0 = alpha * kf0 + k00 * e0 + k01 * e1 + k02 * e2 + k03 * e3;
-                double s1 = alpha * kf1 + k10 * e0 + k11 * e1 + k12 * e2 + k13 * e3;
-                s0 += kp00 * dup0 + kp01 * dup1;
-                s1 += kp01 * dup0 + kp11 * dup1;
-                s0 = open_loop ? alpha * lin0 : s0;
-                s1 = open_loop ? alpha * lin1 : s1;
-                if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
-                if (!kPre) {
-                    ulo0 = alo_ + fmax2(fracu * (c0 - alo_), ms_);
-                    uhi0 = ahi_ - fmax2(fracu * (ahi_ - c0), ms_);
-                    ulo1 = dlo_ + fmax2(fracu * (c1 - dlo_), ms_);
-                    uhi1 = dhi_ - fmax2(fracu * (dhi_ - c1), ms_);
-                    vlo = vlo_ + keep_ * (o3 - vlo_);
-                    vhi = vhi_ - keep_ * (vhi_ - o3);
-                }
-                double u0 = fmin2(fmax2(c0 + s0, ulo0), uhi0);
-                double u1 = fmin2(fmax2(c1 + s1, ulo1), uhi1);
-                {
-                    // v of node k+1 is decided by a_k alone: keep it inside the node's box (kProjKeep of its slack)
-                    const double a = fmin2(fmax2(u0, (vlo - x_3) * idt), (vhi - x_3) * idt);
-                    u0 = fmin2(fmax2(a, ulo0), uhi0);
-                }
-                if (fine_ticks<CTX>::value) c.tick(T_R_CLAMP);
-                double Sn, Cn, sb, cb_;
-                dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
-                double n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
-                // both trigonometric chains (delta and theta) stay in front of the branch below, where the scheduler
-                // interleaves them; without the fence the theta chain sinks behind the branch and runs on its own
-                Sn = c.keep(Sn);
-                Cn = c.keep(Cn);
-                n2 = c.keep(n2);
-                c.sched_fence();
-                if (fine_ticks<CTX>::value) c.tick(T_R_DYN);
-                {
-                    // theta of node k+1 is decided by delta_k alone (theta + dt v/L sin beta(delta)): if it leaves the
-                    // node's box, take the delta that puts it on the edge of the box
-                    if (!kPre) {
-                        tlo = tlo_ + keep_ * (o2 - tlo_);
-                        thi = thi_ - keep_ * (thi_ - o2);
-                    }
-                    if (feas & ((n2 < tlo) | (n2 > thi)) & (x_3 > vmin_)) {
-                        if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
-                        const double sreq = ((n2 < tlo ? tlo : thi) - x_2) * (1.0 / kInvWheelbase) * frcp(dt * x_3);
-                        if (fabs(sreq) < 0.9) {
-                            u1 = fmin2(fmax2(atan_b(K, 2.0 * sreq * frsqrt(1.0 - sreq * sreq)), ulo1), uhi1);
-                            dyn_eval(K, x_2, u1, Sn, Cn, sb, cb_);
-                            n2 = x_2 + dt * (x_3 * kInvWheelbase * sb);
-                        }
-                        if (fine_ticks<CTX>::value) c.tick(T_R_PROJ);
-                    }
-                }
-                if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
-                dup0 = u0 - c0;
-                dup1 = u1 - c1;
-                const int o = bx + k * SL, ou = bu + k * SL;
-                c.st(o + 0, x_0);
-                c.st(o + 1, x_1);
-                c.st(o + 2, x_2);
-                c.st(o + 3, x_3);
-                c.st(ou + 4, u0);
-                c.st(ou + 5, u1);
-                if (fine_ticks<CTX>::value) c.tick(T_R_LDSW);
-                const double n0 = x_0 + dt * (x_3 * Cn);
-                const double n1 = x_1 + dt * (x_3 * Sn);
-                const double n3 = x_3 + dt * u0;
-                if (fine_ticks<CTX>::value) c.tick(T_R_STORE);
-                // a trial that leaves the fraction-to-the-boundary box is infeasible; it is integrated to the end all the
-                // same (its lane would idle otherwise): a uniform trip count and a flag instead of a per-lane `break` keep
-                // the exec-mask bookkeeping out of the loop.  Whatever an infeasible lane computes from here on is never
-                // looked at (no trap can come of it: bounded polynomials, rsq / rcp of garbage give NaN at worst).
-                if (!kPre) {
-                    m2lo = fmax2(frac * (o2 - tlo_), ms_);
-                    m2hi = fmax2(frac * (thi_ - o2), ms_);
-                    m3lo = fmax2(frac * (o3 - vlo_), ms_);
-                    m3hi = fmax2(frac * (vhi_ - o3), ms_);
-                }
-                feas = feas & !((n2 - tlo_ < m2lo) | (thi_ - n2 < m2hi) | (n3 - vlo_ < m3lo) | (vhi_ - n3 < m3hi));
-                if (CC && any_wall && k + 1 < N) {
-                    const double wjv = S(k + 1, W_WJ);
-                    if (wjv >= 0.0) {
-                        double nx, ny;
-                        feas = feas & !(wall_slack(k + 1, n0, n1, (int)wjv, nx, ny) < frac * S(k + 1, W_GW));
-                    }
-                }
-                x_0 = n0;
-                x_1 = n1;
-                x_2 = n2;
-                x_3 = n3;
-                if (fine_ticks<CTX>::value) c.tick(T_R_CHECK);
-            }
-            {
-                const int o = bx + N * SL;
-                c.st(o + 0, x_0);
-                c.st(o + 1, x_1);
-                c.st(o + 2, x_2);
-                c.st(o + 3, x_3);
-            }
-            ls_feas.at(lane) = feas ? 1 : 0;
+            const double ms_ = c.fresh(kMinSlack), nb_ = c.fresh(kNoBound);
+            const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
+            const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
+            S(k, W_PRE + PQ + 0, fmax2(frac * (o2 - tlo_), ms_));
+            S(k, W_PRE + PQ + 1, fmax2(frac * (o3 - vlo_), ms_));
+            S(k, W_PRE + PQ + 2, alo_ + fmax2(fracu * (c0 - alo_), ms_));
+            S(k, W_PRE + PQ + 3, dlo_ + fmax2(fracu * (c1 - dlo_), ms_));
+            S(k, W_PRE + PQ + 4, fmax2(frac * (thi_ - o2), ms_));
+            S(k, W_PRE + PQ + 5, fmax2(frac * (vhi_ - o3), ms_));
+            S(k, W_PRE + PQ + 6, ahi_ - fmax2(fracu * (ahi_ - c0), ms_));
+            S(k, W_PRE + PQ + 7, dhi_ - fmax2(fracu * (dhi_ - c1), ms_));
+            S(k, W_PRE + PQ + 8, tlo_ + keep * (o2 - tlo_));
+            S(k, W_PRE + PQ + 9, -nb_);
+            S(k, W_PRE + PQ + 10, vlo_ + keep * (o3 - vlo_));
+            S(k, W_PRE + PQ + 11, -nb_);
+            S(k, W_PRE + PQ + 12, thi_ - keep * (thi_ - o2));
+            S(k, W_PRE + PQ + 13, nb_);
+            S(k, W_PRE + PQ + 14, vhi_ - keep * (vhi_ - o3));
+            S(k, W_PRE + PQ + 15, nb_);
+            S(k, W_PRE + PC + 0, k >= 1 ? S(k - 1, CB + W_U + 0) : 0.0);
+            S(k, W_PRE + PC + 1, k >= 1 ? S(k - 1, CB + W_U + 1) : 0.0);
         });
+        unsigned long long bad = 0;     // bit l: lane l (theta or v of trial l / 16, or any lane of its row for a wall) left its box
+        rollouts(CB, TB, W_PRE, idt, frac, bad);
+        c.lanes([&](int lane) { ls_feas.at(lane) = ((bad >> (lane & ~15)) & 0xffffull) == 0 ? 1 : 0; });
         c.tick(T_ROLL_DYN);
         int acc = -1;
         if (N <= kLanes / 2) {
@@ -1023,7 +1108,7 @@ struct Solver {
             double alpha = a_pr;
 #pragma unroll 1
             for (int p = 0; p < kTrials / 2 && acc < 0; ++p, alpha *= 0.0625) {
-                const int f0 = c.wave_bcast(ls_feas, 2 * p), f1 = c.wave_bcast(ls_feas, 2 * p + 1);
+                const int f0 = c.wave_bcast(ls_feas, 16 * (2 * p)), f1 = c.wave_bcast(ls_feas, 16 * (2 * p + 1));
                 if (!f0 && !f1) continue;
                 c.phase([&](int lane) {
                     red_a.at(lane) = 0.0;
@@ -1051,7 +1136,7 @@ struct Solver {
             double alpha = a_pr;
 #pragma unroll 1
             for (int t = 0; t < kTrials && acc < 0; ++t, alpha *= 0.25) {
-                if (!c.wave_bcast(ls_feas, t)) continue;
+                if (!c.wave_bcast(ls_feas, 16 * t)) continue;
                 c.phase([&](int lane) {
                     red_a.at(lane) = 0.0;
                     red_b.at(lane) = 0.0;
@@ -1071,7 +1156,7 @@ struct Solver {
             // smallest slack at the current iterate; the dual update turns them into wall constraints
             const int nrej = acc < 0 ? kTrials : acc;
             int fe[kTrials];
-            for (int t = 0; t < kTrials; ++t) fe[t] = c.wave_bcast(ls_feas, t);
+            for (int t = 0; t < kTrials; ++t) fe[t] = c.wave_bcast(ls_feas, 16 * t);
             c.phase([&](int lane) {
                 const int k = lane;
                 if (k < 1 || k >= N) return;
@@ -1215,14 +1300,16 @@ struct Solver {
                     double Sn, Cn, sb, cb_, bp, bpp;
                     dyn_eval(trig(), xk2, u1, Sn, Cn, sb, cb_);
                     beta_derivs(sb, cb_, bp, bpp);
-                    S(k, W_LIN + 0, -dt * xk3 * Sn);
-                    S(k, W_LIN + 1, dt * Cn);
-                    S(k, W_LIN + 2, dt * xk3 * Cn);
-                    S(k, W_LIN + 3, dt * Sn);
-                    S(k, W_LIN + 4, dt * sb * kInvWheelbase);
-                    S(k, W_LIN + 5, -dt * xk3 * Sn * bp);
-                    S(k, W_LIN + 6, dt * xk3 * Cn * bp);
-                    S(k, W_LIN + 7, dt * xk3 * kInvWheelbase * cb_ * bp);
+                    for (int w = 0; w < 20; ++w) S(k, W_LIN + w, 0.0);     // the structural zeros of the F[c][i] table
+                    S(k, W_LIN + LIN_A02, -dt * xk3 * Sn);
+                    S(k, W_LIN + LIN_A03, dt * Cn);
+                    S(k, W_LIN + LIN_A12, dt * xk3 * Cn);
+                    S(k, W_LIN + LIN_A13, dt * Sn);
+                    S(k, W_LIN + LIN_A23, dt * sb * kInvWheelbase);
+                    S(k, W_LIN + LIN_DT, dt);
+                    S(k, W_LIN + LIN_B01, -dt * xk3 * Sn * bp);
+                    S(k, W_LIN + LIN_B11, dt * xk3 * Cn * bp);
+                    S(k, W_LIN + LIN_B21, dt * xk3 * kInvWheelbase * cb_ * bp);
                 }
                 // gradient of the Lagrangian's separable part at node k (cost + bound multipliers), the start of the
                 // adjoint recursion below; lane 0 supplies the terminal node
@@ -1321,7 +1408,7 @@ struct Solver {
                     double h = 0.0;
                     if (lane < N) {
                         h = S(k, W_Y + 2);
-                        if (k < N) h += S(k, W_LIN + 0) * S(k + 1, W_Y + 0) + S(k, W_LIN + 2) * S(k + 1, W_Y + 1);
+                        if (k < N) h += S(k, W_LIN + LIN_A02) * S(k + 1, W_Y + 0) + S(k, W_LIN + LIN_A12) * S(k + 1, W_Y + 1);
                     }
                     s2.at(lane) = h;
                 });
@@ -1336,8 +1423,8 @@ struct Solver {
                     if (lane < N) {
                         h = S(k, W_Y + 3);
                         if (k < N)
-                            h += S(k, W_LIN + 1) * S(k + 1, W_Y + 0) + S(k, W_LIN + 3) * S(k + 1, W_Y + 1) +
-                                 S(k, W_LIN + 4) * S(k + 1, W_Y + 2);
+                            h += S(k, W_LIN + LIN_A03) * S(k + 1, W_Y + 0) + S(k, W_LIN + LIN_A13) * S(k + 1, W_Y + 1) +
+                                 S(k, W_LIN + LIN_A23) * S(k + 1, W_Y + 2);
                     }
                     s3.at(lane) = h;
                 });
@@ -1370,7 +1457,7 @@ struct Solver {
                     r0 -= rd_full * (S(k + 1, CB + W_U + 0) - u0);
                     r1 -= rd_full * (S(k + 1, CB + W_U + 1) - u1);
                 }
-                const double b01 = S(k, W_LIN + 5), b11 = S(k, W_LIN + 6), b21 = S(k, W_LIN + 7);
+                const double b01 = S(k, W_LIN + LIN_B01), b11 = S(k, W_LIN + LIN_B11), b21 = S(k, W_LIN + LIN_B21);
                 r0 += dt * S(k + 1, W_Y + 3);
                 r1 += b01 * S(k + 1, W_Y + 0) + b11 * S(k + 1, W_Y + 1) + b21 * S(k + 1, W_Y + 2);
                 red_a.at(lane) = fmax2(fabs(r0), fabs(r1));
@@ -1564,44 +1651,6 @@ struct Solver {
 
             c.tick(T_RIC_INIT);
             const double tau = c.uni(fmax2(0.99, 1.0 - mu));
-            if (!fuse_linear<CTX>::value) {
-                // ============ linearised Newton step (serial recursion), parked in the adjoint slots; the fused builds run
-                //              the same statements inside the rollout loop of the line search
-                double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
-                ol_mask = 0;
-#pragma unroll 1
-                for (int k = 0; k < N; ++k) {
-                    if (fmax2(fmax2(fmax2(fabs(d0), fabs(d1)), fmax2(fabs(d2), fabs(d3))), fmax2(fabs(dp0), fabs(dp1))) < c.fresh(kOpenLoopStep))
-                        ol_mask |= 1ull << k;
-                    // all LDS reads of the stage in one batch (they do not depend on the recursion)
-                    const double kf0 = S(k, W_KF + 0), kf1 = S(k, W_KF + 1);
-                    const double k00 = S(k, W_KX + 0), k01 = S(k, W_KX + 1), k02 = S(k, W_KX + 2), k03 = S(k, W_KX + 3);
-                    const double k10 = S(k, W_KX + 4), k11 = S(k, W_KX + 5), k12 = S(k, W_KX + 6), k13 = S(k, W_KX + 7);
-                    const double kp00 = S(k, W_KP + 0), kp01 = S(k, W_KP + 1), kp11 = S(k, W_KP + 2);   // zero at stage 0
-                    const double a02 = S(k, W_LIN + 0), a03 = S(k, W_LIN + 1), a12 = S(k, W_LIN + 2), a13 = S(k, W_LIN + 3),
-                                 a23 = S(k, W_LIN + 4);
-                    const double b01 = S(k, W_LIN + 5), b11 = S(k, W_LIN + 6), b21 = S(k, W_LIN + 7);
-                    c.sched_fence();
-                    double du0 = kf0 + k00 * d0 + k01 * d1 + k02 * d2 + k03 * d3;
-                    double du1 = kf1 + k10 * d0 + k11 * d1 + k12 * d2 + k13 * d3;
-                    du0 += kp00 * dp0 + kp01 * dp1;
-                    du1 += kp01 * dp0 + kp11 * dp1;
-                    const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
-                    const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
-                    const double n2 = d2 + a23 * d3 + b21 * du1;
-                    const double n3 = d3 + dt * du0;
-                    d0 = n0; d1 = n1; d2 = n2; d3 = n3;
-                    dp0 = du0; dp1 = du1;
-                    S(k, W_Y + 0, du0);
-                    S(k, W_Y + 1, du1);
-                    S(k + 1, W_Y + 2, d2);
-                    S(k + 1, W_Y + 3, d3);
-                    if (CC && any_wall) {
-                        S(k + 1, W_DXY + 0, d0);
-                        S(k + 1, W_DXY + 1, d1);
-                    }
-                }
-            }
             c.tick(T_LINEAR);
             // ============ wall constraints: slack at the current iterate, which the trials' feasibility test needs
             if (CC && any_wall) {

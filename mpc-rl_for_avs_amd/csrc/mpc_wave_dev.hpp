@@ -48,15 +48,22 @@ __device__ __forceinline__ double row_reduce(double v, OP op) {
     return v;
 }
 
+// Broadcast of lane J of every 16-lane row to the whole row: ONE v_mov_b64_dpp row_newbcast:J (the only DPP control the
+// double-precision ALU of gfx90a+ supports, and exactly what a row-cooperative matrix-vector product needs: lane i of a row
+// holds row i of the matrix and accumulates M[i][j] * bcast_j(x) - no LDS, no pair of 32-bit moves per operand).
+template <int J>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+    static_assert(J >= 0 && J < 16, "a row has 16 lanes");
+    return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, true));
+}
+
 // RELAX = 0 is the build for four resident waves per SIMD (128 registers): fresh() / opaque() hide where a constant or a
 // lane-derived table comes from, so that it is recomputed where it is used instead of living in registers across the
 // iteration loop.  The relaxed builds let the compiler hoist: with both relaxed ~200 registers (two waves per SIMD) and
 // 7 % less time per iteration for a wave that has its SIMD to itself (38.1 against 40.7 us, profiles/r03_latency.txt) -
 // the builds the engine launches when the batch leaves SIMDs that empty anyway (mpc_engine.hip: dispatch_solve).
-template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity, bit 2: kFuseLinear, bit 3: kPreBounds
+template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity, bit 2: the build has its SIMD to itself (opaque_shared)
 struct WaveOpsT {
-    static constexpr bool kFuseLinear = (RELAX & 4) != 0;   // mpc_wave.hpp: linearised step inside the rollout loop
-    static constexpr bool kPreBounds = (RELAX & 8) != 0;    // mpc_wave.hpp: trial bounds precomputed per line search (12 more LDS words per stage)
     static constexpr int kRelax = RELAX;                    // bits 3, 4 in mpc_ltv.hpp: relax_bits
     lds_double_t *L;  // this instance's LDS words
     __device__ __forceinline__ double ld(int i) const { return L[i]; }
@@ -110,6 +117,11 @@ struct WaveOpsT {
         dst.v = t;
     }
     __device__ __forceinline__ double lane_get(PerLane<double> &p, int lane) const { return readlane_f64(p.v, lane); }
+    // dst (every lane) = src of lane J of the same 16-lane row
+    template <int J>
+    __device__ __forceinline__ void row_bcast(PerLane<double> &dst, PerLane<double> &src) const {
+        dst.v = row_bcast_f64<J>(src.v);
+    }
     // A wave-uniform double that the VALU computed sits in two vector registers like any per-lane value; moved to a scalar
     // register pair it costs none (and when scalar registers run out the compiler parks them in lanes of a vector
     // register, 32 doubles per register, instead of spilling vector registers to scratch memory).

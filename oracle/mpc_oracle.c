@@ -776,9 +776,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                     if (dmax < OPEN_LOOP_STEP) {
                         s = alpha * dul[k][i];
                     } else {
-                        for (int j = 0; j < 4; ++j) s += Kx[k][i][j] * (trial.x[k][j] - it->x[k][j]);
+                        /* the order the kernel's row-cooperative rollout adds the terms in (what arrives last on its
+                         * dependency chain - the positions - is added last): kf, Kp, Kx[v], Kx[theta], Kx[x], Kx[y] */
+                        static const int order[4] = {3, 2, 0, 1};
                         if (k >= 1)
                             for (int j = 0; j < 2; ++j) s += Kp[k][i][j] * (trial.u[k - 1][j] - it->u[k - 1][j]);
+                        for (int jj = 0; jj < 4; ++jj) s += Kx[k][i][order[jj]] * (trial.x[k][order[jj]] - it->x[k][order[jj]]);
                     }
                     trial.u[k][i] = it->u[k][i] + s;
                     /* control bounds: clamp each component to the fraction-to-the-boundary box instead of

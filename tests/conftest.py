@@ -57,14 +57,10 @@ def _host_solver(libname, srcname, symbol):
     if warm is not None:
         warm.argtypes = lib.core_solve_batch.argtypes[:17] + [dp] + lib.core_solve_batch.argtypes[17:]
 
-    def solve(ref, inp, N=20, dt=0.1, collision_cost=False, tol=1e-8, max_iter=100, u_init=None, stall_window=0,
-              split_linear=False):
-        """split_linear: the code path of the builds that keep the linearised step in its own loop (default: fused into
-        the rollout loop, the latency build's path)."""
+    def solve(ref, inp, N=20, dt=0.1, collision_cost=False, tol=1e-8, max_iter=100, u_init=None, stall_window=0):
         P = lambda a, t: None if a is None else a.ctypes.data_as(t)
         if hasattr(lib, "wave_set_stall_window"):
             lib.wave_set_stall_window(int(stall_window))
-            lib.wave_set_split_linear(1 if split_linear else 0)
         state = np.ascontiguousarray(inp["state"], dtype=np.float64)
         B = state.shape[0]
         ego = np.ascontiguousarray(inp["ego_index"], dtype=np.int32)

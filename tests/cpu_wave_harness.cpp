@@ -10,23 +10,15 @@
 
 namespace {
 int g_stall_window = 0;
-int g_split = 0;          // 1: the builds with the linearised step in its own loop (wave_set_split_linear)
 template <bool CC>
 void run(const mpc::SolveParams &P, HostCtx &ctx, const double *x0, double ws, double wc, double wd, double wcoll,
          int &st, int &it, int &cur, double &e, bool warm) {
-    if (g_split) {
-        HostCtxSplit &c2 = static_cast<HostCtxSplit &>(ctx);
-        mpc::wave::Solver<CC, HostCtxSplit> s(P, c2, x0, ws, wc, wd, wcoll);
-        s.solve(st, it, cur, e, warm);
-        return;
-    }
     mpc::wave::Solver<CC, HostCtx> s(P, ctx, x0, ws, wc, wd, wcoll);
     s.solve(st, it, cur, e, warm);
 }   // mpc_config.stall_window of the calls that follow (wave_set_stall_window)
 }  // namespace
 
 extern "C" void wave_set_stall_window(int w) { g_stall_window = w > 0 ? w : 0; }
-extern "C" void wave_set_split_linear(int on) { g_split = on ? 1 : 0; }
 
 extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_table, int M, const double *state,
                                      const int32_t *ego_index, const double *vref, const double *weights,
@@ -67,12 +59,11 @@ extern "C" int wave_solve_batch_warm(int B, int N, double dt, const double *ref_
     P.w_distance = w_distance;
     P.stall_window = g_stall_window;
     P.strict_kink = 0;
-    const bool pre = !g_split;   // HostCtx (fused linear step, precomputed trial bounds) or HostCtxSplit (neither)
-    const int SL = mpc::wave::stage_slots(cc, pre);
-    const int nd = mpc::wave::lds_doubles(cc, N, Vuse, pre);
+    const int SL = mpc::wave::stage_slots(cc);
+    const int nd = mpc::wave::lds_doubles(cc, N, Vuse);
     for (int b = 0; b < B; ++b) {
         std::vector<double> L((size_t)nd, NAN);
-        HostCtxSplit ctx{};
+        HostCtx ctx{};
         ctx.L = L.data();
         ctx.table = table.data();
         ctx.e0 = ego_index[b];
@@ -142,8 +133,8 @@ extern "C" int wave_eval_batch(int B, int N, double dt, const double *ref_table,
     mpc::SolveParams P;
     P.N = N; P.V = Vuse; P.max_iter = 0; P.dt = dt; P.tol = 1e-8; P.mu_init = 0.1;
     P.w_distance = w_distance;
-    const int SL = mpc::wave::stage_slots(cc, true);
-    const int nd = mpc::wave::lds_doubles(cc, N, Vuse, true);
+    const int SL = mpc::wave::stage_slots(cc);
+    const int nd = mpc::wave::lds_doubles(cc, N, Vuse);
     for (int b = 0; b < B; ++b) {
         std::vector<double> L((size_t)nd, NAN);
         HostCtx ctx{};

@@ -12,8 +12,6 @@
 
 struct HostCtx {
     static constexpr int kN = 0;
-    static constexpr bool kFuseLinear = true;    // the path of the latency build; HostCtxSplit below is the other
-    static constexpr bool kPreBounds = true;     // likewise: trial bounds precomputed per line search (12 more words per stage)
     double *L;
     const double *table;  // [M][REF_COLS]
     int e0, M;
@@ -67,6 +65,13 @@ struct HostCtx {
         for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
     }
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
+    // v_mov_b64_dpp row_newbcast:J - every lane takes lane J of its own 16-lane row
+    template <int J>
+    void row_bcast(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src) const {
+        double out[mpc::wave::kLanes];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) out[l] = src.v[(l & ~15) + J];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
+    }
     int opaque(int v) const { return v; }
     int opaque_shared(int v) const { return v; }
     double fresh(double v) const { return v; }
@@ -143,11 +148,6 @@ struct HostCtx {
 };
 
 
-// the same context for the builds that keep the linearised step in its own loop (mpc_wave.hpp: fuse_linear)
-struct HostCtxSplit : HostCtx {
-    static constexpr bool kFuseLinear = false;
-    static constexpr bool kPreBounds = false;
-};
 // mpc_ltv.hpp's code path of the latency build (residuals kept in registers, wave-uniform gain rows: relax_bits)
 struct HostCtxLtvRelaxed : HostCtx {
     static constexpr int kRelax = 8 | 16;

@@ -11,12 +11,15 @@
 
 namespace {
 
+#ifndef PROF_FINE
+#define PROF_FINE 1
+#endif
 #ifndef PROF_RELAX
 #define PROF_RELAX 0      // 15: the latency build's configuration (everything hoisted, fused linear step, precomputed trial bounds)
 #endif
 struct ProfCtx : mpc::wave::WaveOpsT<PROF_RELAX> {
     static constexpr int kN = 20;
-    static constexpr bool kFine = true;     // also attribute the parts of a rollout stage
+    static constexpr bool kFine = PROF_FINE != 0;     // also attribute the parts of a rollout stage
     const double *table;
     int e0, M;
     unsigned long long *acc;   // [T_COUNT] accumulators of this instance in LDS, behind the solver's words (lane 0 adds)
@@ -49,8 +52,8 @@ __global__ __launch_bounds__(64, 2) void prof_kernel(mpc::SolveParams P, int B, 
     constexpr int N = 20;
     const int b = blockIdx.x, lane = threadIdx.x;
     constexpr bool kPre = (PROF_RELAX & 8) != 0;
-    constexpr int SL = mpc::wave::stage_slots(CC, kPre);
-    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(smem + mpc::wave::lds_doubles(CC, N, P.V, kPre));
+    constexpr int SL = mpc::wave::stage_slots(CC);
+    unsigned long long *lacc = reinterpret_cast<unsigned long long *>(smem + mpc::wave::lds_doubles(CC, N, P.V));
     if (lane < mpc::wave::T_COUNT) lacc[lane] = 0ull;
     ProfCtx ctx((mpc::wave::lds_double_t *)smem, ref5, ego_index[b], M, lacc);
     const int OTH = SL * (N + 1) + mpc::wave::SC_SIZE;
@@ -99,7 +102,7 @@ extern "C" int wave_sections(int B, int V, int cc, int max_iter, const double *r
     P.stall_window = 0;
     P.strict_kink = 0;
     P.w_distance = 10.0;
-    const size_t lds = (size_t)(mpc::wave::lds_doubles(cc != 0, 20, P.V, (PROF_RELAX & 8) != 0) + mpc::wave::T_COUNT) * sizeof(double);
+    const size_t lds = (size_t)(mpc::wave::lds_doubles(cc != 0, 20, P.V) + mpc::wave::T_COUNT) * sizeof(double);
     if (cc) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(prof_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(prof_kernel<true>, dim3(B), dim3(64), lds, 0, P, B, ref5, M, state, ego_index, vref, weights,
