@@ -297,8 +297,11 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
  * mpc_rollout_record: row pos_dev[0] of the rollout buffer row [T][B][cols] = [obs 80 | action A | reward | episode_start |
  * value | log_prob | (terminal_obs 80 | truncated)] (rollout_buffer.add, agents/ppo_mpc.py:462-469) and of mpc_actions_buf
  * [T][B][2]; last_obs <- new_obs, last_starts <- done; counts [4] += finished / crashed / arrived episodes and solves whose
- * status is not converged; dones_out <- done; pos_dev[0] += 1 (ticket: one zero-initialised int32 of scratch) and, if given,
- * step_counter[0] += 1 (the policy steps taken so far: mpc_policy_act's noise_step).
+ * status is not solved (MPC_STATUS_IS_SOLVED); dones_out <- done; pos_dev[0] += 1 (ticket: one zero-initialised int32 of
+ * scratch) and, if given, step_counter[0] += 1 (the policy steps taken so far: mpc_policy_act's noise_step).  T is the number
+ * of rows of the buffer: a step taken with pos_dev[0] >= T (or < 0) writes NOTHING to row / mpc_actions_buf - the torch path it
+ * replaces raises an index error there - and is counted in counts[4] instead (counts is [5]: finished, crashed, arrived,
+ * unsolved, refused steps); the carry-over, the counters and the position still advance.
  *
  * mpc_rollout_finish: the end of a rollout of T steps (1 <= T <= 8192) over the same buffer (agents/ppo_mpc.py:471-476
  * `rollout_buffer.compute_returns_and_advantage`, stable-baselines3's arithmetic in float32, operation by operation): if
@@ -313,7 +316,7 @@ int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float
                    float *noise, uint64_t noise_seed, int32_t env_offset, const int64_t *noise_step, int32_t version_v1,
                    int32_t clip, float *actions, float *values, float *log_probs, double *mpc_weights, double *mpc_ref_speed,
                    void *stream);
-int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
+int mpc_rollout_record(int32_t device, int32_t T, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
                        double *mpc_actions_buf, int64_t *pos_dev, int32_t *ticket, float *last_obs, float *last_starts,
                        const float *actions, const float *values, const float *log_probs, const double *mpc_act,
                        const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
@@ -338,9 +341,9 @@ int mpc_eval_nlp(mpc_handle *h, int32_t B, const int32_t *ego_index, const doubl
                  double *f, double *x_next);
 
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
- * collision-cost term (V = 0: term off) in a batch of B (the builds for batches that leave LDS to spare keep 12 more
- * words per stage: 12.1 instead of 10.2 KB at horizon 20 with 8 vehicles).  The engine keeps no per-instance solver
- * state in HBM.  (diagnostics / capacity planning) */
+ * collision-cost term (V = 0: term off): 15.2 KB at horizon 20 with 8 vehicles, the same in every build since round 5 (B is
+ * accepted for compatibility and ignored).  The engine keeps no per-instance solver state in HBM.  (diagnostics / capacity
+ * planning) */
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);
 
 #ifdef __cplusplus

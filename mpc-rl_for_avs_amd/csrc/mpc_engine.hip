@@ -478,14 +478,17 @@ __global__ __launch_bounds__(mpc::glue::kMaxHidden2) void mpc_policy_act_kernel(
                             mpc_ref_speed ? mpc_ref_speed + b : nullptr);
 }
 
-__global__ __launch_bounds__(128) void mpc_rollout_record_kernel(mpc::glue::RecordArgs R, long long *__restrict__ pos_dev,
+__global__ __launch_bounds__(128) void mpc_rollout_record_kernel(mpc::glue::RecordArgs R, int T, long long *__restrict__ pos_dev,
                                                                  int32_t *__restrict__ ticket,
                                                                  unsigned long long *__restrict__ counts,
                                                                  long long *__restrict__ step_counter) {
     const int b = blockIdx.x, j = threadIdx.x;
     if (b >= R.B) return;
     const long long pos = *pos_dev;
-    const int bits = mpc::glue::record_thread(R, pos, b, j);
+    // a step past the end of the buffer writes no row (the torch path raises there): refused and counted
+    const bool inside = pos >= 0 && pos < (long long)T;
+    const int bits = mpc::glue::record_thread(R, pos, b, j, inside);
+    if (!inside && b == 0 && j == 0) atomicAdd(counts + 4, 1ull);
     if (bits & 1) atomicAdd(counts + 0, 1ull);
     if (bits & 2) atomicAdd(counts + 1, 1ull);
     if (bits & 4) atomicAdd(counts + 2, 1ull);
@@ -598,22 +601,10 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
     return MPC_OK;
 }
 
-// the buffer of the launch order: grown while the device is idle and never inside a stream capture (a call that finds it
-// too small there runs unordered; mpc_reserve_envs sizes it up front)
-int ensure_order(mpc_handle *h, int B, hipStream_t stream) {
-    if (B <= h->order_cap) return MPC_OK;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return MPC_OK;
-    int cap = h->order_cap > 0 ? h->order_cap : 1024;
-    while (cap < B) cap *= 2;
-    HIP_TRY(hipDeviceSynchronize());
-    if (h->d_order) HIP_TRY(hipFree(h->d_order));
-    h->d_order = nullptr;
-    h->order_cap = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * 2 * sizeof(int32_t)));   // order + tiers
-    h->order_cap = cap;
-    return MPC_OK;
-}
+// the buffer of the launch order is allocated ONCE, at mpc_create, for the largest batch that is ever ordered (8 waves per SIMD:
+// 64 KB on an MI355X) and never moves: a captured hipGraph keeps its address in two kernels (ADVICE r4 - until round 4 it was
+// grown on demand, and a later, larger call on the same handle would have left such a graph replaying against freed memory)
+int ensure_order(mpc_handle *, int, hipStream_t) { return MPC_OK; }
 
 // staging buffer for host-pointer calls: grown on demand, reused across calls
 int ensure_stage(mpc_handle *h, size_t bytes) {
@@ -750,6 +741,11 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
             if (prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount;
             if (prop.maxSharedMemoryPerMultiProcessor > 0) h->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
         }
+    }
+    {
+        const int cap = 8 * 4 * h->num_cu;        // dispatch_solve orders batches of up to 8 waves per SIMD
+        if (hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * 2 * sizeof(int32_t)) == hipSuccess) h->order_cap = cap;
+        else h->d_order = nullptr;                 // (unordered launches are correct, only slower)
     }
     *out = h;
     g_last_error.clear();
@@ -1379,14 +1375,14 @@ int mpc_policy_act(int32_t device, int32_t B, int32_t A, int32_t H2, const float
     return MPC_OK;
 }
 
-int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
+int mpc_rollout_record(int32_t device, int32_t T, int32_t B, int32_t A, int32_t cols, int32_t keep_terminal, float *row,
                        double *mpc_actions_buf, int64_t *pos_dev, int32_t *ticket, float *last_obs, float *last_starts,
                        const float *actions, const float *values, const float *log_probs, const double *mpc_act,
                        const int32_t *mpc_status, const float *new_obs, const float *reward, const uint8_t *done,
                        const float *terminal_obs, const uint8_t *truncated, const uint8_t *crashed, const uint8_t *arrived,
                        int64_t *counts, uint8_t *dones_out, int64_t *step_counter, void *stream_) {
     constexpr int O = mpc::glue::kObsDim;
-    if (B < 0 || A < 1 || A > mpc::glue::kMaxAction || cols != O + A + 4 + (keep_terminal ? O + 1 : 0))
+    if (T < 1 || B < 0 || A < 1 || A > mpc::glue::kMaxAction || cols != O + A + 4 + (keep_terminal ? O + 1 : 0))
         return fail(MPC_ERR_INVALID_ARG, "mpc_rollout_record: bad size / row layout");
     if (!row || !mpc_actions_buf || !pos_dev || !ticket || !last_obs || !last_starts || !actions || !values || !log_probs ||
         !mpc_act || !mpc_status || !new_obs || !reward || !done || !crashed || !arrived || !counts || !dones_out ||
@@ -1397,7 +1393,7 @@ int mpc_rollout_record(int32_t device, int32_t B, int32_t A, int32_t cols, int32
     const mpc::glue::RecordArgs R{(int)B, (int)A, (int)cols, (int)keep_terminal, row, mpc_actions_buf, last_obs, last_starts, actions,
                                  values, log_probs, mpc_act, mpc_status, new_obs, reward, done, terminal_obs, truncated, crashed,
                                  arrived, dones_out};
-    hipLaunchKernelGGL(mpc_rollout_record_kernel, dim3((unsigned)B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream_), R,
+    hipLaunchKernelGGL(mpc_rollout_record_kernel, dim3((unsigned)B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream_), R, (int)T,
                        reinterpret_cast<long long *>(pos_dev), ticket, reinterpret_cast<unsigned long long *>(counts),
                        reinterpret_cast<long long *>(step_counter));
     HIP_TRY(hipGetLastError());

@@ -116,26 +116,29 @@ struct RecordArgs {
     const uint8_t *truncated, *crashed, *arrived;
     uint8_t *dones_out;
 };
-MPC_HD int record_thread(const RecordArgs &r, long long pos, int b, int j) {
+// inside = false (the position is outside the buffer's T rows): nothing is written to the buffer; carry-over and counts as usual
+MPC_HD int record_thread(const RecordArgs &r, long long pos, int b, int j, bool inside = true) {
     constexpr int O = kObsDim;
-    float *row = r.row + ((size_t)pos * r.B + b) * r.cols;
+    float *row = r.row + ((size_t)(inside ? pos : 0) * r.B + b) * r.cols;
     if (j < O) {
-        row[j] = r.last_obs[(size_t)b * O + j];                              // the observation the policy acted on
+        if (inside) row[j] = r.last_obs[(size_t)b * O + j];                  // the observation the policy acted on
         r.last_obs[(size_t)b * O + j] = r.new_obs[(size_t)b * O + j];        // ... and the one it sees next
-        if (r.keep_terminal) row[O + r.A + 4 + j] = r.terminal_obs[(size_t)b * O + j];
+        if (inside && r.keep_terminal) row[O + r.A + 4 + j] = r.terminal_obs[(size_t)b * O + j];
     }
-    if (j < r.A) row[O + j] = r.actions[(size_t)b * r.A + j];
+    if (inside && j < r.A) row[O + j] = r.actions[(size_t)b * r.A + j];
     if (j != 0) return 0;
     const int c = O + r.A;
-    row[c] = r.reward[b];
-    row[c + 1] = r.last_starts[b];
-    row[c + 2] = r.values[b];
-    row[c + 3] = r.log_probs[b];
-    if (r.keep_terminal) row[c + 4 + O] = r.truncated[b] ? 1.0f : 0.0f;
+    if (inside) {
+        row[c] = r.reward[b];
+        row[c + 1] = r.last_starts[b];
+        row[c + 2] = r.values[b];
+        row[c + 3] = r.log_probs[b];
+        if (r.keep_terminal) row[c + 4 + O] = r.truncated[b] ? 1.0f : 0.0f;
+        r.mpc_actions_buf[((size_t)pos * r.B + b) * 2 + 0] = r.mpc_act[(size_t)b * 2 + 0];
+        r.mpc_actions_buf[((size_t)pos * r.B + b) * 2 + 1] = r.mpc_act[(size_t)b * 2 + 1];
+    }
     r.last_starts[b] = r.done[b] ? 1.0f : 0.0f;
     r.dones_out[b] = r.done[b] ? 1 : 0;
-    r.mpc_actions_buf[((size_t)pos * r.B + b) * 2 + 0] = r.mpc_act[(size_t)b * 2 + 0];
-    r.mpc_actions_buf[((size_t)pos * r.B + b) * 2 + 1] = r.mpc_act[(size_t)b * 2 + 1];
     const int st = r.mpc_status[b];
     return (r.done[b] ? 1 : 0) | (r.crashed[b] ? 2 : 0) | (r.arrived[b] ? 4 : 0) | ((st != 0 && (st < 5 || st > 7)) ? 8 : 0);
 }

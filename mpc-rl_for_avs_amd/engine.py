@@ -138,7 +138,7 @@ def load_library(path: str | None = None):
     lib.mpc_get_last_paths.restype = ctypes.c_int
     lib.mpc_policy_act.argtypes = [ctypes.c_int32] * 4 + [vp] * 10 + [ctypes.c_uint64, ctypes.c_int32, vp] + [ctypes.c_int32] * 2 + [vp] * 6
     lib.mpc_policy_act.restype = ctypes.c_int
-    lib.mpc_rollout_record.argtypes = [ctypes.c_int32] * 5 + [vp] * 22
+    lib.mpc_rollout_record.argtypes = [ctypes.c_int32] * 6 + [vp] * 22
     lib.mpc_rollout_record.restype = ctypes.c_int
     lib.mpc_rollout_finish.argtypes = [ctypes.c_int32] * 6 + [vp] * 4 + [ctypes.c_double] * 2 + [vp] * 3
     lib.mpc_rollout_finish.restype = ctypes.c_int

@@ -28,6 +28,8 @@ highway-env, gymnasium and stable-baselines3 are not available offline, so
 """
 from __future__ import annotations
 
+import os
+
 import math
 
 import numpy as np
@@ -430,7 +432,7 @@ class BatchedCollector:
         self._last_episode_starts = torch.ones(B, dtype=torch.float32, device=dev)
         # episode counters of the rollout in one tensor (one reduction + one add per step): finished, crashed, arrived
         # episodes and solves that did not converge
-        counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        counts = torch.zeros(5, dtype=torch.int64, device=dev)     # [4]: steps the record kernel refused (past the buffer's end)
         self._roll = dict(counts=counts, ep_done=counts[0], crashed=counts[1], arrived=counts[2], unconverged=counts[3],
                           dones=torch.zeros(B, dtype=torch.bool, device=dev))
         self.policy.refresh_fused()
@@ -478,6 +480,12 @@ class BatchedCollector:
                     torch.cuda.synchronize(dev)
                     self._graph, self.use_graph = None, False
                     self.graph_fallback_reason = f"{type(e).__name__}: {e}"
+                    # _capture() has put the collector's state back (its finally clause).  What it cannot vouch for is the
+                    # communicator an aborted capture of a collective leaves behind: unless the caller asked for the eager
+                    # fallback explicitly, a sharded run ends here instead of issuing collectives on it
+                    if os.environ.get("MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK", "0") != "1":
+                        raise RuntimeError("hipGraph capture of the sharded rollout step failed (" + self.graph_fallback_reason +
+                                           "); set MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK=1 to step eagerly instead") from e
 
     def mpc_inputs(self, actions):
         """RL action -> (weights[B,3] float64, ref_speed[B] float64 or None) as the reference maps them."""
@@ -532,7 +540,7 @@ class BatchedCollector:
         elif self.warm_start:
             self.engine.reset_env_mask_torch(o["done"], warm_only=True)
         keep = buf.terminal_obs is not None
-        rc = lib.mpc_rollout_record(dev.index, B, A, buf._cols, 1 if keep else 0, p(buf._row), p(buf.mpc_actions), p(buf.pos_dev),
+        rc = lib.mpc_rollout_record(dev.index, buf.n_steps, B, A, buf._cols, 1 if keep else 0, p(buf._row), p(buf.mpc_actions), p(buf.pos_dev),
                                     p(fg["ticket"]), p(self._last_obs), p(self._last_episode_starts), p(fg["act"]), p(fg["val"]),
                                     p(fg["logp"]), p(mpc_action), p(self.last_mpc["status"]), p(o["obs"]), p(o["reward"]),
                                     p(o["done"]), p(o["terminal_obs"]) if keep else None, p(o["truncated"]) if keep else None,
@@ -582,7 +590,7 @@ class BatchedCollector:
         # like the reference (agents/pure_mpc.py:303-305) an unconverged solve still acts with its last iterate; the
         # collector counts them so that a training run can see what fraction of its actions that was
         st = self.last_mpc["status"]
-        r["counts"] += torch.stack((dones, info["crashed"], info["arrived"], (st != 0) & (st != 5))).sum(dim=1)
+        r["counts"][:4] += torch.stack((dones, info["crashed"], info["arrived"], (st != 0) & ((st < 5) | (st > 7)))).sum(dim=1)
 
     def _capture(self):
         """Capture one rollout step (policy -> mpc_predict_batch -> environment step -> buffer row) as a hipGraph: a step
@@ -606,32 +614,36 @@ class BatchedCollector:
         snap_step = self._fg["step"].clone() if self.fused_glue else None
         records = self.engine.save_env_state(B) if hasattr(self.engine, "save_env_state") else None
         side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):                       # allocations and lazy initialisation happen outside the capture
+        try:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):                       # allocations and lazy initialisation happen outside the capture
+                    self._rollout_step(device_pos=True)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            for gen in (self.gen, self.env.gen):
+                g.register_generator_state(gen)
+            with torch.cuda.graph(g, stream=side):
                 self._rollout_step(device_pos=True)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        for gen in (self.gen, self.env.gen):
-            g.register_generator_state(gen)
-        with torch.cuda.graph(g, stream=side):
-            self._rollout_step(device_pos=True)
-        self._graph = g
-        torch.cuda.synchronize(dev)
-        self.buffer.reset()
-        for n in names:                               # in place: the graph replays against these addresses
-            getattr(env, n).copy_(snap[n])
-        self._last_obs.copy_(snap_obs)
-        self._last_episode_starts.copy_(snap_starts)
-        self.gen.set_state(gen_states[0])
-        env.gen.set_state(gen_states[1])
-        if snap_step is not None:
-            self._fg["step"].copy_(snap_step)
-        if records is not None:
-            self.engine.load_env_state(records)       # also forgets the warm-start memory the warm-up steps left
-        self._roll["counts"].zero_()
-        self._roll["dones"].zero_()
+            self._graph = g
+        finally:
+            # put back what the warm-up / capture steps touched - also when the capture FAILED (the eager fallback
+            # must start from the same state as a collector that never tried)
+            torch.cuda.synchronize(dev)
+            self.buffer.reset()
+            for n in names:                               # in place: the graph replays against these addresses
+                getattr(env, n).copy_(snap[n])
+            self._last_obs.copy_(snap_obs)
+            self._last_episode_starts.copy_(snap_starts)
+            self.gen.set_state(gen_states[0])
+            env.gen.set_state(gen_states[1])
+            if snap_step is not None:
+                self._fg["step"].copy_(snap_step)
+            if records is not None:
+                self.engine.load_env_state(records)       # also forgets the warm-start memory the warm-up steps left
+            self._roll["counts"].zero_()
+            self._roll["dones"].zero_()
 
     def _step(self):
         if self._graph is not None:
@@ -716,6 +728,7 @@ class PipelinedCollector:
 
     def collect_rollouts(self, n_rollout_steps: int | None = None):
         n = self.collectors[0].buffer.n_steps if n_rollout_steps is None else int(n_rollout_steps)
+        assert all(n == c.buffer.n_steps for c in self.collectors), "a rollout is exactly one buffer of steps"
         cur = torch.cuda.current_stream(self.env.device)
         for s in self.streams:
             s.wait_stream(cur)                      # the groups see everything enqueued so far (policy update, resets)

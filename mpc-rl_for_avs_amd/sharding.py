@@ -72,7 +72,13 @@ def rank_devices(device, group=None):
         me["pci"] = (f"{getattr(prop, 'pci_domain_id', 0):04x}:{getattr(prop, 'pci_bus_id', -1):02x}:"
                      f"{getattr(prop, 'pci_device_id', -1):02x}")
         me["uuid"] = str(getattr(prop, "uuid", ""))
-        me["key"] = f"{socket.gethostname()}/{me['pci']}/{me['uuid']}"
+        if getattr(prop, "pci_bus_id", None) is None and not me["uuid"]:
+            # a torch / ROCm build that exposes neither a PCI id nor a UUID: every rank would get the same key and a correct
+            # run would be refused - fall back to the device ordinal this process actually drives
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            me["key"] = f"{socket.gethostname()}/ordinal{idx}/visible={os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', 'all'))}"
+        else:
+            me["key"] = f"{socket.gethostname()}/{me['pci']}/{me['uuid']}"
     else:
         me["pci"], me["uuid"] = None, None
         me["key"] = f"{socket.gethostname()}/cpu/{os.getpid()}"

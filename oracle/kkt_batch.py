@@ -27,7 +27,7 @@ from scipy.optimize import lsq_linear
 import nlp_batch as nb
 
 
-def certify(p: nb.Batch, X, U, eps_c=1e-6, wall_tol=1e-6, relax=1e-8, slack_max=10.0, chunk=512):
+def certify(p: nb.Batch, X, U, eps_c=1e-6, wall_tol=1e-6, relax=1e-8, slack_max=10.0, chunk=512, sf=None):
     """Certificates for all instances of `p` at (X[B,N+1,4], U[B,N,2]).
 
     eps_c: complementarity allowed to the multipliers, z_i * slack_i <= eps_c * scale; a number or one value per instance
@@ -43,17 +43,39 @@ def certify(p: nb.Batch, X, U, eps_c=1e-6, wall_tol=1e-6, relax=1e-8, slack_max=
       bound_violation   beyond the bounds relaxed by `relax` (IPOPT's bound_relax_factor)
       n_active       bounds / walls that received a multiplier candidate;  n_wall of them walls
       scale
+      s_c            (with sf) IPOPT's complementarity scaling of the fitted multipliers, see below
+
+    sf (optional, one value per instance: `objective_scale`): IPOPT's criterion is complementarity <= tol * s_c with
+    s_c = max(s_max, |z|_1 / n) / s_max, s_max = 100 (Waechter & Biegler 2006, eq. (6)) in the units of the SCALED objective -
+    an instance whose bound multipliers average more than 100 (a handful per batch of 4096: long saturated stretches) is
+    allowed proportionally more.  With sf the fit is repeated with eps_c * s_c where the fitted multipliers give s_c > 1
+    (their sum in scaled units is sf * sum z); without it s_c = 1 throughout, the stricter reading.
     """
     B, N = p.B, p.N
     eps_c = np.broadcast_to(np.asarray(eps_c, dtype=np.float64), (B,))
     out = {k: np.zeros(B) for k in ("stationarity", "feasibility", "bound_violation", "scale")}
     out["n_active"] = np.zeros(B, dtype=np.int64)
     out["n_wall"] = np.zeros(B, dtype=np.int64)
+    out["zsum"] = np.zeros(B)
     for s in range(0, B, chunk):
         sel = np.arange(s, min(B, s + chunk))
         r = _certify_chunk(p.take(sel), X[sel], U[sel], eps_c[sel], wall_tol, relax, slack_max)
         for k in out:
             out[k][sel] = r[k]
+    out["s_c"] = np.ones(B)
+    if sf is not None:
+        sfv = np.broadcast_to(np.asarray(sf, dtype=np.float64), (B,))
+        nvar = 6 * N
+        for _ in range(3):                                        # the allowance and the multipliers it admits, to a fixed point
+            s_c = np.maximum(100.0, sfv * out["zsum"] / nvar) / 100.0
+            redo = np.nonzero(s_c > out["s_c"] * (1.0 + 1e-9))[0]
+            if redo.size == 0:
+                break
+            out["s_c"][redo] = s_c[redo]
+            r = _certify_chunk(p.take(redo), X[redo], U[redo], eps_c[redo] * s_c[redo], wall_tol, relax, slack_max)
+            better = r["stationarity"] <= out["stationarity"][redo]
+            for k in ("stationarity", "n_active", "n_wall", "zsum"):
+                out[k][redo] = np.where(better, r[k], out[k][redo])
     return out
 
 
@@ -118,6 +140,7 @@ def _certify_chunk(p, X, U, eps_c, wall_tol, relax, slack_max):
     stat = np.zeros(B)
     nact = np.zeros(B, dtype=np.int64)
     nwall = np.zeros(B, dtype=np.int64)
+    zsum = np.zeros(B)
     for b in range(B):
         cols, ub = [], []
         zmax = eps_c[b] * scale[b]
@@ -155,8 +178,9 @@ def _certify_chunk(p, X, U, eps_c, wall_tol, relax, slack_max):
             Gs = G * unit[None, :] / scale[b]
             sol = lsq_linear(Gs, -rb / scale[b], bounds=(np.zeros(len(ub)), hi), method="bvls", tol=1e-15, max_iter=1000)
             res = rb + G @ (sol.x * unit)
+            zsum[b] = float(np.sum((sol.x * unit)[np.isfinite(ubv)]))      # bound multipliers (the walls' are not part of s_c's z)
         else:
             res = rb
         stat[b] = np.abs(res).max() / scale[b]
         nact[b] = len(cols)
-    return dict(stationarity=stat, feasibility=feas, bound_violation=viol, scale=scale, n_active=nact, n_wall=nwall)
+    return dict(stationarity=stat, feasibility=feas, bound_violation=viol, scale=scale, n_active=nact, n_wall=nwall, zsum=zsum)

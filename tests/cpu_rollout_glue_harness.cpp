@@ -29,7 +29,7 @@ extern "C" int glue_policy_act(int B, int A, int H2, const float *obs, const flo
     return 0;
 }
 
-extern "C" int glue_rollout_record(int B, int A, int cols, int keep_terminal, float *row, double *mpc_actions_buf, int64_t *pos_dev,
+extern "C" int glue_rollout_record(int T, int B, int A, int cols, int keep_terminal, float *row, double *mpc_actions_buf, int64_t *pos_dev,
                                    float *last_obs, float *last_starts, const float *actions, const float *values,
                                    const float *log_probs, const double *mpc_act, const int32_t *mpc_status, const float *new_obs,
                                    const float *reward, const uint8_t *done, const float *terminal_obs, const uint8_t *truncated,
@@ -38,9 +38,11 @@ extern "C" int glue_rollout_record(int B, int A, int cols, int keep_terminal, fl
     const mpc::glue::RecordArgs R{B, A, cols, keep_terminal, row, mpc_actions_buf, last_obs, last_starts, actions, values, log_probs,
                                  mpc_act, mpc_status, new_obs, reward, done, terminal_obs, truncated, crashed, arrived, dones_out};
     const long long pos = *pos_dev;
+    const bool inside = pos >= 0 && pos < (long long)T;      // the kernel's rule: a step past the buffer's end writes no row
+    if (!inside) counts[4] += 1;
     for (int b = 0; b < B; ++b)
         for (int j = 0; j < 128; ++j) {
-            const int bits = mpc::glue::record_thread(R, pos, b, j);
+            const int bits = mpc::glue::record_thread(R, pos, b, j, inside);
             for (int q = 0; q < 4; ++q) counts[q] += (bits >> q) & 1;
         }
     *pos_dev = pos + 1;

@@ -25,7 +25,7 @@ def load():
         _lib = ctypes.CDLL(out)
         _lib.glue_policy_act.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 10 + [ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p] + \
             [ctypes.c_int] * 2 + [ctypes.c_void_p] * 5
-        _lib.glue_rollout_record.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 20
+        _lib.glue_rollout_record.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 20
         _lib.glue_rollout_finish.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 4 + [ctypes.c_double] * 2 + \
             [ctypes.c_void_p] * 2
     return _lib

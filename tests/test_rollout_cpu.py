@@ -217,21 +217,21 @@ def test_rollout_glue_code_is_the_policy_and_the_buffer_row(A, version, clip):
         mine = rollout.RolloutBuffer(T, B, A, "cpu", keep_terminal=keep)
         last_obs, starts = torch.randn(B, 10, 8), (torch.rand(B) < 0.3).float()
         my_obs, my_starts = last_obs.clone(), starts.clone()
-        counts = np.zeros(4, np.int64)
-        want_counts = np.zeros(4, np.int64)
+        counts = np.zeros(5, np.int64)                 # finished, crashed, arrived, unsolved, refused steps
+        want_counts = np.zeros(5, np.int64)
         pos = np.zeros(1, np.int64)
         steps_total = np.full(1, 7, np.int64)          # the policy-step counter the record advances (keys the next noise)
         p = lambda t: ctypes.c_void_p(t.data_ptr()) if isinstance(t, torch.Tensor) else ctypes.c_void_p(t.ctypes.data)
         for t in range(T):
             act, val, lp = torch.randn(B, A), torch.randn(B), torch.randn(B)
-            mpc_act, status = torch.randn(B, 2, dtype=torch.float64), torch.randint(0, 6, (B,), dtype=torch.int32)
+            mpc_act, status = torch.randn(B, 2, dtype=torch.float64), torch.randint(0, 9, (B,), dtype=torch.int32)
             new_obs, reward, term = torch.randn(B, 10, 8), torch.randn(B), torch.randn(B, 10, 8)
             done, trunc = (torch.rand(B) < 0.3), (torch.rand(B) < 0.2)
             crashed, arrived = done & (torch.rand(B) < 0.5), done & (torch.rand(B) < 0.5)
             u8 = lambda b: b.to(torch.uint8).contiguous()
             dones_out = torch.zeros(B, dtype=torch.uint8)
             d8, t8, c8, a8 = u8(done), u8(trunc), u8(crashed), u8(arrived)
-            rc = lib.glue_rollout_record(B, A, mine._cols, 1 if keep else 0, p(mine._row), p(mine.mpc_actions), p(pos), p(my_obs),
+            rc = lib.glue_rollout_record(T, B, A, mine._cols, 1 if keep else 0, p(mine._row), p(mine.mpc_actions), p(pos), p(my_obs),
                                          p(my_starts), p(act), p(val), p(lp), p(mpc_act), p(status), p(new_obs), p(reward), p(d8),
                                          p(term) if keep else None, p(t8) if keep else None, p(c8), p(a8), p(counts), p(dones_out),
                                          p(steps_total))
@@ -239,10 +239,21 @@ def test_rollout_glue_code_is_the_policy_and_the_buffer_row(A, version, clip):
             kw = dict(terminal_obs=term, truncated=trunc) if keep else {}
             buf.add(last_obs, act, reward, starts, val, lp, mpc_act, **kw)
             last_obs, starts = new_obs.clone(), done.float()
-            want_counts += np.array([int(done.sum()), int(crashed.sum()), int(arrived.sum()), int(((status != 0) & (status != 5)).sum())])
+            solved = (status == 0) | ((status >= 5) & (status <= 7))      # MPC_STATUS_IS_SOLVED
+            want_counts += np.array([int(done.sum()), int(crashed.sum()), int(arrived.sum()), int((~solved).sum()), 0])
             assert torch.equal(dones_out.bool(), done)
         assert torch.equal(mine._row, buf._row) and torch.equal(mine.mpc_actions, buf.mpc_actions)
         assert torch.equal(my_obs, last_obs) and torch.equal(my_starts, starts) and np.array_equal(counts, want_counts)
+        # a step PAST the end of the buffer (pos == T): the torch path raises an index error there; the kernel's code writes no
+        # row, counts the refusal and still carries the observation over
+        before_row, before_act = mine._row.clone(), mine.mpc_actions.clone()
+        guard = torch.full((B * mine._cols,), 12345.0)          # what an out-of-bounds write would land on is not ours to test,
+        rc = lib.glue_rollout_record(T, B, A, mine._cols, 1 if keep else 0, p(mine._row), p(mine.mpc_actions), p(pos), p(my_obs),
+                                     p(my_starts), p(act), p(val), p(lp), p(mpc_act), p(status), p(new_obs), p(reward), p(d8),
+                                     p(term) if keep else None, p(t8) if keep else None, p(c8), p(a8), p(counts), p(dones_out),
+                                     p(steps_total))            # but the buffer itself must be untouched
+        assert rc == 0 and pos[0] == T + 1 and counts[4] == 1 and torch.equal(mine._row, before_row) and torch.equal(mine.mpc_actions, before_act)
+        assert torch.equal(my_obs, new_obs) and guard[0] == 12345.0
 
 
 @pytest.mark.parametrize("keep", [True, False])
