@@ -298,7 +298,7 @@ def main():
         value = value_all * n_conv_all / float(world * BATCH)     # solves to tolerance per second, counted on every rank
         pmc, pmc_file = pmc_summary()
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "mpc_solve_wave_kernel<CC=true, N=20, OCC=2, RELAX=15> (the latency build, used up to four waves "
+                "kernel": "mpc_solve_wave_kernel<CC=true, N=20, OCC=2, RELAX=7> (the latency build, used up to four waves "
                           "per SIMD of batch depth, mpc_engine.hip: dispatch_solve; kernel_ms brackets the call, i.e. it includes "
                           "the 16 us mpc_order_kernel in front of it)", "kernel_ms": kern_ms,
                 "kernel_ms_median": float(np.median(kern)) if n_str == 1 else None,
@@ -558,7 +558,7 @@ def side_measurements(a, eng, args, inp, out, dev):
                          "calls_per_s": 1e3 / float(np.median(lat_ms))}
     # batches in flight: the straggler tail of one batch overlaps with the bulk of the next ones (same kernel, same inputs,
     # identical outputs) - what a serving loop with several independent environment groups would run
-    n_fl = 6
+    n_fl = 8       # = GPU_MAX_HW_QUEUES above: streams that share a hardware queue serialise (tools/gpu_inflight.py, round 5)
     streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
     outs = []
     for sq in streams:
@@ -576,8 +576,8 @@ def side_measurements(a, eng, args, inp, out, dev):
                         "ms_per_batch": el / k_fl * 1e3, "counts": "all instances (converged fraction as in `solver`)",
                         "identical_outputs_across_streams": bool(all(torch.equal(o["u0"], outs[0]["u0"]) for o in outs)),
                         "frac_u0_within_1e-6_of_the_timed_run": float(((outs[0]["u0"] - out["u0"]).abs().amax(dim=1) <= 1e-6).float().mean()),
-                        "note": "throughput with 6 batches of 4096 in flight (MPC_FLAG_THROUGHPUT: the 128-register build, four waves per "
-                                "SIMD); `value` above is one batch at a time"}
+                        "note": f"throughput with {n_fl} batches of 4096 in flight (MPC_FLAG_THROUGHPUT: the 3-waves-per-SIMD build, 12 "
+                                "instances per CU by LDS); `value` above is one batch at a time"}
     # the same call with HOST pointers (numpy in, numpy out): H2D of the inputs, solve, D2H of u0/status/iters
     ts = []
     for _ in range(6):

@@ -84,49 +84,50 @@ constexpr double kInitPush = 1e-2;
 enum : int {
     W_X = 0,     // 4 (buffer 0; buffer 1 at +6)
     W_U = 4,     // 2
-    // stage linearisation of the current trajectory as the 4 x 4 table F[c][i] at W_LIN + 5 c + i: row i = state component
-    // (x, y, theta, v), column c = what it is multiplied with (d theta, d v, d a, d delta); a fifth entry per column is 0.
-    // In this form lane 8 + i of a rollout row reads row i with four loads at the SAME offsets from its own base (round 5:
-    // row-cooperative rollout, see rollouts()); the zeros and dt are written with the rest by the preparation phase.
-    W_LIN = 12,  // 20
-    W_ZXL = 32,  // 2
-    W_ZXU = 34,  // 2
-    W_ZUL = 36,  // 2
-    W_ZUU = 38,  // 2
-    W_Y = 40,    // 4  node gradient g_k, then adjoint y_k; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
+    // stage linearisation of the current trajectory as the 3 x 4 table F[c][i] at W_LIN + 4 c + i: row i = state component
+    // (x, y, theta, v), column c = what it is multiplied with (d theta, d v, d delta; the d a column is the constant (0, 0, 0, dt)
+    // and lives in a register).  In this form lane 8 + i of a rollout row reads row i with three loads at the SAME offsets from
+    // its own base (round 5: row-cooperative rollout, see rollouts()); the structural zeros are written with the rest by the
+    // preparation phase.
+    W_LIN = 12,  // 12
+    W_ZXL = 24,  // 2
+    W_ZXU = 26,  // 2
+    W_ZUL = 28,  // 2
+    W_ZUU = 30,  // 2
+    W_Y = 32,    // 4  node gradient g_k, then adjoint y_k; after the factorisation: parked Newton step (du0, du1, dtheta, dv)
     // gains, TRANSPOSED since round 5 so that the two control lanes of a rollout row read their rows at the same offsets:
     // Kx[i][j] at W_KX + 2 j + i, Kp[i][j] at W_KP + 2 j + i, kf[i] at W_KF + i - contiguous, 14 words
-    W_KX = 44,   // 8
-    W_KP = 52,   // 4
-    W_KF = 56,   // 2
-    W_RV = 58,   // 1
+    W_KX = 36,   // 8
+    W_KP = 44,   // 4
+    W_KF = 48,   // 2
+    W_RV = 50,   // 1
     // The stage stride is kept ODD: lane k of a stage-parallel phase addresses word k * stride + slot, and with 64 LDS
     // banks of 4 bytes an even number of doubles per stage puts every 4th (56 slots) or 16th (46, 54 slots) stage on the
     // same banks - measured with 56 slots: SQ_LDS_BANK_CONFLICT 17 % of the LDS cycles, against 3 % in round 1.
-    W_SLOTS = 59,
-    W_LX = 59,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
-    W_Q = 61,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
-    W_QG = 64,   // 3  its Gauss-Newton part
-    W_ZW = 67,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
-    W_WJ = 68,   // 1  its vehicle j (as a double), -1: none
-    W_CROSS = 69,  // 1  after the line search: vehicle a rejected trial took across d = 1
-    W_SLOTS_CC = 71   // (one spare word keeps the stride odd)
+    W_SLOTS = 51,
+    W_LX = 51,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
+    W_Q = 53,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
+    W_QG = 56,   // 3  its Gauss-Newton part
+    W_ZW = 59,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
+    W_WJ = 60,   // 1  its vehicle j (as a double), -1: none
+    W_CROSS = 61,  // 1  after the line search: vehicle a rejected trial took across d = 1
+    W_SLOTS_CC = 63   // (one spare word keeps the stride odd)
 };
-// positions in the W_LIN table of the eight values that are not structural constants, and of dt
-enum : int { LIN_A02 = 0, LIN_A12 = 1, LIN_A03 = 5, LIN_A13 = 6, LIN_A23 = 7, LIN_DT = 13, LIN_B01 = 15, LIN_B11 = 16, LIN_B21 = 17 };
+// positions in the W_LIN table of the eight values that are not structural zeros
+enum : int { LIN_A02 = 0, LIN_A12 = 1, LIN_A03 = 4, LIN_A13 = 5, LIN_A23 = 6, LIN_B01 = 8, LIN_B11 = 9, LIN_B21 = 10 };
 // parked values (valid between the factorisation and the next preparation phase)
 enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1 };
 // The four trial trajectories of the line search (x 4, u 2 per node, stage stride like everything else) live in slots
 // that are dead while the line search runs, so that an instance does not pay 24 more words per stage for them:
 //   trial 0  the spare trajectory buffer (the accepted trial ends up there)
 //   trial 1  W_LIN + 0..5          the linearisation is recomputed by the next preparation phase
-//   trial 2  W_LIN + 10..15        likewise
+//   trial 2  W_LIN + 6..11         likewise
 //   trial 3  W_KX + 0..5           the gains of stage k have been read by every lane (one wave, program order) when
 //                                  the stage's results are stored; nothing after the rollout reads gains
 // trial_x(t) is the slot of element 0, trial_u(t) the slot of element 4 minus 4: element e of node k sits at
 // k * stride + (e < 4 ? trial_x : trial_u) + e.
 static_assert(kTrials == 4, "the trial areas below are laid out for four trials");
-MPC_HD constexpr int trial_x(bool, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 10 : W_KX)); }
+MPC_HD constexpr int trial_x(bool, int t, int TB) { return t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 6 : W_KX)); }
 MPC_HD constexpr int trial_u(bool cc, int t, int TB) { return trial_x(cc, t, TB); }
 // scratch behind the stage arrays: the three constants the F operands are made of besides the linearisation values
 enum : int {
@@ -135,7 +136,8 @@ enum : int {
     SC_LOG = SC_TRIG + kTrigWords,   // coefficients of log_pos
     SC_BND = SC_LOG + kLogWords,     // the bounds of the NLP: xlo(0), xhi(0), xlo(1), xhi(1), ulo(0), uhi(0), ulo(1), uhi(1)
     SC_K = SC_BND + 8,               // constants of this solve: objective scale and what is derived from it (K_* below)
-    SC_SIZE = SC_K + 6
+    SC_NB = SC_K + 6,                // -kNoBound, (unused), +kNoBound: the "projection box" of a lane that has none
+    SC_SIZE = SC_NB + 3
 };
 enum : int { K_SF = 0, K_RD, K_RC, K_QTT, K_Q33, K_MUMIN };
 constexpr int kMaxHorizon = kLanes;   // lane k = stage k in the stage-parallel phases
@@ -153,13 +155,13 @@ enum : int {
 // controls, the projection box of theta / v of the next node, the feasibility margins and the previous control of the current
 // iterate - is computed once per line search, stage-parallel, into kPreSlots words per stage behind the stage's own slots
 // (round 3: 12 words, only in the builds with LDS to spare; round 5: every build, laid out for the row-cooperative rollout).
-// PQ[m][j] at 4 m + j: the quadruple m of lane 2 + j of a rollout row (j = 0: theta, 1: v, 2: a, 3: delta)
-//     m = 0, 1   theta, v: feasibility margin at the lower / upper bound        a, delta: lower / upper edge of the clamp box
-//     m = 2, 3   theta: projection box of the next node; a: box that keeps v of the next node inside ITS projection box;
-//                v, delta: none (-kNoBound, +kNoBound)
-// PC[i] at 16 + i: control i of stage k - 1 of the current iterate (0 at stage 0)
-constexpr int kPreSlots = 18;
-enum : int { PQ = 0, PC = 16 };
+// PQ[m][j] at 4 m + j, m = 0, 1: lane 2 + j of a rollout row (j = 0: theta, 1: v, 2: a, 3: delta) - theta, v: feasibility
+//     margin at the lower / upper bound; a, delta: lower / upper edge of the clamp box
+// PB[m][j'] at 8 + 2 m + j', m = 0, 1: lower / upper edge of a projection box - j' = 0 (lane 2): theta of the next node; j' = 1
+//     (lane 4): the box that keeps v of the next node inside ITS projection box.  v and delta have no such box: their lanes read
+//     -kNoBound / +kNoBound from the table of constants (SC_NB)
+constexpr int kPreSlots = 12;
+enum : int { PQ = 0, PB = 8 };
 constexpr double kNoBound = 1e300;
 
 MPC_HD constexpr int stage_slots(bool cc) { return (cc ? W_SLOTS_CC : W_SLOTS) + kPreSlots; }
@@ -747,6 +749,9 @@ struct Solver {
         for (int i = 0; i < kTrigWords; ++i) sc(SC_TRIG + i, trig_coef(i));
         for (int i = 0; i < kLogWords; ++i) sc(SC_LOG + i, log_coef(i));
         sc(SC_K + K_SF, 1.0);            // until the objective scale is known (solve())
+        sc(SC_NB + 0, -kNoBound);
+        sc(SC_NB + 1, 0.0);
+        sc(SC_NB + 2, kNoBound);
         for (int i = 0; i < 2; ++i) {
             sc(SC_BND + 0 + 2 * i, xlo_r(i));
             sc(SC_BND + 1 + 2 * i, xhi_r(i));
@@ -791,8 +796,8 @@ struct Solver {
     // the serial part of the line search: all trials and the linearised step through the N stages (see line_search)
     MPC_HD void rollouts(const int CB, const int TB, const int W_PRE, const double idt, const double frac_wall, unsigned long long &bad) {
         PerLane<double> ZU;                                    // the rows' state, see above
-        PerLane<double> ALPHA, MNL, WDEL, WTH, ISS, ISC, FW0, FW1, FW2, W3DT, LOABS, HIABS, P0, P1, P2, P3, P4, P5;
-        PerLane<int> o_zc, o_ck, o_g, o_q, o_f, o_st, is_ctrl, is_lin, is_lin6, is_th, is_tv, big;
+        PerLane<double> ALPHA, MNL, WDEL, WTH, ISS, ISC, FW0, FW1, FW2, W3DT, F2, LOABS, HIABS, P0, P1, P2, P3, P4, P5;
+        PerLane<int> o_zc, o_ck, o_g, o_q, a_pb, d_pb, o_f, o_st, is_ctrl, is_prev, is_lin, is_lin6, is_th, is_tv, big;
         c.lanes([&](int lane_) {
             const int lane = c.opaque(lane_);
             const int q = lane & 15, t = lane >> 4;
@@ -809,19 +814,27 @@ struct Solver {
             FW1.at(lane_) = q == 1 ? 1.0 : 0.0;                 // y' = y + dt v sin(theta + beta)
             FW2.at(lane_) = q == 2 ? kInvWheelbase : 0.0;       // theta' = theta + dt v sin(beta) / L
             W3DT.at(lane_) = q == 3 ? dt : 0.0;                 // v' = v + dt a
+            F2.at(lane_) = q == 11 ? dt : 0.0;                  // its linearisation: the d a column of F, (0, 0, 0, dt)
             LOABS.at(lane_) = q == 2 ? xlo(0) : xlo(1);
             HIABS.at(lane_) = q == 2 ? xhi(0) : xhi(1);
             const int tw = SCR + SC_TRIG + ((q & 1) ? 6 : 0);   // sine lanes take the sine kernel's coefficients, cosine lanes the cosine's
             P0.at(lane_) = c.ld(tw + 0); P1.at(lane_) = c.ld(tw + 1); P2.at(lane_) = c.ld(tw + 2);
             P3.at(lane_) = c.ld(tw + 3); P4.at(lane_) = c.ld(tw + 4); P5.at(lane_) = c.ld(tw + 5);
             // stage-relative LDS words of this lane (a lane whose value is never used reads a word that is always initialised)
-            o_zc.at(lane_) = st4 ? CB + W_X + q : (ct ? W_PRE + PC + (q - 4) : CB + W_X);      // what ZU is compared with
+            // what ZU is compared with: the node's state; the control lanes hold the PREVIOUS stage's control when a stage begins
+            // (stage 0: nothing, the constant 0 - see load_gains)
+            o_zc.at(lane_) = st4 ? CB + W_X + q : (ct ? CB + W_U + (q - 4) - SL : CB + W_X);
+            is_prev.at(lane_) = ct ? 1 : 0;
             o_ck.at(lane_) = ct ? CB + W_U + (q - 4) : CB + W_U;                                // current control of the stage
             o_g.at(lane_) = W_KX + ((q == 5 || q == 13) ? 1 : 0);                               // this lane's row of the gains
             o_q.at(lane_) = W_PRE + PQ + ((q >= 2 && q < 6) ? q - 2 : 0);                       // its column of the PQ table
-            o_f.at(lane_) = W_LIN + (ls4 ? q - 8 : 4);                                          // its row of F[c][i] (i = 4: zeros)
+            // its projection box: theta (lane 2) and a (lane 4) have one per stage, delta (lane 5) the constants -+kNoBound; the
+            // other lanes' values are never used.  a_pb: LDS word at stage 0, d_pb: what a stage adds
+            a_pb.at(lane_) = q == 5 ? SCR + SC_NB : W_PRE + PB + (q == 4 ? 1 : 0);
+            d_pb.at(lane_) = q == 5 ? 0 : SL;
+            o_f.at(lane_) = W_LIN + (ls4 ? q - 8 : 3);      // its row of F[c][i] (the others: the row of v, which is zeros)
             // where the lane's component is stored: the trial's area, or (row 0) where the linearised step is parked
-            const int tx = t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 10 : W_KX));
+            const int tx = t == 0 ? TB : (t == 1 ? W_LIN : (t == 2 ? W_LIN + 6 : W_KX));
             int so = -1;
             so = (st4 || ct) ? tx + q : so;
             if (t == 0) {
@@ -842,11 +855,11 @@ struct Solver {
         });
         const double vmin_ = c.fresh(1e-6);
         // operands of a stage, requested one stage ahead (below): a lone wave cannot hide the LDS latency at the top of a stage
-        PerLane<double> ZC, CK, G0, G1, G2, G3, G4, G5, G6, Q0, Q1, Q2, Q3, F0, F1, F2, F3;
+        PerLane<double> ZC, CK, G0, G1, G2, G3, G4, G5, G6, Q0, Q1, Q2, Q3, F0, F1, F3;
         auto load_gains = [&](int base) __attribute__((always_inline)) {
             c.lanes([&](int lane) {
                 const int g = base + o_g.at(lane);
-                ZC.at(lane) = c.ld(base + o_zc.at(lane));
+                ZC.at(lane) = c.ld((base == 0 && is_prev.at(lane)) ? SCR + SC_SPARE + 0 : base + o_zc.at(lane));
                 CK.at(lane) = c.ld(base + o_ck.at(lane));
                 G0.at(lane) = c.ld(g + 0); G1.at(lane) = c.ld(g + 2); G2.at(lane) = c.ld(g + 4); G3.at(lane) = c.ld(g + 6);
                 G4.at(lane) = c.ld(g + 8); G5.at(lane) = c.ld(g + 10); G6.at(lane) = c.ld(g + 12);
@@ -855,8 +868,10 @@ struct Solver {
         auto load_bounds = [&](int base) __attribute__((always_inline)) {
             c.lanes([&](int lane) {
                 const int qq = base + o_q.at(lane), f = base + o_f.at(lane);
-                Q0.at(lane) = c.ld(qq + 0); Q1.at(lane) = c.ld(qq + 4); Q2.at(lane) = c.ld(qq + 8); Q3.at(lane) = c.ld(qq + 12);
-                F0.at(lane) = c.ld(f + 0); F1.at(lane) = c.ld(f + 5); F2.at(lane) = c.ld(f + 10); F3.at(lane) = c.ld(f + 15);
+                Q0.at(lane) = c.ld(qq + 0); Q1.at(lane) = c.ld(qq + 4);
+                Q2.at(lane) = c.ld(a_pb.at(lane) + 0); Q3.at(lane) = c.ld(a_pb.at(lane) + 2);
+                a_pb.at(lane) += d_pb.at(lane);
+                F0.at(lane) = c.ld(f + 0); F1.at(lane) = c.ld(f + 4); F3.at(lane) = c.ld(f + 8);
             });
         };
 #pragma unroll 1
@@ -1076,7 +1091,7 @@ struct Solver {
             const int k = lane;
             const double tlo_ = xlo(0), thi_ = xhi(0), vlo_ = xlo(1), vhi_ = xhi(1);
             const double alo_ = ulo(0), ahi_ = uhi(0), dlo_ = ulo(1), dhi_ = uhi(1);
-            const double ms_ = c.fresh(kMinSlack), nb_ = c.fresh(kNoBound);
+            const double ms_ = c.fresh(kMinSlack);
             const double c0 = S(k, CB + W_U + 0), c1 = S(k, CB + W_U + 1);
             const double o2 = S(k + 1, CB + W_X + 2), o3 = S(k + 1, CB + W_X + 3);
             S(k, W_PRE + PQ + 0, fmax2(frac * (o2 - tlo_), ms_));
@@ -1087,16 +1102,10 @@ struct Solver {
             S(k, W_PRE + PQ + 5, fmax2(frac * (vhi_ - o3), ms_));
             S(k, W_PRE + PQ + 6, ahi_ - fmax2(fracu * (ahi_ - c0), ms_));
             S(k, W_PRE + PQ + 7, dhi_ - fmax2(fracu * (dhi_ - c1), ms_));
-            S(k, W_PRE + PQ + 8, tlo_ + keep * (o2 - tlo_));
-            S(k, W_PRE + PQ + 9, -nb_);
-            S(k, W_PRE + PQ + 10, vlo_ + keep * (o3 - vlo_));
-            S(k, W_PRE + PQ + 11, -nb_);
-            S(k, W_PRE + PQ + 12, thi_ - keep * (thi_ - o2));
-            S(k, W_PRE + PQ + 13, nb_);
-            S(k, W_PRE + PQ + 14, vhi_ - keep * (vhi_ - o3));
-            S(k, W_PRE + PQ + 15, nb_);
-            S(k, W_PRE + PC + 0, k >= 1 ? S(k - 1, CB + W_U + 0) : 0.0);
-            S(k, W_PRE + PC + 1, k >= 1 ? S(k - 1, CB + W_U + 1) : 0.0);
+            S(k, W_PRE + PB + 0, tlo_ + keep * (o2 - tlo_));
+            S(k, W_PRE + PB + 1, vlo_ + keep * (o3 - vlo_));
+            S(k, W_PRE + PB + 2, thi_ - keep * (thi_ - o2));
+            S(k, W_PRE + PB + 3, vhi_ - keep * (vhi_ - o3));
         });
         unsigned long long bad = 0;     // bit l: lane l (theta or v of trial l / 16, or any lane of its row for a wall) left its box
         rollouts(CB, TB, W_PRE, idt, frac, bad);
@@ -1300,13 +1309,12 @@ struct Solver {
                     double Sn, Cn, sb, cb_, bp, bpp;
                     dyn_eval(trig(), xk2, u1, Sn, Cn, sb, cb_);
                     beta_derivs(sb, cb_, bp, bpp);
-                    for (int w = 0; w < 20; ++w) S(k, W_LIN + w, 0.0);     // the structural zeros of the F[c][i] table
+                    S(k, W_LIN + 2, 0.0); S(k, W_LIN + 3, 0.0); S(k, W_LIN + 7, 0.0); S(k, W_LIN + 11, 0.0);   // the structural zeros of F[c][i]
                     S(k, W_LIN + LIN_A02, -dt * xk3 * Sn);
                     S(k, W_LIN + LIN_A03, dt * Cn);
                     S(k, W_LIN + LIN_A12, dt * xk3 * Cn);
                     S(k, W_LIN + LIN_A13, dt * Sn);
                     S(k, W_LIN + LIN_A23, dt * sb * kInvWheelbase);
-                    S(k, W_LIN + LIN_DT, dt);
                     S(k, W_LIN + LIN_B01, -dt * xk3 * Sn * bp);
                     S(k, W_LIN + LIN_B11, dt * xk3 * Cn * bp);
                     S(k, W_LIN + LIN_B21, dt * xk3 * kInvWheelbase * cb_ * bp);
