@@ -53,6 +53,17 @@ constexpr double kProjKeepEnd = 1e-3, kProjEndMu = 1e-6;
 // predicted decrease of 1e-6, and the iterate drifts off along the unstable direction by 8 % per iteration (half of round 4's
 // instances at the iteration cap); the regularised exact Hessian takes a long step along the direction of negative curvature.
 constexpr int kGnWatch = 4, kGnSkip = 4;
+// (xi) a negative cost weight (the v1 action domain: weights anywhere in [-1, 1]^3, agents/ppo_mpc.py:407-420) makes the stage
+// cost itself non-convex, so the Gauss-Newton model is not convex either - it only leaves out the constraint curvature.  Far
+// from the solution that is still the better model (fewer iterations); in the end game it costs the quadratic convergence and
+// the iteration dithers between the two models at 1e-6.  Such an instance goes from the failed exact sweep straight to the
+// inertia ladder once mu <= kGnEndMu (tools/v1_study.py: 98.9 -> 99.9 % of the synthetic v1 draw, 151 -> 160 of the 160 fixture
+// states; instances without a negative weight are not touched).
+constexpr double kGnEndMu = 1e-2;
+// ... and its control blocks are indefinite in nearly every iteration: an iteration that follows one which needed the inertia
+// ladder starts at the ladder's first rung directly (a third of the value that worked last), in the same model; every
+// kDwProbe-th iteration tries delta_w = 0 first as before (sweeps per iteration on the c4v1 fixture states 1.99 -> 1.50).
+constexpr int kDwProbe = 4;
 // (viii) a linearised Newton step smaller than this in the states and the previous control of a stage is applied OPEN LOOP
 // there (alpha times the linearised control step) instead of through the feedback law: the feedback acts on the difference of
 // two rolled-out trajectories, which carries the rounding of positions ~50 m (7e-15); times gains of 10 - 100 where a control and
@@ -1285,6 +1296,8 @@ struct Solver {
         int i_mark = 0;
         double e_mark = INFINITY;
         int gn_streak = 0, gn_skip = 0;    // (vii)
+        const bool nonconvex_cost = (ws_ < 0.0) | (wc_ < 0.0) | (wd_ < 0.0);      // (xi)
+        bool prev_needed = false, prev_gn = false;
         double e_streak = INFINITY;
         int n_acceptable = 0;              // (ix)
 
@@ -1516,6 +1529,11 @@ struct Solver {
             double dV1 = 0.0, delta_w = reg;
             bool ok = false, gn = false;
             int nmod = 0;                      // sweeps of this iteration that failed
+            if (nonconvex_cost && prev_needed && iter % kDwProbe != 0) {
+                // (xi) start at the ladder's first rung, in the model the last iteration ended in
+                delta_w = fmax2(reg, c.fresh(1.0 / 3.0) * c.uni(sc(SC_SPARE + 3)));
+                gn = prev_gn && !(mu <= c.fresh(kGnEndMu));
+            }
             bool skipped_gn = false;           // (vii) the whole-sweep Gauss-Newton fallback was skipped in favour of the ladder
             set_roles4(AB);
             for (int attempt = 0; attempt < 16 && !ok; ++attempt) {
@@ -1624,7 +1642,7 @@ struct Solver {
                 if (!ok) {
                     ++nmod;
                     if (gn_skip > 0) skipped_gn = true;
-                    if (!gn && gn_skip == 0) {
+                    if (!gn && gn_skip == 0 && !(nonconvex_cost && mu <= c.fresh(kGnEndMu))) {
                         gn = true;
                     } else {
                         const double dw_last = c.uni(sc(SC_SPARE + 3));
@@ -1643,6 +1661,8 @@ struct Solver {
                 break;
             }
             if (delta_w > reg) sc(SC_SPARE + 3, delta_w);   // the ladder was needed: remember where it ended
+            prev_needed = delta_w > reg;
+            prev_gn = gn;
             if (nmod > 0) {
                 if (gn_streak == 0) e_streak = c.uni(E0);
                 ++gn_streak;

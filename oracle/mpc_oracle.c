@@ -290,7 +290,21 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
      * to the exact Hessian + delta_w I ladder (Waechter & Biegler 2006, section 3.1, with its memory dw_last), whose step along a
      * direction of negative curvature is long.  (Always skipping the Gauss-Newton model is much worse: mean 19.8 iterations.) */
     const int GN_WATCH = 4, GN_SKIP = 4;
+    const double GN_END_MU = 1e-2; /* (xi) below */
     int gn_streak = 0, gn_skip = 0;
+    /* (xi) a negative cost weight (the v1 action domain, agents/ppo_mpc.py:407-420: weights anywhere in [-1, 1]^3) makes the stage
+     * cost itself non-convex, so the "convex" Gauss-Newton model is not convex either: it only removes the constraint curvature,
+     * which far from the solution is still the better model (fewer iterations), but in the end game it costs the quadratic
+     * convergence and the iteration dithers between the two models at 1e-6 (9 of the 160 c4v1 fixture states ended at the cap;
+     * tools/v1_study.py).  From the second barrier decrease on such an instance goes from the exact Hessian straight to the
+     * inertia ladder. */
+    const int nonconvex_cost = (p->ws < 0.0 || p->wc < 0.0 || p->wd < 0.0);
+    /* ... and its control blocks are indefinite in nearly every iteration (sweeps per iteration 2.0 on the c4v1 fixture states):
+     * an iteration that follows one which needed the ladder starts at the ladder's first rung directly (a third of the value that
+     * worked, IPOPT's kappa_w^-), in the same model; every DW_PROBE-th iteration tries delta_w = 0 first as before, so an iterate
+     * that has reached a region where the exact Hessian is positive definite is found out (1.99 -> 1.50 sweeps per iteration). */
+    const int DW_PROBE = 4;
+    int prev_needed = 0, prev_gn = 0;
     double e_streak = INFINITY;
     /* (viii) a Newton step smaller than OPEN_LOOP_STEP in the states and the previous control of a stage is applied OPEN LOOP
      * there (alpha times the linearised control step) instead of through the feedback law.  The feedback acts on the difference
@@ -546,6 +560,12 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
          * multiple of the identity is added. */
         double dV1 = 0.0, delta_w = reg;
         int nmod = 0, ok = 0, gn = 0, skipped_gn = 0;
+        if (nonconvex_cost && prev_needed && iter % DW_PROBE != 0) {
+            /* (xi) the last iteration needed the inertia ladder and the cost is non-convex by its weights: start where the
+             * ladder would start, in the mode it ended in, instead of finding out again that delta_w = 0 does not do */
+            delta_w = fmax(reg, (1.0 / 3.0) * dw_last);
+            gn = prev_gn && !(mu <= GN_END_MU);
+        }
         ++t_cnt_iter;
         for (int attempt = 0; attempt < 60 && !ok; ++attempt) {
             ++t_cnt_sweep;
@@ -677,7 +697,7 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
                  * iteration; if even that is numerically singular, add a small multiple of the identity */
                 ++nmod;
                 if (gn_skip > 0) skipped_gn = 1;
-                if (!gn && gn_skip == 0) {
+                if (!gn && gn_skip == 0 && !(nonconvex_cost && mu <= GN_END_MU)) {
                     gn = 1;
                 } else if (dw_last == 0.0) {
                     /* first inertia correction of this solve (IPOPT's algorithm IC: delta_w^0 = 1e-4, then x 100) */
@@ -696,6 +716,8 @@ static int solve_one(prob_t *p, const opts_t *o, iter_t *it, const double *uinit
             break;
         }
         if (delta_w > reg) dw_last = delta_w; /* the ladder was needed: remember where it ended */
+        prev_needed = delta_w > reg;
+        prev_gn = gn;
         if (nmod > 0) {
             if (gn_streak == 0) e_streak = E0;
             ++gn_streak;
