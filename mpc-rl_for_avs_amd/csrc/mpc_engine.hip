@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
     const int32_t *__restrict__ nveh, double w_collision, const double *u_init, int u_shift, uint8_t *u_valid,
     double *__restrict__ u0_out, double *U_out, double *__restrict__ X_out, int32_t *__restrict__ status_out,
-    int32_t *__restrict__ iters_out, const int32_t *__restrict__ order) {
+    int32_t *__restrict__ iters_out, const int32_t *__restrict__ order, int32_t *__restrict__ iters_keep) {
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     if ((int)blockIdx.x >= B) return;            // grid = B workgroups of one wave
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     if (lane == 0) {
         if (status_out) status_out[b] = status;
         if (iters_out) iters_out[b] = iters;
+        if (iters_keep) iters_keep[b] = iters;      // the handle's record (mpc_predict_batch): next step's launch-order key
     }
 }
 
@@ -186,9 +187,15 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
 // the easy live objective in all but name (no instance with >= 70 iterations had its nearest vehicle farther away, unless it
 // stood still).  Three tiers, each in its original order (a stable partition): 0 = standing ego, or no predicted collision
 // and (collision cost off or a vehicle within kNear); 1 = the other instances without a predicted collision; 2 = the rest.
+// In a closed loop (mpc_predict_batch) there is a better predictor: what the same environment needed one step ago.  Where the
+// handle has that count it decides the tier (>= kPrevSlow iterations: first, >= kPrevMid: second), the geometric tiers are for
+// the first step of an environment (round 5; opt-in, see mpc_handle::order_by_prev: the A/B of profiles/r05_launch_order_prev.txt
+// is negative).
 constexpr double kOrderStanding = 0.1, kOrderNear = 15.0;
+constexpr int kPrevSlow = 28, kPrevMid = 18;
 __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const double *state, const double *others, int V,
-                                          const int32_t *nveh, int i) {
+                                          const int32_t *nveh, const int32_t *prev_iters, int i) {
+    if (prev_iters && prev_iters[i] > 0) return prev_iters[i] >= kPrevSlow ? 0 : (prev_iters[i] >= kPrevMid ? 1 : 2);
     const double *x = state + (size_t)i * 4;
     if (x[3] < kOrderStanding) return 0;
     if (is_collide[i] != 0) return 2;
@@ -205,11 +212,11 @@ __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const doubl
 __global__ __launch_bounds__(1024) void mpc_order_kernel(int B, const uint8_t *__restrict__ is_collide,
                                                          const double *__restrict__ state, const double *__restrict__ others,
                                                          int V, const int32_t *__restrict__ nveh, int32_t *__restrict__ order,
-                                                         int32_t *__restrict__ tier) {
+                                                         int32_t *__restrict__ tier, const int32_t *__restrict__ prev_iters) {
     __shared__ int s_c0[1024], s_c1[1024];
     const int t = threadIdx.x, chunk = (B + 1023) / 1024, lo = min(B, t * chunk), hi = min(B, lo + chunk);
     // tiers first, every thread an interleaved share (neighbouring threads read neighbouring instances), kept in scratch
-    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, i);
+    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, prev_iters, i);
     __syncthreads();
     int n0 = 0, n1 = 0;
     for (int i = lo; i < hi; ++i) {
@@ -447,6 +454,189 @@ __global__ __launch_bounds__(64) void mpc_synth_env_kernel(
     arrived[b] = so.arrived;
 }
 
+// The same step with SIXTEEN lanes per environment (round 5; four environments per wave): lane j of a group owns vehicle j
+// (model step, respawn draws, crash test, its row of the observation - its place among the rows by counting the vehicles that
+// are nearer, which is the stable insertion sort of env::observe), the 85 route points of the lane-centring term are scanned
+// 16 at a time with a min-reduction over the group (lowest index among equal distances, as the serial scan keeps the first),
+// what concerns the ego alone is computed by every lane of the group.  Statement by statement the arithmetic of
+// env::step_env (the host build of that function stays the reference of the tests); one thread per environment spent 30 us
+// per step on 256 environments - a chain of ~2000 dependent operations in 4 of the GPU's 1024 SIMDs.
+__device__ inline void synth_observe_rows(int q, int K, double x, double y, double th, double sp, double px, double py,
+                                          double ps, double ph, bool active, float *s_obs, float *out, bool live) {
+    namespace env = mpc::env;
+    for (int i = q; i < env::kRows * env::kCols; i += 16) s_obs[i] = 0.0f;
+    const double dx = px - x, dy = py - y;
+    const double d = active ? sqrt(dx * dx + dy * dy) : INFINITY;
+    int rank = 0;
+    for (int k = 0; k < K; ++k) {
+        const double dk = __shfl(d, k, 16);
+        const int ak = __shfl((int)active, k, 16);
+        rank += (ak && (dk < d || (dk == d && k < q))) ? 1 : 0;
+    }
+    __syncthreads();
+    if (q == 15) {
+        const double s = sin(th), c = cos(th);
+        s_obs[0] = 1.0f;
+        s_obs[1] = (float)x;
+        s_obs[2] = (float)y;
+        s_obs[3] = (float)(sp * c);
+        s_obs[4] = (float)(sp * s);
+        s_obs[5] = (float)th;
+        s_obs[6] = (float)s;
+        s_obs[7] = (float)c;
+    }
+    if (active) {
+        float *row = s_obs + (1 + rank) * env::kCols;
+        const double sh = sin(ph), ch = cos(ph);
+        row[0] = 1.0f;
+        row[1] = (float)px;
+        row[2] = (float)py;
+        row[3] = (float)(ps * ch);
+        row[4] = (float)(ps * sh);
+        row[5] = (float)ph;
+        row[6] = (float)sh;
+        row[7] = (float)ch;
+    }
+    __syncthreads();
+    if (live)
+        for (int i = q; i < env::kRows * env::kCols; i += 16) out[i] = s_obs[i];
+}
+
+__global__ __launch_bounds__(64) void mpc_synth_env_rows_kernel(
+    int B, int K, double dt, double spawn_probability, uint64_t seed, int env_offset, const double *__restrict__ ref_xy,
+    int M, const double *__restrict__ action, double *__restrict__ ego, double *__restrict__ opos,
+    double *__restrict__ ospeed, double *__restrict__ ohead, uint8_t *__restrict__ oactive, int32_t *__restrict__ t,
+    int64_t *__restrict__ ctr, float *__restrict__ obs, float *__restrict__ terminal_obs, float *__restrict__ reward,
+    uint8_t *__restrict__ done, uint8_t *__restrict__ truncated, uint8_t *__restrict__ crashed,
+    uint8_t *__restrict__ arrived, int reset_all) {
+    namespace env = mpc::env;
+    constexpr int kObs = env::kRows * env::kCols;
+    __shared__ double s_ref[2 * 128];      // M <= 128 (the launch falls back to one thread per environment otherwise)
+    __shared__ float s_obs[4][kObs];
+    for (int i = threadIdx.x; i < 2 * M; i += blockDim.x) s_ref[i] = ref_xy[i];
+    __syncthreads();
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int b_ = blockIdx.x * 4 + g;
+    const bool live = b_ < B;              // a group past the end computes on the last environment and writes nothing
+    const int b = live ? b_ : B - 1;
+    const int Ks = K > 0 ? K : 1;
+    const bool mine = q < K;
+    const int j = mine ? q : 0;
+    double *eg = ego + (size_t)b * 4;
+    const size_t vo = (size_t)b * Ks + j;
+    float *o = obs + (size_t)b * kObs;
+    const int64_t c0 = ctr[b];
+    const env::Rng r(seed, env_offset + b, c0);
+    if (reset_all) {
+        double px = 0.0, py = 0.0, ps = 0.0, ph = 0.0;
+        if (mine) env::spawn_other(r, env::kSlotReset + 4 * j, 5.0, 60.0, px, py, ps, ph);
+        const double ex = 2.0, ey = 45.0 + (-5.0 + 10.0 * r.u01(env::kSlotEgo)), eth = -env::kPiE / 2, esp = 10.0;
+        synth_observe_rows(q, K, ex, ey, eth, esp, px, py, ps, ph, mine, s_obs[g], o, live);
+        if (live && mine) {
+            opos[2 * vo] = px;
+            opos[2 * vo + 1] = py;
+            ospeed[vo] = ps;
+            ohead[vo] = ph;
+            oactive[vo] = 1;
+        }
+        if (live && q == 0) {
+            eg[0] = ex; eg[1] = ey; eg[2] = eth; eg[3] = esp;
+            t[b] = 0;
+            ctr[b] = c0 + 1;
+        }
+        return;
+    }
+    // ---- ego: the MPC's own vehicle model with the action limits of the environment
+    double a = action[(size_t)b * 2], delta = action[(size_t)b * 2 + 1];
+    a = a < -5.0 ? -5.0 : (a > 5.0 ? 5.0 : a);
+    delta = delta < -env::kPiE / 4 ? -env::kPiE / 4 : (delta > env::kPiE / 4 ? env::kPiE / 4 : delta);
+    const double x = eg[0], y = eg[1], th = eg[2], sp = eg[3];
+    const double beta = atan(0.5 * tan(delta));
+    double ex = x + sp * cos(th + beta) * dt;
+    double ey = y + sp * sin(th + beta) * dt;
+    double eth = th + sp / env::kWheelbase * sin(beta) * dt;
+    const double nv = sp + a * dt;
+    double esp = nv < 0.0 ? 0.0 : (nv > 30.0 ? 30.0 : nv);
+    // ---- vehicle j
+    double px = 0.0, py = 0.0, ps = 0.0, ph = 0.0;
+    bool act = false, hit = false;
+    if (mine) {
+        px = opos[2 * vo]; py = opos[2 * vo + 1]; ps = ospeed[vo]; ph = ohead[vo];
+        act = oactive[vo] != 0;
+        px += ps * dt * cos(ph);
+        py += ps * dt * sin(ph);
+        const double ax = fabs(px), ay = fabs(py);
+        const bool gone = (ax > ay ? ax : ay) > 65.0 || !act;
+        if (gone) {
+            const bool respawn = r.u01(env::kSlotRespawn + 5 * j) < spawn_probability;
+            if (respawn) env::spawn_other(r, env::kSlotRespawn + 5 * j + 1, 40.0, 60.0, px, py, ps, ph);
+            act = respawn;
+        }
+        if (act) {
+            const double dx = px - ex, dy = py - ey;
+            hit = sqrt(dx * dx + dy * dy) < env::kCrashDistance;
+        }
+    }
+    const unsigned long long hits = __ballot(hit);
+    const bool crash = ((hits >> (16 * g)) & 0xffffull) != 0;
+    // ---- nearest route point: the first of the nearest, as the serial scan
+    double lateral = INFINITY;
+    int idx = 0;
+    for (int i = q; i < M; i += 16) {
+        const double dx = s_ref[2 * i] - ex, dy = s_ref[2 * i + 1] - ey;
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d < lateral) {
+            lateral = d;
+            idx = i;
+        }
+    }
+    for (int off = 8; off >= 1; off >>= 1) {
+        const double od = __shfl_xor(lateral, off, 16);
+        const int oi = __shfl_xor(idx, off, 16);
+        const bool take = od < lateral || (od == lateral && oi < idx);
+        lateral = take ? od : lateral;
+        idx = take ? oi : idx;
+    }
+    const bool on_road = lateral <= env::kLaneHalfWidth;
+    const bool arr = idx >= M - 3 && on_road;
+    double cen = lateral / env::kLaneHalfWidth;
+    cen = 1.0 - (cen > 1.0 ? 1.0 : cen);
+    const double rew = env::kRewardCollision * (crash ? 1.0 : 0.0) + env::kRewardHighSpeed * (esp / 10.0) +
+                       env::kRewardArrived * (arr ? 1.0 : 0.0) + (on_road ? env::kRewardCenter * cen : env::kRewardOffRoad);
+    const int tn = t[b] + 1;
+    const bool terminated = crash || arr;
+    const bool trunc = tn >= env::kEpisodeSteps && !terminated;
+    const bool fin = terminated || trunc;
+    synth_observe_rows(q, K, ex, ey, eth, esp, px, py, ps, ph, act, s_obs[g], terminal_obs + (size_t)b * kObs, live);
+    if (fin) {      // uniform over the group
+        ex = 2.0;
+        ey = 45.0 + (-5.0 + 10.0 * r.u01(env::kSlotEgo));
+        eth = -env::kPiE / 2;
+        esp = 10.0;
+        if (mine) env::spawn_other(r, env::kSlotReset + 4 * j, 5.0, 60.0, px, py, ps, ph);
+        act = mine;
+    }
+    // (a group that goes on rebuilds the same observation: the four groups of a wave stay in step for the barriers inside)
+    synth_observe_rows(q, K, ex, ey, eth, esp, px, py, ps, ph, act, s_obs[g], o, live);
+    if (live && mine) {
+        opos[2 * vo] = px;
+        opos[2 * vo + 1] = py;
+        ospeed[vo] = ps;
+        ohead[vo] = ph;
+        oactive[vo] = act ? 1 : 0;
+    }
+    if (live && q == 0) {
+        eg[0] = ex; eg[1] = ey; eg[2] = eth; eg[3] = esp;
+        t[b] = fin ? 0 : tn;
+        ctr[b] = c0 + 1;
+        reward[b] = (float)rew;
+        done[b] = fin;
+        truncated[b] = trunc;
+        crashed[b] = crash;
+        arrived[b] = arr;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // rollout glue (mpc_rollout_glue.hpp): the policy forward + sample + MPC inputs, and the buffer row / carry-over /
 // counters of a step.  One workgroup per environment.
@@ -539,6 +729,12 @@ struct mpc_handle {
     // observation-level path (mpc_predict_batch): per-environment detector state and the problem data the
     // preamble kernel writes for the solve kernel
     mpc::pre::EnvState *d_env = nullptr;
+    // iteration count of each environment's last solve through mpc_predict_batch (0: none yet): the launch order's first key
+    int32_t *d_prev_iters = nullptr;
+    // OFF by default: measured neutral to negative (profiles/r05_launch_order_prev.txt) - with a stochastic policy the reference
+    // speed (v0) or the cost weights (v1) change from step to step and so does the iteration count; MPC_ORDER_BY_PREV_ITERS=1 in
+    // the environment turns it on (a deterministic policy late in training may correlate better)
+    bool order_by_prev = false;
     int32_t *d_ids = nullptr;   // scratch of mpc_reset_env_state
     int ids_cap = 0;
     int env_cap = 0;
@@ -580,7 +776,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
                 const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
                 uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters,
-                const int32_t *d_order) {
+                const int32_t *d_order, int32_t *d_keep) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC, RELAX>;
     const size_t lds = (size_t)mpc::wave::lds_doubles(CC, P.N, P.V) * sizeof(double);
     // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
@@ -596,7 +792,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
                        d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_uinit, u_shift, d_uvalid,
-                       d_u0, d_U, d_X, d_status, d_iters, d_order);
+                       d_u0, d_U, d_X, d_status, d_iters, d_order, d_keep);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
@@ -637,7 +833,7 @@ mpc::SolveParams solve_params(const mpc_handle *h, int Vuse) {
 int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, hipStream_t stream, const double *d_state,
                    const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
                    const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
-                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
+                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters, int32_t *d_keep = nullptr) {
     const int N = h->cfg.horizon;
     const int Vuse = cc ? V : 0;
     mpc::SolveParams P = solve_params(h, Vuse);
@@ -651,7 +847,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     int rc;
 #define MPC_LAUNCH_W(CCV, NCV, OCCV, RLX)                                                                              \
     rc = launch_wave<CCV, NCV, OCCV, RLX>(h, P, (int)B, (int)V, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
-                                          d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters, d_order)
+                                          d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters, d_order, d_keep)
     // which build: by how deep the batch fills the SIMDs (see kWaveOccLat above)
     const int simds = 4 * h->num_cu;
     // launch order (mpc_order_kernel): pays as soon as waves share a SIMD.  Not with MPC_FLAG_THROUGHPUT: batches in flight on
@@ -660,7 +856,8 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     // ... and while the batch is not so deep that only throughput counts (beyond 8 waves per SIMD the order changed nothing)
     if (!throughput && B > simds && B <= 8 * simds && h->d_order && h->order_cap >= B) {
         hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, cc ? d_others : nullptr,
-                           (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap);
+                           (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap,
+                           (d_keep && h->order_by_prev) ? (const int32_t *)d_keep : nullptr);
         HIP_TRY(hipGetLastError());
         d_order = h->d_order;
     }
@@ -746,6 +943,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
         const int cap = 8 * 4 * h->num_cu;        // dispatch_solve orders batches of up to 8 waves per SIMD
         if (hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * 2 * sizeof(int32_t)) == hipSuccess) h->order_cap = cap;
         else h->d_order = nullptr;                 // (unordered launches are correct, only slower)
+        if (const char *v = getenv("MPC_ORDER_BY_PREV_ITERS")) h->order_by_prev = v[0] != '0';
     }
     *out = h;
     g_last_error.clear();
@@ -761,6 +959,7 @@ void mpc_destroy(mpc_handle *h) {
     if (h->d_warm) (void)hipFree(h->d_warm);
     if (h->d_warm_valid) (void)hipFree(h->d_warm_valid);
     if (h->d_ltv_u) (void)hipFree(h->d_ltv_u);
+    if (h->d_prev_iters) (void)hipFree(h->d_prev_iters);
     if (h->d_ids) (void)hipFree(h->d_ids);
     if (h->d_pre) (void)hipFree(h->d_pre);
     if (h->d_diag) (void)hipFree(h->d_diag);
@@ -894,24 +1093,27 @@ static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
     int cap = h->env_cap > 0 ? h->env_cap : 256;
     while (cap < B) cap *= 2;
     const size_t wrow = (size_t)h->cfg.horizon * 2 * sizeof(double);
-    void *nb[4] = {nullptr, nullptr, nullptr, nullptr};
-    const size_t bytes[4] = {(size_t)cap * sizeof(mpc::pre::EnvState), (size_t)cap * wrow, (size_t)cap, (size_t)cap * wrow};
-    void *old[4] = {h->d_env, h->d_warm, h->d_warm_valid, h->d_ltv_u};
-    const size_t old_bytes[4] = {(size_t)h->env_cap * sizeof(mpc::pre::EnvState), (size_t)h->env_cap * wrow,
-                                 (size_t)h->env_cap, (size_t)h->env_cap * wrow};
+    constexpr int NB = 5;
+    void *nb[NB] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[NB] = {(size_t)cap * sizeof(mpc::pre::EnvState), (size_t)cap * wrow, (size_t)cap, (size_t)cap * wrow,
+                              (size_t)cap * sizeof(int32_t)};
+    void *old[NB] = {h->d_env, h->d_warm, h->d_warm_valid, h->d_ltv_u, h->d_prev_iters};
+    const size_t old_bytes[NB] = {(size_t)h->env_cap * sizeof(mpc::pre::EnvState), (size_t)h->env_cap * wrow,
+                                  (size_t)h->env_cap, (size_t)h->env_cap * wrow, (size_t)h->env_cap * sizeof(int32_t)};
     hipError_t e = hipDeviceSynchronize();       // in-flight MPC_FLAG_NO_SYNC work on any stream still uses the old buffers
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) {
+    for (int i = 0; i < NB && e == hipSuccess; ++i) {
         e = hipMalloc(&nb[i], bytes[i]);
         if (e == hipSuccess) e = hipMemset(nb[i], 0, bytes[i]);
         if (e == hipSuccess && old[i]) e = hipMemcpy(nb[i], old[i], old_bytes[i], hipMemcpyDeviceToDevice);
     }
     if (e != hipSuccess) {
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NB; ++i)
             if (nb[i]) (void)hipFree(nb[i]);
         return fail(MPC_ERR_HIP, std::string("ensure_env: ") + hipGetErrorString(e));
     }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NB; ++i)
         if (old[i]) (void)hipFree(old[i]);
+    h->d_prev_iters = static_cast<int32_t *>(nb[4]);
     h->d_env = static_cast<mpc::pre::EnvState *>(nb[0]);
     h->d_warm = static_cast<double *>(nb[1]);
     h->d_warm_valid = static_cast<uint8_t *>(nb[2]);
@@ -1047,7 +1249,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
     if (int rc = ensure_order(h, B, stream)) return rc;
     if (int rc = dispatch_solve(h, B, cc, V, flags, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
                                 h->p_others, h->p_nveh, warm ? h->d_warm : nullptr, 1, warm ? h->d_warm_valid : nullptr,
-                                d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters))
+                                d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters, h->d_prev_iters))
         return rc;
 
     if (!dev) {
@@ -1344,10 +1546,16 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
         return fail(MPC_ERR_INVALID_ARG, "mpc_synth_env_step: null output pointer");
     if (B == 0) return MPC_OK;
     HIP_TRY(hipSetDevice(device));
-    hipLaunchKernelGGL(mpc_synth_env_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
-                       (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
-                       ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
-                       (int)reset_all);
+    if (K <= 15 && M <= 128)      // sixteen lanes per environment
+        hipLaunchKernelGGL(mpc_synth_env_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
+                           (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
+                           ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
+                           (int)reset_all);
+    else
+        hipLaunchKernelGGL(mpc_synth_env_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
+                           (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
+                           ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
+                           (int)reset_all);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
