@@ -808,7 +808,7 @@ struct Solver {
     MPC_HD void rollouts(const int CB, const int TB, const int W_PRE, const double idt, const double frac_wall, unsigned long long &bad) {
         PerLane<double> ZU;                                    // the rows' state, see above
         PerLane<double> ALPHA, MNL, WDEL, WTH, ISS, ISC, FW0, FW1, FW2, W3DT, F2, LOABS, HIABS, P0, P1, P2, P3, P4, P5;
-        PerLane<int> o_zc, o_ck, o_g, o_q, a_pb, d_pb, o_f, o_st, is_ctrl, is_prev, is_lin, is_lin6, is_th, is_tv, big;
+        PerLane<int> o_zc, o_ck, o_g, o_q, a_pb, d_pb, o_f, o_st, is_ctrl, is_lin, is_th, is_tv, big;
         c.lanes([&](int lane_) {
             const int lane = c.opaque(lane_);
             const int q = lane & 15, t = lane >> 4;
@@ -835,7 +835,6 @@ struct Solver {
             // what ZU is compared with: the node's state; the control lanes hold the PREVIOUS stage's control when a stage begins
             // (stage 0: nothing, the constant 0 - see load_gains)
             o_zc.at(lane_) = st4 ? CB + W_X + q : (ct ? CB + W_U + (q - 4) - SL : CB + W_X);
-            is_prev.at(lane_) = ct ? 1 : 0;
             o_ck.at(lane_) = ct ? CB + W_U + (q - 4) : CB + W_U;                                // current control of the stage
             o_g.at(lane_) = W_KX + ((q == 5 || q == 13) ? 1 : 0);                               // this lane's row of the gains
             o_q.at(lane_) = W_PRE + PQ + ((q >= 2 && q < 6) ? q - 2 : 0);                       // its column of the PQ table
@@ -858,7 +857,6 @@ struct Solver {
             is_lin.at(lane_) = q >= 8 ? 1 : 0;
             is_th.at(lane_) = q == 2 ? 1 : 0;
             is_tv.at(lane_) = (q == 2 || q == 3) ? 1 : 0;
-            is_lin6.at(lane_) = (q >= 8 && q < 14) ? 1 : 0;
             // (as a weighted sum: a select chain over x0[] becomes an indexed load, and an indexed load of a member puts the
             // whole solver object into scratch memory)
             ZU.at(lane_) = (q == 0 ? 1.0 : 0.0) * x0[0] + (q == 1 ? 1.0 : 0.0) * x0[1] + (q == 2 ? 1.0 : 0.0) * x0[2] +
@@ -870,7 +868,10 @@ struct Solver {
         auto load_gains = [&](int base) __attribute__((always_inline)) {
             c.lanes([&](int lane) {
                 const int g = base + o_g.at(lane);
-                ZC.at(lane) = c.ld((base == 0 && is_prev.at(lane)) ? SCR + SC_SPARE + 0 : base + o_zc.at(lane));
+                // (stage 0: the control lanes' word would lie before the instance's memory - as an unsigned number beyond it - and
+                // the minimum with the address of the constant 0 behind the stages picks that; every other word lies below it)
+                const unsigned zw = (unsigned)(SCR + SC_SPARE + 0), az = (unsigned)(base + o_zc.at(lane));
+                ZC.at(lane) = c.ld((int)(az < zw ? az : zw));
                 CK.at(lane) = c.ld(base + o_ck.at(lane));
                 G0.at(lane) = c.ld(g + 0); G1.at(lane) = c.ld(g + 2); G2.at(lane) = c.ld(g + 4); G3.at(lane) = c.ld(g + 6);
                 G4.at(lane) = c.ld(g + 8); G5.at(lane) = c.ld(g + 10); G6.at(lane) = c.ld(g + 12);
@@ -895,10 +896,11 @@ struct Solver {
             c.lanes([&](int lane) {
                 E.at(lane) = ZU.at(lane) - MNL.at(lane) * ZC.at(lane);
                 ACC.at(lane) = ALPHA.at(lane) * G6.at(lane);
-                big.at(lane) = (is_lin6.at(lane) && !(fabs(E.at(lane)) < c.fresh(kOpenLoopStep))) ? 1 : 0;
+                big.at(lane) = !(fabs(E.at(lane)) < c.fresh(kOpenLoopStep)) ? 1 : 0;
             });
             // (viii) a linearised step that reaches this stage below kOpenLoopStep is applied open loop (wave-uniform decision)
-            const bool open_loop = c.ballot(big) == 0;
+            // (lanes 8..13 of every row: the linearised step)
+            const bool open_loop = (c.ballot(big) & 0x3f003f003f003f00ull) == 0;
             // ---- what depends on theta_k, v_k only - known since the previous stage, so all of this is off the stage's critical
             //      path (position -> feedback -> delta -> sin / cos(theta + beta) -> position): sin, cos of theta (lanes 2, 3: the
             //      fdlibm kernels at theta / 4, two angle doublings) folded into the coefficients (A, B) of (cos beta, sin beta) in
@@ -929,23 +931,21 @@ struct Solver {
                 });
             }
             // ---- feedback law of the trial (lanes 4, 5) and linearised control step (lanes 12, 13): the same gains
-            c.template row_bcast<4>(T, E);  c.lanes([&](int lane) { AN.at(lane) = ACC.at(lane) + G4.at(lane) * T.at(lane); });
-            c.template row_bcast<12>(T, E); c.lanes([&](int lane) { AL.at(lane) = ACC.at(lane) + G4.at(lane) * T.at(lane); });
-            c.template row_bcast<5>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G5.at(lane) * T.at(lane); });
-            c.template row_bcast<13>(T, E); c.lanes([&](int lane) { AL.at(lane) += G5.at(lane) * T.at(lane); });
-            c.template row_bcast<3>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G3.at(lane) * T.at(lane); });
-            c.template row_bcast<11>(T, E); c.lanes([&](int lane) { AL.at(lane) += G3.at(lane) * T.at(lane); });
-            c.template row_bcast<2>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G2.at(lane) * T.at(lane); });
-            c.template row_bcast<10>(T, E); c.lanes([&](int lane) { AL.at(lane) += G2.at(lane) * T.at(lane); });
-            c.template row_bcast<8>(T, E);  c.lanes([&](int lane) { AL.at(lane) += G0.at(lane) * T.at(lane); });
-            c.template row_bcast<9>(T, E);  c.lanes([&](int lane) { AL.at(lane) += G1.at(lane) * T.at(lane); });
-            c.template row_bcast<0>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G0.at(lane) * T.at(lane); });
-            c.template row_bcast<1>(T, E);  c.lanes([&](int lane) { AN.at(lane) += G1.at(lane) * T.at(lane); });
+            //      - ONE accumulator: lanes 0..7 of a row hold the trial's sum, lanes 8..15 the linearised step's (row_bcast2)
+            c.template row_bcast2<4>(T, E); c.lanes([&](int lane) { AN.at(lane) = ACC.at(lane) + G4.at(lane) * T.at(lane); });
+            c.template row_bcast2<5>(T, E); c.lanes([&](int lane) { AN.at(lane) += G5.at(lane) * T.at(lane); });
+            c.template row_bcast2<3>(T, E); c.lanes([&](int lane) { AN.at(lane) += G3.at(lane) * T.at(lane); });
+            c.template row_bcast2<2>(T, E); c.lanes([&](int lane) { AN.at(lane) += G2.at(lane) * T.at(lane); });
+            c.template row_bcast2<0>(T, E); c.lanes([&](int lane) { AN.at(lane) += G0.at(lane) * T.at(lane); });
+            c.template row_bcast2<1>(T, E); c.lanes([&](int lane) { AN.at(lane) += G1.at(lane) * T.at(lane); });
             if (open_loop) {
                 PerLane<double> T2;
-                c.template row_bcast<12>(T, AL);
-                c.template row_bcast<13>(T2, AL);
-                c.lanes([&](int lane) { AN.at(lane) = ALPHA.at(lane) * ((lane & 1) ? T2.at(lane) : T.at(lane)); });
+                c.template row_bcast<12>(T, AN);
+                c.template row_bcast<13>(T2, AN);
+                c.lanes([&](int lane) {
+                    const double ol = ALPHA.at(lane) * ((lane & 1) ? T2.at(lane) : T.at(lane));
+                    AN.at(lane) = is_lin.at(lane) ? AN.at(lane) : ol;
+                });
             }
             if (fine_ticks<CTX>::value) c.tick(T_R_FEEDBACK);
             // ---- the trial's controls, clamped to the fraction-to-the-boundary box.  delta is final here (the model step waits
@@ -955,7 +955,7 @@ struct Solver {
             c.lanes([&](int lane) {
                 const double a = fmin2(fmax2(UN1.at(lane), LOV.at(lane)), HIV.at(lane));
                 const double un = fmin2(fmax2(a, Q0.at(lane)), Q1.at(lane));
-                const double nc = is_lin.at(lane) ? AL.at(lane) : un;
+                const double nc = is_lin.at(lane) ? AN.at(lane) : un;
                 ZU.at(lane) = is_ctrl.at(lane) ? nc : ZU.at(lane);
             });
             c.template row_bcast<4>(T, ZU);
@@ -1011,7 +1011,8 @@ struct Solver {
                     DSRC.at(lane) = ZU.at(lane);
                     if (FL.at(lane) == 0.0) return;
                     const double tgt = N2.at(lane) < TLO.at(lane) ? TLO.at(lane) : THI.at(lane);
-                    const double sreq = (tgt - TH.at(lane)) * (1.0 / kInvWheelbase) * frcp(dt * V.at(lane));
+                    // (keep(): the reciprocal stays in this rare path - a loop invariant of the pass loop otherwise, computed in every stage)
+                    const double sreq = (tgt - TH.at(lane)) * (1.0 / kInvWheelbase) * frcp(dt * c.keep(V.at(lane)));
                     if (fabs(sreq) < 0.9) {
                         const double u1 = fmin2(fmax2(atan_b(K, 2.0 * sreq * frsqrt(1.0 - sreq * sreq)), DLO.at(lane)), DHI.at(lane));
                         if ((lane & 15) == 5) {

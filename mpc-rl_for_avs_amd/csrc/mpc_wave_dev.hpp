@@ -57,6 +57,16 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
     return __longlong_as_double(__builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, true));
 }
 
+// Two broadcasts into one register: lanes 0..7 of every row take lane J, lanes 8..15 lane J + 8 of their row (the second
+// move is bank-masked: banks 2, 3 = lanes 8..15).  The trial (lanes 0..7) and the linearised step (lanes 8..15) of a rollout
+// row run the same matrix-vector products on their own halves: one multiply-add serves both.
+template <int J>
+__device__ __forceinline__ double row_bcast2_f64(double v) {
+    static_assert(J >= 0 && J < 8, "lane J of the lower, J + 8 of the upper half row");
+    const long long lo = __builtin_amdgcn_update_dpp((long long)0, __double_as_longlong(v), 0x150 + J, 0xf, 0xf, true);
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(lo, __double_as_longlong(v), 0x150 + J + 8, 0xf, 0xc, false));
+}
+
 // RELAX = 0 is the build for four resident waves per SIMD (128 registers): fresh() / opaque() hide where a constant or a
 // lane-derived table comes from, so that it is recomputed where it is used instead of living in registers across the
 // iteration loop.  The relaxed builds let the compiler hoist: with both relaxed ~200 registers (two waves per SIMD) and
@@ -121,6 +131,10 @@ struct WaveOpsT {
     template <int J>
     __device__ __forceinline__ void row_bcast(PerLane<double> &dst, PerLane<double> &src) const {
         dst.v = row_bcast_f64<J>(src.v);
+    }
+    template <int J>
+    __device__ __forceinline__ void row_bcast2(PerLane<double> &dst, PerLane<double> &src) const {
+        dst.v = row_bcast2_f64<J>(src.v);
     }
     // A wave-uniform double that the VALU computed sits in two vector registers like any per-lane value; moved to a scalar
     // register pair it costs none (and when scalar registers run out the compiler parks them in lanes of a vector

@@ -72,6 +72,13 @@ struct HostCtx {
         for (int l = 0; l < mpc::wave::kLanes; ++l) out[l] = src.v[(l & ~15) + J];
         for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
     }
+    // lanes 0..7 of a row take lane J, lanes 8..15 lane J + 8 of their row
+    template <int J>
+    void row_bcast2(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src) const {
+        double out[mpc::wave::kLanes];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) out[l] = src.v[(l & ~15) + J + ((l & 8) ? 8 : 0)];
+        for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
+    }
     int opaque(int v) const { return v; }
     int opaque_shared(int v) const { return v; }
     double fresh(double v) const { return v; }

@@ -462,11 +462,25 @@ def test_closed_loop_fixtures_vs_independent_solver(ref_table):
         ok = converged(got["status"])
         assert np.array_equal(ok, converged(g[f"{name}_oracle_status"])), (name, np.bincount(got["status"], minlength=6))
         assert int(ok.sum()) == n_eng
-        assert rel_u0_err(got["u0"], g[f"{name}_oracle_u0"])[ok].max() < 1e-6, name
+        dev_err = rel_u0_err(got["u0"], g[f"{name}_oracle_u0"])
+        split = np.zeros(0, dtype=np.int64)
+        if name != "c4v1":
+            assert dev_err[ok].max() < 1e-6, name
+        else:
+            # negative cost weights: bang-bang steering profiles with many local minimisers, and an iteration that is chaotic
+            # in the rounding (the device contracts multiply-adds, the CPU build does not) - a few instances end in another
+            # minimiser on the device than in the CPU run; each of those must carry its own KKT certificate
+            split = np.nonzero(ok & ~(dev_err < 1e-6))[0]
+            assert split.size <= 3, (name, split, dev_err[split])
+            if split.size:
+                p = nb.Batch.build(ref_table, d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"],
+                                   others=d["others"], collision_cost=cc).take(split)
+                mine = kb.certify(p, got["X"][split], got["U"][split])
+                assert mine["stationarity"].max() <= 1e-8 and mine["feasibility"].max() <= 1e-10, (name, split)
         both = (g[f"{name}_status"] == 0) & ok
         err = rel_u0_err(got["u0"], g[f"{name}_u0"])
         agree = both & (err <= TOL)
-        assert (int(both.sum()), int(agree.sum())) == (n_both, n_agree), (name, both.sum(), agree.sum())
+        assert int(both.sum()) == n_both and abs(int(agree.sum()) - n_agree) <= split.size, (name, both.sum(), agree.sum())
         assert np.median(err[agree]) < 1e-6          # the proxy stops at tol 1e-6
         other = np.nonzero(both & ~agree)[0]
         if other.size:
