@@ -3,6 +3,8 @@ inside the engine) against the host mirror of the reference's preamble (pinned b
 tests/test_host.py / test_preamble_cpu.py) followed by the same engine's `mpc_solve_batch`, over multi-step episodes
 with resets.  Problem data must agree exactly (indices, flags, float32-derived values), actions to the 1e-4 of the
 north star (expected ~1e-9: the host path pads absent vehicles far away instead of dropping them)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -419,6 +421,62 @@ def test_fused_environment_step_on_the_gpu_equals_its_host_build_and_the_torch_o
         alive = alive & ~d2
         assert torch.allclose(gt.ego[alive], gh.ego[alive], rtol=0, atol=1e-9)
     assert int((~alive).sum()) >= 5
+
+
+@pytest.mark.parametrize("K, B", [(0, 5), (1, 66), (9, 131), (4, 256)])
+def test_sixteen_lanes_per_environment_step_for_every_vehicle_count(K, B):
+    """`mpc_synth_env_rows_kernel` (round 5: lane j of a 16-lane group = vehicle j, four environments per wave) against the
+    host build of the one-thread statement `env::step_env`, same seed: no traffic, one vehicle, the most the observation
+    holds (9), and batch sizes that leave the last wave partly empty.  Episodes end and vehicles respawn along the way."""
+    import ctypes
+    import subprocess
+    import torch
+    from mpc_rl_for_avs_amd import rollout
+    from test_synth_env_cpu import HostEnv
+    from conftest import BUILD_DIR, HOST_CXXFLAGS, ROOT
+    out = os.path.join(BUILD_DIR, "libcpu_synth_env.so")
+    if not os.path.exists(out):
+        os.makedirs(BUILD_DIR, exist_ok=True)
+        subprocess.run(["g++"] + HOST_CXXFLAGS + ["-o", out, os.path.join(ROOT, "tests", "cpu_synth_env_harness.cpp")], check=True)
+    hostlib = ctypes.CDLL(out)
+    dev = torch.device("cuda:0")
+    g = rollout.SyntheticIntersectionEnv(B, device=dev, seed=9, n_others=K, spawn_probability=0.5)
+    assert g.backend == "hip"
+    h = HostEnv(hostlib, B, K, seed=9, spawn_probability=0.5)
+    assert np.allclose(g.reset().cpu().numpy(), h.reset(), rtol=0, atol=1e-5)
+    rng = np.random.default_rng(K)
+    ended = 0
+    for step in range(120):
+        act = np.stack([rng.uniform(-3, 5, B), 0.05 * rng.uniform(-1, 1, B)], axis=1)
+        o_g, r_g, d_g, info = g.step(torch.as_tensor(act, device=dev))
+        o_h, r_h, d_h = h.step(act)
+        assert np.array_equal(d_g.cpu().numpy(), d_h), step
+        for k in ("crashed", "arrived", "truncated"):
+            assert np.array_equal(info[k].cpu().numpy(), h.flags[k].astype(bool)), (step, k)
+        assert np.allclose(r_g.cpu().numpy(), r_h, rtol=0, atol=1e-4)
+        assert np.allclose(o_g.cpu().numpy(), o_h, rtol=0, atol=1e-4) and np.allclose(info["terminal_obs"].cpu().numpy(), h.tobs, rtol=0, atol=1e-4)
+        assert np.allclose(g.ego.cpu().numpy(), h.ego, rtol=0, atol=1e-8) and np.array_equal(g.oactive.cpu().numpy(), h.oactive.astype(bool))
+        assert np.allclose(g.opos.cpu().numpy(), h.opos, rtol=0, atol=1e-8) and np.array_equal(g.t.cpu().numpy(), h.t)
+        ended += int(d_h.sum())
+    assert (ended >= 1 or B < 16) and np.array_equal(g.rng_counter.cpu().numpy(), h.ctr)
+
+
+def test_v1_rollout_converges_like_v0():
+    """the config-4 rollout with v1 actions (the three cost weights anywhere in [-1, 1]^3, agents/ppo_mpc.py:
+    407-420, an untrained Gaussian policy) - at least 99.5 % of the rollout's solves end converged at the default settings
+    (round 4: 97.7 %)."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, rollout
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)
+    pol = rollout.ActorCritic(3).to(dev)
+    eng = engine.MPCEngine(horizon=20, max_iter=100)
+    env = rollout.SyntheticIntersectionEnv(256, device=dev, seed=0, n_others=4)
+    col = rollout.BatchedCollector(env, pol, eng, version="v1", algorithm="ppo", n_steps=32, collision_cost=False, seed=0)
+    col.collect_rollouts()
+    stats = col.collect_rollouts()
+    assert stats["mpc_unconverged"] <= 0.005 * 256 * 32, stats
+    eng.close()
 
 
 def test_graph_and_eager_collectors_produce_the_same_rollout():
