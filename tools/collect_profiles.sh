@@ -1,9 +1,9 @@
 #!/bin/bash
 # Copy the evidence of a tools/profile_session.sh run (merged back under gpurun_out/) into profiles/ (tracked).
-# usage: tools/collect_profiles.sh [tag]     default tag r03
+# usage: tools/collect_profiles.sh [tag]     default tag r05
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r04}
+TAG=${1:-r05}
 S=gpurun_out/${TAG}s
 P=profiles
 cp "$(ls -t $S/stats/*/*_kernel_stats.csv | head -1)" $P/${TAG}_bench_kernel_stats.csv
@@ -17,7 +17,7 @@ csv.writer(open(sys.argv[2], "w", newline="")).writerows(keep)
 PY
 cp $S/bench_prof.json $P/${TAG}_bench_profiled_run.json
 cp $S/bench.json $P/${TAG}_bench.json
-for f in latency tail predict parity_sweep ltv_timing run_pure_mpc; do cp $S/$f.txt $P/${TAG}_$f.txt; done
+for f in latency tail predict parity_sweep ltv_timing run_pure_mpc inflight graph_step_trace; do cp $S/$f.txt $P/${TAG}_$f.txt; done
 cp $S/rollout.jsonl $P/${TAG}_rollout.jsonl
 cp $S/bench_rccl_1rank.json $P/${TAG}_bench_rccl_1rank.json
 python3 tools/pmc_summary.py $TAG

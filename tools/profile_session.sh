@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU session that produces the evidence tracked under profiles/ (run through gpurun; tools/collect_profiles.sh copies
-# the summaries from gpurun_out/ into profiles/).  usage: tools/profile_session.sh [tag]     default tag r03
+# the summaries from gpurun_out/ into profiles/).  usage: tools/profile_session.sh [tag]     default tag r05
 # Every rocprofv3 command has the program itself after `--`; PMC passes are their own runs (tools/pmc_run.sh).
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${TAG}s
 mkdir -p $O
@@ -14,6 +14,8 @@ bash tools/pmc_run.sh ${TAG}_bulk python3 tools/gpu_bulk.py > $O/pmc_bulk.log 2>
 python3 tools/pmc_summary.py ${TAG}_bulk >> $O/pmc_bulk.log 2>&1
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/gpu_lat.py --bulk > $O/latency.txt 2>&1
+python3 tools/gpu_capline.py >> $O/latency.txt 2>&1
+python3 tools/gpu_inflight.py > $O/inflight.txt 2>&1
 python3 tools/gpu_tail.py > $O/tail.txt 2>&1
 python3 tools/gpu_predict_timing.py > $O/predict.txt 2>&1
 python3 tools/gpu_parity_sweep.py > $O/parity_sweep.txt 2>&1
@@ -27,6 +29,9 @@ python3 tools/bench_rollout.py --envs 256 --steps 64 --no-graph --env-backend to
 python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 --max-iter 1000 --tol 1e-6 >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 8192 --steps 32 --groups 4 >> $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 2048 --steps 32 --version v1 >> $O/rollout.jsonl 2>> $O/rollout.err
+rocprofv3 --kernel-trace --output-format csv -d $O/steptrace -- python3 tools/bench_rollout.py --envs 256 > /dev/null 2>> $O/rollout.err
+python3 tools/graph_step_gaps.py $O/steptrace > $O/graph_step_trace.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rollout_stats -- python3 tools/bench_rollout.py --envs 256 --steps 64 --no-graph > $O/rollout_prof.json 2> $O/rollout_prof.err
 BENCH_FORCE_DIST=1 python3 bench.py --steps 10 --no-side --no-cpu-baseline > $O/bench_rccl_1rank.json 2>> $O/rollout.err
 python3 tools/run_pure_mpc.py > $O/run_pure_mpc.txt 2>&1
