@@ -1,6 +1,6 @@
 // mpc_wave.hpp - wave-cooperative interior-point DDP solver: ONE wave64 per MPC instance.
 //
-// The NLP is the reference's (agents/pure_mpc.py:80-318), the algorithm the one DESIGN.md section 3 specifies,
+// The NLP is the reference's (agents/pure_mpc.py:80-318), the algorithm the one DESIGN.md section 2 specifies,
 // organised so that the 64 lanes of a wave work on a single instance:
 //   * everything that is independent per stage (trig and linearisation of the dynamics, cost and collision-potential
 //     values and derivatives, barrier terms, complementarity, stage Hessians, dual residual, step-length ratios, dual
@@ -9,15 +9,18 @@
 //     twelve 4x4 products per stage, every operand used where the product before it left it, the 2x2 control block as
 //     wave-uniform scalar algebra (sweep4 below; until round 4 an 8x8 block form with nine products and eight block moves
 //     per stage); nothing is exchanged through LDS;
-//   * the line search integrates all four trial step lengths at once, lane t = trial t;
+//   * the line search integrates all four trial step lengths and the linearised Newton step at once: trial t = the 16-lane
+//     DPP row t, the lanes of a row = the components of the stage, matrix-vector products as v_mov_b64_dpp row_newbcast +
+//     FMA (rollouts() below; until round 4 lane t = trial t, four active lanes);
 //   * the adjoint recursion is three suffix sums over the stages (A' = I + strictly triangular): wave scans;
-//   * only the true recursions (linearised step, one lane's rollout, the Riccati sweep itself) are serial.
+//   * only the true recursions (the rollout with the linearised step, the Riccati sweep) are serial over the stages.
 // Why: measured on MI355X, a one-lane-per-instance kernel (the first design, since removed) is bound by the serial
 // FP64 instruction stream of its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4
 // SIMDs per CU usable because the per-instance state has to sit in LDS.
-// Resources: 128 VGPRs, no scratch, 9.9 KB of LDS at N = 20 with 8 vehicles (16 instances per CU): no constant of the
-// solve lives in a register across the iteration loop (LDS table, CTX::fresh) and the trial trajectories of the line
-// search live in slots that are dead while it runs (trial_x / trial_u below).
+// Resources (round 5, profiles/r05_resource_usage.txt): two builds of this source - 215 VGPRs for a batch up to four waves
+// per SIMD deep, 156 beyond (there no constant of the solve lives in a register across the iteration loop: LDS table,
+// CTX::fresh) - neither with scratch; 13.2 KB of LDS at N = 20 with 8 vehicles (12 instances per CU), the same layout in both;
+// the trial trajectories of the line search live in slots that are dead while it runs (trial_x / trial_u below).
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
 // (f(lane) per lane; other lanes may read afterwards what a lane wrote to LDS); tests/cpu_wave_harness.cpp runs the
