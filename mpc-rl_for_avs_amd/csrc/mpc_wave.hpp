@@ -609,9 +609,10 @@ struct Solver {
         }
         return 10.0 * (4.0 * perp * perp + 2.0 * para * para + WS() * dv * dv + 0.5 * dth * dth);
     }
-    MPC_HD double dist(int k, double x_0, double x_1, double *d8) const {
+    // (j0, dj: the vehicles j0, j0 + dj, ... - the preparation phase splits them over lane groups, collision_parts below)
+    MPC_HD double dist(int k, double x_0, double x_1, double *d8, int j0 = 0, int dj = 1) const {
         double J = 0.0, g0 = 0, g1 = 0, h00 = 0, h01 = 0, h11 = 0, c00 = 0, c01 = 0, c11 = 0;
-        for (int j = 0; j < P.V; ++j) {
+        for (int j = j0; j < P.V; j += dj) {
             const double px = x_0 - (oth(j, 0) + k * oth(j, 2));
             const double py = x_1 - (oth(j, 1) + k * oth(j, 3));
             const double d2 = fma(px, px, py * py);
@@ -1308,6 +1309,26 @@ struct Solver {
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
             c.tick(T_DUALUPD);
+            // ============ collision potential: gradient, exact and Gauss-Newton curvature at the nodes 1 .. N - 1 - a loop over
+            //              the vehicles, 130 instructions each, that occupies the vector unit for the same four cycles per
+            //              instruction whether 19 lanes are active or 57.  The vehicles are dealt to up to three lane groups
+            //              (lane = g (N - 1) + k - 1: group g takes the vehicles g, g + G, ...); a group leaves its partial
+            //              sums in words of the stage that are dead at this point (group 0: where the result goes; 1, 2: the
+            //              gains of the last sweep, the spare trajectory buffer) and the preparation phase adds them up.
+            const int coll_nodes = N - 1;
+            const int coll_groups = (!CC || coll_nodes < 1) ? 1 : (kLanes / coll_nodes >= 3 ? 3 : (kLanes / coll_nodes >= 2 ? 2 : 1));
+            auto coll_word = [&](int g, int i) __attribute__((always_inline)) {
+                return g == 0 ? W_LX + i : (g == 1 ? W_KX + i : (i < 6 ? W_KP + i : (cur ^ 1) * 6 + (i - 6)));
+            };
+            if (CC && coll_nodes >= 1) {
+                c.phase([&](int lane) {
+                    const int g = lane / coll_nodes, k = 1 + lane - g * coll_nodes;
+                    if (g >= coll_groups) return;
+                    double d8[8];
+                    dist(k, S(k, CB + W_X + 0), S(k, CB + W_X + 1), d8, g, coll_groups);
+                    for (int i = 0; i < 8; ++i) S(k, coll_word(g, i), d8[i]);
+                });
+            }
             // ============ stage-parallel preparation: dynamics trig, collision-potential derivatives,
             //              complementarity products
             c.phase([&](int lane) {
@@ -1345,7 +1366,11 @@ struct Solver {
                     double lx0 = SF() * g[0], lx1 = SF() * g[1], lx2 = SF() * g[2], lx3 = SF() * g[3];
                     if (CC) {
                         double d8[8];
-                        dist(k, xk0, xk1, d8);
+                        for (int i = 0; i < 8; ++i) {
+                            d8[i] = S(k, coll_word(0, i));
+                            if (coll_groups >= 2) d8[i] += S(k, coll_word(1, i));
+                            if (coll_groups >= 3) d8[i] += S(k, coll_word(2, i));
+                        }
                         S(k, W_LX + 0, SF() * d8[0]);
                         S(k, W_LX + 1, SF() * d8[1]);
                         S(k, W_Q + 0, SF() * d8[2]);
