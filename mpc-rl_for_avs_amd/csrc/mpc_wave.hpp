@@ -115,19 +115,25 @@ enum : int {
     W_KP = 44,   // 4
     W_KF = 48,   // 2
     W_RV = 50,   // 1
+    // the constants 1 and dt of the stage matrix F = [A B; 0 I], once per stage (written by init_tables, never again): every
+    // operand of a Riccati stage is then a stage-relative word and its address one addition - fetched from the table of
+    // constants behind the stages they cost a select per operand and seven lane masks in scalar registers
+    W_ONE = 51,  // 1
+    W_DTC = 52,  // 1
     // The stage stride is kept ODD: lane k of a stage-parallel phase addresses word k * stride + slot, and with 64 LDS
     // banks of 4 bytes an even number of doubles per stage puts every 4th (56 slots) or 16th (46, 54 slots) stage on the
     // same banks - measured with 56 slots: SQ_LDS_BANK_CONFLICT 17 % of the LDS cycles, against 3 % in round 1.
-    W_SLOTS = 51,
-    W_LX = 51,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
-    W_Q = 53,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
-    W_QG = 56,   // 3  its Gauss-Newton part
-    W_ZW = 59,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
-    W_WJ = 60,   // 1  its vehicle j (as a double), -1: none
-    W_CROSS = 61,  // 1  after the line search: vehicle a rejected trial took across d = 1
-    W_SLOTS_CC = 63   // (one spare word keeps the stride odd)
+    W_SLOTS = 53,
+    W_LX = 53,   // 2  (collision-cost variant) potential gradient; after the factorisation: parked (dx, dy) of the node
+    W_Q = 55,    // 3  exact 2x2 curvature of the potential; after the factorisation: parked wall slack, wall dual step
+    W_QG = 58,   // 3  its Gauss-Newton part
+    W_ZW = 61,   // 1  multiplier of the node's wall constraint |p - o_j|^2 - 1 >= 0
+    W_WJ = 62,   // 1  its vehicle j (as a double), -1: none
+    W_CROSS = 63,  // 1  after the line search: vehicle a rejected trial took across d = 1
+    W_SLOTS_CC = 65   // (one spare word keeps the stride odd)
 };
 // positions in the W_LIN table of the eight values that are not structural zeros
+constexpr int kZeroWord = W_LIN + 2;      // a structural zero of the table: the stage-relative address of the constant 0
 enum : int { LIN_A02 = 0, LIN_A12 = 1, LIN_A03 = 4, LIN_A13 = 5, LIN_A23 = 6, LIN_B01 = 8, LIN_B11 = 9, LIN_B21 = 10 };
 // parked values (valid between the factorisation and the next preparation phase)
 enum : int { W_DXY = W_LX, W_GW = W_Q, W_DZW = W_Q + 1 };
@@ -344,9 +350,12 @@ struct Solver {
     MPC_HD int f_word(int r, int c) const {
         // stage_transition_word() names the eight stored values lin + 0..7 = a02 a03 a12 a13 a23 b01 b11 b21; here they sit in
         // the F[c][i] table of W_LIN
-        const int w = stage_transition_word(r, c, 0, -(SCR + SC_SPARE + 0 + 1), -(SCR + SC_SPARE + 1 + 1),
-                                            -(SCR + SC_SPARE + 2 + 1));
+        // ... and the structural constants in words of the stage too: 0 is one of the zeros of that table, 1 and dt W_ONE, W_DTC
+        const int w = stage_transition_word(r, c, 0, 1000, 1001, 1002);
         int t = w;
+        t = w == 1000 ? kZeroWord : t;
+        t = w == 1001 ? W_ONE : t;
+        t = w == 1002 ? W_DTC : t;
         t = w == 0 ? W_LIN + LIN_A02 : t;
         t = w == 1 ? W_LIN + LIN_A03 : t;
         t = w == 2 ? W_LIN + LIN_A12 : t;
@@ -390,7 +399,7 @@ struct Solver {
         c.lanes([&](int lane_) {
             const int lane = c.opaque(lane_);
             const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
-            const int zero = -(SCR + SC_SPARE + 0 + 1);
+            const int zero = kZeroWord;
             r_a.at(lane_) = f_word(hi, lo);                        // A[hi][lo]
             r_b.at(lane_) = f_word(hi, lo < 2 ? 6 + lo : 4);       // B~[hi][lo]: columns a, delta of F, then zeros
             const int a = hi < lo ? hi : lo, b = hi < lo ? lo : hi;
@@ -415,7 +424,7 @@ struct Solver {
                             PerLane<double> &M, PerLane<double> &QX, PerLane<double> &QU, double &lp0, double &lp1) {
         c.lanes([&](int lane) {
             const int base = k * SL;
-            auto word = [&](int w) { return c.ld(w >= 0 ? base + w : -w - 1); };
+            auto word = [&](int w) { return c.ld(base + w); };      // every operand is a word of the stage (W_ONE, W_DTC, kZeroWord)
             RA.at(lane) = word(r_a.at(lane));
             RB.at(lane) = word(r_b.at(lane));
             QXX.at(lane) = word(r_lxx.at(lane));
@@ -758,7 +767,13 @@ struct Solver {
 
     // the table of constants in LDS that every part of the solver reads bounds and function coefficients from
     MPC_HD void init_tables() {
-        sc(SC_SPARE + 0, 0.0);   // the constants F is made of besides the linearisation values (fetched by address)
+        c.phase([&](int lane) {
+            for (int k = lane; k <= N; k += kLanes) {
+                S(k, W_ONE, 1.0);
+                S(k, W_DTC, dt);
+            }
+        });
+        sc(SC_SPARE + 0, 0.0);
         sc(SC_SPARE + 1, 1.0);
         sc(SC_SPARE + 2, dt);
         for (int i = 0; i < kTrigWords; ++i) sc(SC_TRIG + i, trig_coef(i));
@@ -812,7 +827,7 @@ struct Solver {
     MPC_HD void rollouts(const int CB, const int TB, const int W_PRE, const double idt, const double frac_wall, unsigned long long &bad) {
         PerLane<double> ZU;                                    // the rows' state, see above
         PerLane<double> ALPHA, MNL, WDEL, WTH, ISS, ISC, FW0, FW1, FW2, W3DT, F2, LOABS, HIABS, P0, P1, P2, P3, P4, P5;
-        PerLane<int> o_zc, o_ck, o_g, o_q, a_pb, d_pb, o_f, o_st, is_ctrl, is_lin, is_th, is_tv, big;
+        PerLane<int> o_zc, o_ck, o_g, o_q, a_pb, d_pb, o_f, o_st, m_un, m_an, is_lin, is_th, big;
         c.lanes([&](int lane_) {
             const int lane = c.opaque(lane_);
             const int q = lane & 15, t = lane >> 4;
@@ -830,8 +845,9 @@ struct Solver {
             FW2.at(lane_) = q == 2 ? kInvWheelbase : 0.0;       // theta' = theta + dt v sin(beta) / L
             W3DT.at(lane_) = q == 3 ? dt : 0.0;                 // v' = v + dt a
             F2.at(lane_) = q == 11 ? dt : 0.0;                  // its linearisation: the d a column of F, (0, 0, 0, dt)
-            LOABS.at(lane_) = q == 2 ? xlo(0) : xlo(1);
-            HIABS.at(lane_) = q == 2 ? xhi(0) : xhi(1);
+            // (the bounds the feasibility test of theta, v is made against; every other lane: a test that never fails)
+            LOABS.at(lane_) = q == 2 ? xlo(0) : (q == 3 ? xlo(1) : -kNoBound);
+            HIABS.at(lane_) = q == 2 ? xhi(0) : (q == 3 ? xhi(1) : kNoBound);
             const int tw = SCR + SC_TRIG + ((q & 1) ? 6 : 0);   // sine lanes take the sine kernel's coefficients, cosine lanes the cosine's
             P0.at(lane_) = c.ld(tw + 0); P1.at(lane_) = c.ld(tw + 1); P2.at(lane_) = c.ld(tw + 2);
             P3.at(lane_) = c.ld(tw + 3); P4.at(lane_) = c.ld(tw + 4); P5.at(lane_) = c.ld(tw + 5);
@@ -857,10 +873,10 @@ struct Solver {
                 so = lc ? W_Y + (q - 12) : so;
             }
             o_st.at(lane_) = so;
-            is_ctrl.at(lane_) = (ct || lc) ? 1 : 0;
+            m_un.at(lane_) = c.hide(ct ? -1 : 0);      // lanes that commit the trial's clamped control / the linearised control step
+            m_an.at(lane_) = c.hide(lc ? -1 : 0);
             is_lin.at(lane_) = q >= 8 ? 1 : 0;
             is_th.at(lane_) = q == 2 ? 1 : 0;
-            is_tv.at(lane_) = (q == 2 || q == 3) ? 1 : 0;
             // (as a weighted sum: a select chain over x0[] becomes an indexed load, and an indexed load of a member puts the
             // whole solver object into scratch memory)
             ZU.at(lane_) = (q == 0 ? 1.0 : 0.0) * x0[0] + (q == 1 ? 1.0 : 0.0) * x0[1] + (q == 2 ? 1.0 : 0.0) * x0[2] +
@@ -959,8 +975,7 @@ struct Solver {
             c.lanes([&](int lane) {
                 const double a = fmin2(fmax2(UN1.at(lane), LOV.at(lane)), HIV.at(lane));
                 const double un = fmin2(fmax2(a, Q0.at(lane)), Q1.at(lane));
-                const double nc = is_lin.at(lane) ? AN.at(lane) : un;
-                ZU.at(lane) = is_ctrl.at(lane) ? nc : ZU.at(lane);
+                ZU.at(lane) = c.bit_select(m_un.at(lane), un, c.bit_select(m_an.at(lane), AN.at(lane), ZU.at(lane)));
             });
             c.template row_bcast<4>(T, ZU);
             c.lanes([&](int lane) { BASE.at(lane) = ZU.at(lane) + W3DT.at(lane) * T.at(lane); });      // v' = v + dt a; the others: ZU
@@ -1050,7 +1065,7 @@ struct Solver {
             c.lanes([&](int lane) {
                 const double n = NX.at(lane) + AL.at(lane);
                 ZU.at(lane) = n;
-                viol.at(lane) = (is_tv.at(lane) && ((n - LOABS.at(lane) < Q0.at(lane)) | (HIABS.at(lane) - n < Q1.at(lane)))) ? 1 : 0;
+                viol.at(lane) = ((n - LOABS.at(lane) < Q0.at(lane)) | (HIABS.at(lane) - n < Q1.at(lane))) ? 1 : 0;
             });
             bad |= c.ballot(viol);
             if (CC && any_wall && k + 1 < N) {

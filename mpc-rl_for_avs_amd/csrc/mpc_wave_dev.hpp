@@ -155,6 +155,22 @@ struct WaveOpsT {
         asm volatile("" : "+s"(v));
         return v;
     }
+    // an integer the compiler must keep in a vector register as a value it knows nothing about, in every build: a per-lane
+    // bit mask (0 / ~0) applied with v_bfi_b32 stays a vector operand - known to be a function of the lane id it is turned into
+    // a scalar-register lane mask + v_cndmask, and the scalar file being full, into two v_readlane per use
+    __device__ __forceinline__ int hide(int v) const {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+    // m ? a : b bit by bit, m = 0 or ~0 per lane, the mask a vector operand (hide()).  Written in C the compiler hoists ~m out
+    // of the loop and issues and / and / or per half; forced into two v_bfi_b32 by inline assembly it is two instructions fewer
+    // and - same box, alternating - 0.6 % SLOWER for a lone wave (29.2 against 29.0 us per iteration, straggler 36.7 against
+    // 36.1): the assembly blocks pin the schedule.  The C form stays.
+    __device__ __forceinline__ double bit_select(int m, double a, double b) const {
+        const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+        const unsigned long long mm = ((unsigned long long)(unsigned)m << 32) | (unsigned)m;
+        return __longlong_as_double((long long)((ua & mm) | (ub & ~mm)));
+    }
     __device__ __forceinline__ int opaque(int v) const {
         if (RELAX & 2) return v;
         asm volatile("" : "+v"(v));

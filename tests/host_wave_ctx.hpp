@@ -79,6 +79,17 @@ struct HostCtx {
         for (int l = 0; l < mpc::wave::kLanes; ++l) out[l] = src.v[(l & ~15) + J + ((l & 8) ? 8 : 0)];
         for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
     }
+    int hide(int v) const { return v; }
+    double bit_select(int m, double a, double b) const {      // m ? a : b bit by bit, m = 0 or ~0
+        unsigned long long ua, ub;
+        __builtin_memcpy(&ua, &a, 8);
+        __builtin_memcpy(&ub, &b, 8);
+        const unsigned long long mm = ((unsigned long long)(unsigned)m << 32) | (unsigned)m;
+        const unsigned long long ur = (ua & mm) | (ub & ~mm);
+        double r;
+        __builtin_memcpy(&r, &ur, 8);
+        return r;
+    }
     int opaque(int v) const { return v; }
     int opaque_shared(int v) const { return v; }
     double fresh(double v) const { return v; }

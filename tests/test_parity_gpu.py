@@ -233,15 +233,15 @@ def test_limits_of_the_interface(oracle):
         e.solve_batch(inp["state"], inp["ego_index"], inp["weights"], inp["is_collide"], vref=inp["vref"],
                       others=np.concatenate([oth16, far[:, :1]], axis=1), collision_cost=True)      # 17 vehicles
     e.close()
-    # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (40 KB of LDS): 63 slots per
+    # the largest workspace the interface allows: horizon 64 with 16 vehicles in the collision cost (41 KB of LDS): 65 slots per
     # node + the 12 words of the PQ / PB table of the rollout, the table of constants (3 + 1, 12 trig, 10 log, 8 bounds, 6 solve
-    # constants, 3 no-bound), 4 per vehicle; the BASELINE shape (horizon 20, 8 vehicles) is 13.2 KB, i.e. 12 instances per CU -
+    # constants, 3 no-bound), 4 per vehicle; the BASELINE shape (horizon 20, 8 vehicles) is 13.5 KB, i.e. 12 instances per CU -
     # the same layout in every build since round 5 (rounds 2 - 4: 9.9 / 11.9 KB)
     e = engine.MPCEngine(horizon=64, max_iter=100)
-    assert e.workspace_bytes(1, 16) == (75 * 65 + 43 + 64) * 8
+    assert e.workspace_bytes(1, 16) == (77 * 65 + 43 + 64) * 8
     e20 = engine.MPCEngine(horizon=20, max_iter=100)
-    assert e20.workspace_bytes(65536, 8) == e20.workspace_bytes(1, 8) == (75 * 21 + 43 + 32) * 8 <= 163840 // 12
-    assert e20.workspace_bytes(4096, 0) == e20.workspace_bytes(1024, 0) == (63 * 21 + 43) * 8
+    assert e20.workspace_bytes(65536, 8) == e20.workspace_bytes(1, 8) == (77 * 21 + 43 + 32) * 8 <= 163840 // 12
+    assert e20.workspace_bytes(4096, 0) == e20.workspace_bytes(1024, 0) == (65 * 21 + 43) * 8
     e20.close()
     sub = {k: (v[:24] if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
     vref64 = np.concatenate([sub["vref"], np.repeat(sub["vref"][:, -1:], 44, axis=1)], axis=1)
