@@ -416,7 +416,13 @@ struct Solver {
             r_m.at(lane_) = (hi == 0 && lo == 0) ? A_H66 : ((hi == 1 && lo == 1) ? A_H77 : zero);
             r_lx.at(lane_) = lo == 0 ? AB + A_HV0 + hi : zero;                                 // in the trial buffer
             r_lu.at(lane_) = lo == 0 ? (hi == 0 ? A_HV6 : (hi == 1 ? A_HV7 : zero)) : zero;
-            r_kx.at(lane_) = (blk == 0 && hi < 2) ? W_KX + 2 * lo + hi : -1;      // Kx[hi][lo], transposed layout
+            // where this lane stores its gain: the four blocks of the matrix-core layout hold the same values, so block 0 stores
+            // Kx[hi][lo] (transposed layout), block 1 Kp[hi][lo], block 2 kf[hi] - one ds_write for all fourteen words
+            int out = -1;
+            out = (blk == 0 && hi < 2) ? W_KX + 2 * lo + hi : out;
+            out = (blk == 1 && hi < 2 && lo < 2) ? W_KP + 2 * lo + hi : out;
+            out = (blk == 2 && hi < 2 && lo == 0) ? W_KF + hi : out;
+            r_kx.at(lane_) = out;
         });
     }
 
@@ -583,16 +589,14 @@ struct Solver {
                 PXX.at(lane) = PXXn.at(lane);
                 PXP.at(lane) = PXPn.at(lane);
                 PX.at(lane) = PXn.at(lane);
+                // gains: Kx = -W Qux = Ya / det, Kp = rd W = rd adj(Quu) / det, kf = (det kf) / det - each lane its own word, the
+                // same products in the same order as the scalars kf0, kf1, kp00 .. of the recursion (Kp of stage 0, which no
+                // rollout multiplies with anything but zero, is stored as rd W as well)
                 const int ks = r_kx.at(lane);
-                if (ks >= 0) S(k, ks, idet * Ya.at(lane));        // Kx = -W Qux
-                if (lane == 0) {
-                    S(k, W_KF + 0, kf0);
-                    S(k, W_KF + 1, kf1);
-                    S(k, W_KP + 0, kp00);      // Kp[i][j] at W_KP + 2 j + i (symmetric)
-                    S(k, W_KP + 1, kp01);
-                    S(k, W_KP + 2, kp01);
-                    S(k, W_KP + 3, kp11);
-                }
+                const bool is_kp = (ks >= W_KP) & (ks < W_KF), is_kf = ks >= W_KF;
+                const double t = is_kf ? KFB.at(lane) : (is_kp ? -NWA.at(lane) : Ya.at(lane));
+                const double v = (idet * t) * (is_kp ? rd_full : 1.0);
+                if (ks >= 0) S(k, ks, v);
             });
             pp00 = rdk - rdk * kp00;      // Ppp' = rd I - rd^2 W
             pp01 = -rdk * kp01;
