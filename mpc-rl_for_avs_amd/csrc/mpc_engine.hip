@@ -46,9 +46,9 @@ int fail(int code, const std::string &msg) {
 
 constexpr int kBlock = 64;  // one wave64 per workgroup
 constexpr int kMaxDevices = 64;
-// Waves per SIMD the wave-cooperative kernel is compiled for.  Since round 5 an instance needs 13.2 KB of LDS at N = 20 with
+// Waves per SIMD the wave-cooperative kernel is compiled for.  Since round 5 an instance needs 13.5 KB of LDS at N = 20 with
 // the collision cost and 8 vehicles (the linearisation table and the PQ / PB table of the row-cooperative rollout,
-// mpc_wave.hpp), i.e. 12 instances per CU: the throughput build is compiled for 3 waves per SIMD (156 registers, no scratch),
+// mpc_wave.hpp), i.e. 12 instances per CU: the throughput build is compiled for 3 waves per SIMD (166 registers, no scratch),
 // which is what LDS admits anyway.  (Rounds 2 - 4: 9.9 KB, 128 registers, 4 per SIMD.)
 constexpr int kWaveOcc = 3, kWaveOccGeneric = 3;
 // The build for batches that do not keep the SIMDs deep in work (WaveOpsT<RELAX>, mpc_wave_dev.hpp): occupancy 2, up to 256

@@ -17,9 +17,9 @@
 // Why: measured on MI355X, a one-lane-per-instance kernel (the first design, since removed) is bound by the serial
 // FP64 instruction stream of its slowest instance (~47 k instructions per iteration), with 16 of 64 lanes and 1 of 4
 // SIMDs per CU usable because the per-instance state has to sit in LDS.
-// Resources (round 5, profiles/r05_resource_usage.txt): two builds of this source - 215 VGPRs for a batch up to four waves
-// per SIMD deep, 156 beyond (there no constant of the solve lives in a register across the iteration loop: LDS table,
-// CTX::fresh) - neither with scratch; 13.2 KB of LDS at N = 20 with 8 vehicles (12 instances per CU), the same layout in both;
+// Resources (round 5, profiles/r05_resource_usage.txt): two builds of this source - 229 VGPRs for a batch up to four waves
+// per SIMD deep, 166 beyond (there no constant of the solve lives in a register across the iteration loop: LDS table,
+// CTX::fresh) - neither with scratch; 13.5 KB of LDS at N = 20 with 8 vehicles (12 instances per CU), the same layout in both;
 // the trial trajectories of the line search live in slots that are dead while it runs (trial_x / trial_u below).
 //
 // The code is written as alternating "uniform" sections (identical in every lane) and `ctx.phase(f)` sections
