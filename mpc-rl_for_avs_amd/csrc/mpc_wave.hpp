@@ -67,6 +67,10 @@ constexpr double kGnEndMu = 1e-2;
 // ladder starts at the ladder's first rung directly (a third of the value that worked last), in the same model; every
 // kDwProbe-th iteration tries delta_w = 0 first as before (sweeps per iteration on the c4v1 fixture states 1.99 -> 1.50).
 constexpr int kDwProbe = 4;
+// an instance still iterating after this many iterations is one of the stragglers its batch waits for: its wave asks for the
+// highest issue priority on its SIMD (s_setprio).  Same box, alternating: 0.5 - 1 % on a batch of 4096 (seed 4: 4.36 -> 4.33 ms),
+// inside the run-to-run spread of seed 0; a threshold of 0 or 16 iterations measures the same
+constexpr int kBoostIter = 28;
 // (viii) a linearised Newton step smaller than this in the states and the previous control of a stage is applied OPEN LOOP
 // there (alpha times the linearised control step) instead of through the feedback law: the feedback acts on the difference of
 // two rolled-out trajectories, which carries the rounding of positions ~50 m (7e-15); times gains of 10 - 100 where a control and
@@ -1327,6 +1331,7 @@ struct Solver {
 
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
+            if (iter == kBoostIter) c.set_priority(3);
             c.tick(T_DUALUPD);
             // ============ collision potential: gradient, exact and Gauss-Newton curvature at the nodes 1 .. N - 1 - a loop over
             //              the vehicles, 130 instructions each, that occupies the vector unit for the same four cycles per
