@@ -93,7 +93,7 @@ def test_default_line_is_the_only_stdout_and_carries_every_single_gpu_config():
     d = _line([sys.executable, "bench.py", "--steps", "5", "--warmup", "2"], only_line=True)
     _check(d, 5)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 1e3 and d["cpu_baseline"]["cores"] >= 1
-    assert d["roofline"]["kernel_ms"] > 0 and 0 <= d["parity"]["n_converged"] - d["parity"]["n_certified"] <= 2 and d["parity"]["n_certified_within_10x"] == d["parity"]["n_converged"]
+    assert d["roofline"]["kernel_ms"] > 0 and d["parity"]["n_certified"] == d["parity"]["n_converged"]
     s = d["headline_over_seeds"]
     assert [r["seed"] for r in s["per_seed"]] == [0, 1, 2] and s["ms_min"] <= s["ms_median"] <= s["ms_max"] < 20.0
     c2, c4, b1 = d["config2"], d["config4"], d["predict_b1"]

@@ -314,12 +314,13 @@ def _certified_full_batch(eng, oracle, ref_table, B, V, cc):
     tol_i = np.where(got["status"][sel] >= 6, 1e-6, 1e-8)
     assert (got["status"][sel] >= 6).sum() <= 8
     cert = kb.certify(p.take(sel), got["X"][sel], got["U"][sel], eps_c=tol_i / sf, sf=sf)
-    # The certificate's stationarity is relative to max(1, |grad f|_inf); IPOPT's own test divides by s_d = max(100, (|lambda|_1 +
-    # |z|_1) / (n + m)) / 100 instead, which is the larger allowance on an instance with large equality multipliers: since round 5
-    # (more instances converge inside the cap) one or two of 4096 meet IPOPT's test with 1.0e-8 < stationarity < 3e-8 in the
-    # certificate's units (seed 0: instance 2791, 1.4e-8 for the oracle's answer and 2.7e-8 for the device's)
-    over = cert["stationarity"] > tol_i
-    assert over.sum() <= 2 and (cert["stationarity"] <= 10.0 * tol_i).all(), (cert["stationarity"].max(), sel[cert["stationarity"].argmax()])
+    # Exact gate (round 6): EVERY solution the engine calls converged certifies at its own tolerance, both relative to
+    # max(1, |grad f|_inf) and in IPOPT's own units (residual of the scaled problem / s_d, Waechter & Biegler eq. (5), (6)).
+    # Round 5 had allowed "<= 2 instances over, all within 10 x" here: that was the certifier's least-squares routine stopping
+    # early on instance 2791 (BVLS at 1.4e-8 where the optimum is 2e-16), not the solver - kkt_batch now cross-checks BVLS with
+    # two other exact methods.  Measured on the oracle's answers: worst 4e-11 (own units), 0.27 tol (IPOPT's units).
+    assert (cert["stationarity"] <= tol_i).all(), (cert["stationarity"].max(), sel[cert["stationarity"].argmax()])
+    assert (cert["stationarity_ipopt"] <= tol_i).all(), (cert["stationarity_ipopt"].max(), sel[cert["stationarity_ipopt"].argmax()])
     assert cert["feasibility"].max() <= 1e-10
     assert cert["bound_violation"].max() == 0.0
     # SURVEY section 8(c) pin (1) literally - complementarity 1e-8 in UNSCALED units: holds for all but a handful, and
@@ -436,7 +437,7 @@ def test_stall_window_on_the_gpu(oracle, ref_table):
     e.close()
 
 
-def test_closed_loop_fixtures_vs_independent_solver(ref_table):
+def test_closed_loop_fixtures_vs_independent_solver(oracle, ref_table):
     """tests/golden/closed_loop_ipopt.npz: problem data recorded from closed-loop runs (BASELINE config 1 and the
     config-4 rollout, collision cost off / on, RL speed override / none, and the v1 input domain: cost weights from
     [-1, 1]^3; generator tests/golden/make_closed_loop.py) solved by oracle/ipopt_restated.py - IPOPT's algorithm incl. its
@@ -468,15 +469,16 @@ def test_closed_loop_fixtures_vs_independent_solver(ref_table):
             assert dev_err[ok].max() < 1e-6, name
         else:
             # negative cost weights: bang-bang steering profiles with many local minimisers, and an iteration that is chaotic
-            # in the rounding (the device contracts multiply-adds, the CPU build does not) - a few instances end in another
-            # minimiser on the device than in the CPU run; each of those must carry its own KKT certificate
+            # in the rounding (the device contracts multiply-adds, the CPU build does not) - an instance may end in another
+            # minimiser on the device than in the CPU run.  Round 6: no bare count any more - each such instance goes through
+            # the exact gate of the engine-vs-oracle tests (conftest.unexplained_disagreements): BOTH answers must carry a KKT
+            # certificate AND the oracle itself must jump by more than the tolerance when the ego state moves by 1 - 2 ulp.
             split = np.nonzero(ok & ~(dev_err < 1e-6))[0]
-            assert split.size <= 3, (name, split, dev_err[split])
             if split.size:
-                p = nb.Batch.build(ref_table, d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"],
-                                   others=d["others"], collision_cost=cc).take(split)
-                mine = kb.certify(p, got["X"][split], got["U"][split])
-                assert mine["stationarity"].max() <= 1e-8 and mine["feasibility"].max() <= 1e-10, (name, split)
+                want = oracle.solve_batch(ref_table, d["state"], d["ego_index"], d["weights"], d["is_collide"], vref=d["vref"],
+                                          others=d["others"], collision_cost=cc, max_iter=1000, xy_bounds=False)
+                assert np.array_equal(want["status"], g[f"{name}_oracle_status"]), name     # the fixture's own generator call
+                assert unexplained_disagreements(oracle, ref_table, d, cc, got, want, 1e-6, max_iter=1000) == [], (name, split)
         both = (g[f"{name}_status"] == 0) & ok
         err = rel_u0_err(got["u0"], g[f"{name}_u0"])
         agree = both & (err <= TOL)
