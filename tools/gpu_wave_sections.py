@@ -14,7 +14,7 @@ from mpc_rl_for_avs_amd.reference_path import reference_states
 
 NAMES = ["prep", "adjoint", "dualres", "ric_assembly", "ric_operands", "ric_T", "ric_H", "ric_2x2", "ric_schur",
          "linear", "ratios", "roll_dyn", "roll_cost", "dualupd", "r_feedback", "r_clamp", "r_dyn", "r_store", "r_check", "r_proj", "r_ldsw"]
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "ubench", "libwave_sections.so"))
+lib = ctypes.CDLL(os.environ.get("WAVE_SECTIONS_LIB") or os.path.join(ROOT, "tools", "ubench", "libwave_sections.so"))
 assert lib.wave_sections_count() == len(NAMES)
 dev = torch.device("cuda", 0)
 ref = reference_states()
