@@ -71,7 +71,8 @@ extern "C" {
                                       or MPC_STATUS_ACCEPTABLE_ON_KINK - is reported as MPC_STATUS_KINK_UNSOLVED, i.e. NOT solved,
                                       with the last iterate as the result: what the reference's IPOPT reports for a point no
                                       smooth method accepts (solver.stats()['success'] false, the last iterate is used,
-                                      agents/pure_mpc.py:303-305).  The iterates are the same with and without the flag. */
+                                      agents/pure_mpc.py:303-305).  The iterates OF THAT SOLVE are the same with and without the flag; with
+                                      MPC_FLAG_WARM_START the next closed-loop step differs (a solve reported unsolved does not seed it). */
 
 /* per-instance solver status written to status[] */
 #define MPC_STATUS_CONVERGED 0
@@ -341,7 +342,7 @@ int mpc_eval_nlp(mpc_handle *h, int32_t B, const int32_t *ego_index, const doubl
                  double *f, double *x_next);
 
 /* LDS bytes one workgroup (= one wave = one instance) of the solve kernel uses with V other vehicles in the
- * collision-cost term (V = 0: term off): 15.2 KB at horizon 20 with 8 vehicles, the same in every build since round 5 (B is
+ * collision-cost term (V = 0: term off): 13.5 KB at horizon 20 with 8 vehicles, the same in every build since round 5 (B is
  * accepted for compatibility and ignored).  The engine keeps no per-instance solver state in HBM.  (diagnostics / capacity
  * planning) */
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);

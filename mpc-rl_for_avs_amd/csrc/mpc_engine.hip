@@ -51,6 +51,9 @@ constexpr int kMaxDevices = 64;
 // mpc_wave.hpp), i.e. 12 instances per CU: the throughput build is compiled for 3 waves per SIMD (166 registers, no scratch),
 // which is what LDS admits anyway.  (Rounds 2 - 4: 9.9 KB, 128 registers, 4 per SIMD.)
 constexpr int kWaveOcc = 3, kWaveOccGeneric = 3;
+// ... except the runtime-horizon build WITH the collision cost: at 3 waves per SIMD (168 registers) it spilled two vector
+// registers to scratch memory (12 B per lane, round 5); compiled for 2 waves per SIMD it has none (round 6)
+constexpr int kWaveOccGenericCC = 2;
 // The build for batches that do not keep the SIMDs deep in work (WaveOpsT<RELAX>, mpc_wave_dev.hpp): occupancy 2, up to 256
 // registers, fresh() / opaque() the identity (everything hoisted): less time per iteration for a wave that has its SIMD to
 // itself.  Used up to FOUR waves per SIMD of batch depth (B <= 4096 on 256 CUs: every BASELINE configuration): two are
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     const uint8_t *__restrict__ is_collide, const double *__restrict__ others, int Vin,
     const int32_t *__restrict__ nveh, double w_collision, const double *u_init, int u_shift, uint8_t *u_valid,
     double *__restrict__ u0_out, double *U_out, double *__restrict__ X_out, int32_t *__restrict__ status_out,
-    int32_t *__restrict__ iters_out, const int32_t *__restrict__ order, int32_t *__restrict__ iters_keep) {
+    int32_t *__restrict__ iters_out, const int32_t *__restrict__ order) {
     extern __shared__ double smem[];
     const int N = NC > 0 ? NC : P.N;
     if ((int)blockIdx.x >= B) return;            // grid = B workgroups of one wave
@@ -173,7 +176,6 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
     if (lane == 0) {
         if (status_out) status_out[b] = status;
         if (iters_out) iters_out[b] = iters;
-        if (iters_keep) iters_keep[b] = iters;      // the handle's record (mpc_predict_batch): next step's launch-order key
     }
 }
 
@@ -187,15 +189,12 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
 // the easy live objective in all but name (no instance with >= 70 iterations had its nearest vehicle farther away, unless it
 // stood still).  Three tiers, each in its original order (a stable partition): 0 = standing ego, or no predicted collision
 // and (collision cost off or a vehicle within kNear); 1 = the other instances without a predicted collision; 2 = the rest.
-// In a closed loop (mpc_predict_batch) there is a better predictor: what the same environment needed one step ago.  Where the
-// handle has that count it decides the tier (>= kPrevSlow iterations: first, >= kPrevMid: second), the geometric tiers are for
-// the first step of an environment (round 5; opt-in, see mpc_handle::order_by_prev: the A/B of profiles/r05_launch_order_prev.txt
-// is negative).
+// (Round 5 also built "what the same environment needed one step ago" as the first key for the closed loop; measured neutral to
+// negative - profiles/r05_launch_order_prev.txt, docs/NOT_ADOPTED.md - and removed in round 6 together with its per-environment
+// record and the environment variable that switched it on.)
 constexpr double kOrderStanding = 0.1, kOrderNear = 15.0;
-constexpr int kPrevSlow = 28, kPrevMid = 18;
 __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const double *state, const double *others, int V,
-                                          const int32_t *nveh, const int32_t *prev_iters, int i) {
-    if (prev_iters && prev_iters[i] > 0) return prev_iters[i] >= kPrevSlow ? 0 : (prev_iters[i] >= kPrevMid ? 1 : 2);
+                                          const int32_t *nveh, int i) {
     const double *x = state + (size_t)i * 4;
     if (x[3] < kOrderStanding) return 0;
     if (is_collide[i] != 0) return 2;
@@ -212,11 +211,11 @@ __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const doubl
 __global__ __launch_bounds__(1024) void mpc_order_kernel(int B, const uint8_t *__restrict__ is_collide,
                                                          const double *__restrict__ state, const double *__restrict__ others,
                                                          int V, const int32_t *__restrict__ nveh, int32_t *__restrict__ order,
-                                                         int32_t *__restrict__ tier, const int32_t *__restrict__ prev_iters) {
+                                                         int32_t *__restrict__ tier) {
     __shared__ int s_c0[1024], s_c1[1024];
     const int t = threadIdx.x, chunk = (B + 1023) / 1024, lo = min(B, t * chunk), hi = min(B, lo + chunk);
     // tiers first, every thread an interleaved share (neighbouring threads read neighbouring instances), kept in scratch
-    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, prev_iters, i);
+    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, i);
     __syncthreads();
     int n0 = 0, n1 = 0;
     for (int i = lo; i < hi; ++i) {
@@ -413,48 +412,10 @@ __global__ void mpc_env_reset_kernel(int n, const int32_t *__restrict__ ids, con
 }
 
 // ---------------------------------------------------------------------------------------------------
-// synthetic intersection environment (mpc_synth_env.hpp): one thread per environment; step + terminal observation +
-// auto-reset + next observation in ONE launch (the torch implementation of the same step is ~100 small kernels)
+// synthetic intersection environment (mpc_synth_env.hpp): step + terminal observation + auto-reset + next observation in ONE
+// launch (the torch implementation of the same step is ~100 small kernels)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void mpc_synth_env_kernel(
-    int B, int K, double dt, double spawn_probability, uint64_t seed, int env_offset, const double *__restrict__ ref_xy,
-    int M, const double *__restrict__ action, double *__restrict__ ego, double *__restrict__ opos,
-    double *__restrict__ ospeed, double *__restrict__ ohead, uint8_t *__restrict__ oactive, int32_t *__restrict__ t,
-    int64_t *__restrict__ ctr, float *__restrict__ obs, float *__restrict__ terminal_obs, float *__restrict__ reward,
-    uint8_t *__restrict__ done, uint8_t *__restrict__ truncated, uint8_t *__restrict__ crashed,
-    uint8_t *__restrict__ arrived, int reset_all) {
-    namespace env = mpc::env;
-    // the route (85 x 2 doubles) is scanned point by point for the lane-centring term: from LDS
-    __shared__ double s_ref[2 * 128];
-    const bool staged = M <= 128;
-    if (staged) {
-        for (int i = threadIdx.x; i < 2 * M; i += blockDim.x) s_ref[i] = ref_xy[i];
-        __syncthreads();
-    }
-    const double *route = staged ? (const double *)s_ref : ref_xy;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const int Ks = K > 0 ? K : 1;      // the arrays keep one slot per environment even without traffic
-    const env::View v{ego + (size_t)b * 4, opos + (size_t)b * Ks * 2, ospeed + (size_t)b * Ks, ohead + (size_t)b * Ks,
-                      oactive + (size_t)b * Ks, t + b, ctr + b};
-    float *o = obs + (size_t)b * env::kRows * env::kCols;
-    if (reset_all) {
-        const env::Rng r(seed, env_offset + b, *v.ctr);
-        *v.ctr += 1;
-        env::reset_env(v, K, r);
-        env::observe(v, K, o);
-        return;
-    }
-    const env::StepOut so = env::step_env(v, K, dt, spawn_probability, seed, env_offset + b, route, M, action + (size_t)b * 2,
-                                          terminal_obs + (size_t)b * env::kRows * env::kCols, o);
-    reward[b] = so.reward;
-    done[b] = so.done;
-    truncated[b] = so.truncated;
-    crashed[b] = so.crashed;
-    arrived[b] = so.arrived;
-}
-
-// The same step with SIXTEEN lanes per environment (round 5; four environments per wave): lane j of a group owns vehicle j
+// SIXTEEN lanes per environment (round 5; four environments per wave): lane j of a group owns vehicle j
 // (model step, respawn draws, crash test, its row of the observation - its place among the rows by counting the vehicles that
 // are nearer, which is the stable insertion sort of env::observe), the 85 route points of the lane-centring term are scanned
 // 16 at a time with a min-reduction over the group (lowest index among equal distances, as the serial scan keeps the first),
@@ -729,12 +690,6 @@ struct mpc_handle {
     // observation-level path (mpc_predict_batch): per-environment detector state and the problem data the
     // preamble kernel writes for the solve kernel
     mpc::pre::EnvState *d_env = nullptr;
-    // iteration count of each environment's last solve through mpc_predict_batch (0: none yet): the launch order's first key
-    int32_t *d_prev_iters = nullptr;
-    // OFF by default: measured neutral to negative (profiles/r05_launch_order_prev.txt) - with a stochastic policy the reference
-    // speed (v0) or the cost weights (v1) change from step to step and so does the iteration count; MPC_ORDER_BY_PREV_ITERS=1 in
-    // the environment turns it on (a deterministic policy late in training may correlate better)
-    bool order_by_prev = false;
     int32_t *d_ids = nullptr;   // scratch of mpc_reset_env_state
     int ids_cap = 0;
     int env_cap = 0;
@@ -776,7 +731,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
                 const double *d_state, const int32_t *d_ego, const double *d_vref, const double *d_weights,
                 const uint8_t *d_coll, const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift,
                 uint8_t *d_uvalid, double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters,
-                const int32_t *d_order, int32_t *d_keep) {
+                const int32_t *d_order) {
     auto kern = mpc_solve_wave_kernel<CC, NC, OCC, RELAX>;
     const size_t lds = (size_t)mpc::wave::lds_doubles(CC, P.N, P.V) * sizeof(double);
     // raised once per (kernel, device): the attribute call is not a stream operation and must stay out of a stream
@@ -792,7 +747,7 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kBlock), lds, stream, P, B, h->d_ref, h->M, d_state, d_ego,
                        d_vref, d_weights, d_coll, d_others, V, d_nveh, h->cfg.w_collision, d_uinit, u_shift, d_uvalid,
-                       d_u0, d_U, d_X, d_status, d_iters, d_order, d_keep);
+                       d_u0, d_U, d_X, d_status, d_iters, d_order);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }
@@ -833,7 +788,7 @@ mpc::SolveParams solve_params(const mpc_handle *h, int Vuse) {
 int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, hipStream_t stream, const double *d_state,
                    const int32_t *d_ego, const double *d_vref, const double *d_weights, const uint8_t *d_coll,
                    const double *d_others, const int32_t *d_nveh, const double *d_uinit, int u_shift, uint8_t *d_uvalid,
-                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters, int32_t *d_keep = nullptr) {
+                   double *d_u0, double *d_U, double *d_X, int32_t *d_status, int32_t *d_iters) {
     const int N = h->cfg.horizon;
     const int Vuse = cc ? V : 0;
     mpc::SolveParams P = solve_params(h, Vuse);
@@ -847,7 +802,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     int rc;
 #define MPC_LAUNCH_W(CCV, NCV, OCCV, RLX)                                                                              \
     rc = launch_wave<CCV, NCV, OCCV, RLX>(h, P, (int)B, (int)V, stream, d_state, d_ego, d_vref, d_weights, d_coll, \
-                                          d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters, d_order, d_keep)
+                                          d_others, d_nveh, d_uinit, u_shift, d_uvalid, d_u0, d_U, d_X, d_status, d_iters, d_order)
     // which build: by how deep the batch fills the SIMDs (see kWaveOccLat above)
     const int simds = 4 * h->num_cu;
     // launch order (mpc_order_kernel): pays as soon as waves share a SIMD.  Not with MPC_FLAG_THROUGHPUT: batches in flight on
@@ -856,8 +811,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     // ... and while the batch is not so deep that only throughput counts (beyond 8 waves per SIMD the order changed nothing)
     if (!throughput && B > simds && B <= 8 * simds && h->d_order && h->order_cap >= B) {
         hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, cc ? d_others : nullptr,
-                           (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap,
-                           (d_keep && h->order_by_prev) ? (const int32_t *)d_keep : nullptr);
+                           (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap);
         HIP_TRY(hipGetLastError());
         d_order = h->d_order;
     }
@@ -868,7 +822,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     if (cc) {
         if (N == 20) { MPC_LAUNCH_N(true, 20); }       /* BASELINE horizon */
         else if (N == 16) { MPC_LAUNCH_N(true, 16); }  /* reference cfg.yaml default */
-        else MPC_LAUNCH_W(true, 0, kWaveOccGeneric, 0);
+        else MPC_LAUNCH_W(true, 0, kWaveOccGenericCC, 0);
     } else {
         if (N == 20) { MPC_LAUNCH_N(false, 20); }
         else if (N == 16) { MPC_LAUNCH_N(false, 16); }
@@ -943,7 +897,6 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
         const int cap = 8 * 4 * h->num_cu;        // dispatch_solve orders batches of up to 8 waves per SIMD
         if (hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * 2 * sizeof(int32_t)) == hipSuccess) h->order_cap = cap;
         else h->d_order = nullptr;                 // (unordered launches are correct, only slower)
-        if (const char *v = getenv("MPC_ORDER_BY_PREV_ITERS")) h->order_by_prev = v[0] != '0';
     }
     *out = h;
     g_last_error.clear();
@@ -959,7 +912,6 @@ void mpc_destroy(mpc_handle *h) {
     if (h->d_warm) (void)hipFree(h->d_warm);
     if (h->d_warm_valid) (void)hipFree(h->d_warm_valid);
     if (h->d_ltv_u) (void)hipFree(h->d_ltv_u);
-    if (h->d_prev_iters) (void)hipFree(h->d_prev_iters);
     if (h->d_ids) (void)hipFree(h->d_ids);
     if (h->d_pre) (void)hipFree(h->d_pre);
     if (h->d_diag) (void)hipFree(h->d_diag);
@@ -1093,13 +1045,12 @@ static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
     int cap = h->env_cap > 0 ? h->env_cap : 256;
     while (cap < B) cap *= 2;
     const size_t wrow = (size_t)h->cfg.horizon * 2 * sizeof(double);
-    constexpr int NB = 5;
-    void *nb[NB] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t bytes[NB] = {(size_t)cap * sizeof(mpc::pre::EnvState), (size_t)cap * wrow, (size_t)cap, (size_t)cap * wrow,
-                              (size_t)cap * sizeof(int32_t)};
-    void *old[NB] = {h->d_env, h->d_warm, h->d_warm_valid, h->d_ltv_u, h->d_prev_iters};
+    constexpr int NB = 4;
+    void *nb[NB] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[NB] = {(size_t)cap * sizeof(mpc::pre::EnvState), (size_t)cap * wrow, (size_t)cap, (size_t)cap * wrow};
+    void *old[NB] = {h->d_env, h->d_warm, h->d_warm_valid, h->d_ltv_u};
     const size_t old_bytes[NB] = {(size_t)h->env_cap * sizeof(mpc::pre::EnvState), (size_t)h->env_cap * wrow,
-                                  (size_t)h->env_cap, (size_t)h->env_cap * wrow, (size_t)h->env_cap * sizeof(int32_t)};
+                                  (size_t)h->env_cap, (size_t)h->env_cap * wrow};
     hipError_t e = hipDeviceSynchronize();       // in-flight MPC_FLAG_NO_SYNC work on any stream still uses the old buffers
     for (int i = 0; i < NB && e == hipSuccess; ++i) {
         e = hipMalloc(&nb[i], bytes[i]);
@@ -1113,7 +1064,6 @@ static int ensure_env(mpc_handle *h, int B, hipStream_t stream) {
     }
     for (int i = 0; i < NB; ++i)
         if (old[i]) (void)hipFree(old[i]);
-    h->d_prev_iters = static_cast<int32_t *>(nb[4]);
     h->d_env = static_cast<mpc::pre::EnvState *>(nb[0]);
     h->d_warm = static_cast<double *>(nb[1]);
     h->d_warm_valid = static_cast<uint8_t *>(nb[2]);
@@ -1249,7 +1199,7 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
     if (int rc = ensure_order(h, B, stream)) return rc;
     if (int rc = dispatch_solve(h, B, cc, V, flags, stream, h->p_state, h->p_ego, h->p_vref, d_weights, h->p_coll,
                                 h->p_others, h->p_nveh, warm ? h->d_warm : nullptr, 1, warm ? h->d_warm_valid : nullptr,
-                                d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters, h->d_prev_iters))
+                                d_act, warm ? h->d_warm : nullptr, nullptr, d_status, d_iters))
         return rc;
 
     if (!dev) {
@@ -1546,16 +1496,14 @@ int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double s
         return fail(MPC_ERR_INVALID_ARG, "mpc_synth_env_step: null output pointer");
     if (B == 0) return MPC_OK;
     HIP_TRY(hipSetDevice(device));
-    if (K <= 15 && M <= 128)      // sixteen lanes per environment
-        hipLaunchKernelGGL(mpc_synth_env_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
-                           (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
-                           ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
-                           (int)reset_all);
-    else
-        hipLaunchKernelGGL(mpc_synth_env_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
-                           (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
-                           ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
-                           (int)reset_all);
+    // sixteen lanes per environment (mpc_synth_env_rows_kernel); the one-thread-per-environment kernel it replaced in round 5 is
+    // gone (round 6) - its statement env::step_env stays as the host-side reference of the tests
+    if (K > 15 || M > 128)
+        return fail(MPC_ERR_INVALID_ARG, "mpc_synth_env_step: at most 15 other vehicles and 128 route points");
+    hipLaunchKernelGGL(mpc_synth_env_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_),
+                       (int)B, (int)K, dt, spawn_probability, seed, (int)env_offset, ref_xy, (int)M, action, ego, opos, ospeed,
+                       ohead, oactive, t, rng_counter, obs, terminal_obs, reward, done, truncated, crashed, arrived,
+                       (int)reset_all);
     HIP_TRY(hipGetLastError());
     return MPC_OK;
 }

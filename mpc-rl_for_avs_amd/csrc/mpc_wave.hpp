@@ -1331,7 +1331,7 @@ struct Solver {
 
         for (iter = 0; iter <= P.max_iter; ++iter) {
             const int CB = cur * 6;
-            if (iter == kBoostIter) c.set_priority(3);
+            if (iter == kBoostIter) c.template set_priority<3>();
             c.tick(T_DUALUPD);
             // ============ collision potential: gradient, exact and Gauss-Newton curvature at the nodes 1 .. N - 1 - a loop over
             //              the vehicles, 130 instructions each, that occupies the vector unit for the same four cycles per

@@ -172,7 +172,8 @@ struct WaveOpsT {
         return __longlong_as_double((long long)((ua & mm) | (ub & ~mm)));
     }
     // issue priority of this wave on its SIMD (s_setprio 0..3): a wave that has run many iterations is a straggler of its batch
-    __device__ __forceinline__ void set_priority(int) const { __builtin_amdgcn_s_setprio(3); }
+    template <int PRIO>      // (s_setprio takes an immediate)
+    __device__ __forceinline__ void set_priority() const { __builtin_amdgcn_s_setprio(PRIO); }
     __device__ __forceinline__ int opaque(int v) const {
         if (RELAX & 2) return v;
         asm volatile("" : "+v"(v));

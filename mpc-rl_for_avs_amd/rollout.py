@@ -472,8 +472,11 @@ class BatchedCollector:
                 self._capture()
             else:
                 # sharded runs (config 5): the RCCL all-gather of actions + status is captured INSIDE the graph, so they keep
-                # the one-launch step.  Should this RCCL / torch build refuse to capture a collective, the collector steps
-                # eagerly and says why (graph_fallback_reason) instead of failing the run.
+                # the one-launch step.  Should this RCCL / torch build refuse to capture a collective, the collector RAISES
+                # (graph_fallback_reason says why); only with MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK=1 does it step eagerly
+                # instead.  The abort is PER RANK: a rank whose capture fails raises here, before any collective of the
+                # rollout is issued, and its process ends; the other ranks block in their first all-gather until the process
+                # group's timeout or the launcher (torchrun) tears the job down - the same behaviour as any rank dying.
                 try:
                     self._capture()
                 except Exception as e:      # noqa: BLE001 - whatever the capture raised is the reason reported
@@ -627,23 +630,34 @@ class BatchedCollector:
             with torch.cuda.graph(g, stream=side):
                 self._rollout_step(device_pos=True)
             self._graph = g
-        finally:
-            # put back what the warm-up / capture steps touched - also when the capture FAILED (the eager fallback
-            # must start from the same state as a collector that never tried)
-            torch.cuda.synchronize(dev)
-            self.buffer.reset()
-            for n in names:                               # in place: the graph replays against these addresses
-                getattr(env, n).copy_(snap[n])
-            self._last_obs.copy_(snap_obs)
-            self._last_episode_starts.copy_(snap_starts)
-            self.gen.set_state(gen_states[0])
-            env.gen.set_state(gen_states[1])
-            if snap_step is not None:
-                self._fg["step"].copy_(snap_step)
-            if records is not None:
-                self.engine.load_env_state(records)       # also forgets the warm-start memory the warm-up steps left
-            self._roll["counts"].zero_()
-            self._roll["dones"].zero_()
+        except BaseException as capture_error:
+            # the capture FAILED: put the collector back as if it had never tried, and should the restore itself fail
+            # (a synchronize or a state load after an invalidated capture), chain it so that the capture's error stays visible
+            try:
+                self._restore_after_capture(names, snap, snap_obs, snap_starts, gen_states, snap_step, records)
+            except Exception as restore_error:      # noqa: BLE001
+                raise restore_error from capture_error
+            raise
+        else:
+            self._restore_after_capture(names, snap, snap_obs, snap_starts, gen_states, snap_step, records)
+
+    def _restore_after_capture(self, names, snap, snap_obs, snap_starts, gen_states, snap_step, records):
+        """Put back what the warm-up / capture steps of _capture() touched (in place: a graph replays against these addresses)."""
+        env = self.env
+        torch.cuda.synchronize(env.device)
+        self.buffer.reset()
+        for n in names:
+            getattr(env, n).copy_(snap[n])
+        self._last_obs.copy_(snap_obs)
+        self._last_episode_starts.copy_(snap_starts)
+        self.gen.set_state(gen_states[0])
+        env.gen.set_state(gen_states[1])
+        if snap_step is not None:
+            self._fg["step"].copy_(snap_step)
+        if records is not None:
+            self.engine.load_env_state(records)       # also forgets the warm-start memory the warm-up steps left
+        self._roll["counts"].zero_()
+        self._roll["dones"].zero_()
 
     def _step(self):
         if self._graph is not None:
@@ -678,8 +692,13 @@ class BatchedCollector:
 
     def _rollout_stats(self, n):
         r = self._roll
+        # counts[4]: steps mpc_rollout_record refused because the buffer was already full (the torch path raises IndexError
+        # there); read back with the other counters at the end of the rollout and never silent
+        refused = int(r["counts"][4])
+        if refused:
+            raise IndexError(f"{refused} rollout steps were recorded past the end of the buffer ({self.buffer.n_steps} steps)")
         return dict(steps=n * self.env.num_envs, episodes=int(r["ep_done"]), crashed=int(r["crashed"]),
-                    arrived=int(r["arrived"]), mpc_unconverged=int(r["unconverged"]))
+                    arrived=int(r["arrived"]), mpc_unconverged=int(r["unconverged"]), refused_steps=refused)
 
     def collect_rollouts(self, n_rollout_steps: int | None = None):
         n = self.buffer.n_steps if n_rollout_steps is None else int(n_rollout_steps)

@@ -80,7 +80,8 @@ struct HostCtx {
         for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
     }
     int hide(int v) const { return v; }
-    void set_priority(int) const {}
+    template <int PRIO>
+    void set_priority() const {}
     double bit_select(int m, double a, double b) const {      // m ? a : b bit by bit, m = 0 or ~0
         unsigned long long ua, ub;
         __builtin_memcpy(&ua, &a, 8);

@@ -315,3 +315,118 @@ def test_policy_noise_of_the_kernel_is_standard_normal_and_keyed_by_seed_environ
     finally:
         torch.randn = orig
     assert np.allclose(a["actions"], actions.numpy(), atol=2e-6) and np.allclose(a["log_probs"], logp.numpy(), atol=2e-5)
+
+
+class _RaisingEngine(StubEngine):
+    """StubEngine whose MPC call fails on a chosen call (the hipGraph capture of a step, after two warm-up steps)."""
+
+    def __init__(self, fail_on_call):
+        super().__init__()
+        self.fail_on_call, self.n = fail_on_call, 0
+
+    def predict_batch_torch(self, *a, **k):
+        self.n += 1
+        if self.n == self.fail_on_call:
+            raise RuntimeError("capture refused (test)")
+        return super().predict_batch_torch(*a, **k)
+
+
+def _fake_cuda(monkeypatch):
+    """torch.cuda's stream / graph objects as no-ops, so that BatchedCollector._capture runs its steps eagerly on the CPU."""
+    import contextlib
+
+    class _S:
+        def wait_stream(self, other):
+            pass
+
+    class _G:
+        def register_generator_state(self, gen):
+            pass
+
+        def replay(self):
+            raise AssertionError("a failed capture must not leave a graph behind")
+
+    @contextlib.contextmanager
+    def _ctx(*a, **k):
+        yield
+
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _S())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _S())
+    monkeypatch.setattr(torch.cuda, "stream", _ctx)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", _G)
+    monkeypatch.setattr(torch.cuda, "graph", _ctx)
+
+
+def _collector_state(col):
+    env = col.env
+    st = {n: getattr(env, n).clone() for n in ("ego", "opos", "ospeed", "ohead", "oactive", "t") if hasattr(env, n)}
+    st.update(last_obs=col._last_obs.clone(), starts=col._last_episode_starts.clone(), gen=col.gen.get_state().clone(),
+              env_gen=env.gen.get_state().clone(), counts=col._roll["counts"].clone(), dones=col._roll["dones"].clone())
+    return st, col.buffer.pos
+
+
+def test_failed_graph_capture_leaves_the_collector_as_if_it_had_never_tried(monkeypatch):
+    """a capture that fails (here: the MPC call raises on the captured step, after the two warm-up steps have
+    really stepped environment, generators and buffer) must put everything back; a SHARDED collector then raises unless
+    MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK=1, and with it steps eagerly from exactly the state of a collector that never tried."""
+    from mpc_rl_for_avs_amd import sharding
+    _fake_cuda(monkeypatch)
+    monkeypatch.setattr(sharding, "all_gather_results", lambda act, status, group=None: (act, status))
+
+    def make(engine, **kw):
+        torch.manual_seed(0)
+        env = rollout.SyntheticIntersectionEnv(8, seed=3, n_others=3)
+        pol = rollout.ActorCritic(1)
+        return rollout.BatchedCollector(env, pol, engine, version="v0", algorithm="ppo", n_steps=5, seed=11, **kw)
+
+    ref = make(StubEngine(), use_graph=False)                       # never tried to capture
+    want, want_pos = _collector_state(ref)
+
+    # (1) unsharded: the capture's own error reaches the caller, the state is restored all the same
+    eng = _RaisingEngine(3)
+    with pytest.raises(RuntimeError, match="capture refused"):
+        make(eng, use_graph=True)
+    assert eng.n == 3                                                # two warm-up steps ran for real, the third call raised
+
+    # (2) sharded, default: RuntimeError that names the override
+    monkeypatch.delenv("MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK", raising=False)
+    with pytest.raises(RuntimeError, match="MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK=1") as ei:
+        make(_RaisingEngine(3), use_graph=True, gather_actions=True)
+    assert "capture refused" in str(ei.value.__cause__)
+
+    # (3) sharded with the override: eager stepping, from the state of a collector that never captured
+    monkeypatch.setenv("MPC_ALLOW_EAGER_COLLECTIVE_FALLBACK", "1")
+    col = make(_RaisingEngine(3), use_graph=True, gather_actions=True)
+    assert col._graph is None and col.use_graph is False and "capture refused" in col.graph_fallback_reason
+    got, got_pos = _collector_state(col)
+    assert got_pos == want_pos == 0
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    a, b = ref.collect_rollouts(), col.collect_rollouts()
+    assert a == b and a["refused_steps"] == 0
+    for name in ("obs", "actions", "rewards", "values", "log_probs", "advantages", "returns"):
+        assert torch.equal(getattr(ref.buffer, name), getattr(col.buffer, name)), name
+
+    # (4) a failure of the RESTORE keeps the capture's error visible as its cause
+    class _BadRestore(_RaisingEngine):
+        def save_env_state(self, B):
+            return "records"
+
+        def load_env_state(self, records):
+            raise ValueError("restore failed (test)")
+
+    with pytest.raises(ValueError, match="restore failed") as ei:
+        make(_BadRestore(3), use_graph=True)
+    assert "capture refused" in str(ei.value.__cause__)
+
+
+def test_a_step_past_the_buffer_is_never_silent():
+    """counts[4] (steps mpc_rollout_record refused because the buffer was full) surfaces at the end of the rollout."""
+    torch.manual_seed(0)
+    env = rollout.SyntheticIntersectionEnv(4, seed=1, n_others=2)
+    col = rollout.BatchedCollector(env, rollout.ActorCritic(1), StubEngine(), n_steps=3, use_graph=False)
+    assert col.collect_rollouts()["refused_steps"] == 0
+    col._roll["counts"][4] = 2
+    with pytest.raises(IndexError, match="past the end of the buffer"):
+        col._rollout_stats(3)
