@@ -1216,9 +1216,12 @@ int mpc_predict_batch(mpc_handle *h, int32_t B, const float *obs, int32_t vehicl
 
 // ---- iterative-linear MPC (reference agents/pure_mpc_linear.py) ---------------------------------------------
 // the two builds of mpc_ltv_kernel: waves per SIMD, and what the latency build may keep in registers (fresh / opaque the
-// identity, residuals kept, wave-uniform gain rows: mpc_ltv.hpp relax_bits).  Measured on one box (tools/gpu_ltv_ab.py):
-// per-lane gain rows cost a lone wave 5 % (0.633 against 0.603 ms at B = 1), recomputed residuals 2 %.
-constexpr int kLtvOcc = 3, kLtvOccLat = 2, kLtvRelaxLat = 1 | 2 | 8 | 16;
+// identity, residuals kept: mpc_ltv.hpp relax_bits).  Measured on one box (tools/gpu_ltv_ab.py, round 4): recomputed residuals
+// cost a lone wave 2 %.
+constexpr int kLtvOcc = 3, kLtvOccLat = 2, kLtvRelaxLat = 1 | 2 | 8;
+// ... used up to FOUR waves per SIMD of batch depth, like the solve kernel's (round 6: with the 4x4 factorisation a lone wave is 15 %
+// faster than in round 5 and a batch of 4096 takes 1.50 ms in this build against 1.61 ms in the other, 16 384 the same in both)
+constexpr int kLtvLatDepth = 4;
 static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_state, const float *d_obs, int rows,
                       double *d_U, double *d_u0, double *d_X, int32_t *d_status, int32_t *d_iters, int32_t *d_target) {
     mpc::ltv::LtvParams P;
@@ -1239,7 +1242,7 @@ static int launch_ltv(mpc_handle *h, int B, hipStream_t stream, const double *d_
         }
     }
     // which build: by how deep the batch fills the SIMDs
-    if (B <= kLtvOccLat * 4 * h->num_cu)
+    if (B <= kLtvLatDepth * 4 * h->num_cu)
         hipLaunchKernelGGL((mpc_ltv_kernel<kLtvOccLat, kLtvRelaxLat>), dim3((unsigned)B), dim3(kBlock), lds, stream, P, B,
                            h->d_ref, h->M, d_state, d_obs, rows, d_U, d_u0, d_X, d_status, d_iters, d_target);
     else

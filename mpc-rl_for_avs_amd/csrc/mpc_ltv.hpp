@@ -13,9 +13,10 @@
 // inequality gets a slack, and the QP is solved by an infeasible-start primal-dual interior-point method with
 // Mehrotra's predictor-corrector and one common step length.  Its Newton systems have the optimal-control structure
 // and are solved by a Riccati sweep over the state augmented with the previous control (the rate limit and the
-// input-difference cost couple u_t with u_{t-1}): the 8x8 stage block [x 4 | u_{t-1} 2 | u_t 2] lives in the C/D
-// layout of v_mfma_f64_4x4x4f64 exactly as in mpc_wave.hpp (same operand roles, same nine matrix-core
-// instructions per stage); the corrector reuses the factorisation through a scalar gradient-only sweep.
+// input-difference cost couple u_t with u_{t-1}) in the 4x4 block form of mpc_wave.hpp's sweep4 (round 6: fourteen
+// v_mfma_f64_4x4x4f64 per stage, the rank-two Woodbury terms of the two stiff rows riding in the same products,
+// factor_and_solve below; rounds 1 - 5: an 8x8 block form with nine products and eight block moves); the corrector
+// reuses the factorisation through a scalar gradient-only sweep.
 // Everything separable runs stage-parallel, lane k = stage k: lane k owns the eight inequalities of stage k
 // (a >= -5, a <= 2, d >= -30, d <= 30, rate-, rate+, v_{k+1} >= 0, v_{k+1} <= vmax) with their slacks and multipliers
 // in registers.
@@ -71,9 +72,13 @@ enum : int {
     L_M = 57,    // 12 kap [g1 g2]' (2 x 6): the stiff rows' steps in constraint space are w / lambda, w = t + M [dx; du_prev]
     L_Z = 69,    // 4  Z = Y kap, gives t = kap Fu' kf0 = -Z' hu for a new right-hand side
     L_T = 73,    // 2  t of the current right-hand side
-    L_SLOTS = 75
+    // the constants 1 and dt of the stage matrix F = [A B; 0 I], once per stage (round 6, as in mpc_wave.hpp): every operand of a
+    // Riccati stage is then a stage-relative word (the constant 0: L_G + 0, the x-row of the stage gradient, always zero)
+    L_ONE = 75,  // 1
+    L_DTC = 76,  // 1
+    L_SLOTS = 77 // (odd: lane k of a stage-parallel phase addresses word k * stride + slot)
 };
-enum : int { SC_ZERO = 0, SC_ONE = 1, SC_DT = 2, SC_X0 = 4, SC_SIZE = 8 };   // SC_X0: the ego state x, y, yaw, v
+enum : int { SC_ZERO = 0, SC_ONE = 1, SC_DT = 2, SC_TOLD = 3, SC_X0 = 4, SC_T = 8, SC_MINEQ = 9, SC_SIZE = 10 };   // SC_X0: the ego state x, y, yaw, v; SC_TOLD: the dual tolerance of this solve; SC_T, SC_MINEQ: horizon, number of inequalities
 
 MPC_HD constexpr int lds_doubles(int N) { return L_SLOTS * (N + 1) + SC_SIZE; }
 
@@ -86,7 +91,6 @@ struct LtvParams {
 
 // CTX::kRelax (absent: 0) - what the build may keep in registers (mpc_engine.hip: the two builds of mpc_ltv_kernel):
 //   bit 3: the primal residuals stay in registers from the residual phase to the predictor step instead of being recomputed
-//   bit 4: the gain rows g1, g2 of a Riccati stage are formed once as wave-uniform values instead of per lane
 template <class CTX, class = void>
 struct relax_bits { static constexpr int value = 0; };
 template <class CTX>
@@ -95,7 +99,6 @@ struct relax_bits<CTX, decltype((void)CTX::kRelax)> { static constexpr int value
 template <class CTX>
 struct Solver {
     static constexpr bool kKeepResidual = (relax_bits<CTX>::value & 8) != 0;
-    static constexpr bool kUniformGains = (relax_bits<CTX>::value & 16) != 0;
     const LtvParams &P;
     CTX &c;
     const int N, SCR;
@@ -115,9 +118,9 @@ struct Solver {
 
     PerLane<double> red_a, red_b, red_c, red_d, red_e;
     PerLane<double> s_[8], z_[8], rp_[8], pr_[8];   // slack, multiplier, primal residual, predictor product per inequality
-    // matrix-core roles, as in mpc_wave.hpp: lane l = 16 hi + 4 (2 I + J) + lo holds element (4 I + hi, 4 J + lo)
-    PerLane<int> m_row, m_col, m_fa0, m_fa1, m_fb0, m_fb1;
-    PerLane<int> m_lslot;   // stage-Hessian slot of this lane's element, + 256 where it enters with a minus sign; -1: none
+    // matrix-core roles (round 6: the 4x4 form of mpc_wave.hpp's sweep4): lane l = 16 hi + 4 blk + lo holds element [hi][lo] of a
+    // 4x4 operand, the same in all four blocks; LDS word of this lane's element of each operand, stage-relative
+    PerLane<int> q_a, q_b, q_lxx, q_m, q_lx, q_lu, q_st;
 
     // reference columns of node k: window row min(target + k, M - 1) (:178-187)
     MPC_HD double xr(int k) const { return c.ref(k, R_X); }
@@ -126,27 +129,27 @@ struct Solver {
     MPC_HD double vr(int k) const { return c.refv(k); }
 
     MPC_HD int f_word(int r, int cl) const {
-        return wave::stage_transition_word(r, cl, L_LIN, -(SCR + SC_ZERO + 1), -(SCR + SC_ONE + 1), -(SCR + SC_DT + 1));
+        return wave::stage_transition_word(r, cl, L_LIN, L_G + 0, L_ONE, L_DTC);
     }
     // (pure functions of the lane id, recomputed at the start of every factorisation from a lane id the compiler cannot
-    // see through - as in mpc_wave.hpp - so that their 11 registers are live during the sweep only)
+    // see through - as in mpc_wave.hpp - so that their registers are live during the sweep only)
     MPC_HD void set_roles() {
         c.lanes([&](int lane_) {
             const int lane = c.opaque(lane_);
-            const int hi = lane >> 4, blk = (lane >> 2) & 3, I = blk >> 1, J = blk & 1, lo = lane & 3;
-            const int row = 4 * I + hi, col = 4 * J + lo;
-            m_row.at(lane) = row;
-            m_col.at(lane) = col;
-            m_fa0.at(lane) = f_word(0 + hi, 4 * I + lo);
-            m_fa1.at(lane) = f_word(4 + hi, 4 * I + lo);
-            m_fb0.at(lane) = f_word(0 + hi, 4 * J + lo);
-            m_fb1.at(lane) = f_word(4 + hi, 4 * J + lo);
-            const int a = row < col ? row : col, b = row < col ? col : row;
-            int slot = -1;
-            slot = (a == b && a >= 2) ? L_H + (a - 2) : slot;
-            slot = (a == 4 && b == 6) ? 256 + L_H + 2 : slot;
-            slot = (a == 5 && b == 7) ? 256 + L_H + 3 : slot;
-            m_lslot.at(lane) = slot;
+            const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
+            const int zero = L_G + 0;
+            q_a.at(lane_) = f_word(hi, lo);                          // A[hi][lo]
+            q_b.at(lane_) = f_word(hi, lo < 2 ? 6 + lo : 4);         // B~[hi][lo]: the columns a, delta of F, then zeros
+            q_lxx.at(lane_) = (hi == lo && hi >= 2) ? L_H + (hi - 2) : zero;      // Lxx = diag(0, 0, H_yaw, H_v)
+            q_m.at(lane_) = (hi == lo && hi < 2) ? L_H + 4 + hi : zero;          // Luu = diag(H_a, H_delta) without the stiff rows
+            q_lx.at(lane_) = lo == 0 ? L_G + hi : zero;                          // lx in column 0
+            q_lu.at(lane_) = (lo == 0 && hi < 2) ? L_G + 6 + hi : zero;          // lu in column 0
+            // what this lane stores at the end of the stage: block 0 the gains Kx[hi][lo] (rows 0, 1), block 1 the x-part of
+            // kap [g1 g2]' (held in rows 2, 3)
+            int out = -1;
+            out = (blk == 0 && hi < 2) ? L_KX + 4 * hi + lo : out;
+            out = (blk == 1 && hi >= 2) ? L_M + 6 * (hi - 2) + lo : out;
+            q_st.at(lane_) = out;
         });
     }
 
@@ -236,82 +239,73 @@ struct Solver {
         pT[3] = -S(N, L_QV);
     }
 
-    // ---- Riccati factorisation + first solve on the matrix core (operands as in mpc_wave.hpp) -------------------
+    // ---- Riccati factorisation + first solve on the matrix core ----------------------------------------------------
+    // Round 6: the 4x4 form of mpc_wave.hpp (sweep4) instead of the 8x8 block form with block moves of rounds 1 - 5.  With the
+    // value function of node k + 1 split as V(x, p) = 1/2 x'Pxx x + x'Pxp p + 1/2 p'Ppp p + px'x + pp'p (x: state 4, p: previous
+    // control 2) and F = [A B; 0 I] the BASE block of the stage (everything but the two stiff rows) is
+    //     Qxx = Lxx + A'Pxx A      Qux = (Pxx B + Pxp)'A      Quu = Luu + B'(Pxx B + Pxp) + Pxp'B + Ppp      Qpu = -diag(h)
+    //     qx = lx + A'px           qu = lu + B'px + pp        G = Quu^-1,  K0x = -G Qux,  K0p = G diag(h),  kb = -G qu
+    // and the two stiff rows - speed bounds of node k + 1 (weight l1 on f1 = [e_v; dt e_a]) and the rate limit of the stage (weight
+    // l2 on f2 = [-e_p1; e_delta]) - come back through the Woodbury identity exactly as before (never subtracting large numbers):
+    //     kap = (diag(1/l) + Fu'G Fu)^-1,  Y = G Fu,  Z = Y kap,  g = Fx + K0'Fu (g1 = e_v + dt K0(0,.)', g2 = -e_p1 + K0(1,.)'),
+    //     P = P0 + g kap g',  K = K0 - Z g',  kf = kb - Y (kap Fu'kb),  p = p0(kf) + Fx (kap Fu'kb).
+    // Everything 4-dimensional is a matrix-core block, everything 2-dimensional wave-uniform scalar algebra.  The rank-two
+    // update rides in the SAME products as the base recursion: with Ya4 = -adj(Quu) Qux in rows 0, 1 AND again in rows 2, 3,
+    //     a operand = [Qux / det (rows 0, 1) ; kap [g1 g2]'_x (rows 2, 3)],   b operand = [Ya4 (rows 0, 1) ; [g1 g2]'_x (rows 2, 3)]
+    // gives Pxx' = Qxx + Qux'K0x + gx kap gx' in ONE product, likewise Pxp'.  Fourteen products per stage, no block moves, every
+    // operand a stage-relative word; the 8x8 form needed nine products, eight block moves and per-lane select chains over the
+    // gain rows - 456 instructions per stage against ~200 (the kernel is bound by instruction issue, tools/ubench/issue_probe.hip).
     MPC_HD bool factor_and_solve() {
         set_roles();
         double pT[4];
         terminal_gradient(pT);
         const double T = (double)N;
-        PerLane<double> Pd, pvd;
-        c.lanes([&](int lane) {
-            const int r = m_row.at(lane), cl = m_col.at(lane);
-            double pe = 0.0;
-            if (r == cl && r < 3) pe = r < 2 ? 2.0 * T * kQfXY : 2.0 * T * kQfYaw;
-            Pd.at(lane) = pe;
-            pvd.at(lane) = (cl == 0 && r < 4) ? (r == 0 ? pT[0] : (r == 1 ? pT[1] : (r == 2 ? pT[2] : pT[3]))) : 0.0;
+        PerLane<double> PXX, PXP, PX;
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque(lane_);
+            const int hi = lane >> 4, lo = lane & 3;
+            PXX.at(lane_) = (hi == lo && hi < 3) ? (hi < 2 ? 2.0 * T * kQfXY : 2.0 * T * kQfYaw) : 0.0;
+            PXP.at(lane_) = 0.0;
+            const double c0 = lo == 0 ? 1.0 : 0.0;
+            PX.at(lane_) = c0 * ((hi == 0 ? 1.0 : 0.0) * pT[0] + (hi == 1 ? 1.0 : 0.0) * pT[1] + (hi == 2 ? 1.0 : 0.0) * pT[2] + (hi == 3 ? 1.0 : 0.0) * pT[3]);
         });
+        double pp00 = 0.0, pp01 = 0.0, pp11 = 0.0, ppv0 = 0.0, ppv1 = 0.0;    // Ppp, pp of the node behind the stage
 #pragma unroll 1
         for (int k = N - 1; k >= 0; --k) {
-            PerLane<double> FA0, FA1, FB0, FB1, Hm, hv;
+            PerLane<double> RA, RB, QXX, QUX, M, QX, QU, T0, T1;
             c.lanes([&](int lane) {
                 const int base = k * L_SLOTS;
-                const int w0 = m_fa0.at(lane), w1 = m_fa1.at(lane), w2 = m_fb0.at(lane), w3 = m_fb1.at(lane);
-                FA0.at(lane) = c.ld(w0 >= 0 ? base + w0 : -w0 - 1);
-                FA1.at(lane) = c.ld(w1 >= 0 ? base + w1 : -w1 - 1);
-                FB0.at(lane) = c.ld(w2 >= 0 ? base + w2 : -w2 - 1);
-                FB1.at(lane) = c.ld(w3 >= 0 ? base + w3 : -w3 - 1);
-                const int ls = m_lslot.at(lane);
-                const double lv = c.ld(base + (ls >= 0 ? (ls & 255) : 0));
-                Hm.at(lane) = ls < 0 ? 0.0 : (ls >= 256 ? -lv : lv);
-                const bool col0 = m_col.at(lane) == 0;
-                const double gv = c.ld(base + (col0 ? L_G + m_row.at(lane) : 0));
-                hv.at(lane) = col0 ? gv : 0.0;
+                RA.at(lane) = c.ld(base + q_a.at(lane));
+                RB.at(lane) = c.ld(base + q_b.at(lane));
+                QXX.at(lane) = c.ld(base + q_lxx.at(lane));
+                M.at(lane) = c.ld(base + q_m.at(lane));
+                QX.at(lane) = c.ld(base + q_lx.at(lane));
+                QU.at(lane) = c.ld(base + q_lu.at(lane));
+                QUX.at(lane) = 0.0;
+                T0.at(lane) = 0.0;
+                T1.at(lane) = PXP.at(lane);
             });
-            // T = P F   (P symmetric: block (K, I) in the C/D layout is block (I, K) as A operand)
-            PerLane<double> PA0, PA1, Tm;
-            c.template take_blocks<wave::BM_K0_I>(PA0, Pd);
-            c.template take_blocks<wave::BM_K1_I>(PA1, Pd);
-            c.lanes([&](int lane) { Tm.at(lane) = 0.0; });
-            c.mfma(PA0, FB0, Tm);
-            c.mfma(PA1, FB1, Tm);
-            // H = L + F' T,  h = l + F' p   (F in the C/D layout is F' as A operand)
-            PerLane<double> TB0, TB1, pB0, pB1;
-            c.template take_blocks<wave::BM_K0_J>(TB0, Tm);
-            c.template take_blocks<wave::BM_K1_J>(TB1, Tm);
-            c.template take_blocks<wave::BM_K0_J>(pB0, pvd);
-            c.template take_blocks<wave::BM_K1_J>(pB1, pvd);
-            c.mfma(FA0, TB0, Hm);
-            c.mfma(FA1, TB1, Hm);
-            c.mfma(FA0, pB0, hv);
-            c.mfma(FA1, pB1, hv);
-            PerLane<double> HB, HA;
-            c.template take_blocks<wave::BM_K1_J>(HB, Hm);
-            c.template take_blocks<wave::BM_K1_I>(HA, Hm);
-            // control block: elements (6,6) (6,7) (7,6) (7,7) in lanes 46 47 62 63, gradient rows 6, 7 in lanes 40, 56
-            const double ha = c.lane_get(Hm, 46), hb = 0.5 * (c.lane_get(Hm, 47) + c.lane_get(Hm, 62)),
-                         hc = c.lane_get(Hm, 63);
-            const double hu0 = c.lane_get(hv, 40), hu1 = c.lane_get(hv, 56);
+            const double gp0 = S(k, L_G + 4), gp1 = S(k, L_G + 5), h44 = S(k, L_H + 2), h55 = S(k, L_H + 3);
+            const double l1 = S(k + 1, L_DV), l2 = S(k, L_DR);
+            // ---- the value function of node k + 1 through the stage
+            c.mfma(PXX, RA, T0);       // T0 = Pxx A
+            c.mfma(PXX, RB, T1);       // T1 = Pxx B + Pxp
+            c.mfma(PXP, RB, M);        // M  = Luu + Pxp'B ...
+            c.mfma(RA, PX, QX);        // qx = lx + A'px
+            c.mfma(RB, PX, QU);        // qu = lu + B'px        (+ pp below)
+            c.mfma(RB, T1, M);         // ... + B'T1 = Quu - Ppp
+            c.mfma(T1, RA, QUX);       // Qux = T1'A
+            c.mfma(RA, T0, QXX);       // Qxx = Lxx + A'T0
+            // ---- 2x2 control block (uniform)
+            const double ha = c.lane_get(M, 0) + pp00, hb = c.lane_get(M, 1) + pp01, hc = c.lane_get(M, 17) + pp11;
+            const double hu0 = c.lane_get(QU, 0) + ppv0, hu1 = c.lane_get(QU, 16) + ppv1;
             const double det = ha * hc - hb * hb;
             // (one combined condition, no short-circuit branches: a single branch on the sweep's critical path)
             if (!((ha > 0.0) & (hc > 0.0) & (det > 1e-14 * ha * hc))) return false;
-            // W = adj(Huu) H(u, .) on the matrix core while the reciprocal of the determinant is computed
-            PerLane<double> G, nHA, W, kfB;
-            c.lanes([&](int lane) {
-                const int hi = lane >> 4, lo = lane & 3;
-                G.at(lane) = (hi == 2 && lo == 2) ? hc : ((hi == 3 && lo == 3) ? ha : ((hi >= 2 && lo >= 2) ? -hb : 0.0));
-                W.at(lane) = 0.0;
-            });
-            c.mfma(G, HB, W);
             const double idet = frcp(det);
             const double i00 = hc * idet, i01 = -hb * idet, i11 = ha * idet;
             const double kb0 = -(i00 * hu0 + i01 * hu1), kb1 = -(i01 * hu0 + i11 * hu1);   // feed-forward of the base block
-            // ---- the two barrier terms that make Riccati recursions cancel catastrophically when their weights grow
-            //      like 1/mu - the speed bounds of node k + 1 (weight l1 on f1 = e_v of the next state = [e_v; dt e_u0]
-            //      of this stage) and the rate limit of stage k (weight l2 on f2 = e_u1 - e_p1) - are kept out of the
-            //      block H above and put back through the Woodbury identity, which never subtracts large numbers:
-            //        Huu^-1 = G - Y kap Y',  K = K0 - Y kap g',  P = P0 + g kap g',  kap = (diag(1/l) + Fu' G Fu)^-1,
-            //        Y = G Fu,  g = Fx - H(x,u) G Fu = Fx + K0' Fu            (G, K0, P0: the base block's)
-            const double l1 = S(k + 1, L_DV), l2 = S(k, L_DR);
+            // ---- Woodbury terms of the two stiff rows (scalars; see the head of this function)
             const double y00 = dt * i00, y01 = i01, y10 = dt * i01, y11 = i11;          // Y = G Fu, Fu = diag(dt, 1)
             double k00, k01, k11;                                                       // kap
             {
@@ -322,92 +316,42 @@ struct Solver {
                 k01 = -(a * b) * m01 * rdm;
                 k11 = l2 * m00 * rdm;
             }
-            const double t0 = k00 * (dt * kb0) + k01 * kb1, t1 = k01 * (dt * kb0) + k11 * kb1;   // kap Fu' kf0
+            const double t0 = k00 * (dt * kb0) + k01 * kb1, t1 = k01 * (dt * kb0) + k11 * kb1;   // kap Fu' kb
             const double kf0 = kb0 - (y00 * t0 + y01 * t1), kf1 = kb1 - (y10 * t0 + y11 * t1);
-            c.lanes([&](int lane) {
-                const int hi = lane >> 4;
-                nHA.at(lane) = -idet * HA.at(lane);
-                kfB.at(lane) = (m_col.at(lane) == 0) ? (hi == 2 ? kf0 : (hi == 3 ? kf1 : 0.0)) : 0.0;
-            });
-            c.mfma(nHA, W, Hm);      // Hm <- H - H(., u) G H(u, .)   (base block)
-            c.mfma(HA, kfB, hv);     // hv <- h + H(., u) kf
-            const double h44 = S(k, L_H + 2), h55 = S(k, L_H + 3);
-            // base gains K0 = -G H(u, .): state columns from the matrix core's W = adj(Huu) H(u, .) (row 6 + a, column j
-            // sits in lane 16 (2 + a) + j), previous-control columns in closed form (H(u, p) = -diag(H44, H55)).
-            // g1 = [dt K0(0, .) + e_v], g2 = [K0(1, .) - e_p1] (6 entries each) are needed per lane by row and by column:
-            // every lane selects its entries from the eight raw values of W (scalar registers) and scales them itself,
-            // instead of 20 wave-uniform doubles being kept in vector registers to the end of the stage.
-            if (kUniformGains) {
-                double g1[6], g2[6], kx0[4], kx1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    kx0[j] = -idet * c.lane_get(W, 32 + j);
-                    kx1[j] = -idet * c.lane_get(W, 48 + j);
-                    g1[j] = dt * kx0[j];
-                    g2[j] = kx1[j];
-                }
-                g1[3] += 1.0;
-                const double kp00 = i00 * h44, kp01 = i01 * h55, kp10 = i01 * h44, kp11 = i11 * h55;
-                g1[4] = dt * kp00;
-                g1[5] = dt * kp01;
-                g2[4] = kp10;
-                g2[5] = kp11 - 1.0;
-                const double z00 = y00 * k00 + y01 * k01, z01 = y00 * k01 + y01 * k11;      // Z = Y kap
-                const double z10 = y10 * k00 + y11 * k01, z11 = y10 * k01 + y11 * k11;
-                c.lanes([&](int lane) {
-                    const int r = m_row.at(lane), cl = m_col.at(lane);
-                    double g1r = 0.0, g2r = 0.0, g1c = 0.0, g2c = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        g1r = r == j ? g1[j] : g1r;
-                        g2r = r == j ? g2[j] : g2r;
-                        g1c = cl == j ? g1[j] : g1c;
-                        g2c = cl == j ? g2[j] : g2c;
-                    }
-                    const double add = g1r * (k00 * g1c + k01 * g2c) + g2r * (k01 * g1c + k11 * g2c);
-                    Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) + add : 0.0;
-                    const double padd = r == 3 ? t0 : (r == 5 ? -t1 : 0.0);                  // Fx (kap Fu' kf0)
-                    pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) + padd : 0.0;
-                    if (lane < 4) {
-                        S(k, L_KX + lane, kx0[lane] - (z00 * g1[lane] + z01 * g2[lane]));
-                        S(k, L_KX + 4 + lane, kx1[lane] - (z10 * g1[lane] + z11 * g2[lane]));
-                    }
-                    if (lane == 0) {
-                        S(k, L_KF + 0, kf0);
-                        S(k, L_KF + 1, kf1);
-                        S(k, L_KP + 0, kp00 - (z00 * g1[4] + z01 * g2[4]));
-                        S(k, L_KP + 1, kp01 - (z00 * g1[5] + z01 * g2[5]));
-                        S(k, L_KP + 2, kp10 - (z10 * g1[4] + z11 * g2[4]));
-                        S(k, L_KP + 3, kp11 - (z10 * g1[5] + z11 * g2[5]));
-                        S(k, L_IH + 0, i00 - (z00 * y00 + z01 * y01));
-                        S(k, L_IH + 1, i01 - (z00 * y10 + z01 * y11));
-                        S(k, L_IH + 2, i11 - (z10 * y10 + z11 * y11));
-                        S(k, L_Z + 0, z00);
-                        S(k, L_Z + 1, z01);
-                        S(k, L_Z + 2, z10);
-                        S(k, L_Z + 3, z11);
-                        S(k, L_T + 0, t0);
-                        S(k, L_T + 1, t1);
-                    }
-                    if (lane < 6) {
-                        S(k, L_M + lane, k00 * g1[lane] + k01 * g2[lane]);
-                        S(k, L_M + 6 + lane, k01 * g1[lane] + k11 * g2[lane]);
-                    }
-                });
-                continue;
-            }
-            double w0[4], w1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                w0[j] = c.lane_get(W, 32 + j);
-                w1[j] = c.lane_get(W, 48 + j);
-            }
-            const double kp00 = i00 * h44, kp01 = i01 * h55, kp10 = i01 * h44, kp11 = i11 * h55;
+            const double kp00 = i00 * h44, kp01 = i01 * h55, kp10 = i01 * h44, kp11 = i11 * h55;     // K0p = G diag(h)
+            const double g14 = dt * kp00, g15 = dt * kp01, g24 = kp10, g25 = kp11 - 1.0;           // p-part of g1, g2
             const double z00 = y00 * k00 + y01 * k01, z01 = y00 * k01 + y01 * k11;      // Z = Y kap
             const double z10 = y10 * k00 + y11 * k01, z11 = y10 * k01 + y11 * k11;
-            c.lanes([&](int lane) {
-                if (lane == 0) {
-                    const double g14 = dt * kp00, g15 = dt * kp01, g24 = kp10, g25 = kp11 - 1.0;
+            const double m14 = k00 * g14 + k01 * g24, m24 = k01 * g14 + k11 * g24;      // p-part of kap [g1 g2]'
+            const double m15 = k00 * g15 + k01 * g25, m25 = k01 * g15 + k11 * g25;
+            // ---- matrix-core part of the stage
+            PerLane<double> NWA4, Ya4, GB4, KAP4, GA, AOP, BXX, BXP, KFV, ZN, PXXn, PXPn, PXn, KX;
+            // (the operands are written as sums of products with 0 / 1 weights of the lane's position, not as select chains over
+            // the scalars: a chain of selects between values a lambda captured by reference becomes a select of ADDRESSES plus a
+            // load, which puts every captured scalar - and with them the solver object - into scratch memory)
+            c.lanes([&](int lane_) {
+                const int lane = c.opaque(lane_);
+                const int hi = lane >> 4, lo = lane & 3;
+                auto w = [&](int r, int cc) { return (hi == r && lo == cc) ? 1.0 : 0.0; };
+                const double e00 = w(0, 0), e01 = w(0, 1), e02 = w(0, 2), e03 = w(0, 3), e10 = w(1, 0), e11 = w(1, 1), e12 = w(1, 2), e13 = w(1, 3);
+                const double e20 = w(2, 0), e21 = w(2, 1), e30 = w(3, 0), e31 = w(3, 1);
+                // -adj(Quu) with its two columns repeated: Ya4 = -adj(Quu) Qux in rows 0, 1 and again in rows 2, 3
+                NWA4.at(lane_) = (e01 + e03 + e10 + e12) * hb - (e00 + e02) * hc - (e11 + e13) * ha;
+                Ya4.at(lane_) = 0.0;
+                // kap, placed so that kap [g1 g2]'_x comes out in rows 2, 3
+                KAP4.at(lane_) = e02 * k00 + (e03 + e12) * k01 + e13 * k11;
+                GA.at(lane_) = 0.0;
+                // b operand of Pxp': [adj(Quu) diag(h) (rows 0, 1) ; p-part of [g1 g2]' (rows 2, 3)], columns 0, 1
+                BXP.at(lane_) = e00 * (hc * h44) - e01 * (hb * h55) - e10 * (hb * h44) + e11 * (ha * h55) + e20 * g14 + e21 * g15 + e30 * g24 + e31 * g25;
+                KFV.at(lane_) = e00 * kf0 + e10 * kf1;
+                // -Z' (a operand of the gains' correction K = K0 - Z [g1 g2]')
+                ZN.at(lane_) = -(e00 * z00 + e01 * z10 + e10 * z01 + e11 * z11);
+                PXXn.at(lane_) = QXX.at(lane_);
+                PXPn.at(lane_) = 0.0;
+                PXn.at(lane_) = QX.at(lane_) + e30 * t0;      // ... + Fx (kap Fu'kb), x-part
+                // what the later passes of the iteration need of the stage's scalars (stored here, before the products, so that the
+                // two dozen wave-uniform values of the Woodbury algebra are dead while the matrix core works)
+                if (lane_ == 0) {
                     S(k, L_KF + 0, kf0);
                     S(k, L_KF + 1, kf1);
                     S(k, L_KP + 0, kp00 - (z00 * g14 + z01 * g24));
@@ -423,40 +367,48 @@ struct Solver {
                     S(k, L_Z + 3, z11);
                     S(k, L_T + 0, t0);
                     S(k, L_T + 1, t1);
+                    S(k, L_M + 4, m14);
+                    S(k, L_M + 5, m15);
+                    S(k, L_M + 10, m24);
+                    S(k, L_M + 11, m25);
                 }
             });
+            // ---- the value function's 2x2 part: Ppp' = diag(h) - diag(h) G diag(h) + gp kap gp',  pp' = gp - diag(h) kf - t1 e_p1
+            pp00 = h44 - h44 * kp00 + (g14 * m14 + g24 * m24);
+            pp01 = -h44 * kp01 + (g14 * m15 + g24 * m25);
+            pp11 = h55 - h55 * kp11 + (g15 * m15 + g25 * m25);
+            ppv0 = gp0 - h44 * kf0;
+            ppv1 = gp1 - h55 * kf1 - t1;
+            c.mfma(NWA4, QUX, Ya4);
+            c.mfma(QUX, KFV, PXn);          // px' = qx + Qux'kf (+ t0 e_v)
+            c.lanes([&](int lane_) {
+                const int lane = c.opaque(lane_);
+                const int hi = lane >> 4, lo = lane & 3;
+                const bool ev = (hi & 1) == 0;
+                // [g1 g2]'_x in rows 0, 1 and again in rows 2, 3: g1 = dt K0x(0, .) + e_v, g2 = K0x(1, .), K0x = Ya4 / det
+                const double k0 = idet * Ya4.at(lane_);
+                GB4.at(lane_) = (ev ? dt : 1.0) * k0 + ((ev && lo == 3) ? 1.0 : 0.0);
+                KX.at(lane_) = k0;
+            });
+            c.mfma(KAP4, GB4, GA);          // rows 2, 3: kap [g1 g2]'_x
+            c.mfma(ZN, GB4, KX);            // rows 0, 1: Kx = K0x - Z [g1 g2]'_x
+            c.lanes([&](int lane_) {
+                const int lane = c.opaque(lane_);
+                const int hi = lane >> 4;
+                AOP.at(lane_) = idet * QUX.at(lane_) + GA.at(lane_);        // Qux / det in rows 0, 1 (GA is zero there), GA in rows 2, 3
+                BXX.at(lane_) = hi < 2 ? Ya4.at(lane_) : GB4.at(lane_);
+            });
+            c.mfma(AOP, BXX, PXXn);         // Pxx' = Qxx + Qux'K0x + gx kap gx'
+            c.mfma(AOP, BXP, PXPn);         // Pxp' = Qux'G diag(h) + gx kap gp'
             c.lanes([&](int lane) {
-                const int r = m_row.at(lane), cl = m_col.at(lane);
-                // entry j of g1 / g2 for j = row and j = column of this lane
-                double r0 = 0.0, r1 = 0.0, c0 = 0.0, c1 = 0.0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    r0 = r == j ? w0[j] : r0;
-                    r1 = r == j ? w1[j] : r1;
-                    c0 = cl == j ? w0[j] : c0;
-                    c1 = cl == j ? w1[j] : c1;
-                }
-                const double kr0 = -idet * r0, kr1 = -idet * r1, kc0 = -idet * c0, kc1 = -idet * c1;   // K0(a, row / col)
-                const double g1r = r < 4 ? dt * kr0 + (r == 3 ? 1.0 : 0.0) : (r == 4 ? dt * kp00 : (r == 5 ? dt * kp01 : 0.0));
-                const double g2r = r < 4 ? kr1 : (r == 4 ? kp10 : (r == 5 ? kp11 - 1.0 : 0.0));
-                const double g1c = cl < 4 ? dt * kc0 + (cl == 3 ? 1.0 : 0.0) : (cl == 4 ? dt * kp00 : (cl == 5 ? dt * kp01 : 0.0));
-                const double g2c = cl < 4 ? kc1 : (cl == 4 ? kp10 : (cl == 5 ? kp11 - 1.0 : 0.0));
-                const double mc1 = k00 * g1c + k01 * g2c, mc2 = k01 * g1c + k11 * g2c;     // column cl of kap [g1 g2]'
-                const double add = g1r * mc1 + g2r * mc2;
-                Pd.at(lane) = (r < 6 && cl < 6) ? Hm.at(lane) + add : 0.0;
-                const double padd = r == 3 ? t0 : (r == 5 ? -t1 : 0.0);                  // Fx (kap Fu' kf0)
-                pvd.at(lane) = (r < 6 && cl == 0) ? hv.at(lane) + padd : 0.0;
-                // lanes 0 .. 5 hold row 0, column = lane: their column entries are entry `lane` of g1, g2 and of K0
-                if (lane < 4) {
-                    S(k, L_KX + lane, kc0 - (z00 * g1c + z01 * g2c));
-                    S(k, L_KX + 4 + lane, kc1 - (z10 * g1c + z11 * g2c));
-                }
-                if (lane < 6) {
-                    S(k, L_M + lane, mc1);
-                    S(k, L_M + 6 + lane, mc2);
-                }
+                PXX.at(lane) = PXXn.at(lane);
+                PXP.at(lane) = PXPn.at(lane);
+                PX.at(lane) = PXn.at(lane);
+                const int so = q_st.at(lane);
+                const double v = so >= L_M ? GA.at(lane) : KX.at(lane);
+                if (so >= 0) S(k, so, v);
             });
-                }
+        }
         c.phase([&](int) {});
         return true;
     }
@@ -517,6 +469,33 @@ struct Solver {
         c.phase([&](int) {});
     }
 
+    // sincos_b of mpc_core.hpp with every 64-bit literal behind CTX::fresh: used twice per linearisation pass only, but as plain
+    // literals the fifteen constants are hoisted out of the pass loop and sit in thirty vector registers through every
+    // iteration (the throughput build then spills)
+    MPC_HD void sincos_f(double x, double &sn, double &cs) const {
+        auto F = [&](double v) { return c.fresh(v); };
+        const double n = rint(x * F(6.36619772367581382433e-01));
+        double r = fma(-n, F(1.57079632679489655800e+00), x);
+        r = fma(-n, F(6.12323399573676603587e-17), r);
+        const double z = r * r;
+        const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, F(1.58969099521155010221e-10), F(-2.50507602534068634195e-08)),
+                                                  F(2.75573137070700676789e-06)),
+                                           F(-1.98412698298579493134e-04)),
+                                    F(8.33333333332248946124e-03)),
+                             F(-1.66666666666666324348e-01));
+        const double sr = fma(z * r, ps, r);
+        const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, F(-1.13596475577881948265e-11), F(2.08757232129817482790e-09)),
+                                                  F(-2.75573143513906633035e-07)),
+                                           F(2.48015872894767294178e-05)),
+                                    F(-1.38888888888741095749e-03)),
+                             F(4.16666666666666019037e-02));
+        const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+        const int q = ((int)n) & 3;
+        const double sa = (q & 1) ? cr : sr, ca = (q & 1) ? sr : cr;
+        sn = (q & 2) ? -sa : sa;
+        cs = ((q + 1) & 2) ? -ca : ca;
+    }
+
     // ---- the solve.  On entry L_U holds the stored profile (oa, od); on exit (status 0) the new one, L_X the
     //      predicted states of the linear model ----------------------------------------------------------------
     MPC_HD void solve(int &status_out, int &iters_out) {
@@ -529,11 +508,17 @@ struct Solver {
         c.st(SCR + SC_ZERO, 0.0);
         c.st(SCR + SC_ONE, 1.0);
         c.st(SCR + SC_DT, dt);
+        c.phase([&](int lane) {
+            for (int k = lane; k <= N; k += kLanes) {
+                S(k, L_ONE, 1.0);
+                S(k, L_DTC, dt);
+            }
+        });
         // ---- nominal trajectory (predict_motion, :84-110); only its speed and yaw enter the model
         c.phase([&](int lane) {
             for (int k = lane; k < N; k += kLanes) {
                 double sd, cd;
-                sincos_b(S(k, L_U + 1), sd, cd);
+                sincos_f(S(k, L_U + 1), sd, cd);
                 S(k, L_G + 0, sd / cd);
             }
         });
@@ -554,7 +539,7 @@ struct Solver {
             for (int k = lane; k < N; k += kLanes) {
                 const double vb = S(k, L_G + 1), yb = S(k, L_G + 2);
                 double sy, cy;
-                sincos_b(yb, sy, cy);
+                sincos_f(yb, sy, cy);
                 S(k, L_LIN + 0, -dt * vb * sy);
                 S(k, L_LIN + 1, dt * cy);
                 S(k, L_LIN + 2, dt * vb * cy);
@@ -588,12 +573,17 @@ struct Solver {
                 z_[i].at(lane) = on ? kZInit : 0.0;
             }
         });
-        const double m_ineq = (double)(8 * N - 2);
-        const double T = (double)N;
+        // (wave-uniform values of the whole solve that the vector unit would otherwise hold in registers across every phase: the
+        // horizon-derived constants are re-derived where they are used, the dual tolerance sits in LDS)
+        c.st(SCR + SC_T, (double)N);
+        c.st(SCR + SC_MINEQ, (double)(8 * N - 2));
+        c.phase([&](int) {});
+        auto m_ineq_ = [&]() { return c.ld(SCR + SC_MINEQ); };
+        auto T_ = [&]() { return c.ld(SCR + SC_T); };
         int iter = 0;
-        double tol_d = 0.0;
         for (iter = 0; iter <= P.max_iter; ++iter) {
             // ============ residuals: primal (per inequality), complementarity, node terms of the adjoint
+            const double T = T_();
             const double y0 = 2.0 * T * kQfXY * (S(N, L_X + 0) - xr(N)), y1 = 2.0 * T * kQfXY * (S(N, L_X + 1) - yr(N));
             c.phase([&](int lane) {
                 red_a.at(lane) = 0.0;
@@ -629,7 +619,7 @@ struct Solver {
                     S(j, L_Y + 1, -zv);
                 }
             });
-            const double res_p = c.wave_max(red_a), mu = c.wave_sum(red_b) / m_ineq;
+            const double res_p = c.wave_max(red_a), mu = c.wave_sum(red_b) / m_ineq_();
             // ============ adjoint of (yaw, v): x and y carry y0, y1 unchanged, so the yaw adjoint is a suffix sum of the node
             //              terms and the speed adjoint one of (term + a23 yaw-adjoint of the next node): two wave scans,
             //              lane j = node j + 1
@@ -676,8 +666,8 @@ struct Solver {
             const double res_d = c.wave_max(red_a);
             // all three at the same iterate (the steps of the stiff rows are computed in constraint space, see darg: the
             // measured dual residual keeps falling to ~1e-12 instead of drowning in rounding noise z^2 eps / mu)
-            if (iter == 0) tol_d = kTolDRel * fmax2(1e3, res_d);
-            const bool dual_ok = res_d <= tol_d;
+            if (iter == 0) c.st(SCR + SC_TOLD, kTolDRel * fmax2(1e3, res_d));
+            const bool dual_ok = res_d <= c.ld(SCR + SC_TOLD);
             if (res_p <= kTolP && dual_ok && mu <= kTolMu) {
                 status_out = ST_CONVERGED;
                 break;
@@ -764,7 +754,7 @@ struct Solver {
                 sB = c.wave_sum(red_d);
                 sC = c.wave_sum(red_e);
                 const double a_aff = (rn > rd) ? rd / rn : 1.0;
-                const double mu_aff = (sA + a_aff * (sB + a_aff * sC)) / m_ineq;
+                const double mu_aff = (sA + a_aff * (sB + a_aff * sC)) / m_ineq_();
                 const double ratio = mu_aff / mu;
                 sigma_mu = fmax2(ratio * ratio * ratio * mu, 0.1 * kTolMu);   // never aim below the stopping threshold
             }

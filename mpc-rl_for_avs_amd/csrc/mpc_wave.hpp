@@ -34,9 +34,6 @@ namespace mpc {
 namespace wave {
 
 constexpr int kLanes = 64;
-// block moves of the 8x8 stage matrix (2x2 blocks of 4x4, lane = 16 hi + 4 (2 I + J) + lo): block (I, J) of the result is
-// block (K, I) [BM_K0_I, BM_K1_I] or block (K, J) [BM_K0_J, BM_K1_J] of the source
-enum : int { BM_K0_I = 0, BM_K1_I = 1, BM_K0_J = 2, BM_K1_J = 3 };
 constexpr int kTrials = 4;   // step lengths tried by the line search: a_pr * 4^-t (six gained nothing: 4083 against 4084
                              // of 4096 config-3 instances converged in the oracle, and cost 2 KB of LDS per instance)
 // A rollout that would take theta or v of the next node out of its bounds gets the one control that decides it (delta
@@ -283,7 +280,6 @@ MPC_HD constexpr int stage_transition_word(int r, int c, int lin, int zero, int 
 //   void lanes(F f)                              f(lane) for the 64 lanes, no barrier (register-only work)
 //   void mfma(PerLane<double>& a, PerLane<double>& b, PerLane<double>& cd)   cd += a x b, v_mfma_f64_4x4x4f64:
 //        lane l = 16 hi + 4 blk + lo holds A_blk[row lo][k hi], B_blk[k hi][col lo], C/D_blk[row hi][col lo]
-//   void take_blocks<MOVE>(PerLane<double>& dst, PerLane<double>& src)   block (I, J) of dst <- block MOVE of src
 //   double lane_get(PerLane<double>&, int lane)  value of one lane, in every lane
 //   void wave_suffix_sum(PerLane<double>&)       in place: lane i <- sum of lanes i..63
 //   void sched_fence()                           the compiler schedules no instruction across this point

@@ -74,7 +74,7 @@ __device__ __forceinline__ double row_bcast2_f64(double v) {
 // the builds the engine launches when the batch leaves SIMDs that empty anyway (mpc_engine.hip: dispatch_solve).
 template <int RELAX>   // bit 0: fresh() is the identity, bit 1: opaque() is the identity, bit 2: the build has its SIMD to itself (opaque_shared)
 struct WaveOpsT {
-    static constexpr int kRelax = RELAX;                    // bits 3, 4 in mpc_ltv.hpp: relax_bits
+    static constexpr int kRelax = RELAX;                    // bit 3 in mpc_ltv.hpp: relax_bits
     lds_double_t *L;  // this instance's LDS words
     __device__ __forceinline__ double ld(int i) const { return L[i]; }
     __device__ __forceinline__ void st(int i, double v) { L[i] = v; }
@@ -97,34 +97,6 @@ struct WaveOpsT {
     }
     __device__ __forceinline__ void mfma(PerLane<double> &a, PerLane<double> &b, PerLane<double> &cd) const {
         cd.v = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v, b.v, cd.v, 0, 0, 0);
-    }
-    // Block moves of the 8x8 stage matrix between the C/D layout and the operand positions of the next product: every
-    // one of them moves whole 4-lane quads inside the 16-lane rows, i.e. it is a DPP row shift with a bank mask (two or
-    // three VALU moves per 32-bit half) - no trip through the LDS crossbar (ds_bpermute: ~120 cycles of latency that a
-    // lone wave cannot hide, three times per Riccati stage).
-    template <int CTRL, int BANK>
-    __device__ __forceinline__ static double dpp_merge(double old, double src) {
-        const long long o = __double_as_longlong(old), b = __double_as_longlong(src);
-        const int lo = __builtin_amdgcn_update_dpp((int)(o & 0xffffffffll), (int)(b & 0xffffffffll), CTRL, 0xf, BANK, false);
-        const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, 0xf, BANK, false);
-        return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-    }
-    template <int MOVE>
-    __device__ __forceinline__ void take_blocks(PerLane<double> &dst, PerLane<double> &src) const {
-        constexpr int kShr4 = 0x114, kShr8 = 0x118, kShl4 = 0x104, kShl8 = 0x108;   // row_shr:n reads lane i - n
-        double t = src.v;
-        if (MOVE == BM_K0_I) {          // quads 0 1 2 3 <- 0 0 1 1
-            t = dpp_merge<kShr4, 0x6>(t, src.v);
-            t = dpp_merge<kShr8, 0x8>(t, src.v);
-        } else if (MOVE == BM_K1_I) {   // <- 2 2 3 3
-            t = dpp_merge<kShl8, 0x1>(t, src.v);
-            t = dpp_merge<kShl4, 0x6>(t, src.v);
-        } else if (MOVE == BM_K0_J) {   // <- 0 1 0 1
-            t = dpp_merge<kShr8, 0xc>(t, src.v);
-        } else {                        // BM_K1_J <- 2 3 2 3
-            t = dpp_merge<kShl8, 0x3>(t, src.v);
-        }
-        dst.v = t;
     }
     __device__ __forceinline__ double lane_get(PerLane<double> &p, int lane) const { return readlane_f64(p.v, lane); }
     // dst (every lane) = src of lane J of the same 16-lane row

@@ -53,17 +53,6 @@ struct HostCtx {
         }
         for (int l = 0; l < mpc::wave::kLanes; ++l) cd.v[l] = out[l];
     }
-    template <int MOVE>
-    void take_blocks(mpc::wave::PerLane<double> &dst, mpc::wave::PerLane<double> &src) const {
-        double out[mpc::wave::kLanes];
-        for (int l = 0; l < mpc::wave::kLanes; ++l) {
-            const int blk = (l >> 2) & 3, I = blk >> 1, J = blk & 1;
-            const int K = (MOVE == mpc::wave::BM_K1_I || MOVE == mpc::wave::BM_K1_J) ? 1 : 0;
-            const int from = (MOVE == mpc::wave::BM_K0_I || MOVE == mpc::wave::BM_K1_I) ? 2 * K + I : 2 * K + J;
-            out[l] = src.v[(l & ~12) | (from << 2)];
-        }
-        for (int l = 0; l < mpc::wave::kLanes; ++l) dst.v[l] = out[l];
-    }
     double lane_get(mpc::wave::PerLane<double> &p, int lane) const { return p.v[lane]; }
     // v_mov_b64_dpp row_newbcast:J - every lane takes lane J of its own 16-lane row
     template <int J>
@@ -168,7 +157,7 @@ struct HostCtx {
 };
 
 
-// mpc_ltv.hpp's code path of the latency build (residuals kept in registers, wave-uniform gain rows: relax_bits)
+// mpc_ltv.hpp's code path of the latency build (residuals kept in registers: relax_bits)
 struct HostCtxLtvRelaxed : HostCtx {
-    static constexpr int kRelax = 8 | 16;
+    static constexpr int kRelax = 8;
 };
