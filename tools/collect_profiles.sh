@@ -1,9 +1,9 @@
 #!/bin/bash
 # Copy the evidence of a tools/profile_session.sh run (merged back under gpurun_out/) into profiles/ (tracked).
-# usage: tools/collect_profiles.sh [tag]     default tag r05
+# usage: tools/collect_profiles.sh [tag]     default tag r06
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r05}
+TAG=${1:-r06}
 S=gpurun_out/${TAG}s
 P=profiles
 cp "$(ls -t $S/stats/*/*_kernel_stats.csv | head -1)" $P/${TAG}_bench_kernel_stats.csv

@@ -3,7 +3,7 @@
 # itself follows `--`).  usage: tools/pmc_run.sh <tag> [command...]   default command: the bench without side measurements
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift || true
 if [ $# -eq 0 ]; then set -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-side; fi
 OUT=gpurun_out/pmc_$TAG

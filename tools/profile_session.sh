@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU session that produces the evidence tracked under profiles/ (run through gpurun; tools/collect_profiles.sh copies
-# the summaries from gpurun_out/ into profiles/).  usage: tools/profile_session.sh [tag]     default tag r05
+# the summaries from gpurun_out/ into profiles/).  usage: tools/profile_session.sh [tag]     default tag r06
 # Every rocprofv3 command has the program itself after `--`; PMC passes are their own runs (tools/pmc_run.sh).
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${TAG}s
 mkdir -p $O
