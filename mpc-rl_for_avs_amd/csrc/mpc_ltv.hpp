@@ -413,58 +413,120 @@ struct Solver {
         return true;
     }
 
-    // ---- second solve with the same factorisation: only the feed-forward terms change (uniform, serial) --------
+    // ---- second solve with the same factorisation: only the feed-forward terms change -----------------------------
+    // Round 6: on the matrix core like the factorisation (until round 5 wave-uniform scalar code, 96 instructions and 35 LDS
+    // words per stage in every lane).  h = g_x + A'p and hu = g_u + B'p are the factorisation's own two products, the new
+    // value-function gradient p' = h + Kx'hu a third with the stored gains as A operand; the 2-dimensional rest (kf = -IH hu,
+    // t = -Z'hu, pp' = g_p + Kp'hu) stays scalar.
     MPC_HD void resolve_gradient() {
         double pT[4];
         terminal_gradient(pT);
-        double p0 = pT[0], p1 = pT[1], p2 = pT[2], p3 = pT[3], pp0 = 0.0, pp1 = 0.0;
+        PerLane<int> r_a, r_b, r_lx, r_lu, r_kx;
+        PerLane<double> PX, E00, E10;
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque(lane_);
+            const int hi = lane >> 4, lo = lane & 3;
+            const int zero = L_G + 0;
+            r_a.at(lane_) = f_word(hi, lo);
+            r_b.at(lane_) = f_word(hi, lo < 2 ? 6 + lo : 4);
+            r_lx.at(lane_) = lo == 0 ? L_G + hi : zero;
+            r_lu.at(lane_) = (lo == 0 && hi < 2) ? L_G + 6 + hi : zero;
+            r_kx.at(lane_) = hi < 2 ? L_KX + 4 * hi + lo : zero;            // Kx[hi][lo]: the A operand of Kx'hu
+            const double c0 = lo == 0 ? 1.0 : 0.0;
+            E00.at(lane_) = (hi == 0 && lo == 0) ? 1.0 : 0.0;
+            E10.at(lane_) = (hi == 1 && lo == 0) ? 1.0 : 0.0;
+            PX.at(lane_) = c0 * ((hi == 0 ? 1.0 : 0.0) * pT[0] + (hi == 1 ? 1.0 : 0.0) * pT[1] + (hi == 2 ? 1.0 : 0.0) * pT[2] + (hi == 3 ? 1.0 : 0.0) * pT[3]);
+        });
+        double pp0 = 0.0, pp1 = 0.0;
 #pragma unroll 1
         for (int k = N - 1; k >= 0; --k) {
-            const double a02 = S(k, L_LIN + 0), a03 = S(k, L_LIN + 1), a12 = S(k, L_LIN + 2), a13 = S(k, L_LIN + 3),
-                         a23 = S(k, L_LIN + 4), b01 = S(k, L_LIN + 5), b11 = S(k, L_LIN + 6), b21 = S(k, L_LIN + 7);
-            const double h0 = S(k, L_G + 0) + p0, h1 = S(k, L_G + 1) + p1;
-            const double h2 = S(k, L_G + 2) + a02 * p0 + a12 * p1 + p2;
-            const double h3 = S(k, L_G + 3) + a03 * p0 + a13 * p1 + a23 * p2 + p3;
-            const double hu0 = S(k, L_G + 6) + dt * p3 + pp0;
-            const double hu1 = S(k, L_G + 7) + b01 * p0 + b11 * p1 + b21 * p2 + pp1;
+            PerLane<double> RA, RB, QX, QU, KX, HU;
+            c.lanes([&](int lane) {
+                const int base = k * L_SLOTS;
+                RA.at(lane) = c.ld(base + r_a.at(lane));
+                RB.at(lane) = c.ld(base + r_b.at(lane));
+                QX.at(lane) = c.ld(base + r_lx.at(lane));
+                QU.at(lane) = c.ld(base + r_lu.at(lane));
+                KX.at(lane) = c.ld(base + r_kx.at(lane));
+            });
             const double i00 = S(k, L_IH + 0), i01 = S(k, L_IH + 1), i11 = S(k, L_IH + 2);
-            S(k, L_KF + 0, -(i00 * hu0 + i01 * hu1));
-            S(k, L_KF + 1, -(i01 * hu0 + i11 * hu1));
-            S(k, L_T + 0, -(S(k, L_Z + 0) * hu0 + S(k, L_Z + 2) * hu1));
-            S(k, L_T + 1, -(S(k, L_Z + 1) * hu0 + S(k, L_Z + 3) * hu1));
-            p0 = h0 + S(k, L_KX + 0) * hu0 + S(k, L_KX + 4) * hu1;
-            p1 = h1 + S(k, L_KX + 1) * hu0 + S(k, L_KX + 5) * hu1;
-            p2 = h2 + S(k, L_KX + 2) * hu0 + S(k, L_KX + 6) * hu1;
-            p3 = h3 + S(k, L_KX + 3) * hu0 + S(k, L_KX + 7) * hu1;
-            pp0 = S(k, L_G + 4) + S(k, L_KP + 0) * hu0 + S(k, L_KP + 2) * hu1;
-            pp1 = S(k, L_G + 5) + S(k, L_KP + 1) * hu0 + S(k, L_KP + 3) * hu1;
+            const double z00 = S(k, L_Z + 0), z01 = S(k, L_Z + 1), z10 = S(k, L_Z + 2), z11 = S(k, L_Z + 3);
+            const double kp00 = S(k, L_KP + 0), kp01 = S(k, L_KP + 1), kp10 = S(k, L_KP + 2), kp11 = S(k, L_KP + 3);
+            const double gp0 = S(k, L_G + 4), gp1 = S(k, L_G + 5);
+            c.mfma(RA, PX, QX);        // h  = g_x + A'p
+            c.mfma(RB, PX, QU);        // hu = g_u + B'p        (+ pp below)
+            const double hu0 = c.lane_get(QU, 0) + pp0, hu1 = c.lane_get(QU, 16) + pp1;
+            c.lanes([&](int lane) {
+                HU.at(lane) = E00.at(lane) * hu0 + E10.at(lane) * hu1;
+                if (lane == 0) {
+                    S(k, L_KF + 0, -(i00 * hu0 + i01 * hu1));
+                    S(k, L_KF + 1, -(i01 * hu0 + i11 * hu1));
+                    S(k, L_T + 0, -(z00 * hu0 + z10 * hu1));
+                    S(k, L_T + 1, -(z01 * hu0 + z11 * hu1));
+                }
+            });
+            c.mfma(KX, HU, QX);        // p' = h + Kx'hu
+            c.lanes([&](int lane) { PX.at(lane) = QX.at(lane); });
+            pp0 = gp0 + kp00 * hu0 + kp10 * hu1;
+            pp1 = gp1 + kp01 * hu0 + kp11 * hu1;
         }
+        c.phase([&](int) {});
     }
 
-    // ---- Newton direction from the gains (uniform, serial): L_DU of every stage, L_DX of every node ------------
+    // ---- Newton direction from the gains: L_DU of every stage, L_DX of every node -----------------------------------
+    // Round 6: on the matrix core (until round 5 wave-uniform scalar code, 52 instructions per stage).  The node's step d
+    // (column 0 of a block) and the previous stage's control step dp go through four products per stage -
+    //     du = kf + Kx d + Kp dp        d' = A d + B du
+    // with the gains and the model TRANSPOSED as A operands (role tables of LDS words, nothing is moved), and each lane of
+    // blocks 0 / 1 stores its component of d' / du with one write.
     MPC_HD void forward_sweep() {
-        double d0 = 0, d1 = 0, d2 = 0, d3 = 0, dp0 = 0, dp1 = 0;
-        S(0, L_DX + 0, 0.0); S(0, L_DX + 1, 0.0); S(0, L_DX + 2, 0.0); S(0, L_DX + 3, 0.0);
+        PerLane<int> r_at, r_bt, r_kxt, r_kpt, r_kf, r_st;
+        PerLane<double> D, DP, WB0, WB1;
+        c.lanes([&](int lane_) {
+            const int lane = c.opaque(lane_);
+            const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
+            const int zero = L_G + 0;
+            r_at.at(lane_) = f_word(lo, hi);                                       // A[lo][hi]
+            r_bt.at(lane_) = hi < 2 ? f_word(lo, 6 + hi) : zero;                   // B~[lo][hi]
+            r_kxt.at(lane_) = lo < 2 ? L_KX + 4 * lo + hi : zero;                  // Kx[lo][hi]
+            r_kpt.at(lane_) = (lo < 2 && hi < 2) ? L_KP + 2 * lo + hi : zero;      // Kp[lo][hi]
+            r_kf.at(lane_) = (lo == 0 && hi < 2) ? L_KF + hi : zero;
+            // block 0, column 0: component hi of d' -> L_DX of node k + 1; block 1, column 0, rows 0, 1: du -> L_DU of stage k
+            int out = -1;
+            out = (blk == 0 && lo == 0) ? L_SLOTS + L_DX + hi : out;
+            out = (blk == 1 && lo == 0 && hi < 2) ? L_DU + hi : out;
+            r_st.at(lane_) = out;
+            WB0.at(lane_) = blk == 1 ? 0.0 : 1.0;
+            WB1.at(lane_) = blk == 1 ? 1.0 : 0.0;
+            D.at(lane_) = 0.0;
+            DP.at(lane_) = 0.0;
+        });
+        c.phase([&](int lane) {
+            if (lane < 4) S(0, L_DX + lane, 0.0);
+        });
 #pragma unroll 1
         for (int k = 0; k < N; ++k) {
-            const double du0 = S(k, L_KF + 0) + S(k, L_KX + 0) * d0 + S(k, L_KX + 1) * d1 + S(k, L_KX + 2) * d2 +
-                               S(k, L_KX + 3) * d3 + S(k, L_KP + 0) * dp0 + S(k, L_KP + 1) * dp1;
-            const double du1 = S(k, L_KF + 1) + S(k, L_KX + 4) * d0 + S(k, L_KX + 5) * d1 + S(k, L_KX + 6) * d2 +
-                               S(k, L_KX + 7) * d3 + S(k, L_KP + 2) * dp0 + S(k, L_KP + 3) * dp1;
-            const double a02 = S(k, L_LIN + 0), a03 = S(k, L_LIN + 1), a12 = S(k, L_LIN + 2), a13 = S(k, L_LIN + 3),
-                         a23 = S(k, L_LIN + 4), b01 = S(k, L_LIN + 5), b11 = S(k, L_LIN + 6), b21 = S(k, L_LIN + 7);
-            const double n0 = d0 + a02 * d2 + a03 * d3 + b01 * du1;
-            const double n1 = d1 + a12 * d2 + a13 * d3 + b11 * du1;
-            const double n2 = d2 + a23 * d3 + b21 * du1;
-            const double n3 = d3 + dt * du0;
-            d0 = n0; d1 = n1; d2 = n2; d3 = n3;
-            dp0 = du0; dp1 = du1;
-            S(k, L_DU + 0, du0);
-            S(k, L_DU + 1, du1);
-            S(k + 1, L_DX + 0, d0);
-            S(k + 1, L_DX + 1, d1);
-            S(k + 1, L_DX + 2, d2);
-            S(k + 1, L_DX + 3, d3);
+            PerLane<double> AT, BT, KXT, KPT, DU, DN;
+            c.lanes([&](int lane) {
+                const int base = k * L_SLOTS;
+                AT.at(lane) = c.ld(base + r_at.at(lane));
+                BT.at(lane) = c.ld(base + r_bt.at(lane));
+                KXT.at(lane) = c.ld(base + r_kxt.at(lane));
+                KPT.at(lane) = c.ld(base + r_kpt.at(lane));
+                DU.at(lane) = c.ld(base + r_kf.at(lane));
+                DN.at(lane) = 0.0;
+            });
+            c.mfma(KXT, D, DU);        // du = kf + Kx d
+            c.mfma(AT, D, DN);         // d' = A d
+            c.mfma(KPT, DP, DU);       //      ... + Kp dp
+            c.mfma(BT, DU, DN);        //      ... + B du
+            c.lanes([&](int lane) {
+                const int so = r_st.at(lane);
+                const double v = WB0.at(lane) * DN.at(lane) + WB1.at(lane) * DU.at(lane);      // (exact: products with 0 / 1)
+                if (so >= 0) S(k, so, v);
+                D.at(lane) = DN.at(lane);
+                DP.at(lane) = DU.at(lane);
+            });
         }
         c.phase([&](int) {});
     }
