@@ -887,6 +887,15 @@ struct Solver {
                            (q == 3 ? 1.0 : 0.0) * x0[3];
         });
         const double vmin_ = c.fresh(1e-6);
+        // which nodes 1 .. N - 1 carry a wall constraint, as a bit mask read once in front of the loop (round 6: until then the
+        // loop asked LDS in EVERY stage of an instance with a wall anywhere - a wave-uniform load with nothing to hide its ~80
+        // cycles behind, 1.6 k cycles per line search on exactly the instances a batch waits for)
+        unsigned long long wall_nodes = 0;
+        if (CC && any_wall) {
+            PerLane<int> has;
+            c.lanes([&](int lane) { has.at(lane) = (lane >= 1 && lane < N && S(lane, W_WJ) >= 0.0) ? 1 : 0; });
+            wall_nodes = c.ballot(has);
+        }
         // operands of a stage, requested one stage ahead (below): a lone wave cannot hide the LDS latency at the top of a stage
         PerLane<double> ZC, CK, G0, G1, G2, G3, G4, G5, G6, Q0, Q1, Q2, Q3, F0, F1, F3;
         auto load_gains = [&](int base) __attribute__((always_inline)) {
@@ -1072,7 +1081,7 @@ struct Solver {
                 viol.at(lane) = ((n - LOABS.at(lane) < Q0.at(lane)) | (HIABS.at(lane) - n < Q1.at(lane))) ? 1 : 0;
             });
             bad |= c.ballot(viol);
-            if (CC && any_wall && k + 1 < N) {
+            if (CC && ((wall_nodes >> (k + 1)) & 1ull)) {
                 const double wjv = S(k + 1, W_WJ);
                 if (wjv >= 0.0) {
                     PerLane<double> X0, X1;
