@@ -274,6 +274,7 @@ int mpc_get_last_paths(mpc_handle *h, int32_t B, double *ego_path, int32_t *ego_
  * counter-based generator, so shards of one job draw distinct streams).  action [B][2] acceleration, steer.
  * Outputs: obs [B][10][8] f32 what the policy sees next (after the auto-reset), terminal_obs the same before it, reward [B]
  * f32, done / truncated / crashed / arrived [B] u8.  reset_all != 0: start fresh episodes everywhere and write obs only.
+ * Limits (sixteen lanes per environment): K <= 15 other vehicles, M <= 128 route points; MPC_ERR_INVALID_ARG beyond.
  */
 int mpc_synth_env_step(int32_t device, int32_t B, int32_t K, double dt, double spawn_probability, uint64_t seed,
                        int32_t env_offset, const double *ref_xy, int32_t M, const double *action, double *ego, double *opos,

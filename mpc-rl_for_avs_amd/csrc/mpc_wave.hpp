@@ -1081,7 +1081,7 @@ struct Solver {
                 viol.at(lane) = ((n - LOABS.at(lane) < Q0.at(lane)) | (HIABS.at(lane) - n < Q1.at(lane))) ? 1 : 0;
             });
             bad |= c.ballot(viol);
-            if (CC && ((wall_nodes >> (k + 1)) & 1ull)) {
+            if (CC && k + 1 < N && ((wall_nodes >> (k + 1)) & 1ull)) {      // (k + 1 < N <= 64: the shift stays below 64)
                 const double wjv = S(k + 1, W_WJ);
                 if (wjv >= 0.0) {
                     PerLane<double> X0, X1;
