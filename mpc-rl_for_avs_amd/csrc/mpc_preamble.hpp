@@ -343,7 +343,10 @@ struct OverlapWalk {
                 while (ma >= 0 && ma < na && !agent_inside(ma)) ma += mstep;
             }
             if (nu == 0 || !close2(last, p)) {
-                if (nu == want) out = p;
+                if (nu == want) {
+                    out = p;
+                    return nu + 1;      // (round 6) the second walk wants this element only: it need not go on to the end
+                }
                 last = p;
                 ++nu;
             }

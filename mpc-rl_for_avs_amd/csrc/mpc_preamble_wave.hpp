@@ -87,7 +87,40 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
                               const PreDiag &diag) {
     using wave::PerLane;
     const int M = R.M;
-    const Parsed p = parse_obs(obs, rows);                        // wave-uniform
+    // a2 (agents/base_agent.py:81-116): the observation is read ONCE, every lane its own words (round 6: parse_obs's ten dependent
+    // wave-uniform loads cost 3.3 k cycles, `tools/gpu_preamble_sections.py`), the presence count is a ballot, the ego's fields
+    // are handed out of lanes 1 .. 5
+    Parsed p;
+    {
+        PerLane<int> w0, w1, pr0, pr1;
+        const int nw = rows * kObsCols;                           // <= 17 * 8 = 136 words
+        ctx.phase([&](int lane) {
+            float a = 0.0f, b = 0.0f;
+            if (lane < nw) a = obs[lane];
+            if (lane + wave::kLanes < nw) b = obs[lane + wave::kLanes];
+            int ia, ib;
+            __builtin_memcpy(&ia, &a, 4);
+            __builtin_memcpy(&ib, &b, 4);
+            w0.at(lane) = ia;
+            w1.at(lane) = ib;
+            pr0.at(lane) = ((lane % kObsCols) == 0 && lane < nw && a == 1.0f) ? 1 : 0;
+            pr1.at(lane) = ((lane % kObsCols) == 0 && lane + wave::kLanes < nw && b == 1.0f) ? 1 : 0;
+        });
+        int present = popc64(ctx.ballot(pr0));
+        if (nw > wave::kLanes) present += popc64(ctx.ballot(pr1));
+        if (nw > 2 * wave::kLanes)                                 // rows 16 (words 128 .. 135): beyond two words per lane
+            for (int r = 2 * wave::kLanes / kObsCols; r < rows; ++r) present += (obs[r * kObsCols] == 1.0f) ? 1 : 0;
+        int observed = present - 1;
+        observed = observed < 0 ? 0 : observed;
+        observed = observed > kMaxOthers ? kMaxOthers : observed;
+        auto field = [&](int i) {
+            const int bits = ctx.wave_bcast(w0, i);
+            float f;
+            __builtin_memcpy(&f, &bits, 4);
+            return f;
+        };
+        p = Parsed{field(1), field(2), normalize_angle_f32(field(5)), speed_f32(field(3), field(4)), observed};
+    }
     const double ex = (double)p.ex, ey = (double)p.ey;
 
     // ---- nearest reference point of the ego (first minimum; agents/pure_mpc.py:106-109, 567-570, 471-474)
@@ -135,61 +168,78 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
             const float acc_dt_f = (float)(3.5 * dt);
             const float dt_f = (float)dt;
             double cd_last = 0.0;
+            PerLane<double> cdv;
+            ctx.lanes([&](int lane) { cdv.at(lane) = 0.0; });
+            // (round 6: the same statements without branches - both the float32 and the float64 continuation of a step are
+            // computed and the state flags select; as data-dependent wave-uniform branches a step cost 276 cycles, 8.3 k per call)
 #pragma unroll 1
             for (int step = 0; step < kPredHorizon; ++step) {
                 const double cs_now = s32 ? (double)cs_f : cs_d;
-                if (cs_now < reference_speed) {
-                    if (s32) {
-                        const float t = f32add(cs_f, acc_dt_f);
-                        if (reference_speed < (double)t) {
-                            s32 = false;
-                            cs_d = reference_speed;
-                        } else {
-                            cs_f = t;
-                        }
-                    } else {
-                        const double t = f64add(cs_d, 3.5 * dt);
-                        cs_d = reference_speed < t ? reference_speed : t;
-                    }
-                } else {
-                    s32 = false;
-                    cs_d = reference_speed;
-                }
-                if (s32) {
-                    const float inc = f32mul(cs_f, dt_f);
-                    if (d32) cd_f = f32add(cd_f, inc);
-                    else cd_d = f64add(cd_d, (double)inc);
-                } else {
-                    const double inc = f64mul(cs_d, dt);
-                    if (d32) {
-                        cd_d = f64add((double)cd_f, inc);
-                        d32 = false;
-                    } else {
-                        cd_d = f64add(cd_d, inc);
-                    }
-                }
+                const bool below = cs_now < reference_speed;
+                const float tf = f32add(cs_f, acc_dt_f);                         // the float32 ramp step ...
+                const bool over_f = reference_speed < (double)tf;               // ... and whether it passes the reference speed
+                const double td = f64add(cs_d, 3.5 * dt);                       // the float64 ramp step
+                const double cs_d_ramp = reference_speed < td ? reference_speed : td;
+                const bool keep32 = s32 && below && !over_f;
+                cs_d = !below ? reference_speed : (s32 ? (over_f ? reference_speed : cs_d) : cs_d_ramp);
+                cs_f = keep32 ? tf : cs_f;
+                s32 = keep32;
+                const float incf = f32mul(cs_f, dt_f);
+                const double incd = f64mul(cs_d, dt);
+                const bool both32 = s32 && d32;
+                const double base = d32 ? (double)cd_f : cd_d;
+                const double add = s32 ? (double)incf : incd;
+                const double cd_d_n = both32 ? cd_d : f64add(base, add);
+                cd_f = both32 ? f32add(cd_f, incf) : cd_f;
+                cd_d = cd_d_n;
+                d32 = both32;
                 cd_last = d32 ? (double)cd_f : cd_d;
-                ctx.st(PL_CD + step + 1, cd_last);                 // every lane stores the same value
+                // lane step + 1 keeps this step's distance (one store per lane after the loop: 64 lanes writing ONE LDS word per
+                // step serialise on its bank)
+                ctx.lanes([&](int lane) { cdv.at(lane) = lane == step + 1 ? cd_last : cdv.at(lane); });
             }
-            // ---- route segments behind the start point, kWin at a time; running sums in np.cumsum's order
-            const int nseg = npts - 1 < kWin ? npts - 1 : kWin;
             ctx.phase([&](int lane) {
-                for (int i = lane; i < nseg; i += wave::kLanes)
-                    ctx.st(PL_SEG + i, dist2d(R.x(e0 + i + 1), R.y(e0 + i + 1), R.x(e0 + i), R.y(e0 + i)));
+                if (lane >= 1 && lane <= kPredHorizon) ctx.st(PL_CD + lane, cdv.at(lane));
+            });
+            // ---- route segments behind the start point, kWin at a time; running sums in np.cumsum's order.  Round 6: the segment
+            //      lengths stay in registers (lane i: segments i and i + 64), the serial sum fetches them with v_readlane and
+            //      lane i keeps sum i - until then every step was an LDS load the addition waited for plus a 64-lane store to
+            //      one word (~110 cycles per step)
+            const int nseg = npts - 1 < kWin ? npts - 1 : kWin;
+            PerLane<double> sg0, sg1, cu0, cu1;
+            ctx.phase([&](int lane) {
+                const int i0 = lane, i1 = lane + wave::kLanes;
+                sg0.at(lane) = i0 < nseg ? dist2d(R.x(e0 + i0 + 1), R.y(e0 + i0 + 1), R.x(e0 + i0), R.y(e0 + i0)) : 0.0;
+                sg1.at(lane) = i1 < nseg ? dist2d(R.x(e0 + i1 + 1), R.y(e0 + i1 + 1), R.x(e0 + i1), R.y(e0 + i1)) : 0.0;
+                cu0.at(lane) = 0.0;
+                cu1.at(lane) = 0.0;
+                if (i0 < nseg) ctx.st(PL_SEG + i0, sg0.at(lane));
+                if (i1 < nseg) ctx.st(PL_SEG + i1, sg1.at(lane));
             });
             int ncum = 1;
+            double cum_end = 0.0;
             {
                 double cum = 0.0;
-                ctx.st(PL_CUM, 0.0);
+                static_assert(kWin == 2 * wave::kLanes, "two running sums per lane; the last one (index kWin) apart");
 #pragma unroll 1
                 for (int i = 1; i <= nseg; ++i) {
-                    cum = f64add(cum, ctx.ld(PL_SEG + i - 1));
-                    ctx.st(PL_CUM + i, cum);
+                    const double sgi = i - 1 < wave::kLanes ? ctx.lane_get(sg0, i - 1) : ctx.lane_get(sg1, i - 1 - wave::kLanes);
+                    cum = f64add(cum, sgi);
+                    // running sum i: lane i (i < 64) in cu0, lane i - 64 in cu1
+                    ctx.lanes([&](int lane) {
+                        cu0.at(lane) = lane == i ? cum : cu0.at(lane);
+                        cu1.at(lane) = lane + wave::kLanes == i ? cum : cu1.at(lane);
+                    });
+                    if (i == kWin) cum_end = cum;                  // sum kWin has no lane of its own
                     ncum = i + 1;
                     if (!(cum < cd_last)) break;                   // the look-ahead ends here: nothing beyond is searched
                 }
             }
-            ctx.phase([&](int) {});
+            ctx.phase([&](int lane) {
+                if (lane < ncum) ctx.st(PL_CUM + lane, cu0.at(lane));                                     // (sum 0 = 0)
+                if (lane + wave::kLanes < ncum && lane + wave::kLanes < kWin) ctx.st(PL_CUM + lane + wave::kLanes, cu1.at(lane));
+                if (lane == 0 && ncum == kWin + 1) ctx.st(PL_CUM + kWin, cum_end);
+            });
             // ---- the 30 predicted points: lane k = step k (agents/pure_mpc.py:501-521)
             PerLane<int> inside;
             ctx.phase([&](int lane) {
@@ -389,13 +439,173 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
         });
     }
 
-    // ---- problem data that comes straight from the observation, state machine, ego index, speed profile: lane 0
+    // ---- problem data that comes straight from the observation, state machine, ego index, speed profile.  Round 6: spread over
+    //      the lanes (until round 5 lane 0 ran write_vehicles + finish_env alone: ~10 k cycles of dependent global-memory round
+    //      trips on EVERY call, also when the detector only replays its memory - tools/gpu_preamble_sections.py).  Same
+    //      statements as finish_env (mpc_preamble.hpp), which stays the specification: lane j owns vehicle j's entries of the
+    //      record, lane k node k of the speed profile, the record's scalars are read once and written by lane 0.
+    const bool adv = advance && !degenerate;
+    const int32_t cm_old = st.collision_memory, hm_old = st.has_memorized, nmem_old = st.n_memorized, ncon_old = st.n_conflict;
+    const int32_t col_old = st.is_collide, lvs_old = st.last_valid_stop1;
+    const bool replay_mem = adv && cm_old > 0 && hm_old;          // replays_memory(st)
+    PerLane<int> con, mem, hitl;
     ctx.phase([&](int lane) {
-        if (lane != 0) return;
-        write_vehicles(obs, p, state, others);
-        for (int j = p.observed; j < vslots; ++j) others[j * 4 + 0] = others[j * 4 + 1] = others[j * 4 + 2] = others[j * 4 + 3] = 0.0;
-        nveh_out = p.observed;
-        finish_env(p, R, N, ref_speed, conf, cpt, st, ego_index_out, vref, collide_out, advance && !degenerate, e0);
+        int cj = -1, mj = -1, hj = 0;
+        if (lane < kMaxOthers) {
+            const int j = lane;
+            if (!adv) {
+                cj = st.conflict[j];
+                mj = st.memorized[j];
+            } else if (replay_mem) {
+                mj = st.memorized[j];
+                cj = mj;
+                st.conflict[j] = cj;
+                st.conflict_pt[j][0] = st.memorized_pt[j][0];
+                st.conflict_pt[j][1] = st.memorized_pt[j][1];
+            } else {
+                cj = j < p.observed ? conf[j] : -1;
+                hj = cj >= 0 ? 1 : 0;
+                st.conflict[j] = cj;
+                st.conflict_pt[j][0] = hj ? cpt[j].x : 0.0;
+                st.conflict_pt[j][1] = hj ? cpt[j].y : 0.0;
+                mj = st.memorized[j];
+            }
+        }
+        con.at(lane) = cj;
+        mem.at(lane) = mj;
+        hitl.at(lane) = hj;
+    });
+    const bool any = adv && !replay_mem && ctx.ballot(hitl) != 0;
+    // the record's scalars after the update
+    int32_t cm = cm_old, hm = hm_old, nmem = nmem_old, ncon = ncon_old, col = col_old;
+    if (adv) {
+        if (replay_mem) {
+            ncon = nmem_old;
+            col = 1;
+            cm = cm_old - 1;
+        } else {
+            ncon = p.observed;
+            col = any ? 1 : 0;
+            if (any) {
+                cm = kMemorySteps;
+                hm = 1;
+                nmem = ncon;
+            } else if (cm_old > 0) {
+                cm = cm_old - 1;
+                col = 1;
+            } else {
+                hm = 0;
+            }
+        }
+    }
+    if (any) {
+        ctx.phase([&](int lane) {
+            if (lane < kMaxOthers) {
+                const int j = lane, cj = con.at(lane);
+                st.memorized[j] = cj;
+                st.memorized_pt[j][0] = cj >= 0 ? cpt[j].x : 0.0;
+                st.memorized_pt[j][1] = cj >= 0 ? cpt[j].y : 0.0;
+                mem.at(lane) = cj;
+            }
+        });
+    }
+    // a5: which node the ego stops at (the smallest conflict index of the list that counts - the memorised one while the
+    // memory runs), finish_env's stop / pts
+    const int e = e0;
+    int stop = -1, pts = 0;
+    int32_t stop1 = st.stop_index1, lvs = lvs_old;
+    bool stop_dirty = false;
+    if (!ref_speed && col) {
+        const bool use_mem = cm > 0 && hm;
+        const int nc = use_mem ? nmem : ncon;
+        PerLane<double> cv;
+        ctx.phase([&](int lane) {
+            const int cj = use_mem ? mem.at(lane) : con.at(lane);
+            cv.at(lane) = (lane < nc && lane < kMaxOthers && cj >= 0) ? (double)cj : 1e9;
+        });
+        const double mnd = ctx.wave_min(cv);
+        if (mnd < 1e8) {
+            const int mn = (int)mnd;
+            stop = mn - kSafetyBuffer;
+            stop = stop < e + 1 ? e + 1 : stop;
+            stop = stop > M - 1 ? M - 1 : stop;
+            pts = stop - e;
+            if (pts > 0) {
+                stop1 = stop + 1;
+                lvs = stop + 1;
+                stop_dirty = true;
+            } else if (lvs_old > 0) {
+                stop1 = lvs_old;
+                stop_dirty = true;
+            }
+        }
+    }
+    const float ev = p.ev;
+    const float fstep = pts > 1 ? (-ev) / (float)(pts - 1) : 0.0f;
+    const double vover = ref_speed ? (*ref_speed < 0.0 ? 0.0 : (*ref_speed > kMaxSpeed ? kMaxSpeed : *ref_speed)) : 0.0;
+    ctx.phase([&](int lane) {
+        // ---- speed profile, lane k = node k (np.linspace(ego_speed, 0, pts) in float32, finish_env)
+        for (int k = lane; k <= N; k += wave::kLanes) {
+            double v;
+            if (ref_speed) {
+                v = vover;
+            } else {
+                int idx = e + k;
+                idx = idx > M - 1 ? M - 1 : idx;
+                v = R.v(idx);
+                if (pts > 0) {
+                    if (idx >= stop) {
+                        v = 0.0;
+                    } else {
+                        const int i = idx - e;
+                        float y;
+                        if (pts == 1) y = ev;                               // div = 0: y = 0 * delta + start
+                        else if (i == pts - 1) y = 0.0f;                    // endpoint is set exactly
+                        else if (fstep == 0.0f) y = f32add(f32mul((float)i / (float)(pts - 1), -ev), ev);
+                        else y = f32add(f32mul((float)i, fstep), ev);
+                        v = (double)y;
+                    }
+                }
+            }
+            vref[k] = v;
+        }
+        // ---- the other vehicles' problem data (write_vehicles), lane j = vehicle j; absent slots zero
+        if (lane < vslots) {
+            const int j = lane;
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+            if (j < p.observed) {
+                const float *o = obs + (j + 1) * kObsCols;
+                o0 = (double)o[1];
+                o1 = (double)o[2];
+                o2 = (double)speed_f32(o[3], o[4]);
+                o3 = (double)o[5];             // not wrapped (agents/base_agent.py:112)
+            }
+            others[j * 4 + 0] = o0;
+            others[j * 4 + 1] = o1;
+            others[j * 4 + 2] = o2;
+            others[j * 4 + 3] = o3;
+        }
+        if (lane == 0) {
+            state[0] = (double)p.ex;
+            state[1] = (double)p.ey;
+            state[2] = (double)p.eh;
+            state[3] = (double)p.ev;
+            nveh_out = p.observed;
+            if (adv) {
+                st.collision_memory = cm;
+                st.has_memorized = hm;
+                st.n_memorized = nmem;
+                st.n_conflict = ncon;
+                st.is_collide = col;
+            }
+            st.ego_index = e;
+            ego_index_out = e;
+            collide_out = col ? 1 : 0;
+            if (stop_dirty) {
+                st.stop_index1 = stop1;
+                st.last_valid_stop1 = lvs;
+            }
+        }
     });
 }
 

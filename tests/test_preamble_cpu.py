@@ -286,3 +286,47 @@ def test_collinear_overlaps_stream_merge_equals_the_sorted_list(pre, ref_table):
             assert np.array_equal(out[q], want[q]), (trial, q, out[q], want[q])
         n_overlap += n
     assert n_overlap >= 300
+
+
+@pytest.mark.parametrize("M,rows", [(85, 10), (140, 17), (200, 17), (66, 5)])
+def test_wave_form_equals_the_one_thread_form_on_long_tables_and_fast_egos(pre, M, rows):
+    """Round 6 moved the wave form's serial parts into registers (arc-length sums of up to 128 segments in two registers per
+    lane + one scalar, the travelled distance of step k in lane k, the observation read as one word per lane with the presence
+    count as a ballot, the detector record's update spread over lanes): the cases that reach those corners - tables longer
+    than one and than two words per lane, egos fast enough for the look-ahead to run past 64 and past 128 segments, the
+    maximum number of observation rows (136 words), records in every phase of the collision memory - against the one-thread
+    statement `preamble_env`, every output and the whole record bit for bit."""
+    rng = np.random.default_rng(M * 31 + rows)
+    # a straight-arc-straight route like the reference's, M points, ~0.7 m apart (so that 30 m/s x 3 s passes 128 segments)
+    s_ = np.arange(M) * 0.7
+    th = np.clip((s_ - 0.4 * s_[-1]) / 15.0, 0.0, np.pi / 2)
+    x = 2.0 - np.concatenate([[0.0], np.cumsum(0.7 * np.sin(th[:-1]))])
+    y = 50.0 - np.concatenate([[0.0], np.cumsum(0.7 * np.cos(th[:-1]))])
+    ref = np.stack([x, y, np.full(M, 10.0) + 20.0 * (np.arange(M) % 7 == 0), -np.pi / 2 - th], axis=1)
+    B = 96
+    one, wav = DevicePreamble(pre, ref, N=20, wave=False), DevicePreamble(pre, ref, N=20, wave=True)
+    for t in range(14):
+        obs = np.zeros((B, rows, 8), np.float32)
+        i = rng.integers(0, M, B)
+        obs[:, 0, 0] = 1.0
+        obs[:, 0, 1] = x[i] + rng.uniform(-0.4, 0.4, B)
+        obs[:, 0, 2] = y[i] + rng.uniform(-0.4, 0.4, B)
+        sp = np.where(rng.uniform(size=B) < 0.5, rng.uniform(20.0, 31.0, B), rng.uniform(0.0, 12.0, B))
+        hd = ref[i, 3] + rng.uniform(-0.1, 0.1, B)
+        obs[:, 0, 3], obs[:, 0, 4], obs[:, 0, 5] = sp * np.cos(hd), sp * np.sin(hd), hd
+        nv = rng.integers(0, rows, B)                               # present rows are contiguous after the ego's
+        for b in range(B):
+            for j in range(1, nv[b] + 1):
+                k = rng.integers(0, M)
+                side = rng.uniform(-25.0, 25.0)
+                a = ref[k, 3] + np.pi / 2 if rng.uniform() < 0.7 else ref[k, 3]        # crossing traffic, or same lane
+                obs[b, j, 0] = 1.0
+                obs[b, j, 1] = x[k] + side * np.cos(a)
+                obs[b, j, 2] = y[k] + side * np.sin(a)
+                v = rng.uniform(0.0, 12.0)
+                obs[b, j, 3], obs[b, j, 4], obs[b, j, 5] = -v * np.cos(a) * np.sign(side), -v * np.sin(a) * np.sign(side), a + (np.pi if side > 0 else 0.0)
+        rs = rng.uniform(-1.0, 35.0, B) if t % 5 == 4 else None
+        a_, b_ = one(obs, rs), wav(obs, rs)
+        for k in ("state", "ego_index", "vref", "is_collide", "others", "nveh"):
+            assert np.array_equal(a_[k], b_[k]), (t, k)
+        assert np.array_equal(one.env[:B], wav.env[:B]), t          # the whole detector record, word for word

@@ -28,5 +28,5 @@ for r in (0, 1):
     print(("REPLAY" if r else "FULL DETECTION"), "n", len(rows), "of which complete", len(m), "cycles mean per section:")
     nm = names_replay if r else names_full
     for i in range(L):
-        print(f"   {nm[i] if i < len(nm) else i:14s} mean {m[:, i].mean():9.0f}  p90 {np.percentile(m[:, i], 90):9.0f}  max {m[:, i].max():9.0f}")
+        print(f"   {(nm[i] if i < len(nm) else str(i)):14s} mean {m[:, i].mean():9.0f}  p90 {np.percentile(m[:, i], 90):9.0f}  max {m[:, i].max():9.0f}")
     print("   total mean", m.sum(axis=1).mean(), "max", m.sum(axis=1).max(), " (2.4 GHz: us)", m.sum(axis=1).mean() / 2400)
