@@ -274,16 +274,15 @@ struct CandPtr {            // where the candidates go (indexed dynamically: LDS
     MPC_HD void put(int q, P2 v) const { p[q] = v; }
     MPC_HD P2 get(int q) const { return p[q]; }
 };
-struct NoNodes {            // far ends of a collinear stretch on the ego segments it covers: recomputed on demand ...
+struct NoNodes {            // the one-thread form finds extent and middle node of a collinear stretch itself (OverlapWalk) ...
     static constexpr bool kCached = false;
-    MPC_HD void put(int, P2) const {}
-    MPC_HD P2 get(int) const { return P2{0.0, 0.0}; }
+    MPC_HD P2 far(int) const { return P2{0.0, 0.0}; }
+    MPC_HD P2 mid(int) const { return P2{0.0, 0.0}; }
 };
 
-template <class EGO, class AG, class NODES>
+template <class EGO, class AG>
 struct OverlapWalk {
     const EGO *ego;
-    const NODES *nodes;   // ... or kept by the extent scan (the wave kernel: 2 x 30 words of LDS per vehicle)
     int i, jend;          // ego segments i .. jend - 1 overlap the agent's line
     P2 a, b;
     const AG *ag;
@@ -292,7 +291,6 @@ struct OverlapWalk {
     P2 e_i;               // ego->at(i)
     // ego-derived node q: 0, 1 = the ends of the overlap on segment i; q >= 2 = the far end on segment i + q - 1
     MPC_HD P2 ego_node(int q) const {
-        if (NODES::kCached) return nodes->get(q);
         Hit h[2];
         if (q < 2) {
             seg_intersections(ego->at(i), ego->at(i + 1), a, b, h);
@@ -356,15 +354,22 @@ struct OverlapWalk {
 };
 
 // `hits`: bit i set = ego segment i meets the agent's line at all (the wave kernel tests all (vehicle, segment) pairs in
-// parallel first and the serial part below then visits only those); ~0 = test every segment here.
+// parallel first and the serial part below then visits only those); ~0 = test every segment here.  `twos` (read only with
+// NODES::kCached, the wave kernel): bit i set = segment i OVERLAPS the line (two hits), nodes.far(i) holds the overlap's far end
+// and nodes.mid(r) the middle node of the r-th collinear stretch (= r-th run of ones in `twos`), found by the whole wave before
+// this is called (mpc_preamble_wave.hpp overlap_middle_wave).  Until round 6 the lane found extent and middle itself - up to 30
+// intersection tests and two merges of up to 63 nodes, serial in one lane: ~50 k cycles per same-lane vehicle, the whole
+// difference between a 13 us and a 90 us preamble.
 template <class EGO, class AG, class CAND, class NODES>
-MPC_HD int path_crossings_t(const EGO &ego, int ne, const AG &ag, const CAND &out, int maxc, unsigned hits, const NODES &nodes) {
+MPC_HD int path_crossings_t(const EGO &ego, int ne, const AG &ag, const CAND &out, int maxc, unsigned hits, unsigned twos,
+                            const NODES &nodes) {
     const int na = ag.n;
     if (ne < 2 || na < 2) return 0;
     const P2 a = ag.at(0), b = ag.at(na - 1);
     int nc = 0;
     bool last_is_point = false;      // what out[nc - 1] came from
     P2 line_end{0.0, 0.0};           // far end of the last collinear stretch
+    int nrun = 0;                    // collinear stretches met so far
     for (int i = 0; i < ne - 1 && nc < maxc; ++i) {
         if (!((hits >> i) & 1u)) continue;
         Hit h[2];
@@ -376,7 +381,7 @@ MPC_HD int path_crossings_t(const EGO &ego, int ne, const AG &ag, const CAND &ou
             // the intersection is a point SET: where the ego joins or leaves the other path's line at a vertex, the segment
             // before / behind the collinear stretch touches the line in the stretch's end point, which is part of that piece
             if (!dup && nc > 0 && !last_is_point && close2(line_end, h[0].p)) dup = true;
-            if (!dup && i + 2 < ne) {
+            if (!dup && i + 2 < ne && (!NODES::kCached || ((twos >> (i + 1)) & 1u))) {
                 Hit h2[2];
                 dup = seg_intersections(ego.at(i + 1), ego.at(i + 2), a, b, h2) == 2 && close2(h2[0].p, h[0].p);
             }
@@ -387,40 +392,44 @@ MPC_HD int path_crossings_t(const EGO &ego, int ne, const AG &ag, const CAND &ou
             continue;
         }
         // collinear overlap starting on ego segment i: it goes on over the following segments that overlap too
-        OverlapWalk<EGO, AG, NODES> w;
-        w.ego = &ego;
-        w.nodes = &nodes;
-        w.i = i;
-        w.a = a;
-        w.b = b;
-        w.ag = &ag;
-        w.e_i = ego.at(i);
-        nodes.put(0, h[0].p);
-        nodes.put(1, h[1].p);
         int j = i + 1;
         P2 pl = h[1].p;
-        for (; j < ne - 1; ++j) {
-            Hit h2[2];
-            if (seg_intersections(ego.at(j), ego.at(j + 1), a, b, h2) != 2) break;
-            pl = h2[1].p;
-            nodes.put(j - i + 1, pl);
+        P2 mid{0.0, 0.0};
+        if constexpr (NODES::kCached) {
+            const unsigned rest = ~(twos >> j);                  // bit 0 = segment j; the mask has no bits at or above ne - 1
+            j += __builtin_ctz(rest | 0x80000000u);
+            if (j > i + 1) pl = nodes.far(j - 1);
+            mid = nodes.mid(nrun++);
+        } else {
+            for (; j < ne - 1; ++j) {
+                Hit h2[2];
+                if (seg_intersections(ego.at(j), ego.at(j + 1), a, b, h2) != 2) break;
+                pl = h2[1].p;
+            }
+            OverlapWalk<EGO, AG> w;
+            w.ego = &ego;
+            w.i = i;
+            w.a = a;
+            w.b = b;
+            w.ag = &ag;
+            w.e_i = ego.at(i);
+            w.jend = j;
+            w.sx = b.x - a.x;
+            w.sy = b.y - a.y;
+            w.ss = f64add(f64mul(w.sx, w.sx), f64mul(w.sy, w.sy));
+            const P2 pf = h[0].p;
+            const double k0 = f64add(f64mul(pf.x - a.x, w.sx), f64mul(pf.y - a.y, w.sy));
+            const double k1 = f64add(f64mul(pl.x - a.x, w.sx), f64mul(pl.y - a.y, w.sy));
+            w.klo = fmin(k0, k1) - 1e-12;
+            w.khi = fmax(k0, k1) + 1e-12;
+            const P2 e1 = ego.at(i + 1);
+            w.dx = e1.x - w.e_i.x;
+            w.dy = e1.y - w.e_i.y;
+            w.asc = f64add(f64mul(w.sx, w.dx), f64mul(w.sy, w.dy)) >= 0.0;
+            P2 dummy{0.0, 0.0};
+            const int nu = w.walk(-1, dummy);
+            w.walk(nu / 2, mid);
         }
-        w.jend = j;
-        w.sx = b.x - a.x;
-        w.sy = b.y - a.y;
-        w.ss = f64add(f64mul(w.sx, w.sx), f64mul(w.sy, w.sy));
-        const P2 pf = h[0].p;
-        const double k0 = f64add(f64mul(pf.x - a.x, w.sx), f64mul(pf.y - a.y, w.sy));
-        const double k1 = f64add(f64mul(pl.x - a.x, w.sx), f64mul(pl.y - a.y, w.sy));
-        w.klo = fmin(k0, k1) - 1e-12;
-        w.khi = fmax(k0, k1) + 1e-12;
-        const P2 e1 = ego.at(i + 1);
-        w.dx = e1.x - w.e_i.x;
-        w.dy = e1.y - w.e_i.y;
-        w.asc = f64add(f64mul(w.sx, w.dx), f64mul(w.sy, w.dy)) >= 0.0;
-        P2 mid{0.0, 0.0}, dummy{0.0, 0.0};
-        const int nu = w.walk(-1, dummy);
-        w.walk(nu / 2, mid);
         out.put(nc++, mid);
         last_is_point = false;
         line_end = pl;
@@ -429,7 +438,7 @@ MPC_HD int path_crossings_t(const EGO &ego, int ne, const AG &ag, const CAND &ou
     return nc;
 }
 MPC_HD int path_crossings(const P2 *ego, int ne, const AgentPath &ag, P2 *out, int maxc) {
-    return path_crossings_t(EgoPtr{ego}, ne, ag, CandPtr{out}, maxc, ~0u, NoNodes{});
+    return path_crossings_t(EgoPtr{ego}, ne, ag, CandPtr{out}, maxc, ~0u, 0u, NoNodes{});
 }
 // the first candidate (the only one in all but double-crossing scenes)
 MPC_HD bool first_crossing(const P2 *ego, int ne, const AgentPath &ag, P2 &out) {

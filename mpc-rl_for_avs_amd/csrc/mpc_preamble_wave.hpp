@@ -37,12 +37,15 @@ enum : int {
     PL_CD = PL_EGO + 2 * (kPredHorizon + 1),      // 31            travelled distance after step k (k = 1 .. 30)
     PL_SEG = PL_CD + kPredHorizon + 1,            // kWin          lengths of the route segments behind the start point
     PL_CUM = PL_SEG + kWin,                       // kWin + 1      their running sums (np.cumsum)
+    PL_SORT = PL_SEG,                             // (once the ego points exist) 63 x (x, y): the nodes of one collinear stretch, sorted
+    PL_MID = PL_CUM,                              // (the same)    16 x 4 x (x, y): middle node of each vehicle's r-th collinear stretch
     PL_AG = PL_CUM + kWin + 1,                    // 16 x 31 x (x, y)   vehicle paths (float32 values)
     PL_NODE = PL_AG + kMaxOthers * 2 * (kPredHorizon + 1),   // 16 x 31 x (x, y)   nodes of a collinear stretch (per vehicle)
     PL_CAND = PL_NODE + kMaxOthers * 2 * (kPredHorizon + 1), // 16 x 4 x (x, y)    crossing candidates
     PL_SIZE = PL_CAND + kMaxOthers * kMaxCross * 2
 };
 constexpr int preamble_wave_lds_doubles() { return PL_SIZE; }
+static_assert(2 * (2 * (kPredHorizon + 1) + 1) <= kWin && kMaxOthers * kMaxCross * 2 <= kWin + 1, "PL_SORT / PL_MID reuse PL_SEG / PL_CUM");
 
 template <class CTX>
 struct LdsPts {             // n points (x, y) at consecutive LDS words
@@ -52,7 +55,6 @@ struct LdsPts {             // n points (x, y) at consecutive LDS words
 };
 template <class CTX>
 struct LdsSink {
-    static constexpr bool kCached = true;
     CTX *c;
     int base;
     MPC_HD void put(int q, P2 v) const {
@@ -60,6 +62,16 @@ struct LdsSink {
         c->st(base + 2 * q + 1, v.y);
     }
     MPC_HD P2 get(int q) const { return P2{c->ld(base + 2 * q), c->ld(base + 2 * q + 1)}; }
+};
+
+// what the wave has ready about one vehicle's collinear stretches when lane j walks over its hit segments (path_crossings_t)
+template <class CTX>
+struct StretchStore {
+    static constexpr bool kCached = true;
+    const CTX *c;
+    int fars, mids;         // LDS words: far end of the overlap on ego segment i at fars + 2 i, middle node of stretch r at mids + 2 r
+    MPC_HD P2 far(int i) const { return P2{c->ld(fars + 2 * i), c->ld(fars + 2 * i + 1)}; }
+    MPC_HD P2 mid(int r) const { return P2{c->ld(mids + 2 * r), c->ld(mids + 2 * r + 1)}; }
 };
 
 // wave minimum of a per-lane value that is still needed afterwards (the host model of the reductions works in place)
@@ -70,6 +82,107 @@ MPC_HD double wmin(CTX &ctx, const wave::PerLane<double> &p) {
 }
 MPC_HD int popc64(unsigned long long v) { return __builtin_popcountll(v); }
 MPC_HD int ctz64(unsigned long long v) { return __builtin_ctzll(v); }
+
+// Middle node of the collinear stretch over ego segments i .. jend - 1 with the line of the vehicle whose path is at LDS word
+// `agbase` (far ends of the overlaps at `fars`), by the whole wave: agents/pure_mpc.py:619-622 takes `coords[len(coords) // 2]` of
+// the LineString shapely returns, whose coordinates are the overlap's ends on every ego segment and the vehicle's own vertices
+// inside it, in order along the line, duplicates dropped (tests/host_preamble.py sorts; OverlapWalk in mpc_preamble.hpp, the
+// one-thread form, merges the two families, which come sorted).  Here: lane q < 32 holds ego-derived node q (0 = the near end on
+// segment i, q >= 1 the far end on segment i + q - 1), lane 32 + m the vehicle's vertex m if it lies inside; every node finds
+// its rank in the (key, x, y) order by counting the nodes before it (n <= 63 steps of three lane reads), the nodes go to LDS by
+// rank, "close to the last node kept" (np.allclose: it depends on what was kept before) is decided from each node's distance to
+// its one and two predecessors when no two nodes in a row are dropped - else by the serial rule over the sorted array - and
+// the middle one of the kept is read back.  ~4 k cycles where one lane's two merges took ~50 k.
+template <class CTX>
+MPC_HD P2 overlap_middle_wave(CTX &ctx, const LdsPts<CTX> &ego, int agbase, int fars, int i, int jend) {
+    using wave::PerLane;
+    const LdsPts<CTX> ag{&ctx, agbase, kPredHorizon + 1};
+    const P2 a = ag.at(0), b = ag.at(kPredHorizon);
+    const P2 e_i = ego.at(i), e1 = ego.at(i + 1);
+    Hit h[2];
+    seg_intersections(e_i, e1, a, b, h);                         // two hits: segment i starts the stretch
+    const P2 pf = h[0].p;
+    const P2 pl = jend > i + 1 ? P2{ctx.ld(fars + 2 * (jend - 1)), ctx.ld(fars + 2 * (jend - 1) + 1)} : h[1].p;
+    const double sx = b.x - a.x, sy = b.y - a.y;
+    const double ss = f64add(f64mul(sx, sx), f64mul(sy, sy));
+    const double k0 = f64add(f64mul(pf.x - a.x, sx), f64mul(pf.y - a.y, sy));
+    const double k1 = f64add(f64mul(pl.x - a.x, sx), f64mul(pl.y - a.y, sy));
+    const double klo = fmin(k0, k1) - 1e-12, khi = fmax(k0, k1) + 1e-12;
+    const double dx = e1.x - e_i.x, dy = e1.y - e_i.y;
+    const int ne_nodes = jend - i + 1;
+    PerLane<double> kk, px, py;
+    PerLane<int> val, rank;
+    ctx.phase([&](int lane) {
+        P2 q{0.0, 0.0};
+        int ok = 0;
+        if (lane < 32) {
+            if (lane < ne_nodes) {
+                ok = 1;
+                q = pf;
+                if (lane >= 1) q = P2{ctx.ld(fars + 2 * (i + lane - 1)), ctx.ld(fars + 2 * (i + lane - 1) + 1)};
+            }
+        } else if (lane - 32 <= kPredHorizon) {
+            q = ag.at(lane - 32);
+            const double kv = f64add(f64mul(q.x - a.x, sx), f64mul(q.y - a.y, sy));
+            ok = (ss > 0 && klo <= kv && kv <= khi) ? 1 : 0;
+        }
+        kk.at(lane) = f64add(f64mul(q.x - e_i.x, dx), f64mul(q.y - e_i.y, dy));
+        px.at(lane) = q.x;
+        py.at(lane) = q.y;
+        val.at(lane) = ok;
+        rank.at(lane) = 0;
+    });
+    const unsigned long long vm = ctx.ballot(val);
+    const int n = popc64(vm);
+    for (unsigned long long t = vm; t; t &= t - 1) {
+        const int y = ctz64(t);
+        const double ky = ctx.lane_get(kk, y), xy = ctx.lane_get(px, y), yy = ctx.lane_get(py, y);
+        ctx.phase([&](int lane) {
+            const double kl = kk.at(lane), xl = px.at(lane), yl = py.at(lane);
+            const bool bef = ky < kl || (ky == kl && (xy < xl || (xy == xl && yy < yl)));      // OverlapWalk::before
+            const bool same = ky == kl && xy == xl && yy == yl;                                // equal nodes: by lane
+            rank.at(lane) += (bef || (same && y < lane)) ? 1 : 0;
+        });
+    }
+    ctx.phase([&](int lane) {
+        if (val.at(lane)) {
+            ctx.st(PL_SORT + 2 * rank.at(lane), px.at(lane));
+            ctx.st(PL_SORT + 2 * rank.at(lane) + 1, py.at(lane));
+        }
+    });
+    PerLane<int> c1, c2;
+    ctx.phase([&](int lane) {
+        int f1 = 0, f2 = 0;
+        if (lane >= 1 && lane < n) {
+            const P2 s0{ctx.ld(PL_SORT + 2 * lane), ctx.ld(PL_SORT + 2 * lane + 1)};
+            f1 = close2(P2{ctx.ld(PL_SORT + 2 * lane - 2), ctx.ld(PL_SORT + 2 * lane - 1)}, s0) ? 1 : 0;
+            if (lane >= 2) f2 = close2(P2{ctx.ld(PL_SORT + 2 * lane - 4), ctx.ld(PL_SORT + 2 * lane - 3)}, s0) ? 1 : 0;
+        }
+        c1.at(lane) = f1;
+        c2.at(lane) = f2;
+    });
+    const unsigned long long C = ctx.ballot(c1), D = ctx.ballot(c2);
+    unsigned long long keep;
+    if ((C & (C >> 1)) == 0 && (D & (C << 1)) == 0) {
+        // no two in a row close to their predecessor, and whoever follows a dropped node is not close to the node before that
+        // one: the last node kept is always the predecessor or the one before it, and "kept" = "not close to the predecessor"
+        keep = ((1ull << n) - 1) & ~C;
+    } else {
+        keep = 1ull;
+        P2 last{ctx.ld(PL_SORT), ctx.ld(PL_SORT + 1)};
+        for (int r = 1; r < n; ++r) {
+            const P2 q{ctx.ld(PL_SORT + 2 * r), ctx.ld(PL_SORT + 2 * r + 1)};
+            if (!close2(last, q)) {
+                keep |= 1ull << r;
+                last = q;
+            }
+        }
+    }
+    const int want = popc64(keep) / 2;
+    for (int q = 0; q < want; ++q) keep &= keep - 1;
+    const int r = ctz64(keep);
+    return P2{ctx.ld(PL_SORT + 2 * r), ctx.ld(PL_SORT + 2 * r + 1)};
+}
 
 // what the diagnostics export wants to see (mpc_get_last_paths); nullptr = off
 struct PreDiag {
@@ -334,23 +447,53 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
         });
         // which ego segments meet which vehicle's line at all: 2 vehicles x 32 segment slots per pass
         const LdsPts<CTX> ego{&ctx, PL_EGO, ne};
-        PerLane<int> hits, hit;
-        ctx.phase([&](int lane) { hits.at(lane) = 0; });
+        // (round 6) ... and which of them OVERLAP it (two hits), with the overlap's far end kept per (vehicle, segment): the
+        // serial logic below then finds the extent of a collinear stretch from the mask instead of testing segment after segment
+        PerLane<int> hits, twos, hit, two;
+        ctx.phase([&](int lane) {
+            hits.at(lane) = 0;
+            twos.at(lane) = 0;
+        });
         for (int r = 0; 2 * r < V; ++r) {
             ctx.phase([&](int lane) {
                 const int i = lane & 31, j = 2 * r + (lane >> 5);
-                int h1 = 0;
+                int nh = 0;
                 if (j < V && i < ne - 1) {
                     const LdsPts<CTX> ag{&ctx, PL_AG + j * 2 * (kPredHorizon + 1), kPredHorizon + 1};
                     Hit h[2];
-                    h1 = seg_intersections(ego.at(i), ego.at(i + 1), ag.at(0), ag.at(kPredHorizon), h) > 0 ? 1 : 0;
+                    nh = seg_intersections(ego.at(i), ego.at(i + 1), ag.at(0), ag.at(kPredHorizon), h);
+                    if (nh == 2) {
+                        ctx.st(PL_NODE + j * 2 * (kPredHorizon + 1) + 2 * i, h[1].p.x);
+                        ctx.st(PL_NODE + j * 2 * (kPredHorizon + 1) + 2 * i + 1, h[1].p.y);
+                    }
                 }
-                hit.at(lane) = h1;
+                hit.at(lane) = nh > 0 ? 1 : 0;
+                two.at(lane) = nh == 2 ? 1 : 0;
             });
-            const unsigned long long bm = ctx.ballot(hit);
+            const unsigned long long bm = ctx.ballot(hit), bt = ctx.ballot(two);
             ctx.phase([&](int lane) {
-                if ((lane >> 1) == r && lane < V) hits.at(lane) = (int)(unsigned)((lane & 1) ? (bm >> 32) : (bm & 0xffffffffull));
+                if ((lane >> 1) == r && lane < V) {
+                    hits.at(lane) = (int)(unsigned)((lane & 1) ? (bm >> 32) : (bm & 0xffffffffull));
+                    twos.at(lane) = (int)(unsigned)((lane & 1) ? (bt >> 32) : (bt & 0xffffffffull));
+                }
             });
+        }
+        // collinear stretches (same-lane traffic): the middle node of each, by the whole wave, vehicle after vehicle
+        for (unsigned long long ov = ctx.ballot(twos); ov; ov &= ov - 1) {
+            const int j = ctz64(ov);
+            unsigned tw = (unsigned)ctx.wave_bcast(twos, j);
+            for (int r = 0; tw != 0 && r < kMaxCross; ++r) {         // a stretch is a candidate: the lane stops after kMaxCross
+                const int i = __builtin_ctz(tw);
+                const int len = __builtin_ctz(~(tw >> i) | 0x80000000u);
+                const P2 m = overlap_middle_wave(ctx, ego, PL_AG + j * 2 * (kPredHorizon + 1), PL_NODE + j * 2 * (kPredHorizon + 1), i, i + len);
+                ctx.phase([&](int lane) {
+                    if (lane == 0) {
+                        ctx.st(PL_MID + (j * kMaxCross + r) * 2, m.x);
+                        ctx.st(PL_MID + (j * kMaxCross + r) * 2 + 1, m.y);
+                    }
+                });
+                tw &= ~(((1u << len) - 1u) << i);
+            }
         }
         // candidates (agents/pure_mpc.py:615-633), lane j = vehicle j, only the segments with a hit are visited
         PerLane<int> ncand;
@@ -359,8 +502,8 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
             if (lane < V && hits.at(lane) != 0) {
                 const LdsPts<CTX> ag{&ctx, PL_AG + lane * 2 * (kPredHorizon + 1), kPredHorizon + 1};
                 const LdsSink<CTX> cand{&ctx, PL_CAND + lane * 2 * kMaxCross};
-                const LdsSink<CTX> nodes{&ctx, PL_NODE + lane * 2 * (kPredHorizon + 1)};
-                nc = path_crossings_t(ego, ne, ag, cand, kMaxCross, (unsigned)hits.at(lane), nodes);
+                const StretchStore<CTX> nodes{&ctx, PL_NODE + lane * 2 * (kPredHorizon + 1), PL_MID + lane * kMaxCross * 2};
+                nc = path_crossings_t(ego, ne, ag, cand, kMaxCross, (unsigned)hits.at(lane), (unsigned)twos.at(lane), nodes);
             }
             ncand.at(lane) = nc;
         });
