@@ -559,8 +559,9 @@ def side_measurements(a, eng, args, inp, out, dev):
                          "calls_per_s": 1e3 / float(np.median(lat_ms))}
     # batches in flight: the straggler tail of one batch overlaps with the bulk of the next ones (same kernel, same inputs,
     # identical outputs) - what a serving loop with several independent environment groups would run
-    n_fl = 8       # = GPU_MAX_HW_QUEUES above: streams that share a hardware queue serialise (tools/gpu_inflight.py, round 5)
-    streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
+    n_fl = 8       # = GPU_MAX_HW_QUEUES above: streams that share a hardware queue serialise (tools/gpu_inflight.py, round 5),
+    # and which of torch's pool streams share one is the runtime's choice: each is probed (round 6, mpc_streams_overlap)
+    streams = engine.concurrent_streams(n_fl, dev)
     outs = []
     for sq in streams:
         with torch.cuda.stream(sq):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 7
+#define MPC_ABI_VERSION 8
 #define MPC_MAX_HORIZON 64
 #define MPC_MAX_OTHERS 16
 
@@ -347,6 +347,15 @@ int mpc_eval_nlp(mpc_handle *h, int32_t B, const int32_t *ego_index, const doubl
  * accepted for compatibility and ignored).  The engine keeps no per-instance solver state in HBM.  (diagnostics / capacity
  * planning) */
 int64_t mpc_workspace_bytes(const mpc_handle *h, int32_t B, int32_t V);
+
+/* Do kernels on two streams of `device` run side by side?  *overlap <- 1 if a ~0.3 ms one-wave timer kernel enqueued on each
+ * finishes in the time of one, 0 if they take the time of two: the HIP runtime multiplexes its streams onto a few hardware
+ * queues (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one SERIALISE, whatever the kernels - which of a
+ * process's streams share is decided when they are created (measured round 6: of torch's pool streams 0-7 two shared a
+ * queue, 8-15 none; batches in flight on them gave 2.6 against 3.45 M solves/s).  A caller that keeps several independent
+ * batches in flight (MPC_FLAG_THROUGHPUT; the reference's vectorised environments in groups, agents/a2c_mpc.py:111-180) picks
+ * its streams with this probe (engine.concurrent_streams).  Synchronises both streams; not capturable. */
+int mpc_streams_overlap(int32_t device, void *stream_a, void *stream_b, int32_t *overlap);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -177,6 +178,13 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_solve_wave_kernel(
         if (status_out) status_out[b] = status;
         if (iters_out) iters_out[b] = iters;
     }
+}
+
+// one wave that ends `ticks` of the constant 100 MHz clock after it started (mpc_streams_overlap): the clock advances whatever
+// the wave does, so the loop ends
+__global__ __launch_bounds__(64) void mpc_timer_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 // Launch order of a batch.  The hardware starts workgroups in index order, a SIMD's issue arbiter favours its oldest wave,
@@ -752,8 +760,8 @@ int launch_wave(const mpc_handle *h, const mpc::SolveParams &P, int B, int V, hi
     return MPC_OK;
 }
 
-// the buffer of the launch order is allocated ONCE, at mpc_create, for the largest batch that is ever ordered (8 waves per SIMD:
-// 64 KB on an MI355X) and never moves: a captured hipGraph keeps its address in two kernels (ADVICE r4 - until round 4 it was
+// the buffer of the launch order is allocated ONCE, at mpc_create, for the largest batch that is ever ordered (64 waves per SIMD:
+// 512 KB on an MI355X) and never moves: a captured hipGraph keeps its address in two kernels (ADVICE r4 - until round 4 it was
 // grown on demand, and a later, larger call on the same handle would have left such a graph replaying against freed memory)
 int ensure_order(mpc_handle *, int, hipStream_t) { return MPC_OK; }
 
@@ -806,10 +814,13 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     // which build: by how deep the batch fills the SIMDs (see kWaveOccLat above)
     const int simds = 4 * h->num_cu;
     // launch order (mpc_order_kernel): pays as soon as waves share a SIMD.  Not with MPC_FLAG_THROUGHPUT: batches in flight on
-    // several streams may share this handle, and the order buffer is the handle's
+    // several streams may share this handle, and the order buffer is the handle's.  Until round 5 only up to 8 waves per SIMD
+    // ("beyond that the order changed nothing" - measured with round 4's kernel); a bulk launch ends with whatever started
+    // last running alone, up to 100 iterations x 28 us = 13 % of a launch of 65 536, and the tiers start 85 - 90 % of the
+    // instances with >= 60 iterations in the first 40 % of the launch: 21.2 / 21.3 / 21.4 / 22.2 -> 20.3 / 19.8 / 20.6 / 22.6 ms
+    // on four draws (profiles/r06_bulk_order.txt; tools/sim_schedule.py's occupancy model predicts each to 0.2 ms)
     const int32_t *d_order = nullptr;
-    // ... and while the batch is not so deep that only throughput counts (beyond 8 waves per SIMD the order changed nothing)
-    if (!throughput && B > simds && B <= 8 * simds && h->d_order && h->order_cap >= B) {
+    if (!throughput && B > simds && h->d_order && h->order_cap >= B) {
         hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, cc ? d_others : nullptr,
                            (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap);
         HIP_TRY(hipGetLastError());
@@ -894,7 +905,7 @@ int mpc_create(const mpc_config *cfg, mpc_handle **out) {
         }
     }
     {
-        const int cap = 8 * 4 * h->num_cu;        // dispatch_solve orders batches of up to 8 waves per SIMD
+        const int cap = 64 * 4 * h->num_cu;       // dispatch_solve orders batches of up to 64 waves per SIMD (65 536 instances: 512 KB)
         if (hipMalloc(reinterpret_cast<void **>(&h->d_order), (size_t)cap * 2 * sizeof(int32_t)) == hipSuccess) h->order_cap = cap;
         else h->d_order = nullptr;                 // (unordered launches are correct, only slower)
     }
@@ -1483,6 +1494,35 @@ int mpc_set_env_state(mpc_handle *h, int32_t B, const void *records) {
     // a restored environment is not the episode whose controls the handle remembers: no warm start, no stored LTV profile
     HIP_TRY(hipMemset(h->d_warm_valid, 0, (size_t)B));
     HIP_TRY(hipMemset(h->d_ltv_u, 0, (size_t)B * h->cfg.horizon * 2 * sizeof(double)));
+    return MPC_OK;
+}
+
+int mpc_streams_overlap(int32_t device, void *stream_a, void *stream_b, int32_t *overlap) {
+    if (!overlap) return fail(MPC_ERR_INVALID_ARG, "mpc_streams_overlap: null output pointer");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t sa = static_cast<hipStream_t>(stream_a), sb = static_cast<hipStream_t>(stream_b);
+    if (sa == sb) {
+        *overlap = 0;
+        return MPC_OK;
+    }
+    const long long ticks = 30000;       // of the 100 MHz constant clock: 0.3 ms, long against a launch, short against anything else
+    auto timed = [&](bool both, double &ms) -> int {
+        HIP_TRY(hipStreamSynchronize(sa));
+        HIP_TRY(hipStreamSynchronize(sb));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(mpc_timer_kernel, dim3(1), dim3(64), 0, sa, ticks);
+        if (both) hipLaunchKernelGGL(mpc_timer_kernel, dim3(1), dim3(64), 0, sb, ticks);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(sa));
+        HIP_TRY(hipStreamSynchronize(sb));
+        ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return MPC_OK;
+    };
+    double one = 0.0, two = 0.0, warm = 0.0;
+    if (int rc = timed(true, warm)) return rc;       // first launch of the kernel on these streams: code load, queue wake-up
+    if (int rc = timed(false, one)) return rc;
+    if (int rc = timed(true, two)) return rc;
+    *overlap = two < 1.5 * one ? 1 : 0;
     return MPC_OK;
 }
 

@@ -54,8 +54,8 @@ _EXPORTS = ["mpc_version", "mpc_last_error", "mpc_default_config", "mpc_default_
             "mpc_set_reference", "mpc_solve_batch", "mpc_workspace_bytes", "mpc_predict_batch",
             "mpc_reset_env_state", "mpc_reset_env_mask", "mpc_get_env_state", "mpc_get_last_inputs",
             "mpc_ltv_solve_batch", "mpc_ltv_predict_batch", "mpc_env_state_bytes", "mpc_save_env_state",
-            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record", "mpc_rollout_finish", "mpc_eval_nlp"]
-ABI_VERSION = 7          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
+            "mpc_set_env_state", "mpc_reserve_envs", "mpc_synth_env_step", "mpc_set_diagnostics", "mpc_get_last_paths", "mpc_policy_act", "mpc_rollout_record", "mpc_rollout_finish", "mpc_eval_nlp", "mpc_streams_overlap"]
+ABI_VERSION = 8          # MPC_ABI_VERSION of include/mpc_mi355x.h this binding is written for
 MAX_OTHERS = 16
 _lib = None
 
@@ -144,8 +144,44 @@ def load_library(path: str | None = None):
     lib.mpc_rollout_finish.restype = ctypes.c_int
     lib.mpc_eval_nlp.argtypes = [vp, ctypes.c_int32] + [vp] * 5 + [ctypes.c_int32, ctypes.c_uint32] + [vp] * 4
     lib.mpc_eval_nlp.restype = ctypes.c_int
+    lib.mpc_streams_overlap.argtypes = [ctypes.c_int32, vp, vp, vp]
+    lib.mpc_streams_overlap.restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+def streams_overlap(a, b, device: int = 0) -> bool:
+    """True if kernels enqueued on the torch streams `a` and `b` run side by side (mpc_streams_overlap: two streams that the HIP
+    runtime put on one hardware queue serialise)."""
+    lib = load_library()
+    out = ctypes.c_int32(-1)
+    rc = lib.mpc_streams_overlap(int(device), ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream), ctypes.byref(out))
+    if rc != 0:
+        raise EngineError(f"mpc_streams_overlap failed ({rc}): {lib.mpc_last_error().decode()}")
+    return out.value == 1
+
+
+def concurrent_streams(n: int, device=0, candidates: int = 32):
+    """`n` torch streams on which independent batches really are in flight together: torch hands out the streams of its pool
+    round robin, the runtime spreads them over GPU_MAX_HW_QUEUES hardware queues as it sees fit, and two that share a queue
+    serialise (2.6 against 3.45 M solves/s with 8 batches of 4096 in flight, tools/gpu_queues.py) - so every candidate is
+    probed against the streams already chosen and kept only if it overlaps with each.  Raises if fewer than `n` of the
+    `candidates` qualify (set GPU_MAX_HW_QUEUES >= n before the process touches the GPU)."""
+    import torch
+    dev = torch.device("cuda", device) if isinstance(device, int) else device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    chosen, seen = [], set()
+    for _ in range(candidates):
+        s = torch.cuda.Stream(dev)
+        if s.cuda_stream in seen:
+            continue
+        seen.add(s.cuda_stream)
+        if all(streams_overlap(s, c, idx) for c in chosen):
+            chosen.append(s)
+            if len(chosen) == n:
+                return chosen
+    raise EngineError(f"only {len(chosen)} of {len(seen)} streams run concurrently on device {idx}; "
+                      f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', '(unset: 4)')}")
 
 
 def _ptr(a):

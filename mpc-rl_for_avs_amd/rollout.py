@@ -739,7 +739,14 @@ class PipelinedCollector:
         if len({id(c.engine) for c in self.collectors}) != len(self.collectors):
             raise ValueError("every collector needs its own engine handle (calls on one handle must not overlap)")
         self.policy, self.algorithm, self.env = c0.policy, c0.algorithm, c0.env
-        self.streams = [torch.cuda.Stream(c.env.device) for c in self.collectors]
+        # streams that really overlap (two that share a hardware queue serialise; engine.concurrent_streams probes each): with
+        # more groups than the runtime has queues the rest are taken as they come
+        from . import engine as _engine
+        dev = c0.env.device
+        try:
+            self.streams = _engine.concurrent_streams(len(self.collectors), dev)
+        except _engine.EngineError:
+            self.streams = [torch.cuda.Stream(dev) for _ in self.collectors]
 
     @property
     def num_timesteps(self):

@@ -564,10 +564,11 @@ def test_heading_on_the_bound_and_config1_closed_loop(eng, oracle, ref_table):
     assert outcome == "arrived" and (status != 3).all() and converged(status).mean() >= 0.95
 
 
-@pytest.mark.parametrize("B", [1025, 2047, 4096, 4097, 6000, 8192])
+@pytest.mark.parametrize("B", [1025, 2047, 4096, 4097, 6000, 8192, 8193, 20001])
 def test_launch_order_is_a_permutation(oracle, ref_table, B):
     """mpc_order_kernel (mpc_engine.hip) hands the workgroups their instances through a stable three-tier partition whenever a
-    batch puts between one and eight waves on a SIMD.  Property: EVERY instance is solved exactly once, whatever the batch size
+    batch puts more than one wave on a SIMD (up to 64 per SIMD; since round 6 also the bulk launches of the throughput build,
+    B > 8192).  Property: EVERY instance is solved exactly once, whatever the batch size
     does to the chunked prefix sums (B not a multiple of 1024), with non-finite states (NaN / inf compare false in every tier
     test) among the inputs: status and iteration arrays are prefilled with a sentinel and none may survive; the instances'
     results equal those of the same instances solved in a batch too small to be reordered."""

@@ -24,7 +24,7 @@ for seed in (0, 1):
         one = (time.perf_counter() - t0) / 5 * 1e3
         line = f"seed {seed} cap {cap}: one batch at a time (throughput build) {one:.2f} ms |"
         for n in (2, 3, 4, 6, 8, 12):
-            streams = [torch.cuda.Stream(dev) for _ in range(n)]
+            streams = engine.concurrent_streams(n, dev) if n <= 8 else [torch.cuda.Stream(dev) for _ in range(n)]
             outs = []
             for sq in streams:
                 with torch.cuda.stream(sq):

@@ -40,9 +40,10 @@ inp2 = synth.solver_inputs(1024, 4, seed=0)
 ms, st, it = run(inp2, np.arange(1024), 0)
 line.append(f"config2 {ms:.3f} ms (max {it.max()})")
 if os.environ.get("XB_BULK"):
-    inpb = synth.solver_inputs(65536, 8, seed=0)
-    ms, st, it = run(inpb, np.arange(65536), 1, reps=3)
-    line.append(f"bulk65536 {ms:.2f} ms = {65536/ms/1e3:.3f} M/s")
+    for sd in [int(q) for q in os.environ.get("XB_BULK_SEEDS", "0").split(",")]:
+        inpb = synth.solver_inputs(65536, 8, seed=sd)
+        ms, st, it = run(inpb, np.arange(65536), 1, reps=3)
+        line.append(f"bulk65536 seed {sd} {ms:.2f} ms = {65536/ms/1e3:.3f} M/s")
 print(" | ".join(line), flush=True)
 ''' % ROOT
 
