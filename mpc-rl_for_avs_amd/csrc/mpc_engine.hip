@@ -195,17 +195,28 @@ __global__ __launch_bounds__(64) void mpc_timer_kernel(long long ticks) {
 // 45 - 50 without; of the instances with >= 50 iterations 90 - 100 % have is_collide = 0) unless the ego stands still (speed on
 // its bound 0: every exception found); and with the collision cost on, an instance without a vehicle within 15 m of the ego is
 // the easy live objective in all but name (no instance with >= 70 iterations had its nearest vehicle farther away, unless it
-// stood still).  Three tiers, each in its original order (a stable partition): 0 = standing ego, or no predicted collision
-// and (collision cost off or a vehicle within kNear); 1 = the other instances without a predicted collision; 2 = the rest.
+// stood still).  Tiers, each in its original order (a stable partition): 0 = standing ego, or no predicted collision
+// and (collision cost off or a vehicle within kNear); 1 = the other instances without a predicted collision; 2 = a predicted
+// collision while the route turns; 3 = the rest.  (Tier 3, round 6: with a predicted collision the instances that still need
+// >= 60 iterations - 3 to 6 of 65 536, one or two of them at the cap - sit where the reference heading changes between five rows
+// behind the ego and the end of the look-ahead, 15 of 16 over four draws; started last, one of them alone is 13 % of a bulk
+// launch.  The straight-route half of tier 2, 28 % of a batch with a maximum of 41 - 58 iterations, now ends the launch:
+// 65 536 instances 21.2 -> 19.6 ms in the occupancy model that reproduced the three-tier measurements to 0.2 ms.)
 // (Round 5 also built "what the same environment needed one step ago" as the first key for the closed loop; measured neutral to
 // negative - profiles/r05_launch_order_prev.txt, docs/NOT_ADOPTED.md - and removed in round 6 together with its per-environment
 // record and the environment variable that switched it on.)
-constexpr double kOrderStanding = 0.1, kOrderNear = 15.0;
+constexpr double kOrderStanding = 0.1, kOrderNear = 15.0, kOrderTurn = 0.05;
+constexpr int kOrderBehind = 5;
 __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const double *state, const double *others, int V,
-                                          const int32_t *nveh, int i) {
+                                          const int32_t *nveh, const int32_t *ego, const double *ref5, int M, int N, int i) {
     const double *x = state + (size_t)i * 4;
     if (x[3] < kOrderStanding) return 0;
-    if (is_collide[i] != 0) return 2;
+    if (is_collide[i] != 0) {
+        const int e0 = ego[i];
+        const int a = min(M - 1, max(0, e0 - kOrderBehind)), b = min(M - 1, max(0, e0 + N));
+        const double d = ref5[(size_t)b * mpc::REF_COLS + mpc::R_H] - ref5[(size_t)a * mpc::REF_COLS + mpc::R_H];
+        return fabs(remainder(d, 6.283185307179586)) > kOrderTurn ? 2 : 3;      // (NaN compares false: tier 3)
+    }
     if (!others || V <= 0) return 0;
     const int nv = nveh ? min(V, max(0, nveh[i])) : V;
     bool near = false;
@@ -218,37 +229,42 @@ __device__ __forceinline__ int order_tier(const uint8_t *is_collide, const doubl
 }
 __global__ __launch_bounds__(1024) void mpc_order_kernel(int B, const uint8_t *__restrict__ is_collide,
                                                          const double *__restrict__ state, const double *__restrict__ others,
-                                                         int V, const int32_t *__restrict__ nveh, int32_t *__restrict__ order,
-                                                         int32_t *__restrict__ tier) {
-    __shared__ int s_c0[1024], s_c1[1024];
+                                                         int V, const int32_t *__restrict__ nveh, const int32_t *__restrict__ ego,
+                                                         const double *__restrict__ ref5, int M, int N,
+                                                         int32_t *__restrict__ order, int32_t *__restrict__ tier) {
+    __shared__ int s_c0[1024], s_c1[1024], s_c2[1024];
     const int t = threadIdx.x, chunk = (B + 1023) / 1024, lo = min(B, t * chunk), hi = min(B, lo + chunk);
     // tiers first, every thread an interleaved share (neighbouring threads read neighbouring instances), kept in scratch
-    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, i);
+    for (int i = t; i < B; i += 1024) tier[i] = order_tier(is_collide, state, others, V, nveh, ego, ref5, M, N, i);
     __syncthreads();
-    int n0 = 0, n1 = 0;
+    int n0 = 0, n1 = 0, n2 = 0;
     for (int i = lo; i < hi; ++i) {
         const int k = tier[i];
         n0 += k == 0;
         n1 += k == 1;
+        n2 += k == 2;
     }
     s_c0[t] = n0;
     s_c1[t] = n1;
+    s_c2[t] = n2;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {          // inclusive scans of the tier counts
-        const int v0 = t >= d ? s_c0[t - d] : 0, v1 = t >= d ? s_c1[t - d] : 0;
+        const int v0 = t >= d ? s_c0[t - d] : 0, v1 = t >= d ? s_c1[t - d] : 0, v2 = t >= d ? s_c2[t - d] : 0;
         __syncthreads();
         s_c0[t] += v0;
         s_c1[t] += v1;
+        s_c2[t] += v2;
         __syncthreads();
     }
-    const int tot0 = s_c0[1023], tot1 = s_c1[1023];
-    const int b0 = s_c0[t] - n0, b1 = s_c1[t] - n1;     // members of tier 0 / 1 before this chunk
-    int p0 = b0, p1 = tot0 + b1, p2 = tot0 + tot1 + (lo - b0 - b1);
+    const int tot0 = s_c0[1023], tot1 = s_c1[1023], tot2 = s_c2[1023];
+    const int b0 = s_c0[t] - n0, b1 = s_c1[t] - n1, b2 = s_c2[t] - n2;     // members of tier 0 / 1 / 2 before this chunk
+    int p0 = b0, p1 = tot0 + b1, p2 = tot0 + tot1 + b2, p3 = tot0 + tot1 + tot2 + (lo - b0 - b1 - b2);
     for (int i = lo; i < hi; ++i) {
         const int k = tier[i];
         if (k == 0) order[p0++] = i;
         else if (k == 1) order[p1++] = i;
-        else order[p2++] = i;
+        else if (k == 2) order[p2++] = i;
+        else order[p3++] = i;
     }
 }
 
@@ -822,7 +838,7 @@ int dispatch_solve(const mpc_handle *h, int B, bool cc, int V, uint32_t flags, h
     const int32_t *d_order = nullptr;
     if (!throughput && B > simds && h->d_order && h->order_cap >= B) {
         hipLaunchKernelGGL(mpc_order_kernel, dim3(1), dim3(1024), 0, stream, (int)B, d_coll, d_state, cc ? d_others : nullptr,
-                           (int)Vuse, d_nveh, h->d_order, h->d_order + h->order_cap);
+                           (int)Vuse, d_nveh, d_ego, h->d_ref, h->M, N, h->d_order, h->d_order + h->order_cap);
         HIP_TRY(hipGetLastError());
         d_order = h->d_order;
     }

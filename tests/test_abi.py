@@ -56,6 +56,7 @@ def test_default_config_and_argument_checks():
     assert lib.mpc_rollout_finish(0, 8, 4, 1, 85, 0, None, p, p, None, 0.99, 0.95, p, p, None) == -1   # null row
     assert lib.mpc_policy_act(0, 4, 0, 128, *([p] * 10), 0, 0, None, 0, 1, p, p, p, None, p, None) == -1   # action_dim 0
     assert lib.mpc_policy_act(0, 4, 3, 128, *([p] * 10), 0, 0, None, 1, 1, p, p, p, None, None, None) == -1  # v1 without weights out
+    assert lib.mpc_streams_overlap(0, None, None, None) == -1                 # nowhere to put the answer
 
 
 def test_sized_default_config_refuses_a_short_struct():

@@ -636,3 +636,34 @@ def test_rollout_finish_on_the_gpu_is_the_torch_gae_bit_for_bit(algorithm):
     assert rc == 0, lib.mpc_last_error()
     ref.compute_returns_and_advantage(lv, dn.bool())
     assert torch.equal(big.advantages, ref.advantages) and torch.equal(big.returns, ref.returns)
+
+
+@pytest.mark.gpu
+def test_concurrent_streams_are_probed_not_assumed():
+    """engine.concurrent_streams (mpc_streams_overlap): the streams it returns run kernels side by side pairwise - the probe's
+    own statement, checked again stream by stream - a stream does not "overlap" with itself, and two batches in flight on two
+    of them give the results of the same batches solved one after the other."""
+    import torch
+    from mpc_rl_for_avs_amd import engine, synth
+    dev = torch.device("cuda", 0)
+    streams = engine.concurrent_streams(4, dev)
+    assert len({s.cuda_stream for s in streams}) == 4
+    for i in range(4):
+        assert not engine.streams_overlap(streams[i], streams[i], 0)
+        for j in range(i + 1, 4):
+            assert engine.streams_overlap(streams[i], streams[j], 0)
+    inp = synth.solver_inputs(1024, 4, seed=5)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=dev)
+    args = dict(state=t(inp["state"], torch.float64), ego_index=t(inp["ego_index"], torch.int32), weights=t(inp["weights"], torch.float64),
+                is_collide=t(inp["is_collide"], torch.uint8), vref=t(inp["vref"], torch.float64), others=t(inp["others"], torch.float64),
+                collision_cost=True)
+    e = engine.MPCEngine(horizon=20, max_iter=60)
+    want = e.solve_batch_torch(**args, throughput=True, sync=True)
+    outs = []
+    for s in streams[:2]:
+        with torch.cuda.stream(s):
+            outs.append(e.solve_batch_torch(**args, throughput=True))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o["u0"], want["u0"]) and torch.equal(o["status"], want["status"]) and torch.equal(o["iters"], want["iters"])
+    e.close()

@@ -16,6 +16,7 @@ python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 tools/gpu_lat.py --bulk > $O/latency.txt 2>&1
 python3 tools/gpu_capline.py >> $O/latency.txt 2>&1
 python3 tools/gpu_inflight.py > $O/inflight.txt 2>&1
+python3 tools/gpu_queues.py > $O/stream_queues.txt 2>&1
 python3 tools/gpu_tail.py > $O/tail.txt 2>&1
 python3 tools/gpu_predict_timing.py > $O/predict.txt 2>&1
 python3 tools/gpu_parity_sweep.py > $O/parity_sweep.txt 2>&1
@@ -29,6 +30,7 @@ python3 tools/bench_rollout.py --envs 256 --steps 64 --no-graph --env-backend to
 python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 256 --steps 64 --version v1 --max-iter 1000 --tol 1e-6 >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 8192 --steps 32 --groups 4 >> $O/rollout.jsonl 2>> $O/rollout.err
+python3 tools/bench_rollout.py --envs 2048 --steps 64 --groups 2 >> $O/rollout.jsonl 2>> $O/rollout.err
 python3 tools/bench_rollout.py --envs 2048 --steps 32 --version v1 >> $O/rollout.jsonl 2>> $O/rollout.err
 rocprofv3 --kernel-trace --output-format csv -d $O/steptrace -- python3 tools/bench_rollout.py --envs 256 > /dev/null 2>> $O/rollout.err
 python3 tools/graph_step_gaps.py $O/steptrace > $O/graph_step_trace.txt 2>&1
