@@ -64,6 +64,10 @@ struct LdsSink {
     MPC_HD P2 get(int q) const { return P2{c->ld(base + 2 * q), c->ld(base + 2 * q + 1)}; }
 };
 
+// section ids for CTX::tick (cycle attribution in tools/ubench/preamble_sections.hip; a no-op in the product kernel and on the host)
+enum : int { PT_PARSE = 0, PT_NEAREST, PT_RAMP, PT_ARC, PT_POINTS, PT_PATHS, PT_HITS, PT_STRETCHES, PT_CROSSINGS, PT_CANDIDATES,
+             PT_EXPORT, PT_FINISH, PT_COUNT };
+
 // what the wave has ready about one vehicle's collinear stretches when lane j walks over its hit segments (path_crossings_t)
 template <class CTX>
 struct StretchStore {
@@ -234,6 +238,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
         };
         p = Parsed{field(1), field(2), normalize_angle_f32(field(5)), speed_f32(field(3), field(4)), observed};
     }
+    ctx.tick(PT_PARSE);
     const double ex = (double)p.ex, ey = (double)p.ey;
 
     // ---- nearest reference point of the ego (first minimum; agents/pure_mpc.py:106-109, 567-570, 471-474)
@@ -256,6 +261,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
     int e0 = (int)wmin(ctx, bi);
     e0 = (e0 < 0 || e0 >= M) ? 0 : e0;
 
+    ctx.tick(PT_NEAREST);
     const bool replay = !advance || replays_memory(st);
     int ne = 0;
     bool degenerate = false;      // the ego's predicted path has a single point (it stands on the last reference point):
@@ -275,45 +281,44 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
             // ---- speed ramp and travelled distance, agents/pure_mpc.py:489-499: float32 until the ramp reaches the float64
             //      reference speed (see ego_future); wave-uniform, every lane keeps the same values
             const double reference_speed = R.v(e0);
-            bool s32 = true, d32 = true;
             float cs_f = p.ev, cd_f = 0.0f;
-            double cs_d = 0.0, cd_d = 0.0;
             const float acc_dt_f = (float)(3.5 * dt);
             const float dt_f = (float)dt;
             double cd_last = 0.0;
             PerLane<double> cdv;
             ctx.lanes([&](int lane) { cdv.at(lane) = 0.0; });
-            // (round 6: the same statements without branches - both the float32 and the float64 continuation of a step are
-            // computed and the state flags select; as data-dependent wave-uniform branches a step cost 276 cycles, 8.3 k per call)
+            // ego_future's state machine (mpc_preamble.hpp) has two phases and never goes back: (A) speed and distance float32,
+            // the speed climbing by 3.5 dt per step while it stays below the reference speed; (B) from the step at which the
+            // ramp reaches or passes it the speed IS the float64 reference and the distance a float64 that grows by the
+            // constant reference_speed * dt (its first value: the float32 distance widened, plus that).  Round 6, second pass: as
+            // two plain loops - 8 and 1 arithmetic instructions per step - instead of one loop that carried both continuations
+            // and selected (45 instructions, 25 of them selects, on a lone wave's dependent-issue clock: 9.1 k cycles per call,
+            // the largest section of a typical preamble; tools/gpu_preamble_sections.py).  Lane step + 1 keeps the step's
+            // distance (one store per lane after the loops: 64 lanes writing ONE LDS word per step serialise on its bank).
+            int step = 0;
 #pragma unroll 1
-            for (int step = 0; step < kPredHorizon; ++step) {
-                const double cs_now = s32 ? (double)cs_f : cs_d;
-                const bool below = cs_now < reference_speed;
-                const float tf = f32add(cs_f, acc_dt_f);                         // the float32 ramp step ...
-                const bool over_f = reference_speed < (double)tf;               // ... and whether it passes the reference speed
-                const double td = f64add(cs_d, 3.5 * dt);                       // the float64 ramp step
-                const double cs_d_ramp = reference_speed < td ? reference_speed : td;
-                const bool keep32 = s32 && below && !over_f;
-                cs_d = !below ? reference_speed : (s32 ? (over_f ? reference_speed : cs_d) : cs_d_ramp);
-                cs_f = keep32 ? tf : cs_f;
-                s32 = keep32;
-                const float incf = f32mul(cs_f, dt_f);
-                const double incd = f64mul(cs_d, dt);
-                const bool both32 = s32 && d32;
-                const double base = d32 ? (double)cd_f : cd_d;
-                const double add = s32 ? (double)incf : incd;
-                const double cd_d_n = both32 ? cd_d : f64add(base, add);
-                cd_f = both32 ? f32add(cd_f, incf) : cd_f;
-                cd_d = cd_d_n;
-                d32 = both32;
-                cd_last = d32 ? (double)cd_f : cd_d;
-                // lane step + 1 keeps this step's distance (one store per lane after the loop: 64 lanes writing ONE LDS word per
-                // step serialise on its bank)
+            for (; step < kPredHorizon; ++step) {
+                if (!((double)cs_f < reference_speed)) break;                    // at (or NaN against) the reference speed
+                const float tf = f32add(cs_f, acc_dt_f);
+                if (reference_speed < (double)tf) break;                        // min(t, reference) returns the float64 reference
+                cs_f = tf;
+                cd_f = f32add(cd_f, f32mul(cs_f, dt_f));
+                cd_last = (double)cd_f;
                 ctx.lanes([&](int lane) { cdv.at(lane) = lane == step + 1 ? cd_last : cdv.at(lane); });
+            }
+            if (step < kPredHorizon) {
+                const double incd = f64mul(reference_speed, dt);
+                cd_last = (double)cd_f;
+#pragma unroll 1
+                for (; step < kPredHorizon; ++step) {
+                    cd_last = f64add(cd_last, incd);
+                    ctx.lanes([&](int lane) { cdv.at(lane) = lane == step + 1 ? cd_last : cdv.at(lane); });
+                }
             }
             ctx.phase([&](int lane) {
                 if (lane >= 1 && lane <= kPredHorizon) ctx.st(PL_CD + lane, cdv.at(lane));
             });
+            ctx.tick(PT_RAMP);
             // ---- route segments behind the start point, kWin at a time; running sums in np.cumsum's order.  Round 6: the segment
             //      lengths stay in registers (lane i: segments i and i + 64), the serial sum fetches them with v_readlane and
             //      lane i keeps sum i - until then every step was an LDS load the addition waited for plus a 64-lane store to
@@ -326,33 +331,55 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
                 sg1.at(lane) = i1 < nseg ? dist2d(R.x(e0 + i1 + 1), R.y(e0 + i1 + 1), R.x(e0 + i1), R.y(e0 + i1)) : 0.0;
                 cu0.at(lane) = 0.0;
                 cu1.at(lane) = 0.0;
-                if (i0 < nseg) ctx.st(PL_SEG + i0, sg0.at(lane));
-                if (i1 < nseg) ctx.st(PL_SEG + i1, sg1.at(lane));
             });
             int ncum = 1;
             double cum_end = 0.0;
             {
+                // segment i - 1 and running sum i sit in lanes i - 1 and i of the first register pair while they exist (i < 64),
+                // then of the second; a loop per pair and the two seams (i = 64, i = kWin) apart keep each loop body at one
+                // v_readlane pair, the addition, one select pair and the test (as ONE loop with the pair chosen per step the
+                // compiler carried both pairs through every step: six register copies and four branches per step)
                 double cum = 0.0;
+                bool more = true;
                 static_assert(kWin == 2 * wave::kLanes, "two running sums per lane; the last one (index kWin) apart");
+                const int n0 = nseg < wave::kLanes - 1 ? nseg : wave::kLanes - 1;
+                int i = 1;
 #pragma unroll 1
-                for (int i = 1; i <= nseg; ++i) {
-                    const double sgi = i - 1 < wave::kLanes ? ctx.lane_get(sg0, i - 1) : ctx.lane_get(sg1, i - 1 - wave::kLanes);
-                    cum = f64add(cum, sgi);
-                    // running sum i: lane i (i < 64) in cu0, lane i - 64 in cu1
-                    ctx.lanes([&](int lane) {
-                        cu0.at(lane) = lane == i ? cum : cu0.at(lane);
-                        cu1.at(lane) = lane + wave::kLanes == i ? cum : cu1.at(lane);
-                    });
-                    if (i == kWin) cum_end = cum;                  // sum kWin has no lane of its own
-                    ncum = i + 1;
-                    if (!(cum < cd_last)) break;                   // the look-ahead ends here: nothing beyond is searched
+                for (; i <= n0; ++i) {
+                    cum = f64add(cum, ctx.lane_get(sg0, i - 1));
+                    ctx.lanes([&](int lane) { cu0.at(lane) = lane == i ? cum : cu0.at(lane); });
+                    if (!(cum < cd_last)) {                        // the look-ahead ends here: nothing beyond is searched
+                        more = false;
+                        ++i;
+                        break;
+                    }
                 }
+                if (more && i <= nseg) {                           // i = 64: the last segment of the first pair, the first sum of the second
+                    cum = f64add(cum, ctx.lane_get(sg0, wave::kLanes - 1));
+                    ctx.lanes([&](int lane) { cu1.at(lane) = lane == 0 ? cum : cu1.at(lane); });
+                    more = cum < cd_last;
+                    ++i;
+                    const int n1 = nseg < kWin - 1 ? nseg : kWin - 1;
+#pragma unroll 1
+                    for (; more && i <= n1; ++i) {
+                        cum = f64add(cum, ctx.lane_get(sg1, i - 1 - wave::kLanes));
+                        ctx.lanes([&](int lane) { cu1.at(lane) = lane + wave::kLanes == i ? cum : cu1.at(lane); });
+                        more = cum < cd_last;
+                    }
+                    if (more && i <= nseg) {                       // i = kWin: its sum has no lane of its own
+                        cum = f64add(cum, ctx.lane_get(sg1, wave::kLanes - 1));
+                        cum_end = cum;
+                        ++i;
+                    }
+                }
+                ncum = i;                                          // sums 0 .. i - 1 exist
             }
             ctx.phase([&](int lane) {
                 if (lane < ncum) ctx.st(PL_CUM + lane, cu0.at(lane));                                     // (sum 0 = 0)
                 if (lane + wave::kLanes < ncum && lane + wave::kLanes < kWin) ctx.st(PL_CUM + lane + wave::kLanes, cu1.at(lane));
                 if (lane == 0 && ncum == kWin + 1) ctx.st(PL_CUM + kWin, cum_end);
             });
+            ctx.tick(PT_ARC);
             // ---- the 30 predicted points: lane k = step k (agents/pure_mpc.py:501-521)
             PerLane<int> inside;
             ctx.phase([&](int lane) {
@@ -421,6 +448,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
         }
     }
 
+    ctx.tick(PT_POINTS);
     // ---- the other vehicles
     const int V = p.observed;
     if (!replay && !degenerate) {
@@ -445,6 +473,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
                 cpt[lane] = P2{0.0, 0.0};
             }
         });
+        ctx.tick(PT_PATHS);
         // which ego segments meet which vehicle's line at all: 2 vehicles x 32 segment slots per pass
         const LdsPts<CTX> ego{&ctx, PL_EGO, ne};
         // (round 6) ... and which of them OVERLAP it (two hits), with the overlap's far end kept per (vehicle, segment): the
@@ -478,6 +507,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
                 }
             });
         }
+        ctx.tick(PT_HITS);
         // collinear stretches (same-lane traffic): the middle node of each, by the whole wave, vehicle after vehicle
         for (unsigned long long ov = ctx.ballot(twos); ov; ov &= ov - 1) {
             const int j = ctz64(ov);
@@ -495,6 +525,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
                 tw &= ~(((1u << len) - 1u) << i);
             }
         }
+        ctx.tick(PT_STRETCHES);
         // candidates (agents/pure_mpc.py:615-633), lane j = vehicle j, only the segments with a hit are visited
         PerLane<int> ncand;
         ctx.phase([&](int lane) {
@@ -507,6 +538,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
             }
             ncand.at(lane) = nc;
         });
+        ctx.tick(PT_CROSSINGS);
         // candidate loop of agents/pure_mpc.py:635-654, the whole wave per candidate: nearest sample of the ego's path (lanes
         // 0..30) and of the vehicle's (lanes 32..62); the first candidate whose sample indices differ by less than
         // TIME_THRESHOLD decides, and its nearest reference point is the conflict index
@@ -567,6 +599,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
         }
     }
 
+    ctx.tick(PT_CANDIDATES);
     // ---- diagnostics export (mpc_get_last_paths)
     if (diag.len) {
         const int nexp = replay ? 0 : ne;
@@ -582,6 +615,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
         });
     }
 
+    ctx.tick(PT_EXPORT);
     // ---- problem data that comes straight from the observation, state machine, ego index, speed profile.  Round 6: spread over
     //      the lanes (until round 5 lane 0 ran write_vehicles + finish_env alone: ~10 k cycles of dependent global-memory round
     //      trips on EVERY call, also when the detector only replays its memory - tools/gpu_preamble_sections.py).  Same
@@ -750,6 +784,7 @@ MPC_HD void preamble_env_wave(CTX &ctx, const float *obs, int rows, const RefTab
             }
         }
     });
+    ctx.tick(PT_FINISH);
 }
 
 }  // namespace pre
