@@ -580,6 +580,37 @@ def side_measurements(a, eng, args, inp, out, dev):
                         "frac_u0_within_1e-6_of_the_timed_run": float(((outs[0]["u0"] - out["u0"]).abs().amax(dim=1) <= 1e-6).float().mean()),
                         "note": f"throughput with {n_fl} batches of 4096 in flight (MPC_FLAG_THROUGHPUT: the 3-waves-per-SIMD build, 12 "
                                 "instances per CU by LDS); `value` above is one batch at a time"}
+    # ONE launch of 65 536 instances of the same workload (the bulk regime: every SIMD holds three waves until the launch drains):
+    # what the tail costs when nothing else is in flight to cover it (launch-order tiers, mpc_engine.hip mpc_order_kernel)
+    inp_b = synth.solver_inputs(65536, V, seed=0, N=HORIZON)
+    t_ = lambda x, dt_: torch.as_tensor(np.ascontiguousarray(x), dtype=dt_, device=dev)
+    a_b = dict(state=t_(inp_b["state"], torch.float64), ego_index=t_(inp_b["ego_index"], torch.int32),
+               weights=t_(inp_b["weights"], torch.float64), is_collide=t_(inp_b["is_collide"], torch.uint8),
+               vref=t_(inp_b["vref"], torch.float64), others=t_(inp_b["others"], torch.float64), collision_cost=True)
+    o_b = eng.solve_batch_torch(**a_b, sync=True)
+    ms_b = timed(lambda: eng.solve_batch_torch(**a_b, out=o_b), reps=3)
+    st_b = o_b["status"].cpu().numpy()
+    res["bulk_launch"] = {"workload": "one launch of 65 536 instances of config 3 (16 x the headline batch), cap 100", "ms": ms_b,
+                          "value": 65536 / (ms_b * 1e-3), "unit": "solves/s", "converged_frac": float(conv_mask(st_b).mean()),
+                          "counts": "all instances"}
+    del a_b, o_b
+    # BASELINE configs[4]'s total (2048 environments, 8 GPUs x 256 there) on ONE GPU: two groups of 1024 environments stepped on two
+    # streams that run side by side (rollout.PipelinedCollector, engine.concurrent_streams).  In a child process with the
+    # runtime's default of 4 hardware queues: with more than 4 (this process runs with 8 for the in_flight measurement above) the
+    # same two groups are 20 % slower - 1.80 against 2.22 M env-steps/s for 5, 6, 7, 8 or 16 queues against 2, 3 or 4
+    # (profiles/r06_stream_queues.txt) - although the streams pass the overlap probe
+    import subprocess
+    env5 = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r5 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_rollout.py"), "--envs", "2048", "--groups", "2", "--steps", "64"],
+                        env=env5, capture_output=True, text=True, timeout=600)
+    if r5.returncode != 0:
+        raise RuntimeError("tools/bench_rollout.py --envs 2048 --groups 2 failed:\n" + r5.stderr[-2000:])
+    d5 = json.loads(r5.stdout.strip().splitlines()[-1])
+    res["config5_one_gpu"] = {"workload": "2048 parallel intersection envs (BASELINE configs[4]'s total) on one GPU, two groups of 1024 on two "
+                                          "streams, MPC-in-the-loop rollout of 64 steps, v0, hipGraph steps (child process: "
+                                          "tools/bench_rollout.py --envs 2048 --groups 2)",
+                              "value": d5["env_steps_per_s"], "unit": "env-steps/s", "ms_per_step": d5["ms_per_step"],
+                              "converged_frac_rollout": d5["converged_frac_rollout"], "graph": d5["graph"], "groups": d5["groups"]}
     # the same call with HOST pointers (numpy in, numpy out): H2D of the inputs, solve, D2H of u0/status/iters
     ts = []
     for _ in range(6):
