@@ -138,14 +138,29 @@ MPC_HD P2 overlap_middle_wave(CTX &ctx, const LdsPts<CTX> &ego, int agbase, int 
     });
     const unsigned long long vm = ctx.ballot(val);
     const int n = popc64(vm);
+    // rank = number of nodes before this one in the (key, x, y) order (equal nodes: by lane).  First by KEY alone over all nodes (two
+    // lane reads, two compares per step), remembering who shares a key with someone; then the full comparison only against the
+    // nodes that do (typically two: an end of the overlap and the vehicle's vertex on it)
+    PerLane<int> tie;
+    ctx.phase([&](int lane) { tie.at(lane) = 0; });
     for (unsigned long long t = vm; t; t &= t - 1) {
+        const int y = ctz64(t);
+        const double ky = ctx.lane_get(kk, y);
+        ctx.phase([&](int lane) {
+            const double kl = kk.at(lane);
+            rank.at(lane) += ky < kl ? 1 : 0;
+            tie.at(lane) |= (ky == kl && y != lane) ? 1 : 0;
+        });
+    }
+    ctx.phase([&](int lane) { tie.at(lane) = (tie.at(lane) && val.at(lane)) ? 1 : 0; });
+    for (unsigned long long t = ctx.ballot(tie); t; t &= t - 1) {
         const int y = ctz64(t);
         const double ky = ctx.lane_get(kk, y), xy = ctx.lane_get(px, y), yy = ctx.lane_get(py, y);
         ctx.phase([&](int lane) {
             const double kl = kk.at(lane), xl = px.at(lane), yl = py.at(lane);
-            const bool bef = ky < kl || (ky == kl && (xy < xl || (xy == xl && yy < yl)));      // OverlapWalk::before
-            const bool same = ky == kl && xy == xl && yy == yl;                                // equal nodes: by lane
-            rank.at(lane) += (bef || (same && y < lane)) ? 1 : 0;
+            const bool bef = xy < xl || (xy == xl && yy < yl);                                 // OverlapWalk::before, keys equal
+            const bool same = xy == xl && yy == yl;                                            // equal nodes: by lane
+            rank.at(lane) += (ky == kl && (bef || (same && y < lane))) ? 1 : 0;
         });
     }
     ctx.phase([&](int lane) {
