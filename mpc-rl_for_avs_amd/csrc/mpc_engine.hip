@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kBlock, OCC) void mpc_ltv_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // observation -> problem data: ONE wave per environment (mpc_preamble_wave.hpp says which lanes do what).  Workgroup = one
-// wave, grid = B, 21 KB of LDS (predicted paths, running arc lengths, crossing candidates), nothing in scratch.
+// wave, grid = B, 20 KB of LDS (predicted paths, running arc lengths - later the sorted nodes and middles of collinear stretches -, crossing candidates), nothing in scratch.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock, 2) void mpc_preamble_kernel(
     int B, const float *__restrict__ obs, int rows, const double *__restrict__ ref5, int M, int N, double dt,

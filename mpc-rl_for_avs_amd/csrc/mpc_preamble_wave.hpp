@@ -3,21 +3,28 @@
 // environment.  Same arithmetic, statement for statement, as the one-thread form `preamble_env` (which stays the host
 // harness's reference and the specification of every rounding): what changes is who computes what.
 //
+//   observation (base_agent.py:81-116)     every lane its own words, the presence count a ballot (round 6)
 //   nearest reference point of the ego     64 lanes x M / 64 points, two wave reductions (value, then first index)
-//   ego speed ramp / travelled distance    30 dependent steps of float32 / float64 additions, wave-uniform (they ARE serial)
-//   arc length along the route             segment lengths by 128 lanes' worth of loads at once, then one uniform running sum
-//                                          that stops where the 3 s look-ahead ends (np.cumsum order: sequential by definition)
+//   ego speed ramp / travelled distance    30 dependent steps of float32, then float64 additions, wave-uniform (they ARE serial): one
+//                                          plain loop per phase of the ramp, the distance of step k kept in lane k (round 6)
+//   arc length along the route             segment lengths for 128 points at once, kept in two registers per lane; the running sum
+//                                          (np.cumsum order: sequential by definition) fetches them with v_readlane, lane i keeps
+//                                          sum i, and it stops where the 3 s look-ahead ends (round 6)
 //   the 30 predicted ego points            lane k = prediction step k: binary search in the running sums + interpolation
 //   vehicle paths (30 float32 additions)   lane j = vehicle j
 //   path x path crossing tests             all (vehicle, ego segment) pairs at once, 2 vehicles x 32 segments per pass; the
-//                                          hit masks (wave ballots) tell the serial candidate logic which segments to visit
-//   candidate logic (agents/pure_mpc.py:615-633: points, collinear stretches, order)   lane j, only on segments with a hit
+//                                          hit masks (wave ballots) tell the serial candidate logic which segments to visit, the
+//                                          overlap masks where collinear stretches are, each overlap's far end stays in LDS
+//   collinear stretches (:619-622)         the whole wave per stretch: overlap_middle_wave below (round 6)
+//   candidate logic (agents/pure_mpc.py:615-633: points, stretches, order)             lane j, only on segments with a hit
 //   candidate test (:635-654: nearest sample of either path, nearest reference point)  the whole wave per candidate
-//   state machine, speed profile (:558-563, 661-724)                                   lane 0, unchanged code (finish_env)
+//   state machine, speed profile (:558-563, 661-724)    lane j = vehicle j's entries of the record, lane k = node k of the
+//                                          profile, the record's scalars by lane 0 (round 6; finish_env stays the specification)
 //
 // Until round 3 the kernel ran 4 environments per wave with lane 0 of each 16-lane group doing the ego path, the state
 // machine and the speed profile alone: 76 us per call at 256 environments, 303 us when every environment runs the full
-// detection (profiles/r03_rollout_kernel_stats.csv), 256 VGPRs.  profiles/r04_rollout_kernel_stats.csv has this one.
+// detection (profiles/r03_rollout_kernel_stats.csv), 256 VGPRs.  Rounds 4 - 5: one wave per environment, 32 - 36 us (120 us when
+// every environment runs the full detection); round 6: 15.9 us (28 us), profiles/r06_rollout_kernel_stats.csv.
 //
 // CTX: the wave interface of mpc_wave.hpp (phase / ld / st / wave_min / ballot / wave_bcast): WaveOpsT on the device
 // (mpc_wave_dev.hpp), HostCtx in tests/host_wave_ctx.hpp, where tests/cpu_preamble_harness.cpp runs this file on the CPU
@@ -93,10 +100,11 @@ MPC_HD int ctz64(unsigned long long v) { return __builtin_ctzll(v); }
 // inside it, in order along the line, duplicates dropped (tests/host_preamble.py sorts; OverlapWalk in mpc_preamble.hpp, the
 // one-thread form, merges the two families, which come sorted).  Here: lane q < 32 holds ego-derived node q (0 = the near end on
 // segment i, q >= 1 the far end on segment i + q - 1), lane 32 + m the vehicle's vertex m if it lies inside; every node finds
-// its rank in the (key, x, y) order by counting the nodes before it (n <= 63 steps of three lane reads), the nodes go to LDS by
-// rank, "close to the last node kept" (np.allclose: it depends on what was kept before) is decided from each node's distance to
+// its rank in the (key, x, y) order by counting the nodes before it (n <= 63 steps by key alone, then the full comparison against
+// the few nodes that share a key), the nodes go to LDS by rank, "close to the last node kept" (np.allclose: it depends on what was kept before) is decided from each node's distance to
 // its one and two predecessors when no two nodes in a row are dropped - else by the serial rule over the sorted array - and
-// the middle one of the kept is read back.  ~4 k cycles where one lane's two merges took ~50 k.
+// the middle one of the kept is read back.  ~4 k cycles where one lane's two merges took ~50 k
+// (tools/gpu_preamble_sections.py, profiles/r06_preamble_sections.txt).
 template <class CTX>
 MPC_HD P2 overlap_middle_wave(CTX &ctx, const LdsPts<CTX> &ego, int agbase, int fars, int i, int jend) {
     using wave::PerLane;
