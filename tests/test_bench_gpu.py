@@ -112,6 +112,6 @@ def test_default_line_is_the_only_stdout_and_carries_every_single_gpu_config():
     assert v1["unit"] == "env-steps/s" and v1["value"] > 5e4 and v1["converged_frac_rollout"] > 0.95
     # round 6: the regimes beside the headline - batches in flight on streams probed to overlap, one bulk launch, config 5's total
     fl, bl, c5 = d["in_flight"], d["bulk_launch"], d["config5_one_gpu"]
-    assert fl["streams"] == 8 and fl["identical_outputs_across_streams"] and fl["value"] > 2.0 * d["value"]
+    assert fl["streams"] == 8 and fl["streams_probed_to_overlap"] and fl["identical_outputs_across_streams"] and fl["value"] > 2.0 * d["value"]
     assert bl["unit"] == "solves/s" and bl["value"] > 2.0 * d["value"] and bl["converged_frac"] > 0.995
     assert c5["unit"] == "env-steps/s" and c5["value"] > 1e6 and c5["groups"] == 2 and c5["converged_frac_rollout"] > 0.99
