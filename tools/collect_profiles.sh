@@ -17,7 +17,7 @@ csv.writer(open(sys.argv[2], "w", newline="")).writerows(keep)
 PY
 cp $S/bench_prof.json $P/${TAG}_bench_profiled_run.json
 cp $S/bench.json $P/${TAG}_bench.json
-for f in latency tail predict parity_sweep ltv_timing run_pure_mpc inflight stream_queues graph_step_trace; do cp $S/$f.txt $P/${TAG}_$f.txt; done
+for f in latency tail predict preamble_sections parity_sweep ltv_timing run_pure_mpc inflight stream_queues graph_step_trace; do cp $S/$f.txt $P/${TAG}_$f.txt; done
 cp $S/rollout.jsonl $P/${TAG}_rollout.jsonl
 cp $S/bench_rccl_1rank.json $P/${TAG}_bench_rccl_1rank.json
 python3 tools/pmc_summary.py $TAG

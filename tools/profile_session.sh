@@ -19,6 +19,8 @@ python3 tools/gpu_inflight.py > $O/inflight.txt 2>&1
 python3 tools/gpu_queues.py > $O/stream_queues.txt 2>&1
 python3 tools/gpu_tail.py > $O/tail.txt 2>&1
 python3 tools/gpu_predict_timing.py > $O/predict.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/ubench/libpreamble_sections.so tools/ubench/preamble_sections.hip > $O/preamble_sections.err 2>&1
+python3 tools/gpu_preamble_sections.py > $O/preamble_sections.txt 2>> $O/preamble_sections.err
 python3 tools/gpu_parity_sweep.py > $O/parity_sweep.txt 2>&1
 ls $O
 python3 tools/gpu_ltv_timing.py > $O/ltv_timing.txt 2>&1
