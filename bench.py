@@ -601,7 +601,7 @@ def side_measurements(a, eng, args, inp, out, dev):
     # streams that run side by side (rollout.PipelinedCollector, engine.concurrent_streams).  In a child process with the
     # runtime's default of 4 hardware queues: with more than 4 (this process runs with 8 for the in_flight measurement above) the
     # same two groups are 20 % slower - 1.80 against 2.22 M env-steps/s for 5, 6, 7, 8 or 16 queues against 2, 3 or 4
-    # (profiles/r06_stream_queues.txt) - although the streams pass the overlap probe
+    # (profiles/r06_hw_queues_scan.txt) - although the streams pass the overlap probe
     import subprocess
     env5 = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     try:      # a side measurement in another process must not cost the run its line
