@@ -57,9 +57,15 @@ def run(streams, label):
 
 
 pool = [torch.cuda.Stream(dev) for _ in range(32)]
-print("mpc_streams_overlap of pool stream 0 against 1..15:", [int(engine.streams_overlap(pool[0], pool[j], 0)) for j in range(1, 16)], flush=True)
-base = chain_time(pool[0], None)
-print("chain on pool stream 0 alone %.2f ms; with pool stream j busy: " % base + " ".join(f"{j}:{chain_time(pool[0], pool[j]):.2f}" for j in range(1, 16)), flush=True)
-for a_, b_ in ((0, 1), (0, 2), (0, 3), (0, 4), (0, 5), (0, 8), (0, 9), (8, 9), (1, 2), (4, 5), (9, 10), (16, 17)):
-    run([pool[a_], pool[b_]], f"pool streams {a_} and {b_}")
-run(None, "PipelinedCollector's own choice")
+n = 10
+chain_time(pool[0], pool[1])
+print("chain matrix (rows: stream with the chain; columns: busy stream; ms, alone on the diagonal)")
+mat = [[chain_time(pool[i], None if j == i else pool[j]) for j in range(n)] for i in range(n)]
+for i in range(n):
+    print(f"{i:3d} " + " ".join(f"{v:5.2f}" for v in mat[i]), flush=True)
+for b_ in range(1, n):
+    tag = "serialise" if max(mat[0][b_], mat[b_][0]) > 5 else ("chain slowed: " + ("0|b " if mat[0][b_] > 0.6 else "") + ("b|0" if mat[b_][0] > 0.6 else "")) if max(mat[0][b_], mat[b_][0]) > 0.6 else "clean"
+    run([pool[0], pool[b_]], f"pool streams 0 and {b_} ({tag})")
+for a_, b_ in ((1, 2), (2, 3), (4, 5), (6, 8)):
+    tag = "serialise" if max(mat[a_][b_], mat[b_][a_]) > 5 else ("chain slowed" if max(mat[a_][b_], mat[b_][a_]) > 0.6 else "clean")
+    run([pool[a_], pool[b_]], f"pool streams {a_} and {b_} ({tag})")

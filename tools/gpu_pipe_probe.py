@@ -1,13 +1,16 @@
+"""Development aid (round 6): a graph of 200 dependent tiny kernels on stream i, alone and while stream j runs one long kernel -
+the full matrix over torch's first pool streams (GPU_MAX_HW_QUEUES from Q, default 8).  Dependent dispatches on one hardware queue
+slow down while certain other queues are busy (shared dispatch pipe); tools/gpu_pipe_groups.py has what that does to rollout groups."""
 import os, sys, time
 os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("Q", "8")
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
-from mpc_rl_for_avs_amd import engine
 dev = torch.device("cuda", 0)
-ch = engine.concurrent_streams(int(os.environ.get("NS", "8")), dev)
+n = int(os.environ.get("NS", "12"))
+pool = [torch.cuda.Stream(dev) for _ in range(32)][:n]
 x = torch.zeros(1, device=dev)
 g = torch.cuda.CUDAGraph()
-# a captured chain of 200 dependent tiny kernels (like a rollout's step chain, no host in the loop)
 s_cap = torch.cuda.Stream(dev)
 with torch.cuda.stream(s_cap):
     x.add_(1)
@@ -17,11 +20,12 @@ with torch.cuda.graph(g, stream=s_cap):
         x.add_(1)
 torch.cuda.synchronize()
 
+
 def chain_time(sa, sb):
     torch.cuda.synchronize()
     if sb is not None:
         with torch.cuda.stream(sb):
-            torch.cuda._sleep(int(2.0e9 * 0.03))
+            torch.cuda._sleep(int(2.0e9 * 0.02))
     t0 = time.perf_counter()
     with torch.cuda.stream(sa):
         g.replay()
@@ -30,9 +34,9 @@ def chain_time(sa, sb):
     torch.cuda.synchronize()
     return t * 1e3
 
-for rep in range(2):
-    base = chain_time(ch[0], None)
-    line = f"chain of 200 dependent kernels on stream 0 alone: {base:.2f} ms; with stream j busy: "
-    for j in range(1, len(ch)):
-        line += f"{j}:{chain_time(ch[0], ch[j]):.2f} "
-    print(line, flush=True)
+
+chain_time(pool[0], pool[1])
+print("rows: stream with the chain; columns: busy stream; ms (alone on the diagonal)")
+print("      " + " ".join(f"{j:5d}" for j in range(n)))
+for i in range(n):
+    print(f"{i:5d} " + " ".join(f"{chain_time(pool[i], None if j == i else pool[j]):5.2f}" for j in range(n)), flush=True)
